@@ -1,0 +1,115 @@
+"""Acquisition functions -- hyperbo/bo_utils/acfun.py:36-185.
+
+For a plain GP the posterior and the EI/PI/UCB epilogue run fused on the GPU (hbo_acq); the `*_sub`
+functions are the host restatement used for HGP sample averaging and as documentation of the maths.
+"""
+import functools
+from typing import Any, Callable, Union
+
+import numpy as np
+
+from hyperbo_amd import _model
+from hyperbo_amd import _native as nat
+from hyperbo_amd.gp_utils import gp
+
+partial = functools.partial
+
+
+def random_search(model, x_queries, **unused_kwargs):
+  """Uniformly sampled random array (acfun.py:29-34) from model.rng (numpy Generator)."""
+  assert model.rng is not None, 'Random search requires random key.'
+  return model.rng.uniform(size=(x_queries.shape[0], 1))
+
+
+def _norm_pdf(x):
+  return np.exp(-0.5 * x * x) / np.sqrt(2 * np.pi)
+
+
+def _norm_cdf(x):
+  from math import erfc
+  return 0.5 * np.vectorize(erfc)(-np.asarray(x, dtype=np.float64) / np.sqrt(2.0))
+
+
+def expected_improvement_sub(mu, std, target):
+  gamma = (target - mu) / std
+  return (_norm_pdf(gamma) - gamma * (1 - _norm_cdf(gamma))) * std
+
+
+def probability_of_improvement_sub(mu, std, target):
+  gamma = (target - mu) / std
+  return -gamma
+
+
+def ucb_sub(mu, std, beta=3.):
+  return mu + beta * std
+
+
+_NATIVE_ID = {expected_improvement_sub: nat.ACQ_EI, probability_of_improvement_sub: nat.ACQ_PI,
+              ucb_sub: nat.ACQ_UCB}
+
+
+def acfun_wrapper(acfun_sub, acfun_callback_default):
+  """acfun.py:36-93."""
+
+  def acquisition_function(*, model, sub_dataset_key, x_queries, acfun_callback=acfun_callback_default):
+    x_queries = np.asarray(x_queries)
+    if isinstance(model, gp.HGP):
+      predicts = model.predict(x_queries, sub_dataset_key=sub_dataset_key, full_cov=False, with_noise=True)
+      acfun_param = acfun_callback(model, sub_dataset_key)
+      ac_vals = [acfun_sub(mu, np.sqrt(var), acfun_param) for mu, var in predicts]
+      return np.mean(ac_vals, axis=0)
+    acfun_param = acfun_callback(model, sub_dataset_key)
+    # fused device path: posterior (gp.py:562-620 incl. +noise and T/(T-1)) + acquisition epilogue
+    handle = None
+    if sub_dataset_key in model.dataset:
+      model.setup_predictor(sub_dataset_key)
+      handle = model.params.cache[sub_dataset_key].handle
+    dtype = handle.dtype if handle is not None else _model.infer_dtype(x_queries)
+    xq = np.ascontiguousarray(x_queries, dtype=dtype)
+    out = np.empty((xq.shape[0], 1), dtype=dtype)
+    if xq.shape[0] == 0:
+      return out
+    add_noise, scale = model.predict_noise_and_scale(True, True)
+    bm = _model.BuiltModel(model.mean_func, model.cov_func, model.params, model.warp_func, dtype,
+                           model.input_dim)
+    ctx = handle.ctx if handle is not None else nat.default_context()
+    ctx.check(nat.lib().hbo_acq(ctx.handle, bm.ref(), handle.handle if handle is not None else None,
+                                nat.ptr(xq), xq.shape[0], _NATIVE_ID[acfun_sub], float(acfun_param),
+                                float(add_noise), float(scale), nat.ptr(out)))
+    return out
+
+  return acquisition_function
+
+
+def ei_callback_default(model, key, **unused_kwargs):
+  if key not in model.dataset or model.dataset[key].y.shape[0] == 0:
+    return 0.0
+  return np.max(model.dataset[key].y)
+
+
+expected_improvement = acfun_wrapper(acfun_sub=expected_improvement_sub,
+                                     acfun_callback_default=ei_callback_default)
+ei = expected_improvement
+
+
+def pi_callback_default(model, key, zeta=0.1, use_std=False, **unused_kwargs):
+  if key not in model.dataset or model.dataset[key].y.shape[0] == 0:
+    return 0.0
+  if use_std:
+    return np.max(model.dataset[key].y) + zeta * np.std(model.dataset[key].y)
+  return np.max(model.dataset[key].y) + zeta
+
+
+probability_of_improvement = acfun_wrapper(acfun_sub=probability_of_improvement_sub,
+                                           acfun_callback_default=pi_callback_default)
+pi = probability_of_improvement
+pi2 = acfun_wrapper(acfun_sub=probability_of_improvement_sub,
+                    acfun_callback_default=partial(pi_callback_default, use_std=True))
+pi3 = acfun_wrapper(acfun_sub=probability_of_improvement_sub,
+                    acfun_callback_default=partial(pi_callback_default, zeta=0.05))
+
+ucb4 = acfun_wrapper(acfun_sub=ucb_sub, acfun_callback_default=lambda a, b: 4.)
+ucb3 = acfun_wrapper(acfun_sub=ucb_sub, acfun_callback_default=lambda a, b: 3.)
+ucb2 = acfun_wrapper(acfun_sub=ucb_sub, acfun_callback_default=lambda a, b: 2.)
+ucb = ucb3
+rand = random_search

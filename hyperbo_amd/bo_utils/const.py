@@ -1,0 +1,30 @@
+"""Registries -- hyperbo/bo_utils/const.py:22-50: the closed set the native dispatcher covers."""
+from hyperbo_amd.bo_utils import acfun
+from hyperbo_amd.gp_utils import kernel
+from hyperbo_amd.gp_utils import mean
+
+MEAN = {'constant': mean.constant, 'linear': mean.linear, 'linear_mlp': mean.linear_mlp, 'zero': mean.zero}
+KERNEL = {
+    'squared_exponential': kernel.squared_exponential,
+    'matern32': kernel.matern32,
+    'matern52': kernel.matern52,
+    'dot_product': kernel.dot_product,
+    'dot_product_mlp': kernel.dot_product_mlp,
+    'squared_exponential_mlp': kernel.squared_exponential_mlp,
+    'matern32_mlp': kernel.matern32_mlp,
+    'matern52_mlp': kernel.matern52_mlp,
+}
+ACFUN = {
+    'expected_improvement': acfun.expected_improvement,
+    'probability_of_improvement': acfun.probability_of_improvement,
+    'ucb3': acfun.ucb3,
+    'random_search': acfun.random_search,
+    'ucb2': acfun.ucb2,
+    'ucb': acfun.ucb,
+}
+ACFUN_SUB = {
+    'expected_improvement': acfun.expected_improvement_sub,
+    'probability_of_improvement': acfun.probability_of_improvement_sub,
+    'ucb': acfun.ucb_sub,
+}
+EPS = 1e-6

@@ -1,0 +1,952 @@
+// C ABI of libhbo (see include/hbo.h): context, device memory, orchestration of the HIP kernels
+// for the GP hot path, profiling with HIP events, and the RCCL all-reduce used by task sharding.
+#include "hbo_internal.h"
+
+#include <dlfcn.h>
+#include <limits.h>
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+#include <map>
+#include <string>
+#include <vector>
+
+static thread_local std::string g_err;
+
+struct ProfEntry { std::string name; hipEvent_t e0, e1; };
+
+struct hbo_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  std::string err;
+  ModelDev h_model;
+  ModelDev* d_model = nullptr;
+  void* d_mlp_w[HBO_MAX_MLP_LAYERS] = {nullptr};
+  void* d_mlp_b[HBO_MAX_MLP_LAYERS] = {nullptr};
+  size_t mlp_w_bytes[HBO_MAX_MLP_LAYERS] = {0};
+  size_t mlp_b_bytes[HBO_MAX_MLP_LAYERS] = {0};
+  int opt_group = 2;         // 128-wide panels per trailing update (K = 128*group)
+  int prof_level = 0;
+  std::vector<ProfEntry> prof_pending;
+  std::vector<std::string> prof_names;
+  std::vector<double> prof_ms;
+  std::vector<int> prof_count;
+  // RCCL
+  void* rccl_lib = nullptr;
+  void* comm = nullptr;
+  double* d_comm_buf = nullptr;
+  int comm_buf_count = 0;
+};
+
+#define HIPCHK(ctx, call)                                                                     \
+  do {                                                                                        \
+    hipError_t e__ = (call);                                                                  \
+    if (e__ != hipSuccess) {                                                                  \
+      char buf__[512];                                                                        \
+      snprintf(buf__, sizeof buf__, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e__),   \
+               __FILE__, __LINE__);                                                           \
+      if (ctx) (ctx)->err = buf__; else g_err = buf__;                                        \
+      return HBO_ERR_HIP;                                                                     \
+    }                                                                                         \
+  } while (0)
+
+static int fail(hbo_ctx* ctx, int code, const std::string& msg) {
+  if (ctx) ctx->err = msg; else g_err = msg;
+  return code;
+}
+static inline size_t esize(int dtype) { return dtype == HBO_F64 ? 8 : 4; }
+static inline int round_up(int64_t n, int q) { return (int)(((n + q - 1) / q) * q); }
+
+// ---- profiling ---------------------------------------------------------------------------
+struct ProfScope {
+  hbo_ctx* c; bool on; ProfEntry e;
+  ProfScope(hbo_ctx* ctx, const char* name, int level) : c(ctx), on(ctx->prof_level >= level) {
+    if (!on) return;
+    e.name = name;
+    hipEventCreate(&e.e0); hipEventCreate(&e.e1);
+    hipEventRecord(e.e0, c->stream);
+  }
+  ~ProfScope() {
+    if (!on) return;
+    hipEventRecord(e.e1, c->stream);
+    c->prof_pending.push_back(e);
+  }
+};
+static void prof_begin(hbo_ctx* c) {
+  c->prof_names.clear(); c->prof_ms.clear(); c->prof_count.clear();
+  for (auto& p : c->prof_pending) { hipEventDestroy(p.e0); hipEventDestroy(p.e1); }
+  c->prof_pending.clear();
+}
+static void prof_collect(hbo_ctx* c) {  // stream must be synchronised
+  for (auto& p : c->prof_pending) {
+    float ms = 0;
+    hipEventElapsedTime(&ms, p.e0, p.e1);
+    size_t k = 0;
+    for (; k < c->prof_names.size(); ++k) if (c->prof_names[k] == p.name) break;
+    if (k == c->prof_names.size()) { c->prof_names.push_back(p.name); c->prof_ms.push_back(0); c->prof_count.push_back(0); }
+    c->prof_ms[k] += ms; c->prof_count[k] += 1;
+    hipEventDestroy(p.e0); hipEventDestroy(p.e1);
+  }
+  c->prof_pending.clear();
+}
+
+// ---- context -----------------------------------------------------------------------------
+extern "C" const char* hbo_version(void) { return "hbo 0.1 (gfx950)"; }
+extern "C" int hbo_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+  return n;
+}
+extern "C" const char* hbo_last_error(hbo_ctx* ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
+
+extern "C" int hbo_ctx_create(int device, hbo_ctx** out) {
+  if (!out) return fail(nullptr, HBO_ERR_ARG, "hbo_ctx_create: out is null");
+  *out = nullptr;
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+    return fail(nullptr, HBO_ERR_NODEV, "hbo_ctx_create: no HIP device visible");
+  if (device < 0 || device >= n) return fail(nullptr, HBO_ERR_ARG, "hbo_ctx_create: bad device index");
+  hbo_ctx* c = new hbo_ctx();
+  c->device = device;
+  hbo_ctx* nullctx = nullptr;
+  hipError_t e = hipSetDevice(device);
+  if (e == hipSuccess) e = hipStreamCreate(&c->stream);
+  if (e == hipSuccess) e = hipMalloc((void**)&c->d_model, sizeof(ModelDev));
+  if (e != hipSuccess) {
+    g_err = std::string("hbo_ctx_create: ") + hipGetErrorString(e);
+    delete c;
+    (void)nullctx;
+    return HBO_ERR_HIP;
+  }
+  *out = c;
+  return HBO_OK;
+}
+extern "C" int hbo_comm_destroy(hbo_ctx* ctx);
+extern "C" int hbo_ctx_destroy(hbo_ctx* c) {
+  if (!c) return HBO_OK;
+  hipSetDevice(c->device);
+  hbo_comm_destroy(c);
+  prof_begin(c);
+  for (int l = 0; l < HBO_MAX_MLP_LAYERS; ++l) { if (c->d_mlp_w[l]) hipFree(c->d_mlp_w[l]); if (c->d_mlp_b[l]) hipFree(c->d_mlp_b[l]); }
+  if (c->d_model) hipFree(c->d_model);
+  if (c->stream) hipStreamDestroy(c->stream);
+  delete c;
+  return HBO_OK;
+}
+extern "C" int hbo_set_option(hbo_ctx* c, const char* name, int64_t value) {
+  if (!c || !name) return HBO_ERR_ARG;
+  if (!strcmp(name, "potrf_group")) { if (value < 1 || value > 8) return fail(c, HBO_ERR_ARG, "potrf_group in 1..8"); c->opt_group = (int)value; return HBO_OK; }
+  return fail(c, HBO_ERR_ARG, std::string("unknown option ") + name);
+}
+extern "C" int hbo_profile_enable(hbo_ctx* c, int level) { if (!c) return HBO_ERR_ARG; c->prof_level = level; return HBO_OK; }
+extern "C" int hbo_profile_get(hbo_ctx* c, char names[][32], double* ms, int32_t* launches, int32_t* n) {
+  if (!c || !n) return HBO_ERR_ARG;
+  int k = (int)std::min<size_t>(c->prof_names.size(), HBO_MAX_PROFILE_STAGES);
+  for (int i = 0; i < k; ++i) {
+    if (names) { strncpy(names[i], c->prof_names[i].c_str(), 31); names[i][31] = 0; }
+    if (ms) ms[i] = c->prof_ms[i];
+    if (launches) launches[i] = c->prof_count[i];
+  }
+  *n = k;
+  return HBO_OK;
+}
+
+// ---- model ---------------------------------------------------------------------------------
+static int feature_dim(const hbo_model* m) {
+  return m->kernel_uses_mlp ? m->features[m->n_layers - 1] : m->input_dim;
+}
+static int mean_feature_dim(const hbo_model* m) {
+  if (m->mean_id == HBO_MEAN_LINEAR) return m->input_dim;
+  if (m->mean_id == HBO_MEAN_LINEAR_MLP) return m->features[m->n_layers - 1];
+  return 0;
+}
+static bool needs_mlp(const hbo_model* m) { return m->kernel_uses_mlp || m->mean_id == HBO_MEAN_LINEAR_MLP; }
+
+static int validate_model(hbo_ctx* c, const hbo_model* m) {
+  if (!m) return fail(c, HBO_ERR_ARG, "model is null");
+  if (m->dtype != HBO_F32 && m->dtype != HBO_F64) return fail(c, HBO_ERR_ARG, "bad dtype");
+  if (m->kernel_id < 0 || m->kernel_id > HBO_KERNEL_DOT) return fail(c, HBO_ERR_ARG, "bad kernel_id");
+  if (m->mean_id < 0 || m->mean_id > HBO_MEAN_LINEAR_MLP) return fail(c, HBO_ERR_ARG, "bad mean_id");
+  if (m->input_dim <= 0 || m->input_dim > HBO_MAX_FEATURE_DIM) return fail(c, HBO_ERR_ARG, "bad input_dim");
+  if (needs_mlp(m)) {
+    if (m->n_layers <= 0 || m->n_layers > HBO_MAX_MLP_LAYERS) return fail(c, HBO_ERR_ARG, "bad n_layers");
+    for (int l = 0; l < m->n_layers; ++l) {
+      if (m->features[l] <= 0 || m->features[l] > HBO_MAX_FEATURE_DIM) return fail(c, HBO_ERR_ARG, "bad mlp feature size");
+      if (!m->mlp_kernel[l] || !m->mlp_bias[l]) return fail(c, HBO_ERR_ARG, "mlp parameters missing");
+    }
+  }
+  const int fd = feature_dim(m);
+  if (m->kernel_id != HBO_KERNEL_DOT) {
+    if (!m->lengthscale) return fail(c, HBO_ERR_ARG, "lengthscale missing");
+    if (m->n_lengthscale != 1 && m->n_lengthscale != fd)
+      return fail(c, HBO_ERR_ARG, "lengthscale must have 1 or feature-dim entries");
+  }
+  if (mean_feature_dim(m) > 0 && !m->linear_kernel) return fail(c, HBO_ERR_ARG, "linear_mean kernel missing");
+  return HBO_OK;
+}
+
+static double host_elem(const void* p, int dtype, int64_t i) {
+  return dtype == HBO_F64 ? ((const double*)p)[i] : (double)((const float*)p)[i];
+}
+
+// fills ctx->h_model, uploads it and the MLP weights
+static int upload_model(hbo_ctx* c, const hbo_model* m) {
+  int rc = validate_model(c, m);
+  if (rc) return rc;
+  ModelDev& h = c->h_model;
+  memset(&h, 0, sizeof h);
+  h.kernel_id = m->kernel_id; h.mean_id = m->mean_id; h.fdim = feature_dim(m);
+  h.n_ls = (m->kernel_id == HBO_KERNEL_DOT) ? 0 : m->n_lengthscale;
+  h.sv = m->signal_variance; h.noise = m->noise_variance; h.eps = m->eps; h.constant = m->constant;
+  h.dot_sigma = m->dot_prod_sigma; h.dot_bias = m->dot_prod_bias; h.linear_bias = m->linear_bias;
+  if (m->kernel_id == HBO_KERNEL_DOT) { if (h.dot_sigma == 0) h.dot_sigma = 1; }
+  else { h.dot_sigma = 1; }
+  for (int d = 0; d < h.fdim; ++d) {
+    double ls = 1.0;
+    if (m->kernel_id != HBO_KERNEL_DOT) ls = host_elem(m->lengthscale, m->dtype, m->n_lengthscale == 1 ? 0 : d);
+    h.inv_ls[d] = 1.0 / ls;
+  }
+  const int fm = mean_feature_dim(m);
+  for (int d = 0; d < fm; ++d) h.lin_w[d] = host_elem(m->linear_kernel, m->dtype, d);
+  HIPCHK(c, hipMemcpyAsync(c->d_model, &h, sizeof h, hipMemcpyHostToDevice, c->stream));
+  if (needs_mlp(m)) {
+    int fin = m->input_dim;
+    for (int l = 0; l < m->n_layers; ++l) {
+      const size_t wb = (size_t)fin * m->features[l] * esize(m->dtype), bb = (size_t)m->features[l] * esize(m->dtype);
+      if (c->mlp_w_bytes[l] < wb) { if (c->d_mlp_w[l]) hipFree(c->d_mlp_w[l]); HIPCHK(c, hipMalloc(&c->d_mlp_w[l], wb)); c->mlp_w_bytes[l] = wb; }
+      if (c->mlp_b_bytes[l] < bb) { if (c->d_mlp_b[l]) hipFree(c->d_mlp_b[l]); HIPCHK(c, hipMalloc(&c->d_mlp_b[l], bb)); c->mlp_b_bytes[l] = bb; }
+      HIPCHK(c, hipMemcpyAsync(c->d_mlp_w[l], m->mlp_kernel[l], wb, hipMemcpyHostToDevice, c->stream));
+      HIPCHK(c, hipMemcpyAsync(c->d_mlp_b[l], m->mlp_bias[l], bb, hipMemcpyHostToDevice, c->stream));
+      fin = m->features[l];
+    }
+  }
+  // pageable host memory: make sure the copies have consumed h before it can change
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return HBO_OK;
+}
+
+extern "C" int hbo_grad_layout_of(const hbo_model* m, hbo_grad_layout* out) {
+  if (!m || !out) return HBO_ERR_ARG;
+  int pos = 0;
+  const bool dot = m->kernel_id == HBO_KERNEL_DOT;
+  out->lengthscale = dot ? -1 : pos; if (!dot) pos += m->n_lengthscale;
+  out->signal_variance = dot ? -1 : pos; if (!dot) pos += 1;
+  out->noise_variance = pos++;
+  out->constant = (m->mean_id == HBO_MEAN_CONSTANT) ? pos++ : -1;
+  out->dot_prod_sigma = dot ? pos++ : -1;
+  out->dot_prod_bias = dot ? pos++ : -1;
+  const int fm = mean_feature_dim(m);
+  out->linear_kernel = fm ? pos : -1; pos += fm;
+  out->linear_bias = fm ? pos++ : -1;
+  for (int l = 0; l < HBO_MAX_MLP_LAYERS; ++l) { out->mlp_kernel[l] = -1; out->mlp_bias[l] = -1; }
+  if (needs_mlp(m)) {
+    int fin = m->input_dim;
+    for (int l = 0; l < m->n_layers; ++l) {
+      out->mlp_kernel[l] = pos; pos += fin * m->features[l];
+      out->mlp_bias[l] = pos; pos += m->features[l];
+      fin = m->features[l];
+    }
+  }
+  out->total = pos;
+  return HBO_OK;
+}
+
+// ---- feature pipeline ----------------------------------------------------------------------
+// Computes the MLP activations of x (n x D, device) into acts[l] (allocated by the caller: n x f_l)
+static void run_mlp(hbo_ctx* c, const hbo_model* m, const void* x, int64_t n, void* const* acts) {
+  const void* in = x;
+  int fin = m->input_dim;
+  for (int l = 0; l < m->n_layers; ++l) {
+    launch_dense_tanh(m->dtype, in, c->d_mlp_w[l], c->d_mlp_b[l], acts[l], n, fin, m->features[l], c->stream);
+    in = acts[l];
+    fin = m->features[l];
+  }
+}
+
+struct FeatBuf {   // device activations of one input matrix
+  std::vector<void*> acts; std::vector<size_t> bytes;
+  ~FeatBuf() { for (void* p : acts) if (p) hipFree(p); }
+  int ensure(hbo_ctx* c, const hbo_model* m, int64_t n) {
+    acts.resize(HBO_MAX_MLP_LAYERS, nullptr); bytes.resize(HBO_MAX_MLP_LAYERS, 0);
+    for (int l = 0; l < m->n_layers; ++l) {
+      const size_t need = (size_t)std::max<int64_t>(n, 1) * m->features[l] * esize(m->dtype);
+      if (bytes[l] < need) { if (acts[l]) hipFree(acts[l]); acts[l] = nullptr; HIPCHK(c, hipMalloc(&acts[l], need)); bytes[l] = need; }
+    }
+    return HBO_OK;
+  }
+};
+
+// ---- blocked factorisation drivers -----------------------------------------------------------
+static void run_potrf(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, int max_nblk, int* d_info) {
+  const int q = c->opt_group;
+  hipStream_t st = c->stream;
+  for (int g0 = 0; g0 < max_nblk; g0 += q) {
+    const int g1 = std::min(g0 + q, max_nblk);
+    for (int p = g0; p < g1; ++p) {
+      if (p > g0) {  // left-looking update of block column p with the group's earlier panels
+        ProfScope ps(c, "syrk_col", 2);
+        GemmArgs a = {}; a.tasks = d_tasks; a.mode = GEMM_SYRK; a.p0 = g0; a.kt = p - g0; a.c_lo = p; a.c_hi = p + 1; a.aug = 1;
+        launch_gemm(dtype, a, dim3(max_nblk + 1 - p, 1, ntasks), st);
+      }
+      { ProfScope ps(c, "potf2", 2); launch_potf2(dtype, d_tasks, ntasks, p, d_info, st); }
+      { ProfScope ps(c, "trsm", 2); launch_trsm(dtype, d_tasks, ntasks, p, max_nblk, st); }
+    }
+    if (g1 < max_nblk) {
+      ProfScope ps(c, "syrk_trailing", 2);
+      GemmArgs a = {}; a.tasks = d_tasks; a.mode = GEMM_SYRK; a.p0 = g0; a.kt = g1 - g0; a.c_lo = g1; a.c_hi = max_nblk; a.aug = 1;
+      launch_gemm(dtype, a, dim3(max_nblk + 1 - g1, max_nblk - g1, ntasks), st);
+    }
+  }
+}
+static void run_trtri(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, int max_nblk) {
+  hipStream_t st = c->stream;
+  { ProfScope ps(c, "trtri_diag", 2); launch_trtri_diag(dtype, d_tasks, ntasks, max_nblk, st); }
+  for (int s = 1; s < max_nblk; s *= 2) {
+    const int ngroups = (max_nblk + 2 * s - 1) / (2 * s);
+    GemmArgs a = {}; a.tasks = d_tasks; a.p0 = s;
+    { ProfScope ps(c, "trtri_gemm", 2);
+      a.mode = GEMM_TRTRI_A; launch_gemm(dtype, a, dim3(s, ngroups * s, ntasks), st);
+      a.mode = GEMM_TRTRI_B; launch_gemm(dtype, a, dim3(s, ngroups * s, ntasks), st); }
+  }
+}
+static void run_lauum(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, int max_nblk) {
+  ProfScope ps(c, "lauum", 2);
+  GemmArgs a = {}; a.tasks = d_tasks; a.mode = GEMM_LAUUM;
+  launch_gemm(dtype, a, dim3(max_nblk, max_nblk, ntasks), c->stream);
+}
+
+// ---- datasets ----------------------------------------------------------------------------
+struct TaskHost {
+  int64_t n = 0; int m = 0; int npad = 0, nblk = 0;
+  void* X = nullptr; void* ysum = nullptr;
+  void* A = nullptr; void* W = nullptr; void* S = nullptr; void* svec = nullptr;
+  FeatBuf feat;
+};
+struct hbo_dataset {
+  int dtype = 0, D = 0, ntasks = 0, max_nblk = 0;
+  std::vector<TaskHost*> tasks;
+  std::vector<TaskDesc> h_desc;
+  TaskDesc* d_desc = nullptr;
+  int* d_info = nullptr;
+  double* d_nll = nullptr;
+  double* d_partials = nullptr; size_t partials_bytes = 0;
+  double* d_gradout = nullptr; size_t gradout_bytes = 0;
+  bool has_S = false;
+};
+
+static void free_task(TaskHost* t) {
+  if (!t) return;
+  for (void* p : {t->X, t->ysum, t->A, t->W, t->S, t->svec}) if (p) hipFree(p);
+  delete t;
+}
+
+extern "C" int hbo_dataset_free(hbo_ctx* c, hbo_dataset* ds) {
+  if (!ds) return HBO_OK;
+  if (c) hipSetDevice(c->device);
+  for (TaskHost* t : ds->tasks) free_task(t);
+  for (void* p : {(void*)ds->d_desc, (void*)ds->d_info, (void*)ds->d_nll, (void*)ds->d_partials, (void*)ds->d_gradout}) if (p) hipFree(p);
+  delete ds;
+  return HBO_OK;
+}
+
+extern "C" int hbo_dataset_create(hbo_ctx* c, int dtype, int input_dim, const hbo_task* tasks, int n_tasks,
+                                  hbo_dataset** out) {
+  if (!c || !out || (n_tasks > 0 && !tasks)) return fail(c, HBO_ERR_ARG, "hbo_dataset_create: null argument");
+  if (dtype != HBO_F32 && dtype != HBO_F64) return fail(c, HBO_ERR_ARG, "hbo_dataset_create: bad dtype");
+  if (input_dim <= 0 || input_dim > HBO_MAX_FEATURE_DIM) return fail(c, HBO_ERR_ARG, "hbo_dataset_create: bad input_dim");
+  HIPCHK(c, hipSetDevice(c->device));
+  hbo_dataset* ds = new hbo_dataset();
+  ds->dtype = dtype; ds->D = input_dim;
+  const size_t es = esize(dtype);
+  for (int k = 0; k < n_tasks; ++k) {
+    const hbo_task& tk = tasks[k];
+    if (tk.n <= 0) continue;  // objectives.py:184-185: empty sub-datasets are skipped
+    if (tk.m <= 0 || !tk.x || !tk.y) { hbo_dataset_free(c, ds); return fail(c, HBO_ERR_ARG, "hbo_dataset_create: bad task"); }
+    TaskHost* t = new TaskHost();
+    ds->tasks.push_back(t);
+    t->n = tk.n; t->m = tk.m; t->npad = round_up(tk.n, HBO_TILE); t->nblk = t->npad / HBO_TILE;
+    // ysum on the host (sum over columns, in double then cast)
+    std::vector<unsigned char> ys((size_t)tk.n * es);
+    for (int64_t i = 0; i < tk.n; ++i) {
+      double s = 0;
+      for (int a = 0; a < tk.m; ++a) s += host_elem(tk.y, dtype, i * tk.m + a);
+      if (dtype == HBO_F64) ((double*)ys.data())[i] = s; else ((float*)ys.data())[i] = (float)s;
+    }
+    hipError_t e = hipMalloc(&t->X, (size_t)tk.n * input_dim * es);
+    if (e == hipSuccess) e = hipMalloc(&t->ysum, (size_t)tk.n * es);
+    if (e == hipSuccess) e = hipMemcpy(t->X, tk.x, (size_t)tk.n * input_dim * es, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(t->ysum, ys.data(), (size_t)tk.n * es, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { hbo_dataset_free(c, ds); return fail(c, HBO_ERR_HIP, std::string("hbo_dataset_create: ") + hipGetErrorString(e)); }
+    ds->max_nblk = std::max(ds->max_nblk, t->nblk);
+  }
+  ds->ntasks = (int)ds->tasks.size();
+  // largest tasks first: their tiles are dispatched first
+  std::stable_sort(ds->tasks.begin(), ds->tasks.end(), [](TaskHost* a, TaskHost* b) { return a->n > b->n; });
+  *out = ds;
+  return HBO_OK;
+}
+
+static int ensure_task_workspace(hbo_ctx* c, int dtype, TaskHost* t, bool need_S, int naug_cols) {
+  const size_t es = esize(dtype);
+  const size_t ld = t->npad;
+  if (!t->A) HIPCHK(c, hipMalloc(&t->A, (size_t)(t->npad + HBO_TILE) * ld * es));
+  if (!t->W) { HIPCHK(c, hipMalloc(&t->W, (size_t)t->npad * ld * es)); HIPCHK(c, hipMemsetAsync(t->W, 0, (size_t)t->npad * ld * es, c->stream)); }
+  if (need_S && !t->S) HIPCHK(c, hipMalloc(&t->S, (size_t)t->npad * ld * es));
+  if (!t->svec) { HIPCHK(c, hipMalloc(&t->svec, (size_t)t->npad * es * naug_cols)); HIPCHK(c, hipMemsetAsync(t->svec, 0, (size_t)t->npad * es * naug_cols, c->stream)); }
+  return HBO_OK;
+}
+
+static void fill_desc(TaskDesc& d, TaskHost* t, const hbo_model* m, int dtype) {
+  memset(&d, 0, sizeof d);
+  d.A = t->A; d.W = t->W; d.S = t->S; d.X = t->X; d.ysum = t->ysum; d.svec = t->svec;
+  d.n = (int)t->n; d.npad = t->npad; d.nblk = t->nblk; d.m = t->m; d.ld = t->npad;
+  const void* last = needs_mlp(m) ? t->feat.acts[m->n_layers - 1] : nullptr;
+  d.F = m->kernel_uses_mlp ? last : t->X;
+  d.fdim = feature_dim(m);
+  d.fmean = mean_feature_dim(m);
+  d.Fm = (m->mean_id == HBO_MEAN_LINEAR) ? t->X : (m->mean_id == HBO_MEAN_LINEAR_MLP ? last : nullptr);
+  (void)dtype;
+}
+
+extern "C" int hbo_nll(hbo_ctx* c, const hbo_model* m, hbo_dataset* ds, double* nll_sum, double* nll_per_task,
+                       double* grad_sum) {
+  if (!c || !ds || !nll_sum) return fail(c, HBO_ERR_ARG, "hbo_nll: null argument");
+  HIPCHK(c, hipSetDevice(c->device));
+  int rc = validate_model(c, m);
+  if (rc) return rc;
+  if (m->dtype != ds->dtype || m->input_dim != ds->D) return fail(c, HBO_ERR_ARG, "hbo_nll: model/dataset dtype or input_dim mismatch");
+  hbo_grad_layout lay;
+  hbo_grad_layout_of(m, &lay);
+  const bool want_grad = grad_sum != nullptr;
+  if (want_grad && needs_mlp(m)) return fail(c, HBO_ERR_UNSUPPORTED, "hbo_nll: gradients through the MLP basis are not implemented yet");
+  *nll_sum = 0;
+  if (want_grad) for (int i = 0; i < lay.total; ++i) grad_sum[i] = 0;
+  const int T = ds->ntasks;
+  if (T == 0) return HBO_OK;
+  const int dtype = ds->dtype;
+  hipStream_t st = c->stream;
+  prof_begin(c);
+  rc = upload_model(c, m);
+  if (rc) return rc;
+
+  // workspaces + descriptors
+  ds->h_desc.resize(T);
+  for (int k = 0; k < T; ++k) {
+    TaskHost* t = ds->tasks[k];
+    rc = ensure_task_workspace(c, dtype, t, want_grad, 1);
+    if (rc) return rc;
+    if (needs_mlp(m)) { rc = t->feat.ensure(c, m, t->n); if (rc) return rc; }
+    fill_desc(ds->h_desc[k], t, m, dtype);
+  }
+  if (!ds->d_desc) HIPCHK(c, hipMalloc((void**)&ds->d_desc, sizeof(TaskDesc) * T));
+  if (!ds->d_info) HIPCHK(c, hipMalloc((void**)&ds->d_info, sizeof(int) * T));
+  if (!ds->d_nll) HIPCHK(c, hipMalloc((void**)&ds->d_nll, sizeof(double) * T));
+  HIPCHK(c, hipMemcpyAsync(ds->d_desc, ds->h_desc.data(), sizeof(TaskDesc) * T, hipMemcpyHostToDevice, st));
+  std::vector<int> h_info(T, INT_MAX);
+  HIPCHK(c, hipMemcpyAsync(ds->d_info, h_info.data(), sizeof(int) * T, hipMemcpyHostToDevice, st));
+  HIPCHK(c, hipStreamSynchronize(st));
+
+  const int max_nblk = ds->max_nblk, max_npad = max_nblk * HBO_TILE;
+  {
+    ProfScope ps(c, "features", 1);
+    if (needs_mlp(m)) for (int k = 0; k < T; ++k) run_mlp(c, m, ds->tasks[k]->X, ds->tasks[k]->n, ds->tasks[k]->feat.acts.data());
+    launch_aug_rows(dtype, ds->d_desc, T, max_npad, c->d_model, 1, 1, st);
+  }
+  {
+    ProfScope ps(c, "gram", 1);
+    GramArgs g = {}; g.tasks = ds->d_desc; g.fdim = feature_dim(m); g.symmetric = 1; g.padded = 1;
+    launch_gram(dtype, g, c->d_model, dim3(max_nblk, max_nblk, T), st);
+  }
+  { ProfScope ps(c, "potrf", 1); run_potrf(c, dtype, ds->d_desc, T, max_nblk, ds->d_info); }
+  { ProfScope ps(c, "nll_reduce", 1); launch_nll_reduce(dtype, ds->d_desc, T, ds->d_info, ds->d_nll, st); }
+
+  const int fdim = feature_dim(m);
+  const int nacc = grad_nacc(m->kernel_id, fdim);
+  const int out_stride = (m->kernel_id == HBO_KERNEL_DOT ? 0 : m->n_lengthscale) + 6 + mean_feature_dim(m);
+  const int64_t stride_task = (int64_t)(max_nblk * (max_nblk + 1) / 2) * nacc;
+  if (want_grad) {
+    const size_t pb = sizeof(double) * stride_task * T, gb = sizeof(double) * out_stride * T;
+    if (ds->partials_bytes < pb) { if (ds->d_partials) hipFree(ds->d_partials); HIPCHK(c, hipMalloc((void**)&ds->d_partials, pb)); ds->partials_bytes = pb; }
+    if (ds->gradout_bytes < gb) { if (ds->d_gradout) hipFree(ds->d_gradout); HIPCHK(c, hipMalloc((void**)&ds->d_gradout, gb)); ds->gradout_bytes = gb; }
+    { ProfScope ps(c, "trtri", 1); run_trtri(c, dtype, ds->d_desc, T, max_nblk); }
+    { ProfScope ps(c, "wt_z", 1); launch_wt_z(dtype, ds->d_desc, T, max_nblk, 0, 0, max_npad, st); }
+    { ProfScope ps(c, "lauum", 1); run_lauum(c, dtype, ds->d_desc, T, max_nblk); }
+    { ProfScope ps(c, "grad_contract", 1);
+      launch_grad_contract(dtype, ds->d_desc, T, max_nblk, c->d_model, m->kernel_id, fdim, ds->d_partials, stride_task, st);
+      launch_grad_finalize(dtype, ds->d_desc, T, c->d_model, m->kernel_id, fdim, ds->d_partials, stride_task, ds->d_gradout, out_stride, st); }
+  }
+  std::vector<double> h_nll(T), h_grad(want_grad ? (size_t)out_stride * T : 0);
+  HIPCHK(c, hipMemcpyAsync(h_nll.data(), ds->d_nll, sizeof(double) * T, hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipMemcpyAsync(h_info.data(), ds->d_info, sizeof(int) * T, hipMemcpyDeviceToHost, st));
+  if (want_grad) HIPCHK(c, hipMemcpyAsync(h_grad.data(), ds->d_gradout, sizeof(double) * out_stride * T, hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipStreamSynchronize(st));
+  HIPCHK(c, hipGetLastError());
+  prof_collect(c);
+
+  bool notpd = false;
+  double total = 0;
+  for (int k = 0; k < T; ++k) { total += h_nll[k]; if (h_info[k] != INT_MAX) notpd = true; if (nll_per_task) nll_per_task[k] = h_nll[k]; }
+  *nll_sum = total;
+  if (want_grad) {
+    const int n_ls = m->kernel_id == HBO_KERNEL_DOT ? 0 : m->n_lengthscale;
+    const int fm = mean_feature_dim(m);
+    for (int k = 0; k < T; ++k) {
+      const double* o = h_grad.data() + (size_t)k * out_stride;
+      const bool bad = h_info[k] != INT_MAX;
+      auto add = [&](int off, double v) { if (off >= 0) grad_sum[off] += bad ? NAN : v; };
+      for (int d = 0; d < n_ls; ++d) add(lay.lengthscale < 0 ? -1 : lay.lengthscale + d, o[d]);
+      add(lay.signal_variance, o[n_ls]);
+      add(lay.noise_variance, o[n_ls + 1]);
+      add(lay.constant, o[n_ls + 2]);
+      add(lay.dot_prod_sigma, o[n_ls + 3]);
+      add(lay.dot_prod_bias, o[n_ls + 4]);
+      for (int d = 0; d < fm; ++d) add(lay.linear_kernel + d, o[n_ls + 5 + d]);
+      add(lay.linear_bias, o[n_ls + 5 + fm]);
+    }
+  }
+  return notpd ? HBO_NOT_PD : HBO_OK;
+}
+
+// ---- GPCache -----------------------------------------------------------------------------
+struct hbo_cache {
+  int dtype = 0, D = 0, m = 0;
+  TaskHost* t = nullptr;
+  TaskDesc h_desc; TaskDesc* d_desc = nullptr;
+  int* d_info = nullptr; int info = INT_MAX;
+  void* resid = nullptr;   // m x npad : y - mu
+};
+
+extern "C" int hbo_cache_free(hbo_ctx* c, hbo_cache* k) {
+  if (!k) return HBO_OK;
+  if (c) hipSetDevice(c->device);
+  free_task(k->t);
+  for (void* p : {(void*)k->d_desc, (void*)k->d_info, k->resid}) if (p) hipFree(p);
+  delete k;
+  return HBO_OK;
+}
+
+extern "C" int hbo_factor(hbo_ctx* c, const hbo_model* m, const void* x, int64_t n, const void* y, int32_t mcols,
+                          hbo_cache** out) {
+  if (!c || !out || !x || !y) return fail(c, HBO_ERR_ARG, "hbo_factor: null argument");
+  if (n <= 0 || mcols <= 0 || mcols > HBO_TILE) return fail(c, HBO_ERR_ARG, "hbo_factor: need n>0 and 1<=m<=128");
+  HIPCHK(c, hipSetDevice(c->device));
+  prof_begin(c);
+  int rc = upload_model(c, m);
+  if (rc) return rc;
+  const int dtype = m->dtype;
+  const size_t es = esize(dtype);
+  hipStream_t st = c->stream;
+  hbo_cache* k = new hbo_cache();
+  k->dtype = dtype; k->D = m->input_dim; k->m = mcols;
+  TaskHost* t = k->t = new TaskHost();
+  t->n = n; t->m = mcols; t->npad = round_up(n, HBO_TILE); t->nblk = t->npad / HBO_TILE;
+  auto bail = [&](int code) { hbo_cache_free(c, k); return code; };
+#define HIPCHK_K(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) { c->err = std::string(#call " failed: ") + hipGetErrorString(e__); return bail(HBO_ERR_HIP); } } while (0)
+  HIPCHK_K(hipMalloc(&t->X, (size_t)n * m->input_dim * es));
+  HIPCHK_K(hipMemcpy(t->X, x, (size_t)n * m->input_dim * es, hipMemcpyHostToDevice));
+  // y^T (m x n) so that aug row a = column a of y
+  std::vector<unsigned char> yt((size_t)n * mcols * es);
+  for (int64_t i = 0; i < n; ++i)
+    for (int a = 0; a < mcols; ++a) memcpy(yt.data() + ((size_t)a * n + i) * es, (const unsigned char*)y + ((size_t)i * mcols + a) * es, es);
+  HIPCHK_K(hipMalloc(&t->ysum, (size_t)n * mcols * es));
+  HIPCHK_K(hipMemcpy(t->ysum, yt.data(), (size_t)n * mcols * es, hipMemcpyHostToDevice));
+  rc = ensure_task_workspace(c, dtype, t, true, mcols);
+  if (rc) return bail(rc);
+  if (needs_mlp(m)) { rc = t->feat.ensure(c, m, n); if (rc) return bail(rc); }
+  fill_desc(k->h_desc, t, m, dtype);
+  HIPCHK_K(hipMalloc((void**)&k->d_desc, sizeof(TaskDesc)));
+  HIPCHK_K(hipMalloc((void**)&k->d_info, sizeof(int)));
+  HIPCHK_K(hipMalloc(&k->resid, (size_t)mcols * t->npad * es));
+  HIPCHK_K(hipMemcpy(k->d_desc, &k->h_desc, sizeof(TaskDesc), hipMemcpyHostToDevice));
+  int inf = INT_MAX;
+  HIPCHK_K(hipMemcpy(k->d_info, &inf, sizeof(int), hipMemcpyHostToDevice));
+
+  { ProfScope ps(c, "features", 1);
+    if (needs_mlp(m)) run_mlp(c, m, t->X, n, t->feat.acts.data());
+    launch_aug_rows(dtype, k->d_desc, 1, t->npad, c->d_model, mcols, 0, st); }
+  HIPCHK_K(hipMemcpyAsync(k->resid, (char*)t->A + (size_t)t->npad * t->npad * es, (size_t)mcols * t->npad * es, hipMemcpyDeviceToDevice, st));
+  { ProfScope ps(c, "gram", 1);
+    GramArgs g = {}; g.tasks = k->d_desc; g.fdim = feature_dim(m); g.symmetric = 1; g.padded = 1;
+    launch_gram(dtype, g, c->d_model, dim3(t->nblk, t->nblk, 1), st); }
+  { ProfScope ps(c, "potrf", 1); run_potrf(c, dtype, k->d_desc, 1, t->nblk, k->d_info); }
+  { ProfScope ps(c, "trtri", 1); run_trtri(c, dtype, k->d_desc, 1, t->nblk); }
+  { ProfScope ps(c, "wt_z", 1);
+    for (int a = 0; a < mcols; ++a) launch_wt_z(dtype, k->d_desc, 1, t->nblk, a, a, t->npad, st); }
+  HIPCHK_K(hipMemcpyAsync(&k->info, k->d_info, sizeof(int), hipMemcpyDeviceToHost, st));
+  HIPCHK_K(hipStreamSynchronize(st));
+  HIPCHK_K(hipGetLastError());
+  prof_collect(c);
+#undef HIPCHK_K
+  *out = k;
+  return k->info != INT_MAX ? HBO_NOT_PD : HBO_OK;
+}
+
+static void fill_nan(void* p, size_t count, int dtype) {
+  if (dtype == HBO_F64) for (size_t i = 0; i < count; ++i) ((double*)p)[i] = NAN;
+  else for (size_t i = 0; i < count; ++i) ((float*)p)[i] = NAN;
+}
+
+extern "C" int hbo_cache_export(hbo_ctx* c, hbo_cache* k, void* chol_out, void* kinvy_out, void* ymu_out) {
+  if (!c || !k) return fail(c, HBO_ERR_ARG, "hbo_cache_export: null argument");
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t es = esize(k->dtype);
+  TaskHost* t = k->t;
+  const int64_t n = t->n;
+  const bool bad = k->info != INT_MAX;
+  if (chol_out) {
+    if (bad) fill_nan(chol_out, (size_t)n * n, k->dtype);
+    else {
+      void* tmp = nullptr;
+      HIPCHK(c, hipMalloc(&tmp, (size_t)n * n * es));
+      launch_extract_lower(k->dtype, t->A, t->npad, n, tmp, c->stream);
+      hipError_t e = hipMemcpyAsync(chol_out, tmp, (size_t)n * n * es, hipMemcpyDeviceToHost, c->stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+      hipFree(tmp);
+      HIPCHK(c, e);
+    }
+  }
+  std::vector<unsigned char> buf((size_t)k->m * t->npad * es);
+  auto export_cols = [&](const void* dev, void* outp, bool nanfill) -> int {
+    if (nanfill) { fill_nan(outp, (size_t)n * k->m, k->dtype); return HBO_OK; }
+    HIPCHK(c, hipMemcpy(buf.data(), dev, buf.size(), hipMemcpyDeviceToHost));
+    for (int a = 0; a < k->m; ++a)
+      for (int64_t i = 0; i < n; ++i)
+        memcpy((unsigned char*)outp + ((size_t)i * k->m + a) * es, buf.data() + ((size_t)a * t->npad + i) * es, es);
+    return HBO_OK;
+  };
+  if (kinvy_out) { int rc = export_cols(t->svec, kinvy_out, bad); if (rc) return rc; }
+  if (ymu_out) { int rc = export_cols(k->resid, ymu_out, false); if (rc) return rc; }
+  return HBO_OK;
+}
+
+// ---- posterior / acquisition ---------------------------------------------------------------
+static int posterior(hbo_ctx* c, const hbo_model* m, hbo_cache* k, const void* xq, int64_t M, int full_cov,
+                     void* mu_out, void* var_out, void* acq_out, int acq_id, double param, double add_noise,
+                     double scale) {
+  if (!c || !xq) return fail(c, HBO_ERR_ARG, "posterior: null argument");
+  if (M <= 0) return HBO_OK;
+  HIPCHK(c, hipSetDevice(c->device));
+  prof_begin(c);
+  int rc = upload_model(c, m);
+  if (rc) return rc;
+  const int dtype = m->dtype;
+  if (k && (k->dtype != dtype || k->D != m->input_dim)) return fail(c, HBO_ERR_ARG, "posterior: cache/model mismatch");
+  const size_t es = esize(dtype);
+  hipStream_t st = c->stream;
+  const int fdim = feature_dim(m), fm = mean_feature_dim(m);
+  const int64_t CH = 65536;  // candidates per pass (bounds the cross-Gram workspace)
+  const int64_t mc_max = std::min<int64_t>(M, CH);
+  const int mpad_max = round_up(mc_max, HBO_TILE);
+  void *d_xq = nullptr, *d_mu0 = nullptr, *d_kd = nullptr, *d_mu = nullptr, *d_var = nullptr, *d_acq = nullptr;
+  void *d_K = nullptr, *d_colsq = nullptr, *d_V = nullptr, *d_Kqq = nullptr, *d_cov = nullptr;
+  FeatBuf fq;
+  std::vector<void*> to_free;
+  auto cleanup = [&]() { for (void* p : {d_xq, d_mu0, d_kd, d_mu, d_var, d_acq, d_K, d_colsq, d_V, d_Kqq, d_cov}) if (p) hipFree(p); };
+#define HIPCHK_P(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) { c->err = std::string(#call " failed: ") + hipGetErrorString(e__); cleanup(); return HBO_ERR_HIP; } } while (0)
+  if (full_cov && M > CH) { return fail(c, HBO_ERR_UNSUPPORTED, "posterior: full_cov limited to 65536 queries"); }
+  HIPCHK_P(hipMalloc(&d_xq, (size_t)mc_max * m->input_dim * es));
+  HIPCHK_P(hipMalloc(&d_mu0, (size_t)mc_max * es));
+  HIPCHK_P(hipMalloc(&d_kd, (size_t)mc_max * es));
+  HIPCHK_P(hipMalloc(&d_mu, (size_t)mc_max * es));
+  HIPCHK_P(hipMalloc(&d_var, (size_t)mc_max * es));
+  if (acq_out) HIPCHK_P(hipMalloc(&d_acq, (size_t)mc_max * es));
+  if (needs_mlp(m)) { rc = fq.ensure(c, m, mc_max); if (rc) { cleanup(); return rc; } }
+  TaskHost* t = k ? k->t : nullptr;
+  if (k) {
+    HIPCHK_P(hipMalloc(&d_K, (size_t)t->npad * mpad_max * es));
+    HIPCHK_P(hipMalloc(&d_colsq, (size_t)t->nblk * mpad_max * es));
+    if (full_cov) HIPCHK_P(hipMalloc(&d_V, (size_t)t->npad * mpad_max * es));
+  }
+  if (full_cov) { HIPCHK_P(hipMalloc(&d_Kqq, (size_t)M * M * es)); HIPCHK_P(hipMalloc(&d_cov, (size_t)M * M * es)); }
+  const bool bad = k && k->info != INT_MAX;
+
+  for (int64_t q0 = 0; q0 < M; q0 += CH) {
+    const int64_t mc = std::min<int64_t>(CH, M - q0);
+    const int mpad = round_up(mc, HBO_TILE);
+    HIPCHK_P(hipMemcpyAsync(d_xq, (const char*)xq + (size_t)q0 * m->input_dim * es, (size_t)mc * m->input_dim * es, hipMemcpyHostToDevice, st));
+    const void* fq_last = nullptr;
+    { ProfScope ps(c, "features", 1);
+      if (needs_mlp(m)) { run_mlp(c, m, d_xq, mc, fq.acts.data()); fq_last = fq.acts[m->n_layers - 1]; } }
+    const void* Fq = m->kernel_uses_mlp ? fq_last : d_xq;
+    const void* Fmq = (m->mean_id == HBO_MEAN_LINEAR) ? d_xq : (m->mean_id == HBO_MEAN_LINEAR_MLP ? fq_last : nullptr);
+    launch_mean(dtype, Fmq, mc, fm, c->d_model, d_mu0, st);
+    launch_kdiag(dtype, Fq, mc, fdim, c->d_model, d_kd, st);
+    if (!k) {  // prior branch (gp.py:275-282)
+      if (mu_out) HIPCHK_P(hipMemcpyAsync((char*)mu_out + (size_t)q0 * es, d_mu0, (size_t)mc * es, hipMemcpyDeviceToHost, st));
+      if (full_cov) {
+        GramArgs g = {}; g.x1 = Fq; g.x2 = Fq; g.out = d_cov; g.n1 = mc; g.n2 = mc; g.ldo = mc; g.fdim = fdim;
+        launch_gram(dtype, g, c->d_model, dim3((unsigned)((mc + 127) / 128), (unsigned)((mc + 127) / 128), 1), st);
+        if (var_out) HIPCHK_P(hipMemcpyAsync(var_out, d_cov, (size_t)M * M * es, hipMemcpyDeviceToHost, st));
+      } else if (var_out) {
+        HIPCHK_P(hipMemcpyAsync((char*)var_out + (size_t)q0 * es, d_kd, (size_t)mc * es, hipMemcpyDeviceToHost, st));
+      }
+      if (acq_out) {   // acquisition on the prior
+        PostArgs pa = {}; pa.Kxq = nullptr; pa.n = 0; pa.nblk = 0; pa.ldq = mpad; pa.alpha = nullptr; pa.colsq = nullptr;
+        pa.kdiag = d_kd; pa.muq = d_mu0; pa.acq_out = d_acq; pa.M = mc; pa.acq_id = acq_id; pa.param = param; pa.add_noise = add_noise; pa.scale = scale;
+        launch_post_epilogue(dtype, pa, st);
+        HIPCHK_P(hipMemcpyAsync((char*)acq_out + (size_t)q0 * es, d_acq, (size_t)mc * es, hipMemcpyDeviceToHost, st));
+      }
+      HIPCHK_P(hipStreamSynchronize(st));
+      continue;
+    }
+    { ProfScope ps(c, "cross_gram", 1);
+      GramArgs g = {}; g.x1 = k->h_desc.F; g.x2 = Fq; g.out = d_K; g.n1 = t->n; g.n2 = mc; g.ldo = mpad;
+      g.n1pad = t->npad; g.n2pad = mpad; g.fdim = fdim; g.symmetric = 0; g.padded = 1;
+      launch_gram(dtype, g, c->d_model, dim3(mpad / HBO_TILE, t->nblk, 1), st); }
+    { ProfScope ps(c, "post_gemm", 1);
+      GemmArgs a = {}; a.tasks = k->d_desc; a.mode = GEMM_POST; a.B = d_K; a.ldb = mpad; a.V = full_cov ? d_V : nullptr; a.colsq = d_colsq;
+      launch_gemm(dtype, a, dim3(mpad / HBO_TILE, t->nblk, 1), st); }
+    { ProfScope ps(c, "post_epilogue", 1);
+      PostArgs pa = {}; pa.Kxq = d_K; pa.ldq = mpad; pa.npad = t->npad; pa.n = (int)t->n; pa.nblk = t->nblk; pa.alpha = t->svec; pa.colsq = d_colsq;
+      pa.kdiag = d_kd; pa.muq = d_mu0; pa.mu_out = d_mu; pa.var_out = d_var; pa.acq_out = d_acq; pa.M = mc;
+      pa.acq_id = acq_id; pa.param = param; pa.add_noise = add_noise; pa.scale = scale;
+      launch_post_epilogue(dtype, pa, st); }
+    if (mu_out) HIPCHK_P(hipMemcpyAsync((char*)mu_out + (size_t)q0 * es, d_mu, (size_t)mc * es, hipMemcpyDeviceToHost, st));
+    if (full_cov) {
+      GramArgs g = {}; g.x1 = Fq; g.x2 = Fq; g.out = d_Kqq; g.n1 = mc; g.n2 = mc; g.ldo = mc; g.fdim = fdim;
+      launch_gram(dtype, g, c->d_model, dim3((unsigned)((mc + 127) / 128), (unsigned)((mc + 127) / 128), 1), st);
+      launch_fullcov(dtype, d_V, mpad, t->npad, d_Kqq, mc, d_cov, st);
+      if (var_out) HIPCHK_P(hipMemcpyAsync(var_out, d_cov, (size_t)M * M * es, hipMemcpyDeviceToHost, st));
+    } else if (var_out) {
+      HIPCHK_P(hipMemcpyAsync((char*)var_out + (size_t)q0 * es, d_var, (size_t)mc * es, hipMemcpyDeviceToHost, st));
+    }
+    if (acq_out) HIPCHK_P(hipMemcpyAsync((char*)acq_out + (size_t)q0 * es, d_acq, (size_t)mc * es, hipMemcpyDeviceToHost, st));
+    HIPCHK_P(hipStreamSynchronize(st));
+  }
+  HIPCHK_P(hipGetLastError());
+#undef HIPCHK_P
+  prof_collect(c);
+  cleanup();
+  if (bad) {
+    if (mu_out) fill_nan(mu_out, (size_t)M, dtype);
+    if (var_out) fill_nan(var_out, full_cov ? (size_t)M * M : (size_t)M, dtype);
+    if (acq_out) fill_nan(acq_out, (size_t)M, dtype);
+    return HBO_NOT_PD;
+  }
+  return HBO_OK;
+}
+
+extern "C" int hbo_predict(hbo_ctx* c, const hbo_model* m, hbo_cache* k, const void* xq, int64_t M, int full_cov,
+                           void* mu_out, void* var_out) {
+  return posterior(c, m, k, xq, M, full_cov, mu_out, var_out, nullptr, 0, 0, 0, 1);
+}
+extern "C" int hbo_acq(hbo_ctx* c, const hbo_model* m, hbo_cache* k, const void* xq, int64_t M, int acq_id,
+                       double param, double add_noise, double scale, void* out) {
+  if (acq_id < 0 || acq_id > HBO_ACQ_UCB) return fail(c, HBO_ERR_ARG, "hbo_acq: bad acq_id");
+  if (!out) return fail(c, HBO_ERR_ARG, "hbo_acq: out is null");
+  return posterior(c, m, k, xq, M, 0, nullptr, nullptr, out, acq_id, param, add_noise, scale);
+}
+
+// ---- Gram / mean on host arrays --------------------------------------------------------------
+extern "C" int hbo_gram(hbo_ctx* c, const hbo_model* m, const void* x1, int64_t n1, const void* x2, int64_t n2,
+                        int diag, void* out) {
+  if (!c || !x1 || !out) return fail(c, HBO_ERR_ARG, "hbo_gram: null argument");
+  if (diag && x2) return fail(c, HBO_ERR_ARG, "hbo_gram: diag requires x2 == NULL (kernel.py:54-57)");
+  if (n1 <= 0) return HBO_OK;
+  HIPCHK(c, hipSetDevice(c->device));
+  int rc = upload_model(c, m);
+  if (rc) return rc;
+  const int dtype = m->dtype; const size_t es = esize(dtype);
+  hipStream_t st = c->stream;
+  if (!x2) n2 = n1;
+  if (n2 <= 0) return HBO_OK;
+  void *d1 = nullptr, *d2 = nullptr, *dout = nullptr;
+  FeatBuf f1, f2;
+  auto cleanup = [&]() { for (void* p : {d1, d2, dout}) if (p) hipFree(p); };
+#define HIPCHK_G(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) { c->err = std::string(#call " failed: ") + hipGetErrorString(e__); cleanup(); return HBO_ERR_HIP; } } while (0)
+  HIPCHK_G(hipMalloc(&d1, (size_t)n1 * m->input_dim * es));
+  HIPCHK_G(hipMemcpyAsync(d1, x1, (size_t)n1 * m->input_dim * es, hipMemcpyHostToDevice, st));
+  const void* F1 = d1; const void* F2 = d1;
+  if (m->kernel_uses_mlp) { rc = f1.ensure(c, m, n1); if (rc) { cleanup(); return rc; } run_mlp(c, m, d1, n1, f1.acts.data()); F1 = F2 = f1.acts[m->n_layers - 1]; }
+  if (x2) {
+    HIPCHK_G(hipMalloc(&d2, (size_t)n2 * m->input_dim * es));
+    HIPCHK_G(hipMemcpyAsync(d2, x2, (size_t)n2 * m->input_dim * es, hipMemcpyHostToDevice, st));
+    F2 = d2;
+    if (m->kernel_uses_mlp) { rc = f2.ensure(c, m, n2); if (rc) { cleanup(); return rc; } run_mlp(c, m, d2, n2, f2.acts.data()); F2 = f2.acts[m->n_layers - 1]; }
+  }
+  const int fdim = feature_dim(m);
+  if (diag) {
+    HIPCHK_G(hipMalloc(&dout, (size_t)n1 * es));
+    launch_kdiag(dtype, F1, n1, fdim, c->d_model, dout, st);
+    HIPCHK_G(hipMemcpyAsync(out, dout, (size_t)n1 * es, hipMemcpyDeviceToHost, st));
+  } else {
+    HIPCHK_G(hipMalloc(&dout, (size_t)n1 * n2 * es));
+    GramArgs g = {}; g.x1 = F1; g.x2 = F2; g.out = dout; g.n1 = n1; g.n2 = n2; g.ldo = n2; g.fdim = fdim;
+    launch_gram(dtype, g, c->d_model, dim3((unsigned)((n2 + 127) / 128), (unsigned)((n1 + 127) / 128), 1), st);
+    HIPCHK_G(hipMemcpyAsync(out, dout, (size_t)n1 * n2 * es, hipMemcpyDeviceToHost, st));
+  }
+  HIPCHK_G(hipStreamSynchronize(st));
+  HIPCHK_G(hipGetLastError());
+#undef HIPCHK_G
+  cleanup();
+  return HBO_OK;
+}
+
+extern "C" int hbo_mean(hbo_ctx* c, const hbo_model* m, const void* x, int64_t n, void* out) {
+  if (!c || !x || !out) return fail(c, HBO_ERR_ARG, "hbo_mean: null argument");
+  if (n <= 0) return HBO_OK;
+  HIPCHK(c, hipSetDevice(c->device));
+  int rc = upload_model(c, m);
+  if (rc) return rc;
+  const int dtype = m->dtype; const size_t es = esize(dtype);
+  hipStream_t st = c->stream;
+  void *dx = nullptr, *dout = nullptr;
+  FeatBuf f;
+  auto cleanup = [&]() { for (void* p : {dx, dout}) if (p) hipFree(p); };
+  hipError_t e = hipMalloc(&dx, (size_t)n * m->input_dim * es);
+  if (e == hipSuccess) e = hipMalloc(&dout, (size_t)n * es);
+  if (e == hipSuccess) e = hipMemcpyAsync(dx, x, (size_t)n * m->input_dim * es, hipMemcpyHostToDevice, st);
+  if (e != hipSuccess) { cleanup(); return fail(c, HBO_ERR_HIP, hipGetErrorString(e)); }
+  const void* Fm = (m->mean_id == HBO_MEAN_LINEAR) ? dx : nullptr;
+  if (m->mean_id == HBO_MEAN_LINEAR_MLP) { rc = f.ensure(c, m, n); if (rc) { cleanup(); return rc; } run_mlp(c, m, dx, n, f.acts.data()); Fm = f.acts[m->n_layers - 1]; }
+  launch_mean(dtype, Fm, n, mean_feature_dim(m), c->d_model, dout, st);
+  e = hipMemcpyAsync(out, dout, (size_t)n * es, hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  if (e == hipSuccess) e = hipGetLastError();
+  cleanup();
+  if (e != hipSuccess) return fail(c, HBO_ERR_HIP, hipGetErrorString(e));
+  return HBO_OK;
+}
+
+// ---- dense SPD building block ---------------------------------------------------------------
+extern "C" int hbo_spd_solve(hbo_ctx* c, int dtype, const void* a, int64_t n, const void* b, int32_t mcols,
+                             void* chol_out, void* inv_out, void* x_out, double* logdet_half) {
+  if (!c || !a) return fail(c, HBO_ERR_ARG, "hbo_spd_solve: null argument");
+  if (n <= 0) return fail(c, HBO_ERR_ARG, "hbo_spd_solve: n must be positive");
+  if (b && (mcols <= 0 || mcols > HBO_TILE)) return fail(c, HBO_ERR_ARG, "hbo_spd_solve: 1 <= m <= 128");
+  if (dtype != HBO_F32 && dtype != HBO_F64) return fail(c, HBO_ERR_ARG, "hbo_spd_solve: bad dtype");
+  HIPCHK(c, hipSetDevice(c->device));
+  prof_begin(c);
+  const size_t es = esize(dtype);
+  hipStream_t st = c->stream;
+  TaskHost* t = new TaskHost();
+  t->n = n; t->m = b ? mcols : 1; t->npad = round_up(n, HBO_TILE); t->nblk = t->npad / HBO_TILE;
+  void *d_a = nullptr, *d_b = nullptr, *d_tmp = nullptr; TaskDesc* d_desc = nullptr; int* d_info = nullptr;
+  auto cleanup = [&]() { free_task(t); for (void* p : {d_a, d_b, d_tmp, (void*)d_desc, (void*)d_info}) if (p) hipFree(p); };
+#define HIPCHK_S(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) { c->err = std::string(#call " failed: ") + hipGetErrorString(e__); cleanup(); return HBO_ERR_HIP; } } while (0)
+  const bool need_inv = inv_out != nullptr || x_out != nullptr;
+  { int rc = ensure_task_workspace(c, dtype, t, need_inv, t->m); if (rc) { cleanup(); return rc; } }
+  HIPCHK_S(hipMalloc(&d_a, (size_t)n * n * es));
+  HIPCHK_S(hipMemcpyAsync(d_a, a, (size_t)n * n * es, hipMemcpyHostToDevice, st));
+  if (b) { HIPCHK_S(hipMalloc(&d_b, (size_t)n * mcols * es)); HIPCHK_S(hipMemcpyAsync(d_b, b, (size_t)n * mcols * es, hipMemcpyHostToDevice, st)); }
+  launch_fill_spd(dtype, d_a, n, t->A, t->npad, t->npad, st);
+  launch_set_aug(dtype, d_b, n, b ? mcols : 0, t->A, t->npad, t->npad, st);
+  TaskDesc h; memset(&h, 0, sizeof h);
+  h.A = t->A; h.W = t->W; h.S = t->S; h.svec = t->svec; h.n = (int)n; h.npad = t->npad; h.nblk = t->nblk; h.m = t->m; h.ld = t->npad;
+  HIPCHK_S(hipMalloc((void**)&d_desc, sizeof h));
+  HIPCHK_S(hipMalloc((void**)&d_info, sizeof(int)));
+  int inf = INT_MAX;
+  HIPCHK_S(hipMemcpyAsync(d_desc, &h, sizeof h, hipMemcpyHostToDevice, st));
+  HIPCHK_S(hipMemcpyAsync(d_info, &inf, sizeof(int), hipMemcpyHostToDevice, st));
+  HIPCHK_S(hipStreamSynchronize(st));
+  { ProfScope ps(c, "potrf", 1); run_potrf(c, dtype, d_desc, 1, t->nblk, d_info); }
+  if (need_inv) {
+    { ProfScope ps(c, "trtri", 1); run_trtri(c, dtype, d_desc, 1, t->nblk); }
+    if (x_out && b) for (int col = 0; col < mcols; ++col) launch_wt_z(dtype, d_desc, 1, t->nblk, col, col, t->npad, st);
+    if (inv_out) { ProfScope ps(c, "lauum", 1); run_lauum(c, dtype, d_desc, 1, t->nblk); }
+  }
+  HIPCHK_S(hipMemcpyAsync(&inf, d_info, sizeof(int), hipMemcpyDeviceToHost, st));
+  HIPCHK_S(hipMalloc(&d_tmp, (size_t)n * n * es));
+  std::vector<unsigned char> hchol;
+  if (chol_out || logdet_half) {
+    launch_extract_lower(dtype, t->A, t->npad, n, d_tmp, st);
+    void* dst = chol_out;
+    if (!dst) { hchol.resize((size_t)n * n * es); dst = hchol.data(); }
+    HIPCHK_S(hipMemcpyAsync(dst, d_tmp, (size_t)n * n * es, hipMemcpyDeviceToHost, st));
+    HIPCHK_S(hipStreamSynchronize(st));
+    if (logdet_half) { double s = 0; for (int64_t i = 0; i < n; ++i) s += log(host_elem(dst, dtype, i * n + i)); *logdet_half = s; }
+  }
+  if (inv_out) {
+    launch_symmetrize_from_lower(dtype, t->S, t->npad, n, d_tmp, st);
+    HIPCHK_S(hipMemcpyAsync(inv_out, d_tmp, (size_t)n * n * es, hipMemcpyDeviceToHost, st));
+  }
+  HIPCHK_S(hipStreamSynchronize(st));
+  if (x_out && b) {
+    std::vector<unsigned char> buf((size_t)mcols * t->npad * es);
+    HIPCHK_S(hipMemcpy(buf.data(), t->svec, buf.size(), hipMemcpyDeviceToHost));
+    for (int col = 0; col < mcols; ++col)
+      for (int64_t i = 0; i < n; ++i)
+        memcpy((unsigned char*)x_out + ((size_t)i * mcols + col) * es, buf.data() + ((size_t)col * t->npad + i) * es, es);
+  }
+  HIPCHK_S(hipGetLastError());
+#undef HIPCHK_S
+  prof_collect(c);
+  const bool bad = inf != INT_MAX;
+  if (bad) {
+    if (chol_out) fill_nan(chol_out, (size_t)n * n, dtype);
+    if (inv_out) fill_nan(inv_out, (size_t)n * n, dtype);
+    if (x_out && b) fill_nan(x_out, (size_t)n * mcols, dtype);
+    if (logdet_half) *logdet_half = NAN;
+  }
+  cleanup();
+  return bad ? HBO_NOT_PD : HBO_OK;
+}
+
+// ---- RCCL (loaded lazily; libhbo itself does not link against it) ----------------------------
+struct hbo_nccl_id { char internal[HBO_UNIQUE_ID_BYTES]; };
+typedef int (*fn_ncclAllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t);
+typedef int (*fn_ncclCommDestroy)(void*);
+typedef const char* (*fn_ncclGetErrorString)(int);
+
+static void* rccl_open() {
+  static void* lib = nullptr;
+  if (lib) return lib;
+  for (const char* name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+    lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+    if (lib) break;
+  }
+  return lib;
+}
+
+extern "C" int hbo_comm_unique_id(void* out128) {
+  if (!out128) return HBO_ERR_ARG;
+  void* lib = rccl_open();
+  if (!lib) return fail(nullptr, HBO_ERR_COMM, "librccl.so not found");
+  auto f = (int (*)(hbo_nccl_id*))dlsym(lib, "ncclGetUniqueId");
+  if (!f) return fail(nullptr, HBO_ERR_COMM, "ncclGetUniqueId not found");
+  hbo_nccl_id id; memset(&id, 0, sizeof id);
+  int rc = f(&id);
+  if (rc != 0) return fail(nullptr, HBO_ERR_COMM, "ncclGetUniqueId failed");
+  memcpy(out128, &id, HBO_UNIQUE_ID_BYTES);
+  return HBO_OK;
+}
+extern "C" int hbo_comm_init(hbo_ctx* c, int rank, int nranks, const void* unique_id128) {
+  if (!c || !unique_id128 || nranks <= 0 || rank < 0 || rank >= nranks) return fail(c, HBO_ERR_ARG, "hbo_comm_init: bad argument");
+  HIPCHK(c, hipSetDevice(c->device));
+  void* lib = rccl_open();
+  if (!lib) return fail(c, HBO_ERR_COMM, "librccl.so not found");
+  c->rccl_lib = lib;
+  auto f = (int (*)(void**, int, hbo_nccl_id, int))dlsym(lib, "ncclCommInitRank");
+  if (!f) return fail(c, HBO_ERR_COMM, "ncclCommInitRank not found");
+  hbo_nccl_id id; memcpy(&id, unique_id128, HBO_UNIQUE_ID_BYTES);
+  int rc = f(&c->comm, nranks, id, rank);
+  if (rc != 0) { c->comm = nullptr; return fail(c, HBO_ERR_COMM, "ncclCommInitRank failed with code " + std::to_string(rc)); }
+  return HBO_OK;
+}
+extern "C" int hbo_comm_allreduce_sum(hbo_ctx* c, double* buf, int32_t count) {
+  if (!c || !buf || count <= 0) return fail(c, HBO_ERR_ARG, "hbo_comm_allreduce_sum: bad argument");
+  if (!c->comm) return fail(c, HBO_ERR_COMM, "hbo_comm_allreduce_sum: communicator not initialised");
+  HIPCHK(c, hipSetDevice(c->device));
+  if (c->comm_buf_count < count) { if (c->d_comm_buf) hipFree(c->d_comm_buf); HIPCHK(c, hipMalloc((void**)&c->d_comm_buf, sizeof(double) * count)); c->comm_buf_count = count; }
+  auto f = (fn_ncclAllReduce)dlsym(c->rccl_lib, "ncclAllReduce");
+  if (!f) return fail(c, HBO_ERR_COMM, "ncclAllReduce not found");
+  HIPCHK(c, hipMemcpyAsync(c->d_comm_buf, buf, sizeof(double) * count, hipMemcpyHostToDevice, c->stream));
+  const int ncclFloat64 = 8, ncclSum = 0;
+  int rc = f(c->d_comm_buf, c->d_comm_buf, (size_t)count, ncclFloat64, ncclSum, c->comm, c->stream);
+  if (rc != 0) return fail(c, HBO_ERR_COMM, "ncclAllReduce failed with code " + std::to_string(rc));
+  HIPCHK(c, hipMemcpyAsync(buf, c->d_comm_buf, sizeof(double) * count, hipMemcpyDeviceToHost, c->stream));
+  HIPCHK(c, hipStreamSynchronize(c->stream));
+  return HBO_OK;
+}
+extern "C" int hbo_comm_destroy(hbo_ctx* c) {
+  if (!c) return HBO_OK;
+  if (c->comm && c->rccl_lib) {
+    auto f = (fn_ncclCommDestroy)dlsym(c->rccl_lib, "ncclCommDestroy");
+    if (f) f(c->comm);
+  }
+  c->comm = nullptr;
+  if (c->d_comm_buf) { hipFree(c->d_comm_buf); c->d_comm_buf = nullptr; c->comm_buf_count = 0; }
+  return HBO_OK;
+}

@@ -1,0 +1,323 @@
+// MFMA tile GEMM for gfx950 (CDNA4): the workhorse behind the trailing update of the blocked
+// Cholesky (syrk), the recursive triangular inverse (trtri), K^-1 = W^T W (lauum) and the
+// posterior V = L^-1 Kxq.  128x128 output tile per 256-thread workgroup (4 waves as 2x2, each
+// wave 64x64 = 4x4 v_mfma_{f64,f32}_16x16x4 accumulators), K stepped in 128-byte slabs,
+// global -> register -> LDS staging with a two-deep LDS ring (one barrier per K step).
+// Every matrix is padded to a multiple of 128 with zeros / identity, so the core has no edge
+// predicates; triangular structure is exploited by per-tile K ranges, never by masking.
+//
+// Replaces, for the reference, what XLA lowers jax.scipy.linalg.cholesky / cho_solve /
+// solve_triangular to (hyperbo/basics/linalg.py:29-33,139-145; hyperbo/gp_utils/gp.py:297).
+#include "hbo_internal.h"
+
+namespace {
+
+template <typename T> struct Mma;
+template <> struct Mma<double> {
+  typedef double acc_t __attribute__((ext_vector_type(4)));
+  typedef double vec_t __attribute__((ext_vector_type(2)));
+  static __device__ __forceinline__ acc_t mma(double a, double b, acc_t c) {
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+  }
+  // C/D layout of v_mfma_f64_16x16x4_f64: col = lane&15, row = (lane>>4) + 4*reg
+  static __device__ __forceinline__ int crow(int lane, int r) { return (lane >> 4) + 4 * r; }
+};
+template <> struct Mma<float> {
+  typedef float acc_t __attribute__((ext_vector_type(4)));
+  typedef float vec_t __attribute__((ext_vector_type(4)));
+  static __device__ __forceinline__ acc_t mma(float a, float b, acc_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+  }
+  // C/D layout of v_mfma_f32_16x16x4_f32: col = lane&15, row = 4*(lane>>4) + reg
+  static __device__ __forceinline__ int crow(int lane, int r) { return 4 * (lane >> 4) + r; }
+};
+
+// LDS strides (elements).  k-contiguous operand: [128][SKC]; m-contiguous operand: [BKE][SMC].
+//   f64: SKC = 18 (== 2 mod 32 -> conflict-free ds_read_b64 fragment reads), f32: SKC = 36.
+//   SMC = 144 (== 16 mod 32) for both.  Both layouts take 18432 bytes per operand stage.
+template <typename T> __device__ __host__ constexpr int skc() { return sizeof(T) == 8 ? 18 : 36; }
+constexpr int SMC = 144;
+constexpr int OPERAND_BYTES = 18432;
+constexpr int GEMM_LDS_BYTES = 4 * OPERAND_BYTES;  // A,B x 2 stages
+
+template <typename T, bool KC>
+__device__ __forceinline__ void stage_load(const T* __restrict__ g, int64_t ld, int kt,
+                                           typename Mma<T>::vec_t (&r)[4], int tid) {
+  typedef typename Mma<T>::vec_t vec_t;
+  constexpr int VEC = 16 / sizeof(T);
+  constexpr int BKE = 128 / sizeof(T);
+  if (KC) {
+    const int c = tid & 7, row = tid >> 3;
+    const T* p = g + (int64_t)row * ld + (int64_t)kt * BKE + c * VEC;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) r[q] = *reinterpret_cast<const vec_t*>(p + (int64_t)(32 * q) * ld);
+  } else {
+    constexpr int CPR = 128 / VEC;  // 16-byte chunks per 128-element row
+    constexpr int RPP = 256 / CPR;  // k rows per pass
+    const int c = tid % CPR, kr = tid / CPR;
+    const T* p = g + ((int64_t)kt * BKE + kr) * ld + c * VEC;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) r[q] = *reinterpret_cast<const vec_t*>(p + (int64_t)(RPP * q) * ld);
+  }
+}
+
+template <typename T, bool KC>
+__device__ __forceinline__ void stage_store(T* s, const typename Mma<T>::vec_t (&r)[4], int tid) {
+  typedef typename Mma<T>::vec_t vec_t;
+  constexpr int VEC = 16 / sizeof(T);
+  if (KC) {
+    const int c = tid & 7, row = tid >> 3;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) *reinterpret_cast<vec_t*>(s + (row + 32 * q) * skc<T>() + c * VEC) = r[q];
+  } else {
+    constexpr int CPR = 128 / VEC;
+    constexpr int RPP = 256 / CPR;
+    const int c = tid % CPR, kr = tid / CPR;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) *reinterpret_cast<vec_t*>(s + (kr + RPP * q) * SMC + c * VEC) = r[q];
+  }
+}
+
+template <typename T, bool KC>
+__device__ __forceinline__ T frag_read(const T* s, int mn, int k) {
+  return KC ? s[mn * skc<T>() + k] : s[k * SMC + mn];
+}
+
+template <typename T>
+struct TileJob {
+  const T* A; int64_t lda;   // points at (tile row 0, k_begin)
+  const T* B; int64_t ldb;   // points at (tile col 0, k_begin)
+  T* C; int64_t ldc;         // may be null (POST without V)
+  T* colsq;                  // POST: 128 partial column sums of squares, may be null
+  int ksteps;
+  T alpha;
+  int beta;                  // 0: C = alpha*acc ; 1: C += alpha*acc
+};
+
+template <typename T>
+__device__ __forceinline__ bool decode_job(const GemmArgs& g, TileJob<T>& j) {
+  constexpr int BKE = 128 / sizeof(T);
+  const TaskDesc& t = g.tasks[blockIdx.z];
+  const int64_t ld = t.ld;
+  const int nblk = t.nblk;
+  j.colsq = nullptr;
+  switch (g.mode) {
+    case GEMM_SYRK: {
+      const int c = g.c_lo + (int)blockIdx.y;
+      const int r = g.c_lo + (int)blockIdx.x;
+      const int nrt = nblk + (g.aug ? 1 : 0);
+      const int chi = g.c_hi < nblk ? g.c_hi : nblk;
+      if (c >= chi || r < c || r >= nrt) return false;
+      T* Am = static_cast<T*>(t.A);
+      j.A = Am + (int64_t)r * HBO_TILE * ld + (int64_t)g.p0 * HBO_TILE;
+      j.B = Am + (int64_t)c * HBO_TILE * ld + (int64_t)g.p0 * HBO_TILE;
+      j.C = Am + (int64_t)r * HBO_TILE * ld + (int64_t)c * HBO_TILE;
+      j.lda = j.ldb = j.ldc = ld;
+      j.ksteps = g.kt * HBO_TILE / BKE;
+      j.alpha = (T)-1; j.beta = 1;
+      return true;
+    }
+    case GEMM_TRTRI_A:
+    case GEMM_TRTRI_B: {
+      const int s = g.p0;
+      const int jt = blockIdx.x;            // column tile inside the first half
+      const int grp = (int)blockIdx.y / s;
+      const int it = (int)blockIdx.y % s;   // row tile inside the second half
+      const int o = grp * 2 * s;
+      const int R = o + s + it;
+      if (R >= nblk) return false;
+      const int Cc = o + jt;
+      const T* L = static_cast<const T*>(t.A);
+      T* W = static_cast<T*>(t.W);
+      T* S = static_cast<T*>(t.S);
+      if (g.mode == GEMM_TRTRI_A) {
+        // S21 = L21 * W11 ; W11 lower-triangular => k >= column tile jt
+        j.A = L + (int64_t)R * HBO_TILE * ld + (int64_t)(o + jt) * HBO_TILE;
+        j.B = W + (int64_t)(o + jt) * HBO_TILE * ld + (int64_t)Cc * HBO_TILE;
+        j.C = S + (int64_t)R * HBO_TILE * ld + (int64_t)Cc * HBO_TILE;
+        j.ksteps = (s - jt) * HBO_TILE / BKE;
+        j.alpha = (T)1;
+      } else {
+        // W21 = -W22 * S21 ; W22 lower-triangular => k <= row tile it
+        j.A = W + (int64_t)R * HBO_TILE * ld + (int64_t)(o + s) * HBO_TILE;
+        j.B = S + (int64_t)(o + s) * HBO_TILE * ld + (int64_t)Cc * HBO_TILE;
+        j.C = W + (int64_t)R * HBO_TILE * ld + (int64_t)Cc * HBO_TILE;
+        j.ksteps = (it + 1) * HBO_TILE / BKE;
+        j.alpha = (T)-1;
+      }
+      j.lda = j.ldb = j.ldc = ld;
+      j.beta = 0;
+      return true;
+    }
+    case GEMM_LAUUM: {
+      const int i = blockIdx.x, jt = blockIdx.y;
+      if (i >= nblk || jt > i) return false;
+      const T* W = static_cast<const T*>(t.W);
+      // C[i,j] = sum_{k >= i*128} W[k, i-tile]^T W[k, j-tile]
+      j.A = W + (int64_t)i * HBO_TILE * ld + (int64_t)i * HBO_TILE;
+      j.B = W + (int64_t)i * HBO_TILE * ld + (int64_t)jt * HBO_TILE;
+      j.C = static_cast<T*>(t.S) + (int64_t)i * HBO_TILE * ld + (int64_t)jt * HBO_TILE;
+      j.lda = j.ldb = j.ldc = ld;
+      j.ksteps = (nblk - i) * HBO_TILE / BKE;
+      j.alpha = (T)1; j.beta = 0;
+      return true;
+    }
+    case GEMM_POST: {
+      const int i = nblk - 1 - (int)blockIdx.y;  // heavy (long K) row tiles first
+      if (i < 0) return false;
+      const int jq = blockIdx.x;
+      const T* W = static_cast<const T*>(t.W);
+      j.A = W + (int64_t)i * HBO_TILE * ld;
+      j.lda = ld;
+      j.B = static_cast<const T*>(g.B) + (int64_t)jq * HBO_TILE;
+      j.ldb = g.ldb;
+      j.C = g.V ? static_cast<T*>(g.V) + (int64_t)i * HBO_TILE * g.ldb + (int64_t)jq * HBO_TILE : nullptr;
+      j.ldc = g.ldb;
+      j.colsq = g.colsq ? static_cast<T*>(g.colsq) + (int64_t)i * g.ldb + (int64_t)jq * HBO_TILE : nullptr;
+      j.ksteps = (i + 1) * HBO_TILE / BKE;
+      j.alpha = (T)1; j.beta = 0;
+      return true;
+    }
+  }
+  return false;
+}
+
+template <typename T, bool AKC, bool BKC>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
+  typedef typename Mma<T>::acc_t acc_t;
+  typedef typename Mma<T>::vec_t vec_t;
+  constexpr int BKE = 128 / sizeof(T);
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+  TileJob<T> job;
+  if (!decode_job<T>(g, job)) return;
+
+  T* sA0 = reinterpret_cast<T*>(smem);
+  T* sA1 = reinterpret_cast<T*>(smem + OPERAND_BYTES);
+  T* sB0 = reinterpret_cast<T*>(smem + 2 * OPERAND_BYTES);
+  T* sB1 = reinterpret_cast<T*>(smem + 3 * OPERAND_BYTES);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l15 = lane & 15, lq = lane >> 4;
+
+  acc_t acc[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) acc[a][b] = (acc_t){0, 0, 0, 0};
+
+  vec_t ra[4], rb[4];
+  const int nk = job.ksteps;
+  stage_load<T, AKC>(job.A, job.lda, 0, ra, tid);
+  stage_load<T, BKC>(job.B, job.ldb, 0, rb, tid);
+  stage_store<T, AKC>(sA0, ra, tid);
+  stage_store<T, BKC>(sB0, rb, tid);
+  __syncthreads();
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const T* cA = (kt & 1) ? sA1 : sA0;
+    const T* cB = (kt & 1) ? sB1 : sB0;
+    const bool more = (kt + 1 < nk);
+    if (more) {
+      stage_load<T, AKC>(job.A, job.lda, kt + 1, ra, tid);
+      stage_load<T, BKC>(job.B, job.ldb, kt + 1, rb, tid);
+    }
+#pragma unroll
+    for (int kk = 0; kk < BKE / 4; ++kk) {
+      const int k = kk * 4 + lq;
+      T af[4], bf[4];
+#pragma unroll
+      for (int a = 0; a < 4; ++a) af[a] = frag_read<T, AKC>(cA, wm * 64 + a * 16 + l15, k);
+#pragma unroll
+      for (int b = 0; b < 4; ++b) bf[b] = frag_read<T, BKC>(cB, wn * 64 + b * 16 + l15, k);
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = Mma<T>::mma(af[a], bf[b], acc[a][b]);
+    }
+    if (more) {
+      stage_store<T, AKC>((kt & 1) ? sA0 : sA1, ra, tid);
+      stage_store<T, BKC>((kt & 1) ? sB0 : sB1, rb, tid);
+    }
+    __syncthreads();
+  }
+
+  // epilogue
+  if (job.C) {
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = wm * 64 + a * 16 + Mma<T>::crow(lane, r);
+          const int col = wn * 64 + b * 16 + l15;
+          T* p = job.C + (int64_t)row * job.ldc + col;
+          T v = job.alpha * acc[a][b][r];
+          if (job.beta) v += *p;
+          *p = v;
+        }
+  }
+  if (job.colsq) {
+    // sum over this tile's 128 rows of acc^2, per column
+    T* red = reinterpret_cast<T*>(smem);  // [4 waves][64]
+    T part[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      T s = 0;
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s += acc[a][b][r] * acc[a][b][r];
+      s += __shfl_xor(s, 16);
+      s += __shfl_xor(s, 32);
+      part[b] = s;
+    }
+    // (the k-loop ended with a barrier, so smem is free)
+    if (lq == 0) {
+#pragma unroll
+      for (int b = 0; b < 4; ++b) red[wave * 64 + b * 16 + l15] = part[b];
+    }
+    __syncthreads();
+    if (tid < 128) {
+      const int wn2 = tid >> 6, c = tid & 63;
+      // waves (wm=0,wn2) and (wm=1,wn2)
+      job.colsq[wn2 * 64 + c] = red[(0 * 2 + wn2) * 64 + c] + red[(1 * 2 + wn2) * 64 + c];
+    }
+  }
+}
+
+template <typename T>
+void launch_gemm_t(const GemmArgs& a, dim3 grid, hipStream_t st) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T, true, true>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T, true, false>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T, false, false>),
+                        hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
+    attr_set = true;
+  }
+  switch (a.mode) {
+    case GEMM_SYRK:
+      hipLaunchKernelGGL((gemm_kernel<T, true, true>), grid, dim3(256), GEMM_LDS_BYTES, st, a);
+      break;
+    case GEMM_TRTRI_A:
+    case GEMM_TRTRI_B:
+    case GEMM_POST:
+      hipLaunchKernelGGL((gemm_kernel<T, true, false>), grid, dim3(256), GEMM_LDS_BYTES, st, a);
+      break;
+    case GEMM_LAUUM:
+      hipLaunchKernelGGL((gemm_kernel<T, false, false>), grid, dim3(256), GEMM_LDS_BYTES, st, a);
+      break;
+  }
+}
+
+}  // namespace
+
+void launch_gemm(int dtype, const GemmArgs& a, dim3 grid, hipStream_t st) {
+  if (dtype == HBO_F64) launch_gemm_t<double>(a, grid, st);
+  else launch_gemm_t<float>(a, grid, st);
+}

@@ -1,0 +1,685 @@
+// HBM-bound / elementwise kernels of the GP hot path on gfx950: pairwise-kernel Gram build
+// (LDS-tiled X blocks, coalesced 16-byte stores, fused +(sigma^2+eps) I), MLP features,
+// mean / augmented residual rows, NLL reduction, s = W^T z, gradient contraction
+// sum_ij G_ij dK_ij/dtheta (K recomputed on the fly, K^-1 read once), posterior epilogue with
+// fused EI / PI / UCB.
+//
+// Reference restated: hyperbo/gp_utils/kernel.py:29-145 (Gram), basis_functions.py:24-36 (MLP),
+// mean.py:30-79, basics/linalg.py:36-69 (jitter), objectives.py:144-156 (NLL),
+// gp.py:242-305 (posterior), bo_utils/acfun.py:96-142 (acquisition).
+#include "hbo_internal.h"
+#include <math.h>
+
+namespace {
+
+template <typename T> struct V16;
+template <> struct V16<double> { typedef double type __attribute__((ext_vector_type(2))); };
+template <> struct V16<float> { typedef float type __attribute__((ext_vector_type(4))); };
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+// sum over a 256-thread block; sred must hold 4 doubles. Result valid in every thread.
+__device__ __forceinline__ double block_sum(double v, double* sred) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sred[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return sred[0] + sred[1] + sred[2] + sred[3];
+}
+
+template <typename T>
+__device__ __forceinline__ T kfun(int kid, T acc, T sv, T inv_sigma2, T bias2) {
+  switch (kid) {
+    case HBO_KERNEL_SE: return sv * exp((T)-0.5 * acc);
+    case HBO_KERNEL_MATERN32: { T r = sqrt((T)3 * acc); return sv * ((T)1 + r) * exp(-r); }
+    case HBO_KERNEL_MATERN52: { T r = sqrt((T)5 * acc); return sv * ((T)1 + r + r * r / (T)3) * exp(-r); }
+    default: return acc * inv_sigma2 + bias2;
+  }
+}
+// d k / d u (u = scaled squared distance); 0 where u == 0 for Matern (linalg.py:183-188)
+template <typename T>
+__device__ __forceinline__ T dk_du(int kid, T u, T k, T sv) {
+  switch (kid) {
+    case HBO_KERNEL_SE: return (T)-0.5 * k;
+    case HBO_KERNEL_MATERN32: { T r = sqrt((T)3 * u); return u == (T)0 ? (T)0 : -sv * (T)1.5 * exp(-r); }
+    case HBO_KERNEL_MATERN52: { T r = sqrt((T)5 * u); return u == (T)0 ? (T)0 : -sv * ((T)5 / (T)6) * exp(-r) * ((T)1 + r); }
+    default: return (T)0;
+  }
+}
+
+constexpr int DC = 16;     // feature chunk staged in LDS
+constexpr int SXS = 132;   // LDS row stride of a staged [DC][128] block
+
+// stage rows [r0, r0+128) x features [d0, d0+DC) of x (n x fdim) into s[dd][row], scaled
+template <typename T>
+__device__ __forceinline__ void stage_x(T* s, const T* __restrict__ x, int64_t n, int fdim, int64_t r0,
+                                        int d0, const double* inv_ls, bool scale, int tid) {
+  const int dd = tid & 15, rr0 = tid >> 4;
+  const int d = d0 + dd;
+  const T sc = (scale && d < fdim) ? (T)inv_ls[d] : (T)1;
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const int rr = rr0 + 16 * q;
+    const int64_t row = r0 + rr;
+    T v = (T)0;
+    if (row < n && d < fdim) v = x[row * fdim + d] * sc;
+    s[dd * SXS + rr] = v;
+  }
+}
+
+template <typename T, bool PADDED>
+__global__ __launch_bounds__(256) void gram_kernel(GramArgs g, const ModelDev* __restrict__ md) {
+  typedef typename V16<T>::type vec_t;
+  constexpr int VEC = 16 / sizeof(T);
+  __shared__ T sA[DC * SXS];
+  __shared__ T sB[DC * SXS];
+  const int ti = blockIdx.y, tj = blockIdx.x;
+  const T* x1; const T* x2; T* out; int64_t n1, n2, ldo; int64_t e1, e2;  // e*: padded extents
+  if (g.tasks) {
+    const TaskDesc& t = g.tasks[blockIdx.z];
+    if (ti >= t.nblk || tj >= t.nblk) return;
+    x1 = x2 = static_cast<const T*>(t.F);
+    out = static_cast<T*>(t.A);
+    n1 = n2 = t.n; ldo = t.ld; e1 = e2 = t.npad;
+  } else {
+    x1 = static_cast<const T*>(g.x1); x2 = static_cast<const T*>(g.x2); out = static_cast<T*>(g.out);
+    n1 = g.n1; n2 = g.n2; ldo = g.ldo; e1 = PADDED ? g.n1pad : g.n1; e2 = PADDED ? g.n2pad : g.n2;
+  }
+  if (g.symmetric && tj > ti) return;
+  const int fdim = g.fdim;
+  const int kid = md->kernel_id;
+  const bool is_dot = (kid == HBO_KERNEL_DOT);
+  const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+  const int64_t r0 = (int64_t)ti * HBO_TILE, c0 = (int64_t)tj * HBO_TILE;
+
+  T acc[8][8];
+#pragma unroll
+  for (int a = 0; a < 8; ++a)
+#pragma unroll
+    for (int b = 0; b < 8; ++b) acc[a][b] = (T)0;
+
+  for (int d0 = 0; d0 < fdim; d0 += DC) {
+    __syncthreads();
+    stage_x<T>(sA, x1, n1, fdim, r0, d0, md->inv_ls, !is_dot, tid);
+    stage_x<T>(sB, x2, n2, fdim, c0, d0, md->inv_ls, !is_dot, tid);
+    __syncthreads();
+    const int dlim = (fdim - d0) < DC ? (fdim - d0) : DC;
+    for (int dd = 0; dd < dlim; ++dd) {
+      T av[8], bv[8];
+#pragma unroll
+      for (int a = 0; a < 8; ++a) av[a] = sA[dd * SXS + ty + 16 * a];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) bv[q] = sB[dd * SXS + 16 * VEC * (q / VEC) + VEC * tx + (q % VEC)];
+      if (is_dot) {
+#pragma unroll
+        for (int a = 0; a < 8; ++a)
+#pragma unroll
+          for (int q = 0; q < 8; ++q) acc[a][q] += av[a] * bv[q];
+      } else {
+#pragma unroll
+        for (int a = 0; a < 8; ++a)
+#pragma unroll
+          for (int q = 0; q < 8; ++q) { const T df = av[a] - bv[q]; acc[a][q] += df * df; }
+      }
+    }
+  }
+
+  const T sv = (T)md->sv;
+  const T inv_sigma2 = (T)(1.0 / (md->dot_sigma * md->dot_sigma));
+  const T bias2 = (T)(md->dot_bias * md->dot_bias);
+  const T diag_add = (T)(md->noise + md->eps);
+#pragma unroll
+  for (int a = 0; a < 8; ++a) {
+    const int64_t row = r0 + ty + 16 * a;
+    if (row >= e1) continue;
+#pragma unroll
+    for (int qb = 0; qb < 8 / VEC; ++qb) {
+      const int64_t col0 = c0 + 16 * VEC * qb + VEC * tx;
+      T vals[VEC];
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        const int64_t col = col0 + e;
+        T v;
+        if (row < n1 && col < n2) {
+          v = kfun<T>(kid, acc[a][qb * VEC + e], sv, inv_sigma2, bias2);
+          if (g.symmetric && row == col) v += diag_add;
+        } else {
+          v = (g.symmetric && row == col) ? (T)1 : (T)0;   // identity / zero padding
+        }
+        vals[e] = v;
+      }
+      if (PADDED) {
+        vec_t vv;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) vv[e] = vals[e];
+        *reinterpret_cast<vec_t*>(out + row * ldo + col0) = vv;
+      } else {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e)
+          if (col0 + e < e2) out[row * ldo + col0 + e] = vals[e];
+      }
+    }
+  }
+}
+
+template <typename T>
+__global__ void kdiag_kernel(const T* __restrict__ f, int64_t n, int fdim, const ModelDev* __restrict__ md,
+                             T* out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (md->kernel_id == HBO_KERNEL_DOT) {
+    T s = 0;
+    for (int d = 0; d < fdim; ++d) { const T v = f[i * fdim + d]; s += v * v; }
+    out[i] = s * (T)(1.0 / (md->dot_sigma * md->dot_sigma)) + (T)(md->dot_bias * md->dot_bias);
+  } else {
+    out[i] = (T)md->sv;
+  }
+}
+
+// out[i][o] = tanh(sum_k in[i][k] w[k][o] + b[o])   (flax Dense + tanh)
+template <typename T>
+__global__ void dense_tanh_kernel(const T* __restrict__ in, const T* __restrict__ w, const T* __restrict__ b,
+                                  T* __restrict__ out, int64_t n, int fin, int fout) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n * fout) return;
+  const int64_t i = idx / fout;
+  const int o = (int)(idx % fout);
+  T s = b[o];
+  for (int k = 0; k < fin; ++k) s += in[i * fin + k] * w[(int64_t)k * fout + o];
+  out[idx] = tanh(s);
+}
+
+template <typename T>
+__device__ __forceinline__ T mean_at(const ModelDev* md, const T* fm, int fmean, int64_t i) {
+  switch (md->mean_id) {
+    case HBO_MEAN_ZERO: return (T)0;
+    case HBO_MEAN_CONSTANT: return (T)md->constant;
+    default: {
+      T s = (T)md->linear_bias;
+      for (int d = 0; d < fmean; ++d) s += fm[i * fmean + d] * (T)md->lin_w[d];
+      return s;
+    }
+  }
+}
+
+template <typename T>
+__global__ void mean_kernel(const T* __restrict__ fm, int64_t n, int fmean, const ModelDev* __restrict__ md,
+                            T* out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  out[i] = mean_at<T>(md, fm, fmean, i);
+}
+
+// augmented tile-row: row a < m' holds  ysum[a*n + j] - mult * mu_j ; everything else zero.
+// NLL path: one row, ysum = sum of y columns, mult = m.  Factor path: m rows, mult = 1.
+template <typename T>
+__global__ void aug_rows_kernel(const TaskDesc* tasks, const ModelDev* __restrict__ md, int naug_rows,
+                                int mult_is_m) {
+  const TaskDesc& t = tasks[blockIdx.z];
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= t.npad) return;
+  T* Ar = static_cast<T*>(t.A) + (int64_t)t.npad * t.ld + j;
+  const T* ys = static_cast<const T*>(t.ysum);
+  T mu = (T)0;
+  if (j < t.n) mu = mean_at<T>(md, static_cast<const T*>(t.Fm), t.fmean, j);
+  const T mult = mult_is_m ? (T)t.m : (T)1;
+  for (int a = 0; a < HBO_TILE; ++a) {
+    T v = (T)0;
+    if (a < naug_rows && j < t.n) v = ys[(int64_t)a * t.n + j] - mult * mu;
+    Ar[(int64_t)a * t.ld] = v;
+  }
+}
+
+// nll_t = 0.5 |z|^2 + m^2 (sum log diag L + 0.5 n log 2 pi)     (objectives.py:153-155)
+template <typename T>
+__global__ __launch_bounds__(256) void nll_reduce_kernel(const TaskDesc* tasks, const int* info, double* out) {
+  __shared__ double sred[4];
+  const TaskDesc& t = tasks[blockIdx.x];
+  const T* A = static_cast<const T*>(t.A);
+  double ld_sum = 0, q = 0;
+  for (int64_t i = threadIdx.x; i < t.n; i += 256) {
+    ld_sum += log((double)A[i * t.ld + i]);
+    const double z = (double)A[(int64_t)t.npad * t.ld + i];
+    q += z * z;
+  }
+  ld_sum = block_sum(ld_sum, sred);
+  q = block_sum(q, sred);
+  if (threadIdx.x == 0) {
+    double v = 0.5 * q + (double)t.m * t.m * (ld_sum + 0.5 * t.n * log(2.0 * M_PI));
+    if (info[blockIdx.x] != 0x7fffffff) v = NAN;
+    out[blockIdx.x] = v;
+  }
+}
+
+// s = W^T z, stage 1: partial[rc][col] over 512-row chunks, stored in the scratch matrix S.
+template <typename T>
+__global__ __launch_bounds__(256) void wtz_partial_kernel(const TaskDesc* tasks, int aug_row) {
+  __shared__ T sred[256];
+  const TaskDesc& t = tasks[blockIdx.z];
+  const int cb = blockIdx.x, rc = blockIdx.y;
+  if (cb >= t.nblk) return;
+  const int64_t row_lo = (int64_t)rc * 512;
+  if (row_lo >= t.npad) return;
+  T* part = static_cast<T*>(t.S) + (int64_t)rc * t.ld + (int64_t)cb * HBO_TILE;
+  const int col = threadIdx.x & 127, half = threadIdx.x >> 7;
+  T acc = (T)0;
+  if (row_lo + 512 > (int64_t)cb * HBO_TILE) {  // chunk reaches the lower triangle
+    const T* W = static_cast<const T*>(t.W);
+    const T* z = static_cast<const T*>(t.A) + ((int64_t)t.npad + aug_row) * t.ld;
+    int64_t r_begin = row_lo + half * 256, r_end = r_begin + 256;
+    if (r_end > t.npad) r_end = t.npad;
+    const int64_t diag0 = (int64_t)cb * HBO_TILE;
+    if (r_begin < diag0) r_begin = diag0;
+    for (int64_t r = r_begin; r < r_end; ++r) acc += W[r * t.ld + diag0 + col] * z[r];
+  }
+  sred[threadIdx.x] = acc;
+  __syncthreads();
+  if (half == 0) part[col] = sred[col] + sred[col + 128];
+}
+template <typename T>
+__global__ void wtz_final_kernel(const TaskDesc* tasks, int out_col, int out_ld) {
+  const TaskDesc& t = tasks[blockIdx.z];
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= t.npad) return;
+  const T* part = static_cast<const T*>(t.S);
+  const int nrc = (t.npad + 511) / 512;
+  T s = (T)0;
+  for (int rc = 0; rc < nrc; ++rc) s += part[(int64_t)rc * t.ld + j];
+  static_cast<T*>(t.svec)[(int64_t)out_col * out_ld + j] = s;
+}
+
+// ---------------------------------------------------------------------------------------
+// gradient contraction over the lower tiles of S = K^-1:
+//   G_ij = 1/2 (m^2 Kinv_ij - s_i s_j),  partial sums of G_ij * dK_ij/dtheta per tile.
+// accumulators: SE/Matern: [0] sum G K, [1] tr G, [2+d] sum G dk/du ds_d^2
+//               dot      : [0] sum G <fi,fj>, [1] tr G, [2] sum G
+// ---------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void grad_contract_kernel(const TaskDesc* tasks, const ModelDev* __restrict__ md,
+                                                            int fdim, int nacc, double* partials,
+                                                            int64_t stride_task) {
+  __shared__ T sA[DC * SXS];
+  __shared__ T sB[DC * SXS];
+  __shared__ double sred[4];
+  const TaskDesc& t = tasks[blockIdx.z];
+  const int ti = blockIdx.x, tj = blockIdx.y;
+  if (ti >= t.nblk || tj > ti) return;
+  constexpr int VEC = 16 / sizeof(T);
+  const int kid = md->kernel_id;
+  const bool is_dot = (kid == HBO_KERNEL_DOT);
+  const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+  const int64_t r0 = (int64_t)ti * HBO_TILE, c0 = (int64_t)tj * HBO_TILE;
+  const T* F = static_cast<const T*>(t.F);
+  const T* S = static_cast<const T*>(t.S);
+  const T* sv_ = static_cast<const T*>(t.svec);
+  const int64_t n = t.n;
+  double* out = partials + (int64_t)blockIdx.z * stride_task + ((int64_t)ti * (ti + 1) / 2 + tj) * nacc;
+
+  T acc[8][8];
+#pragma unroll
+  for (int a = 0; a < 8; ++a)
+#pragma unroll
+    for (int b = 0; b < 8; ++b) acc[a][b] = (T)0;
+  for (int d0 = 0; d0 < fdim; d0 += DC) {
+    __syncthreads();
+    stage_x<T>(sA, F, n, fdim, r0, d0, md->inv_ls, !is_dot, tid);
+    stage_x<T>(sB, F, n, fdim, c0, d0, md->inv_ls, !is_dot, tid);
+    __syncthreads();
+    const int dlim = (fdim - d0) < DC ? (fdim - d0) : DC;
+    for (int dd = 0; dd < dlim; ++dd) {
+      T av[8], bv[8];
+#pragma unroll
+      for (int a = 0; a < 8; ++a) av[a] = sA[dd * SXS + ty + 16 * a];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) bv[q] = sB[dd * SXS + 16 * VEC * (q / VEC) + VEC * tx + (q % VEC)];
+#pragma unroll
+      for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          if (is_dot) acc[a][q] += av[a] * bv[q];
+          else { const T df = av[a] - bv[q]; acc[a][q] += df * df; }
+        }
+    }
+  }
+  const T sv = (T)md->sv;
+  const T inv_sigma2 = (T)(1.0 / (md->dot_sigma * md->dot_sigma));
+  const T bias2 = (T)(md->dot_bias * md->dot_bias);
+  const T m2 = (T)((double)t.m * t.m);
+  const T wt = (ti == tj) ? (T)1 : (T)2;   // off-diagonal tiles stand for their mirror image too
+  double a_gk = 0, a_tr = 0, a_g = 0;
+  // gw[a][q] = weight * G_ij * dk/du  (re-uses acc storage)
+#pragma unroll
+  for (int a = 0; a < 8; ++a) {
+    const int64_t row = r0 + ty + 16 * a;
+    const T si = row < n ? sv_[row] : (T)0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int64_t col = c0 + 16 * VEC * (q / VEC) + VEC * tx + (q % VEC);
+      T gw = (T)0;
+      if (row < n && col < n) {
+        const T u = acc[a][q];
+        const T k = kfun<T>(kid, u, sv, inv_sigma2, bias2);
+        const T kinv = S[row * t.ld + col];
+        const T G = (T)0.5 * (m2 * kinv - si * sv_[col]) * wt;
+        if (is_dot) { a_gk += (double)(G * u); a_g += (double)G; }
+        else { a_gk += (double)(G * k); gw = G * dk_du<T>(kid, u, k, sv); }
+        if (row == col) a_tr += (double)G;
+      }
+      acc[a][q] = gw;
+    }
+  }
+  a_gk = block_sum(a_gk, sred);
+  a_tr = block_sum(a_tr, sred);
+  if (is_dot) a_g = block_sum(a_g, sred);
+  if (tid == 0) { out[0] = a_gk; out[1] = a_tr; if (is_dot) out[2] = a_g; }
+  if (is_dot) return;
+  // second pass over the features: sum gw * ds_d^2
+  for (int d0 = 0; d0 < fdim; d0 += DC) {
+    __syncthreads();
+    stage_x<T>(sA, F, n, fdim, r0, d0, md->inv_ls, true, tid);
+    stage_x<T>(sB, F, n, fdim, c0, d0, md->inv_ls, true, tid);
+    __syncthreads();
+    const int dlim = (fdim - d0) < DC ? (fdim - d0) : DC;
+    for (int dd = 0; dd < dlim; ++dd) {
+      T av[8], bv[8];
+#pragma unroll
+      for (int a = 0; a < 8; ++a) av[a] = sA[dd * SXS + ty + 16 * a];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) bv[q] = sB[dd * SXS + 16 * VEC * (q / VEC) + VEC * tx + (q % VEC)];
+      T s = (T)0;
+#pragma unroll
+      for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { const T df = av[a] - bv[q]; s += acc[a][q] * df * df; }
+      const double tot = block_sum((double)s, sred);
+      if (tid == 0) out[2 + d0 + dd] = tot;
+    }
+  }
+}
+
+// per task: reduce tile partials and apply the chain-rule factors; also mean-parameter grads.
+// out layout per task (doubles): [lengthscale(n_ls)] [signal_variance] [noise_variance] [constant]
+//                                [dot_prod_sigma] [dot_prod_bias] [linear_kernel(fmean)] [linear_bias]
+template <typename T>
+__global__ __launch_bounds__(256) void grad_finalize_kernel(const TaskDesc* tasks, const ModelDev* __restrict__ md,
+                                                            int fdim, int nacc, const double* partials,
+                                                            int64_t stride_task, double* out, int out_stride) {
+  __shared__ double sred[4];
+  const TaskDesc& t = tasks[blockIdx.x];
+  const double* part = partials + (int64_t)blockIdx.x * stride_task;
+  double* o = out + (int64_t)blockIdx.x * out_stride;
+  const int ntile = t.nblk * (t.nblk + 1) / 2;
+  const int n_ls = md->n_ls;
+  const bool is_dot = (md->kernel_id == HBO_KERNEL_DOT);
+  int pos = 0;
+  double ls_total = 0;
+  for (int q = 0; q < nacc; ++q) {
+    double s = 0;
+    for (int tl = threadIdx.x; tl < ntile; tl += 256) s += part[(int64_t)tl * nacc + q];
+    s = block_sum(s, sred);
+    if (threadIdx.x == 0) {
+      if (!is_dot) {
+        if (q == 0) o[n_ls] = s / md->sv;                 // signal_variance
+        else if (q == 1) o[n_ls + 1] = s;                 // noise_variance
+        else {
+          const int d = q - 2;
+          const double gd = s * (-2.0 * md->inv_ls[d]);   // du/dls_d = -2 ds_d^2 / ls_d
+          if (n_ls == 1) ls_total += gd; else o[d] = gd;
+        }
+      } else {
+        if (q == 0) o[n_ls + 3] = s * (-2.0 / (md->dot_sigma * md->dot_sigma * md->dot_sigma));
+        else if (q == 1) o[n_ls + 1] = s;
+        else o[n_ls + 4] = s * 2.0 * md->dot_bias;
+      }
+    }
+  }
+  if (threadIdx.x == 0) {
+    if (!is_dot) { if (n_ls == 1) o[0] = ls_total; o[n_ls + 3] = 0; o[n_ls + 4] = 0; }
+    else { for (int d = 0; d < n_ls; ++d) o[d] = 0; o[n_ls] = 0; }
+  }
+  pos = n_ls + 2;
+  // mean parameters: d nll / d mu_i = -m s_i
+  const T* sv_ = static_cast<const T*>(t.svec);
+  double ssum = 0;
+  for (int64_t i = threadIdx.x; i < t.n; i += 256) ssum += (double)sv_[i];
+  ssum = block_sum(ssum, sred);
+  if (threadIdx.x == 0) {
+    o[pos] = (md->mean_id == HBO_MEAN_CONSTANT) ? -(double)t.m * ssum : 0.0;     // constant
+  }
+  const int lin0 = n_ls + 5;
+  const bool lin = (md->mean_id == HBO_MEAN_LINEAR || md->mean_id == HBO_MEAN_LINEAR_MLP);
+  const T* fm = static_cast<const T*>(t.Fm);
+  for (int d = 0; d < t.fmean; ++d) {
+    double s = 0;
+    if (lin) for (int64_t i = threadIdx.x; i < t.n; i += 256) s += (double)sv_[i] * (double)fm[i * t.fmean + d];
+    s = block_sum(s, sred);
+    if (threadIdx.x == 0) o[lin0 + d] = -(double)t.m * s;
+  }
+  if (threadIdx.x == 0) o[lin0 + t.fmean] = lin ? -(double)t.m * ssum : 0.0;
+}
+
+// ---------------------------------------------------------------------------------------
+// posterior epilogue: mu = Kxq^T alpha + mean(xq); var = kdiag - sum colsq; acquisition.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ double norm_pdf(double x) { return exp(-0.5 * x * x) * 0.3989422804014327; }
+__device__ __forceinline__ double norm_cdf(double x) { return 0.5 * erfc(-x * 0.7071067811865476); }
+
+template <typename T>
+__global__ void post_epilogue_kernel(PostArgs a) {
+  const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= a.M) return;
+  const T* K = static_cast<const T*>(a.Kxq);
+  const T* al = static_cast<const T*>(a.alpha);
+  T mu = (T)0;
+  for (int64_t i = 0; i < a.n; ++i) mu += K[i * a.ldq + q] * al[i];
+  mu += static_cast<const T*>(a.muq)[q];
+  T var = static_cast<const T*>(a.kdiag)[q];
+  const T* cs = static_cast<const T*>(a.colsq);
+  T ss = (T)0;
+  for (int b = 0; b < a.nblk; ++b) ss += cs[(int64_t)b * a.ldq + q];
+  var -= ss;
+  if (a.mu_out) static_cast<T*>(a.mu_out)[q] = mu;
+  if (a.var_out) static_cast<T*>(a.var_out)[q] = var;
+  if (a.acq_out) {
+    // GP.predict post-processing (gp.py:607-619) then acfun.py:96-142 in the model dtype
+    const T v2 = (var + (T)a.add_noise) * (T)a.scale;
+    const T sd = sqrt(v2);
+    T r;
+    if (a.acq_id == HBO_ACQ_UCB) r = mu + (T)a.param * sd;
+    else {
+      const T gamma = ((T)a.param - mu) / sd;
+      if (a.acq_id == HBO_ACQ_PI) r = -gamma;
+      else r = (T)((norm_pdf((double)gamma) - (double)gamma * (1.0 - norm_cdf((double)gamma)))) * sd;
+    }
+    static_cast<T*>(a.acq_out)[q] = r;
+  }
+}
+
+// out[a][b] = Kqq[a][b] - sum_i V[i][a] V[i][b]
+template <typename T>
+__global__ void fullcov_kernel(const T* __restrict__ V, int64_t ldq, int npad, const T* __restrict__ Kqq, int64_t M,
+                               T* out) {
+  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t a = blockIdx.y;
+  if (b >= M) return;
+  T s = (T)0;
+  for (int64_t i = 0; i < npad; ++i) s += V[i * ldq + a] * V[i * ldq + b];
+  out[a * M + b] = Kqq[a * M + b] - s;
+}
+
+template <typename T>
+__global__ void extract_lower_kernel(const T* __restrict__ A, int64_t ld, int64_t n, T* out) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t r = blockIdx.y;
+  if (c >= n) return;
+  out[r * n + c] = (c <= r) ? A[r * ld + c] : (T)0;
+}
+template <typename T>
+__global__ void symmetrize_kernel(const T* __restrict__ S, int64_t ld, int64_t n, T* out) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t r = blockIdx.y;
+  if (c >= n) return;
+  // lower tiles of S are valid (full 128x128 tiles on and below the tile diagonal)
+  const bool lower_tile = (c / HBO_TILE) <= (r / HBO_TILE);
+  out[r * n + c] = lower_tile ? S[r * ld + c] : S[c * ld + r];
+}
+// dense SPD (n x n host layout, already on device) -> padded A (identity on the padded diagonal)
+template <typename T>
+__global__ void fill_spd_kernel(const T* __restrict__ a, int64_t n, T* A, int64_t ld, int npad) {
+  const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t r = blockIdx.y;
+  if (c >= npad) return;
+  T v;
+  if (r < n && c < n) v = a[r * n + c];
+  else v = (r == c) ? (T)1 : (T)0;
+  A[r * ld + c] = v;
+}
+// augmented rows from b (n x m, row-major): A[(npad+a)*ld + j] = b[j*m + a]; the rest zero
+template <typename T>
+__global__ void set_aug_kernel(const T* __restrict__ b, int64_t n, int m, T* A, int64_t ld, int npad) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int a = blockIdx.y;
+  if (j >= npad) return;
+  T v = (T)0;
+  if (b && a < m && j < n) v = b[j * m + a];
+  A[((int64_t)npad + a) * ld + j] = v;
+}
+// y = W x (trans=0, rows) or W^T x (trans=1) for lower-triangular W (npad x ld), x: [m][npad]
+template <typename T>
+__global__ __launch_bounds__(256) void tri_matvec_kernel(const T* __restrict__ W, int64_t ld, int npad,
+                                                         const T* __restrict__ x, int64_t xld, int trans,
+                                                         T* out, int64_t old) {
+  const int col = blockIdx.y;
+  if (!trans) {
+    // one wave per output row
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= npad) return;
+    const int lane = threadIdx.x & 63;
+    double s = 0;
+    for (int64_t j = lane; j <= r; j += 64) s += (double)W[r * ld + j] * (double)x[(int64_t)col * xld + j];
+    s = wave_sum(s);
+    if (lane == 0) out[(int64_t)col * old + r] = (T)s;
+  } else {
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= npad) return;
+    T s = (T)0;
+    for (int64_t r = j; r < npad; ++r) s += W[r * ld + j] * x[(int64_t)col * xld + r];
+    out[(int64_t)col * old + j] = s;
+  }
+}
+
+template <typename T>
+void launch_gram_t(const GramArgs& a, const ModelDev* md, dim3 grid, hipStream_t st) {
+  if (a.padded || a.tasks) hipLaunchKernelGGL((gram_kernel<T, true>), grid, dim3(256), 0, st, a, md);
+  else hipLaunchKernelGGL((gram_kernel<T, false>), grid, dim3(256), 0, st, a, md);
+}
+
+}  // namespace
+
+#define DISPATCH(dtype, FN, ...) \
+  do { if ((dtype) == HBO_F64) FN<double>(__VA_ARGS__); else FN<float>(__VA_ARGS__); } while (0)
+
+void launch_gram(int dtype, const GramArgs& a, const ModelDev* md, dim3 grid, hipStream_t st) {
+  DISPATCH(dtype, launch_gram_t, a, md, grid, st);
+}
+void launch_kdiag(int dtype, const void* f, int64_t n, int fdim, const ModelDev* md, void* out, hipStream_t st) {
+  if (n <= 0) return;
+  dim3 grid((unsigned)((n + 255) / 256));
+  if (dtype == HBO_F64) hipLaunchKernelGGL((kdiag_kernel<double>), grid, dim3(256), 0, st, (const double*)f, n, fdim, md, (double*)out);
+  else hipLaunchKernelGGL((kdiag_kernel<float>), grid, dim3(256), 0, st, (const float*)f, n, fdim, md, (float*)out);
+}
+void launch_dense_tanh(int dtype, const void* in, const void* w, const void* b, void* out, int64_t n, int fin,
+                       int fout, hipStream_t st) {
+  if (n <= 0) return;
+  dim3 grid((unsigned)((n * fout + 255) / 256));
+  if (dtype == HBO_F64) hipLaunchKernelGGL((dense_tanh_kernel<double>), grid, dim3(256), 0, st, (const double*)in, (const double*)w, (const double*)b, (double*)out, n, fin, fout);
+  else hipLaunchKernelGGL((dense_tanh_kernel<float>), grid, dim3(256), 0, st, (const float*)in, (const float*)w, (const float*)b, (float*)out, n, fin, fout);
+}
+void launch_mean(int dtype, const void* fm, int64_t n, int fmean, const ModelDev* md, void* mu, hipStream_t st) {
+  if (n <= 0) return;
+  dim3 grid((unsigned)((n + 255) / 256));
+  if (dtype == HBO_F64) hipLaunchKernelGGL((mean_kernel<double>), grid, dim3(256), 0, st, (const double*)fm, n, fmean, md, (double*)mu);
+  else hipLaunchKernelGGL((mean_kernel<float>), grid, dim3(256), 0, st, (const float*)fm, n, fmean, md, (float*)mu);
+}
+void launch_aug_rows(int dtype, const TaskDesc* tasks, int ntasks, int max_npad, const ModelDev* md,
+                     int naug_rows, int mult_is_m, hipStream_t st) {
+  dim3 grid((max_npad + 255) / 256, 1, ntasks);
+  if (dtype == HBO_F64) hipLaunchKernelGGL((aug_rows_kernel<double>), grid, dim3(256), 0, st, tasks, md, naug_rows, mult_is_m);
+  else hipLaunchKernelGGL((aug_rows_kernel<float>), grid, dim3(256), 0, st, tasks, md, naug_rows, mult_is_m);
+}
+void launch_nll_reduce(int dtype, const TaskDesc* tasks, int ntasks, const int* info, double* out, hipStream_t st) {
+  if (dtype == HBO_F64) hipLaunchKernelGGL((nll_reduce_kernel<double>), dim3(ntasks), dim3(256), 0, st, tasks, info, out);
+  else hipLaunchKernelGGL((nll_reduce_kernel<float>), dim3(ntasks), dim3(256), 0, st, tasks, info, out);
+}
+void launch_wt_z(int dtype, const TaskDesc* tasks, int ntasks, int max_nblk, int aug_row, int out_col,
+                 int out_ld, hipStream_t st) {
+  const int max_npad = max_nblk * HBO_TILE;
+  dim3 g1(max_nblk, (max_npad + 511) / 512, ntasks);
+  dim3 g2((max_npad + 255) / 256, 1, ntasks);
+  if (dtype == HBO_F64) {
+    hipLaunchKernelGGL((wtz_partial_kernel<double>), g1, dim3(256), 0, st, tasks, aug_row);
+    hipLaunchKernelGGL((wtz_final_kernel<double>), g2, dim3(256), 0, st, tasks, out_col, out_ld);
+  } else {
+    hipLaunchKernelGGL((wtz_partial_kernel<float>), g1, dim3(256), 0, st, tasks, aug_row);
+    hipLaunchKernelGGL((wtz_final_kernel<float>), g2, dim3(256), 0, st, tasks, out_col, out_ld);
+  }
+}
+int grad_nacc(int kernel_id, int fdim) { return kernel_id == HBO_KERNEL_DOT ? 3 : 2 + fdim; }
+void launch_grad_contract(int dtype, const TaskDesc* tasks, int ntasks, int max_nblk, const ModelDev* md,
+                          int kernel_id, int fdim, double* partials, int64_t stride_task, hipStream_t st) {
+  dim3 grid(max_nblk, max_nblk, ntasks);
+  const int nacc = grad_nacc(kernel_id, fdim);
+  if (dtype == HBO_F64) hipLaunchKernelGGL((grad_contract_kernel<double>), grid, dim3(256), 0, st, tasks, md, fdim, nacc, partials, stride_task);
+  else hipLaunchKernelGGL((grad_contract_kernel<float>), grid, dim3(256), 0, st, tasks, md, fdim, nacc, partials, stride_task);
+}
+void launch_grad_finalize(int dtype, const TaskDesc* tasks, int ntasks, const ModelDev* md, int kernel_id,
+                          int fdim, const double* partials, int64_t stride_task, double* out, int out_stride,
+                          hipStream_t st) {
+  const int nacc = grad_nacc(kernel_id, fdim);
+  if (dtype == HBO_F64) hipLaunchKernelGGL((grad_finalize_kernel<double>), dim3(ntasks), dim3(256), 0, st, tasks, md, fdim, nacc, partials, stride_task, out, out_stride);
+  else hipLaunchKernelGGL((grad_finalize_kernel<float>), dim3(ntasks), dim3(256), 0, st, tasks, md, fdim, nacc, partials, stride_task, out, out_stride);
+}
+void launch_post_epilogue(int dtype, const PostArgs& a, hipStream_t st) {
+  if (a.M <= 0) return;
+  dim3 grid((unsigned)((a.M + 255) / 256));
+  if (dtype == HBO_F64) hipLaunchKernelGGL((post_epilogue_kernel<double>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((post_epilogue_kernel<float>), grid, dim3(256), 0, st, a);
+}
+void launch_fullcov(int dtype, const void* V, int64_t ldq, int npad, const void* Kqq, int64_t M, void* out,
+                    hipStream_t st) {
+  if (M <= 0) return;
+  dim3 grid((unsigned)((M + 255) / 256), (unsigned)M);
+  if (dtype == HBO_F64) hipLaunchKernelGGL((fullcov_kernel<double>), grid, dim3(256), 0, st, (const double*)V, ldq, npad, (const double*)Kqq, M, (double*)out);
+  else hipLaunchKernelGGL((fullcov_kernel<float>), grid, dim3(256), 0, st, (const float*)V, ldq, npad, (const float*)Kqq, M, (float*)out);
+}
+void launch_extract_lower(int dtype, const void* A, int64_t ld, int64_t n, void* out, hipStream_t st) {
+  if (n <= 0) return;
+  dim3 grid((unsigned)((n + 255) / 256), (unsigned)n);
+  if (dtype == HBO_F64) hipLaunchKernelGGL((extract_lower_kernel<double>), grid, dim3(256), 0, st, (const double*)A, ld, n, (double*)out);
+  else hipLaunchKernelGGL((extract_lower_kernel<float>), grid, dim3(256), 0, st, (const float*)A, ld, n, (float*)out);
+}
+void launch_symmetrize_from_lower(int dtype, const void* S, int64_t ld, int64_t n, void* out, hipStream_t st) {
+  if (n <= 0) return;
+  dim3 grid((unsigned)((n + 255) / 256), (unsigned)n);
+  if (dtype == HBO_F64) hipLaunchKernelGGL((symmetrize_kernel<double>), grid, dim3(256), 0, st, (const double*)S, ld, n, (double*)out);
+  else hipLaunchKernelGGL((symmetrize_kernel<float>), grid, dim3(256), 0, st, (const float*)S, ld, n, (float*)out);
+}
+void launch_fill_spd(int dtype, const void* a, int64_t n, void* A, int64_t ld, int npad, hipStream_t st) {
+  dim3 grid((npad + 255) / 256, npad);
+  if (dtype == HBO_F64) hipLaunchKernelGGL((fill_spd_kernel<double>), grid, dim3(256), 0, st, (const double*)a, n, (double*)A, ld, npad);
+  else hipLaunchKernelGGL((fill_spd_kernel<float>), grid, dim3(256), 0, st, (const float*)a, n, (float*)A, ld, npad);
+}
+void launch_set_aug(int dtype, const void* b, int64_t n, int m, void* A, int64_t ld, int npad, hipStream_t st) {
+  dim3 grid((npad + 255) / 256, HBO_TILE);
+  if (dtype == HBO_F64) hipLaunchKernelGGL((set_aug_kernel<double>), grid, dim3(256), 0, st, (const double*)b, n, m, (double*)A, ld, npad);
+  else hipLaunchKernelGGL((set_aug_kernel<float>), grid, dim3(256), 0, st, (const float*)b, n, m, (float*)A, ld, npad);
+}
+void launch_tri_matvec(int dtype, const void* W, int64_t ld, int npad, const void* x, int64_t xld, int m,
+                       int trans, void* out, int64_t old, hipStream_t st) {
+  dim3 grid(trans ? (npad + 255) / 256 : (npad + 3) / 4, m);
+  if (dtype == HBO_F64) hipLaunchKernelGGL((tri_matvec_kernel<double>), grid, dim3(256), 0, st, (const double*)W, ld, npad, (const double*)x, xld, trans, (double*)out, old);
+  else hipLaunchKernelGGL((tri_matvec_kernel<float>), grid, dim3(256), 0, st, (const float*)W, ld, npad, (const float*)x, xld, trans, (float*)out, old);
+}

@@ -1,0 +1,113 @@
+// Internal declarations shared by the HIP translation units of libhbo (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/hbo.h"
+
+#define HBO_TILE 128     // square tile / panel width of every blocked algorithm
+#define HBO_LEAF 16      // MFMA tile edge (v_mfma_*_16x16x4)
+
+// One GP sub-dataset (or one GPCache) as the kernels see it.  All matrices are row-major with
+// leading dimension ld = npad (n rounded up to HBO_TILE); A has one extra tile-row (rows
+// npad..npad+127) whose first row carries the residual  r = sum_a(y_a) - m*mu  so that the
+// blocked Cholesky produces z = L^-1 r for free (see DESIGN.md "augmented row").
+struct TaskDesc {
+  void* A;           // (npad+128) x ld : Gram+jitter -> L (lower)
+  void* W;           // npad x ld       : L^-1 (lower, zeros above)
+  void* S;           // npad x ld       : scratch (trtri temp) -> K^-1 (lower tiles)
+  const void* X;     // n x D inputs
+  const void* F;     // n x fdim kernel features (== X when the kernel has no MLP)
+  const void* Fm;    // n x fmean features feeding a linear mean (X or MLP output) or null
+  const void* ysum;  // n : sum over the m columns of y
+  void* svec;        // npad : s = K^-1 r (row-sum of kinvy)
+  void* dF;          // n x fdim : d nll / d features (MLP kernels / linear_mlp mean)
+  int n, npad, nblk, m;
+  int64_t ld;
+  int fdim, fmean;
+};
+
+// Device-side copy of the (already warped) model hyper-parameters.
+struct ModelDev {
+  int kernel_id, mean_id, fdim, n_ls;
+  double sv, noise, eps, constant, dot_sigma, dot_bias, linear_bias;
+  double inv_ls[HBO_MAX_FEATURE_DIM];   // 1/lengthscale per feature (broadcast if n_ls==1)
+  double lin_w[HBO_MAX_FEATURE_DIM];    // linear mean weights
+};
+
+enum GemmMode {
+  GEMM_SYRK = 0,     // A[r,c] -= P[r,:] P[c,:]^T over panel columns (trailing / look-ahead update)
+  GEMM_TRTRI_A = 1,  // S21 = L21 * W11
+  GEMM_TRTRI_B = 2,  // W21 = -W22 * S21
+  GEMM_LAUUM = 3,    // S = W^T W (lower tiles)
+  GEMM_POST = 4,     // V = W * Kxq (column sums of squares and/or V itself)
+};
+
+struct GemmArgs {
+  const TaskDesc* tasks;
+  int mode;
+  int p0;        // SYRK: first panel tile-column of the K range;   TRTRI: half size s (tiles)
+  int kt;        // SYRK: number of 128-wide K tiles
+  int c_lo;      // SYRK: first updated tile column
+  int c_hi;      // SYRK: end (exclusive) of updated tile columns
+  int aug;       // SYRK: 1 -> include the augmented tile-row
+  void* B;       // POST: Kxq (npad x ldb)
+  int64_t ldb;
+  void* V;       // POST: optional V output (npad x ldb), may be null
+  void* colsq;   // POST: partial column sums of squares [nblk][ldb], may be null
+};
+
+// ---- launchers (defined in the .hip files) ---------------------------------------------
+void launch_gemm(int dtype, const GemmArgs& a, dim3 grid, hipStream_t st);
+
+void launch_potf2(int dtype, const TaskDesc* tasks, int ntasks, int p, int* info, hipStream_t st);
+void launch_trsm(int dtype, const TaskDesc* tasks, int ntasks, int p, int max_nblk, hipStream_t st);
+void launch_trtri_diag(int dtype, const TaskDesc* tasks, int ntasks, int max_nblk, hipStream_t st);
+
+struct GramArgs {
+  const TaskDesc* tasks;   // batched symmetric mode (tasks != null): out = tasks[z].A, x = tasks[z].F
+  const void* x1; const void* x2; void* out;  // direct mode
+  int64_t n1, n2, ldo;
+  int n1pad, n2pad;        // direct padded mode: extents up to which zeros are written
+  int fdim;
+  int symmetric;           // lower tiles only + (noise+eps) on the diagonal + identity padding
+  int padded;              // out has a padded ld/extent (16-byte vector stores, zero fill)
+};
+void launch_gram(int dtype, const GramArgs& a, const ModelDev* model, dim3 grid, hipStream_t st);
+void launch_kdiag(int dtype, const void* f, int64_t n, int fdim, const ModelDev* model, void* out,
+                  hipStream_t st);
+void launch_dense_tanh(int dtype, const void* in, const void* w, const void* b, void* out, int64_t n,
+                       int fin, int fout, hipStream_t st);
+void launch_mean(int dtype, const void* fm, int64_t n, int fmean, const ModelDev* model, void* mu,
+                 hipStream_t st);
+void launch_aug_rows(int dtype, const TaskDesc* tasks, int ntasks, int max_npad, const ModelDev* md,
+                     int naug_rows, int mult_is_m, hipStream_t st);
+void launch_nll_reduce(int dtype, const TaskDesc* tasks, int ntasks, const int* info, double* out,
+                       hipStream_t st);
+// s = W^T z_a (z_a = augmented row a of A) -> tasks[t].svec[out_col*out_ld + j]; uses S as scratch
+void launch_wt_z(int dtype, const TaskDesc* tasks, int ntasks, int max_nblk, int aug_row, int out_col,
+                 int out_ld, hipStream_t st);
+int grad_nacc(int kernel_id, int fdim);
+void launch_grad_contract(int dtype, const TaskDesc* tasks, int ntasks, int max_nblk, const ModelDev* md,
+                          int kernel_id, int fdim, double* partials, int64_t stride_task, hipStream_t st);
+void launch_grad_finalize(int dtype, const TaskDesc* tasks, int ntasks, const ModelDev* md, int kernel_id,
+                          int fdim, const double* partials, int64_t stride_task, double* out, int out_stride,
+                          hipStream_t st);
+struct PostArgs {
+  const void* Kxq; int64_t ldq; int npad; int n; int nblk;   // cross Gram (npad x ldq)
+  const void* alpha;    // kinvy [npad] (first column)
+  const void* colsq;    // partial [nblk][ldq]
+  const void* kdiag;    // prior variance at the queries [M]
+  const void* muq;      // prior mean at the queries [M]
+  void* mu_out; void* var_out; void* acq_out;
+  int64_t M;
+  int acq_id; double param, add_noise, scale;
+};
+void launch_post_epilogue(int dtype, const PostArgs& a, hipStream_t st);
+void launch_fullcov(int dtype, const void* V, int64_t ldq, int npad, const void* Kqq, int64_t M, void* out,
+                    hipStream_t st);
+void launch_extract_lower(int dtype, const void* A, int64_t ld, int64_t n, void* out, hipStream_t st);
+void launch_symmetrize_from_lower(int dtype, const void* S, int64_t ld, int64_t n, void* out, hipStream_t st);
+void launch_fill_spd(int dtype, const void* a_dense, int64_t n, void* A, int64_t ld, int npad, hipStream_t st);
+void launch_set_aug(int dtype, const void* b, int64_t n, int m, void* A, int64_t ld, int npad, hipStream_t st);
+void launch_tri_matvec(int dtype, const void* W, int64_t ld, int npad, const void* x, int64_t xld, int m,
+                       int trans, void* out, int64_t old, hipStream_t st);

@@ -1,0 +1,216 @@
+"""GP model object and posterior -- hyperbo/gp_utils/gp.py:242-305 (predict), :308-620 (GP).
+
+Same method names / arguments / cache semantics as the reference; factorisation, posterior and
+NLL run on the GPU.  `GP.train` (the Adam / L-BFGS host loop, gp.py:53-195) is listed as the next
+row in SURVEY.md 8(f) and is provided by hyperbo_amd.gp_utils.train once built.
+"""
+import ctypes as C
+from typing import Any, Callable, Dict, List, Tuple, Union
+
+import numpy as np
+
+from hyperbo_amd import _model
+from hyperbo_amd import _native as nat
+from hyperbo_amd.basics import definitions as defs
+from hyperbo_amd.basics import linalg
+from hyperbo_amd.basics import params_utils
+from hyperbo_amd.gp_utils import objectives as obj
+
+retrieve_params = params_utils.retrieve_params
+GPCache = defs.GPCache
+SubDataset = defs.SubDataset
+GPParams = defs.GPParams
+
+
+def _predict_native(mean_func, cov_func, params, x_query, warp_func, full_cov, handle, input_dim):
+  xq = np.asarray(x_query)
+  dtype = handle.dtype if handle is not None else _model.infer_dtype(xq)
+  xq = np.ascontiguousarray(xq, dtype=dtype)
+  nq = xq.shape[0]
+  mu = np.empty((nq, 1), dtype=dtype)
+  cov = np.empty((nq, nq) if full_cov else (nq, 1), dtype=dtype)
+  if nq == 0:
+    return mu, cov
+  bm = _model.BuiltModel(mean_func, cov_func, params, warp_func, dtype, input_dim)
+  ctx = handle.ctx if handle is not None else nat.default_context()
+  ctx.check(nat.lib().hbo_predict(ctx.handle, bm.ref(), handle.handle if handle is not None else None,
+                                  nat.ptr(xq), nq, int(full_cov), nat.ptr(mu), nat.ptr(cov)))
+  return mu, cov
+
+
+def predict(mean_func, cov_func, params, x_observed, y_observed, x_query, warp_func=None, full_cov=False,
+            cache=None):
+  """Posterior mean (n',1) and covariance (n',n') / variance (n',1) at x_query (gp.py:242-305)."""
+  x_query = np.asarray(x_query)
+  if x_observed is None or np.asarray(x_observed).shape[0] == 0:
+    return _predict_native(mean_func, cov_func, params, x_query, warp_func, full_cov, None,
+                           x_query.shape[1])
+  handle = getattr(cache, 'handle', None) if cache is not None else None
+  owned = False
+  if handle is None:
+    handle = linalg.factor(mean_func, cov_func, params, x_observed, y_observed, warp_func)
+    owned = True
+  try:
+    return _predict_native(mean_func, cov_func, params, x_query, warp_func, full_cov, handle,
+                           np.asarray(x_observed).shape[1])
+  finally:
+    if owned:
+      handle.close()
+
+
+class GP:
+  """A Gaussian process that supports learning with historical data (gp.py:308-620)."""
+  dataset: Dict[Union[int, str], SubDataset]
+
+  def __init__(self, dataset, mean_func: Callable[..., np.ndarray], cov_func: Callable[..., np.ndarray],
+               params: GPParams, warp_func=None):
+    self.mean_func = mean_func
+    self.cov_func = cov_func
+    self.params = params if params is not None else GPParams()
+    self.warp_func = warp_func
+    self.set_dataset(dataset)
+    if 'objective' not in self.params.config:
+      self.params.config['objective'] = obj.neg_log_marginal_likelihood
+    self.rng = None
+
+  def initialize_params(self, key):
+    """gp.py:346-401 with a numpy Generator (or int seed) in place of a JAX PRNG key."""
+    if not self.dataset:
+      raise ValueError('Cannot initialize GPParams without dataset.')
+    rng = key if isinstance(key, np.random.Generator) else np.random.default_rng(key)
+    if isinstance(self.params.config['objective'], str):
+      self.params.config['objective'] = getattr(obj, self.params.config['objective'])
+    model = self.params.model
+    if 'mlp' in self.mean_func.__name__ or 'mlp' in self.cov_func.__name__:
+      if not isinstance(self.params.config.get('mlp_features'), tuple):
+        self.params.config['mlp_features'] = (2 * self.input_dim,)
+      last_layer_size = self.params.config['mlp_features'][-1]
+      if not isinstance(model.get('mlp_params'), dict):
+        fin = self.input_dim
+        mlp = {}
+        for l, f in enumerate(self.params.config['mlp_features']):
+          # flax Dense default: lecun_normal kernel, zero bias
+          mlp[f'Dense_{l}'] = {'kernel': rng.normal(size=(fin, f)) / np.sqrt(fin), 'bias': np.zeros((f,))}
+          fin = f
+        model['mlp_params'] = mlp
+    else:
+      last_layer_size = self.input_dim
+    if 'linear' in self.mean_func.__name__:
+      if not isinstance(model.get('linear_mean'), dict):
+        fin = last_layer_size if 'mlp' in self.mean_func.__name__ else self.input_dim
+        model['linear_mean'] = {'kernel': rng.normal(size=(fin, 1)) / np.sqrt(fin), 'bias': np.zeros((1,))}
+    if isinstance(model.get('lengthscale'), float):
+      if 'mlp' not in self.cov_func.__name__:
+        last_layer_size = self.input_dim
+      model['lengthscale'] = np.ones(last_layer_size) * model['lengthscale']
+    self.rng = rng
+
+  def set_dataset(self, dataset):
+    """Reset GP dataset (gp.py:403-419); clears the cache."""
+    self.dataset = {}
+    self._drop_cache()
+    if isinstance(dataset, list):
+      dataset = {i: dataset[i] for i in range(len(dataset))}
+    for key, val in dataset.items():
+      self.dataset[key] = SubDataset(*val)
+
+  def _drop_cache(self):
+    for c in getattr(self.params, 'cache', {}).values():
+      h = getattr(c, 'handle', None)
+      if h is not None:
+        h.close()
+    self.params.cache = {}
+
+  @property
+  def input_dim(self) -> int:
+    key = list(self.dataset.keys())[0]
+    return self.dataset[key].x.shape[1]
+
+  def update_sub_dataset(self, sub_dataset, sub_dataset_key: Union[int, str] = 0, is_append: bool = False):
+    """gp.py:426-452."""
+    sub_dataset = SubDataset(*sub_dataset)
+    if is_append:
+      if sub_dataset_key not in self.dataset:
+        assert self.dataset, 'dataset cannot be empty.'
+        self.dataset[sub_dataset_key] = SubDataset(x=np.empty((0, self.input_dim)), y=np.empty((0, 1)))
+      new_x = np.vstack((self.dataset[sub_dataset_key].x, sub_dataset.x))
+      new_y = np.vstack((self.dataset[sub_dataset_key].y, sub_dataset.y))
+      self.dataset[sub_dataset_key] = SubDataset(x=new_x, y=new_y)
+    else:
+      self.dataset[sub_dataset_key] = sub_dataset
+    if sub_dataset_key in self.params.cache:
+      self.params.cache[sub_dataset_key].needs_update = True
+
+  def neg_log_marginal_likelihood(self):
+    """Total nll and key->nll dict (gp.py:487-497).  NB the reference uses the SVD variant here;
+    the Cholesky variant agrees with it to ~2 decimals in the reference's own tests
+    (objectives_test.py:168) and is what runs natively."""
+    return obj.neg_log_marginal_likelihood(
+        mean_func=self.mean_func, cov_func=self.cov_func, params=self.params, dataset=self.dataset,
+        warp_func=self.warp_func, return_key2nll=True, use_cholesky=True)
+
+  def update_model_params(self, model_params: Dict[str, Any]):
+    """gp.py:535-538."""
+    self.params.model = model_params
+    self._drop_cache()
+
+  def setup_predictor(self, sub_dataset_key: Union[int, str] = 0):
+    """gp.py:540-560."""
+    if sub_dataset_key in self.params.cache and not self.params.cache[sub_dataset_key].needs_update:
+      return
+    old = self.params.cache.get(sub_dataset_key)
+    if old is not None and getattr(old, 'handle', None) is not None:
+      old.handle.close()
+    sd = self.dataset[sub_dataset_key]
+    handle = linalg.factor(self.mean_func, self.cov_func, self.params, sd.x, sd.y, self.warp_func)
+    chol, kinvy, _ = handle.export()
+    self.params.cache[sub_dataset_key] = GPCache(chol=chol, kinvy=kinvy, needs_update=False, handle=handle)
+
+  def predict(self, queried_inputs, sub_dataset_key: Union[int, str] = 0, full_cov: bool = False,
+              with_noise: bool = True, unbiased: bool = True) -> Tuple[np.ndarray, np.ndarray]:
+    """gp.py:562-620."""
+    if sub_dataset_key not in self.dataset:
+      mu, cov = predict(self.mean_func, self.cov_func, self.params, None, None, queried_inputs,
+                        warp_func=self.warp_func, full_cov=full_cov)
+    else:
+      self.setup_predictor(sub_dataset_key)
+      sd = self.dataset[sub_dataset_key]
+      mu, cov = predict(self.mean_func, self.cov_func, self.params, sd.x, sd.y, queried_inputs,
+                        warp_func=self.warp_func, full_cov=full_cov,
+                        cache=self.params.cache[sub_dataset_key])
+    add_noise, scale = self.predict_noise_and_scale(with_noise, unbiased)
+    if with_noise:
+      if full_cov:
+        cov = cov + np.eye(cov.shape[0], dtype=cov.dtype) * cov.dtype.type(add_noise)
+      else:
+        cov = cov + cov.dtype.type(add_noise)
+    if scale != 1.0:
+      cov = cov * cov.dtype.type(scale)
+    return mu, cov
+
+  def predict_noise_and_scale(self, with_noise=True, unbiased=True):
+    """The (noise_variance, T/(T-1)) post-processing constants of gp.py:607-619."""
+    add_noise = 0.0
+    if with_noise:
+      nv, = retrieve_params(self.params, ['noise_variance'], warp_func=self.warp_func)
+      add_noise = float(np.squeeze(nv))
+    scale = 1.0
+    if unbiased:
+      len_dataset = len([k for k, v in self.dataset.items() if v.aligned is None])
+      if len_dataset > 1:
+        scale = len_dataset / (len_dataset - 1.)
+    return add_noise, scale
+
+
+class HGP(GP):
+  """Hierarchical GP: predictions for every sample of model params (gp.py:623-682)."""
+
+  def get_model_params_samples(self):
+    return self.params.samples if self.params.samples else [self.params.model]
+
+  def predict(self, queried_inputs, sub_dataset_key=0, full_cov=False, with_noise=True):
+    results = []
+    for model_params in self.get_model_params_samples():
+      self.update_model_params(model_params)
+      results.append(super().predict(queried_inputs, sub_dataset_key, full_cov, with_noise))
+    return results

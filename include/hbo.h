@@ -1,0 +1,174 @@
+/*
+ * hbo.h -- C ABI of libhbo: MI355X-native (gfx950) implementation of HyperBO's GP hot path.
+ *
+ * The reference (google-research/hyperbo) has no FFI: the path sits behind plain Python
+ * callables traced by JAX.  Each entry point below names the reference callable it replaces
+ * (file:line relative to the reference repo root); hyperbo_amd/ binds them with ctypes and
+ * re-exposes the reference's Python signatures.
+ *
+ * Conventions
+ *   - all host arrays are C-contiguous row-major, element type = hbo_model.dtype
+ *     (HBO_F32 -> float, HBO_F64 -> double); gradients and NLL values are always double.
+ *   - every function returns an int status: 0 ok, <0 usage/runtime error, >0 numerical
+ *     (HBO_NOT_PD: the jittered Gram matrix was not positive definite; outputs are NaN-filled,
+ *     mirroring jax.scipy.linalg.cholesky which yields NaNs instead of raising).
+ *   - never aborts, never throws across the ABI; hbo_last_error(ctx) returns a message.
+ *   - a ctx is not re-entrant; use one ctx per GPU / per thread.  Calls are synchronous.
+ *   - hyper-parameters in hbo_model are ALREADY WARPED (softplus etc. stay in Python so that
+ *     arbitrary warp_func dicts keep working: hyperbo/basics/params_utils.py:97-111).
+ */
+#ifndef HBO_H_
+#define HBO_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HBO_OK 0
+#define HBO_ERR_ARG (-1)
+#define HBO_ERR_HIP (-2)
+#define HBO_ERR_NODEV (-3)
+#define HBO_ERR_UNSUPPORTED (-4)
+#define HBO_ERR_COMM (-5)
+#define HBO_NOT_PD 1
+
+/* closed registries: hyperbo/bo_utils/const.py:22-50 */
+enum hbo_kernel_id { HBO_KERNEL_SE = 0, HBO_KERNEL_MATERN32 = 1, HBO_KERNEL_MATERN52 = 2, HBO_KERNEL_DOT = 3 };
+enum hbo_mean_id { HBO_MEAN_ZERO = 0, HBO_MEAN_CONSTANT = 1, HBO_MEAN_LINEAR = 2, HBO_MEAN_LINEAR_MLP = 3 };
+enum hbo_dtype { HBO_F32 = 0, HBO_F64 = 1 };
+enum hbo_acq_id { HBO_ACQ_EI = 0, HBO_ACQ_PI = 1, HBO_ACQ_UCB = 2 };
+
+#define HBO_MAX_MLP_LAYERS 8
+#define HBO_MAX_FEATURE_DIM 256
+
+typedef struct hbo_ctx hbo_ctx;
+typedef struct hbo_dataset hbo_dataset; /* device-resident sub-datasets (x, y) */
+typedef struct hbo_cache hbo_cache;     /* device-resident GPCache: x, chol, chol^-1, kinvy */
+
+/* Model descriptor: kernel (hyperbo/gp_utils/kernel.py:63-183), mean (gp_utils/mean.py:54-79),
+ * MLP basis (gp_utils/basis_functions.py:24-36, flax Dense: y = x @ kernel + bias, tanh on every
+ * layer) and the jitter eps of hyperbo/basics/linalg.py:42,78 (default 1e-6). */
+typedef struct hbo_model {
+  int32_t kernel_id;        /* hbo_kernel_id */
+  int32_t mean_id;          /* hbo_mean_id */
+  int32_t dtype;            /* hbo_dtype */
+  int32_t input_dim;        /* D */
+  int32_t kernel_uses_mlp;  /* 1: base kernel evaluated on MLP features (kernel.py:148-183) */
+  int32_t n_layers;         /* MLP depth (0 if unused) */
+  int32_t features[HBO_MAX_MLP_LAYERS]; /* params.config['mlp_features'] */
+  int32_t n_lengthscale;    /* 1 (broadcast) or the kernel's feature dimension */
+  int32_t reserved0;
+  double eps;
+  double signal_variance;
+  double noise_variance;
+  double constant;          /* mean.constant */
+  double dot_prod_sigma;
+  double dot_prod_bias;
+  double linear_bias;       /* linear_mean['bias'] */
+  const void* lengthscale;                       /* [n_lengthscale] */
+  const void* mlp_kernel[HBO_MAX_MLP_LAYERS];    /* [in, out] row-major */
+  const void* mlp_bias[HBO_MAX_MLP_LAYERS];      /* [out] */
+  const void* linear_kernel;                     /* [Fin] (linear_mean['kernel'][:,0]) */
+} hbo_model;
+
+/* Flat layout (in doubles) of the gradient w.r.t. the WARPED parameters written by hbo_nll.
+ * Offsets of absent parameters are -1.  total = number of doubles. */
+typedef struct hbo_grad_layout {
+  int32_t lengthscale;      /* n_lengthscale entries */
+  int32_t signal_variance;
+  int32_t noise_variance;
+  int32_t constant;
+  int32_t dot_prod_sigma;
+  int32_t dot_prod_bias;
+  int32_t linear_kernel;    /* Fin entries */
+  int32_t linear_bias;
+  int32_t mlp_kernel[HBO_MAX_MLP_LAYERS]; /* in*out entries each, row-major [in,out] */
+  int32_t mlp_bias[HBO_MAX_MLP_LAYERS];
+  int32_t total;
+} hbo_grad_layout;
+
+typedef struct hbo_task {
+  const void* x; /* [n, input_dim] */
+  const void* y; /* [n, m] */
+  int64_t n;
+  int32_t m;
+  int32_t reserved0;
+} hbo_task;
+
+/* ---- context ------------------------------------------------------------------------- */
+int hbo_ctx_create(int device, hbo_ctx** out);
+int hbo_ctx_destroy(hbo_ctx* ctx);
+const char* hbo_last_error(hbo_ctx* ctx); /* ctx may be NULL: last error of ctx-less calls */
+const char* hbo_version(void);
+int hbo_device_count(void);
+
+int hbo_grad_layout_of(const hbo_model* model, hbo_grad_layout* out);
+
+/* ---- kernel.py:33-58 cov_func(params, vx1, vx2=None, diag=False) ------------------------ */
+/* out: [n1,n2] (x2 may be NULL -> x2 = x1), or [n1] when diag != 0 (requires x2 == NULL). */
+int hbo_gram(hbo_ctx* ctx, const hbo_model* model, const void* x1, int64_t n1, const void* x2,
+             int64_t n2, int diag, void* out);
+/* ---- mean.py:34-49 mean_func(params, vx) -> [n,1] -------------------------------------- */
+int hbo_mean(hbo_ctx* ctx, const hbo_model* model, const void* x, int64_t n, void* out);
+
+/* ---- objectives.py:109-210 neg_log_marginal_likelihood + its jax.value_and_grad
+ *      (gp.py:134, lbfgs.py:238) over device-resident sub-datasets ------------------------ */
+int hbo_dataset_create(hbo_ctx* ctx, int dtype, int input_dim, const hbo_task* tasks, int n_tasks,
+                       hbo_dataset** out);
+int hbo_dataset_free(hbo_ctx* ctx, hbo_dataset* ds);
+/* nll_sum: sum over the tasks of this dataset of the per-task Cholesky NLL (objectives.py:144-156,
+ * incl. the (m,m)+scalar broadcast quirk for m>1); the caller divides by the number of tasks
+ * (objectives.py:192-195) -- a sum so that task shards on different GPUs can be all-reduced.
+ * nll_per_task (nullable): [n_tasks].  grad_sum (nullable): [layout.total] sum over tasks of
+ * d nll_task / d warped-parameter.  Returns HBO_NOT_PD if any task failed (its values are NaN). */
+int hbo_nll(hbo_ctx* ctx, const hbo_model* model, hbo_dataset* ds, double* nll_sum,
+            double* nll_per_task, double* grad_sum);
+
+/* ---- linalg.py:72-110 solve_gp_linear_system -> GPCache(chol, kinvy) (gp.py:540-560) ----- */
+int hbo_factor(hbo_ctx* ctx, const hbo_model* model, const void* x, int64_t n, const void* y,
+               int32_t m, hbo_cache** out);
+/* chol_out [n,n] (lower, zeros above the diagonal), kinvy_out [n,m], y_minus_mu_out [n,m];
+ * any may be NULL. */
+int hbo_cache_export(hbo_ctx* ctx, hbo_cache* cache, void* chol_out, void* kinvy_out,
+                     void* y_minus_mu_out);
+int hbo_cache_free(hbo_ctx* ctx, hbo_cache* cache);
+
+/* ---- gp.py:242-305 predict ------------------------------------------------------------- */
+/* cache == NULL -> prior branch (gp.py:275-282).  mu_out [M,1]; var_out [M,1] or [M,M] if
+ * full_cov.  No noise / unbiased scaling here (that is GP.predict, gp.py:607-619). */
+int hbo_predict(hbo_ctx* ctx, const hbo_model* model, hbo_cache* cache, const void* xq, int64_t M,
+                int full_cov, void* mu_out, void* var_out);
+/* ---- acfun.py:51-142 acquisition on top of GP.predict(full_cov=False) ------------------- */
+/* var' = (var + add_noise) * scale (gp.py:607-619); EI/PI: param = target; UCB: param = beta. */
+int hbo_acq(hbo_ctx* ctx, const hbo_model* model, hbo_cache* cache, const void* xq, int64_t M,
+            int acq_id, double param, double add_noise, double scale, void* out);
+
+/* ---- dense building blocks (linalg.py:29-33 solve_linear_system); host in/out ----------- */
+/* a: [n,n] SPD (only the lower triangle is read).  chol_out: lower factor (zeros above diag);
+ * inv_out (nullable): full symmetric a^-1;  b/x_out (nullable): [n,m] solve a x = b. */
+int hbo_spd_solve(hbo_ctx* ctx, int dtype, const void* a, int64_t n, const void* b, int32_t m,
+                  void* chol_out, void* inv_out, void* x_out, double* logdet_half);
+
+/* ---- profiling: per-stage device time of the last hbo_nll / hbo_factor / hbo_acq call,
+ *      measured with HIP events on the stream the kernels were launched on ---------------- */
+#define HBO_MAX_PROFILE_STAGES 32
+int hbo_profile_enable(hbo_ctx* ctx, int level); /* 0 off, 1 per stage, 2 per launch */
+/* names: array of HBO_MAX_PROFILE_STAGES char[32]; ms: total ms; launches: count */
+int hbo_profile_get(hbo_ctx* ctx, char names[][32], double* ms, int32_t* launches, int32_t* n);
+
+/* tuning knobs (integers by name), e.g. "potrf_group", "lookahead", "streams". */
+int hbo_set_option(hbo_ctx* ctx, const char* name, int64_t value);
+
+/* ---- multi-GPU: one process per GPU; sum-all-reduce of [nll, grads] over RCCL (xGMI) ------ */
+#define HBO_UNIQUE_ID_BYTES 128
+int hbo_comm_unique_id(void* out128);
+int hbo_comm_init(hbo_ctx* ctx, int rank, int nranks, const void* unique_id128);
+int hbo_comm_allreduce_sum(hbo_ctx* ctx, double* buf, int32_t count);
+int hbo_comm_destroy(hbo_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HBO_H_ */
