@@ -294,7 +294,7 @@ static void run_potrf(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks
       { ProfScope ps(c, "trsm", 2); launch_trsm(dtype, d_tasks, ntasks, p, max_nblk, st); }
     }
     if (g1 < max_nblk) {
-      ProfScope ps(c, "syrk_trailing", 2);
+      ProfScope ps(c, "syrk_trailing", 1);
       GemmArgs a = {}; a.tasks = d_tasks; a.mode = GEMM_SYRK; a.p0 = g0; a.kt = g1 - g0; a.c_lo = g1; a.c_hi = max_nblk; a.aug = 1;
       launch_gemm(dtype, a, dim3(max_nblk + 1 - g1, max_nblk - g1, ntasks), st);
     }

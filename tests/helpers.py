@@ -1,0 +1,73 @@
+"""Shared builders for the oracle / native parameter containers used by the tests."""
+import numpy as np
+
+KERNELS = ['squared_exponential', 'matern32', 'matern52', 'dot_product']
+MEANS = ['zero', 'constant', 'linear', 'linear_mlp']
+MLP_FEATURES = (4, 5)
+
+
+def inv_softplus(v):
+  return np.log(np.expm1(np.asarray(v, dtype=np.float64)))
+
+
+def make_model(rng, mean_name, mlp_kernel, d, dtype=np.float64):
+  """Raw (un-warped) params.model with every key the given mean/kernel combination needs."""
+  feat = MLP_FEATURES[-1] if mlp_kernel else d
+  model = {
+      'lengthscale': (rng.normal(size=feat) * 0.3 + 0.5).astype(dtype),
+      'signal_variance': np.array(0.3, dtype=dtype),
+      'noise_variance': np.array(-2.0, dtype=dtype),
+      'constant': np.array(0.4, dtype=dtype),
+      'dot_prod_sigma': np.array(0.7, dtype=dtype),
+      'dot_prod_bias': np.array(0.2, dtype=dtype),
+  }
+  if mlp_kernel or mean_name == 'linear_mlp':
+    fin = d
+    mlp = {}
+    for l, f in enumerate(MLP_FEATURES):
+      mlp[f'Dense_{l}'] = {'kernel': (rng.normal(size=(fin, f)) * 0.7).astype(dtype),
+                           'bias': (rng.normal(size=f) * 0.1).astype(dtype)}
+      fin = f
+    model['mlp_params'] = mlp
+  if mean_name in ('linear', 'linear_mlp'):
+    fin = MLP_FEATURES[-1] if mean_name == 'linear_mlp' else d
+    model['linear_mean'] = {'kernel': rng.normal(size=(fin, 1)).astype(dtype),
+                            'bias': rng.normal(size=1).astype(dtype)}
+  return model
+
+
+def flatten(tree):
+  out = []
+  def rec(t):
+    if isinstance(t, dict):
+      for k in sorted(t):
+        rec(t[k])
+    else:
+      out.append(np.asarray(t, dtype=np.float64).ravel())
+  rec(tree)
+  return np.concatenate(out) if out else np.zeros(0)
+
+
+def unflatten_like(tree, vec):
+  pos = [0]
+  def rec(t):
+    if isinstance(t, dict):
+      return {k: rec(t[k]) for k in sorted(t)}
+    a = np.asarray(t, dtype=np.float64)
+    v = vec[pos[0]:pos[0] + a.size].reshape(a.shape)
+    pos[0] += a.size
+    return v
+  return rec(tree)
+
+
+def rel_err(a, b):
+  a = np.asarray(a, dtype=np.float64)
+  b = np.asarray(b, dtype=np.float64)
+  return float(np.max(np.abs(a - b)) / (np.max(np.abs(b)) + 1e-300)) if a.size else 0.0
+
+
+def synthetic_task(rng, n, d, m=1, dtype=np.float64):
+  x = rng.uniform(size=(n, d))
+  w = rng.normal(size=(d, m))
+  y = np.sin(2 * np.pi * x @ w) + 0.1 * rng.normal(size=(n, m))
+  return x.astype(dtype), y.astype(dtype)

@@ -1,0 +1,64 @@
+"""world_size-2 gloo test of the task-sharded objective's reduction path (CPU, no GPU):
+each rank evaluates ITS shard with the oracle standing in for the device call, the
+[nll_sum, count, grad_sum] buffer goes through parallel.TorchDistComm (gloo), and the result must
+equal the single-process mean over all tasks."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+  s = socket.socket(); s.bind(('127.0.0.1', 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def _worker(rank, world, port, out_dir):
+  sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+  import torch.distributed as dist
+  import helpers
+  from hyperbo_amd import parallel
+  from hyperbo_amd.basics import definitions as defs
+  from oracle import hyperbo_oracle as o
+  os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+  dist.init_process_group('gloo', rank=rank, world_size=world)
+  rng = np.random.default_rng(0)
+  model = helpers.make_model(rng, 'constant', False, 2)
+  sizes = [9, 14, 6, 11, 8]
+  full = {i: defs.SubDataset(*helpers.synthetic_task(rng, n, 2)) for i, n in enumerate(sizes)}
+  full[99] = defs.SubDataset(*helpers.synthetic_task(rng, 4, 2, m=2), aligned=1)   # skipped
+  mine = parallel.shard_dataset(full, rank, world)
+  params = o.GPParams(model=model)
+  nll_sum, grad_sum = 0.0, np.zeros(helpers.flatten(model).size)
+  for k, s in mine.items():
+    v, g = o.nll_sub_dataset_value_and_grad(o.constant, o.squared_exponential, params, s.x, s.y, o.DEFAULT_WARP_FUNC)
+    nll_sum += v; grad_sum += helpers.flatten(g)
+  comm = parallel.TorchDistComm()
+  value, grad, count = parallel.sharded_mean_nll(nll_sum, len(mine), grad_sum, comm)
+  np.savez(os.path.join(out_dir, f'r{rank}.npz'), value=value, grad=grad, count=count, keys=np.array(sorted(mine)))
+  dist.barrier()
+  dist.destroy_process_group()
+
+
+def test_sharded_objective_matches_single_process(tmp_path):
+  torch = pytest.importorskip('torch')
+  import torch.multiprocessing as mp
+  sys.path.insert(0, os.path.join(ROOT, 'tests'))
+  import helpers
+  from oracle import hyperbo_oracle as o
+  port = _free_port()
+  mp.start_processes(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True, start_method='spawn')
+  r0, r1 = np.load(tmp_path / 'r0.npz'), np.load(tmp_path / 'r1.npz')
+  assert int(r0['count']) == int(r1['count']) == 5
+  assert not set(r0['keys']) & set(r1['keys']) and len(r0['keys']) + len(r1['keys']) == 5
+  rng = np.random.default_rng(0)
+  model = helpers.make_model(rng, 'constant', False, 2)
+  full = {i: o.SubDataset(*helpers.synthetic_task(rng, n, 2)) for i, n in enumerate([9, 14, 6, 11, 8])}
+  full[99] = o.SubDataset(*helpers.synthetic_task(rng, 4, 2, m=2), aligned=1)
+  val, g = o.nll_value_and_grad(o.constant, o.squared_exponential, o.GPParams(model=model), full, o.DEFAULT_WARP_FUNC)
+  for r in (r0, r1):
+    assert abs(float(r['value']) - val) <= 1e-12 * abs(val)
+    np.testing.assert_allclose(r['grad'], helpers.flatten(g), rtol=1e-11, atol=1e-12)

@@ -1,0 +1,416 @@
+"""GPU parity tests (run with `-m gpu` on an MI355X): the HIP path, called through the C ABI via
+hyperbo_amd, against the CPU oracle on the same seeded inputs, against the committed golden
+fixtures, and -- at BASELINE.json's full sizes -- through size-independent properties.
+
+Tolerances (stated per north_star "to a stated fp64 tolerance"):
+  fp64: NLL rel 1e-10, gradient 1e-8 of max|g|, chol/kinvy/mu/var 1e-9 (x cond. headroom);
+  fp32: 2e-4 relative on values, 5e-3 on gradients/variances (fp32 Cholesky of a jittered Gram).
+"""
+import os
+
+import numpy as np
+import pytest
+import scipy.linalg as spla
+
+import helpers
+from oracle import hyperbo_oracle as o
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+WFO = o.DEFAULT_WARP_FUNC
+
+
+def _native():
+  from hyperbo_amd.basics import definitions as defs, linalg
+  from hyperbo_amd.bo_utils import acfun
+  from hyperbo_amd.gp_utils import gp, kernel, mean, objectives, utils
+  return defs, linalg, acfun, gp, kernel, mean, objectives, utils
+
+
+def _pair(model, cfg=None):
+  defs = _native()[0]
+  cfg = cfg or {'mlp_features': helpers.MLP_FEATURES}
+  return o.GPParams(model=model, config=dict(cfg)), defs.GPParams(model=model, config=dict(cfg))
+
+
+# ---- dense building blocks vs LAPACK ---------------------------------------------------------
+@pytest.mark.parametrize('dtype,tol', [(np.float64, 1e-12), (np.float32, 2e-5)])
+@pytest.mark.parametrize('n', [1, 5, 127, 128, 129, 300, 1000])
+def test_spd_solve_vs_lapack(gpu_ctx, dtype, tol, n):
+  _, linalg, *_ = _native()
+  rng = np.random.default_rng(n)
+  m_ = rng.normal(size=(n, n))
+  a = (m_ @ m_.T / n + np.eye(n)).astype(dtype)
+  b = rng.normal(size=(n, 3)).astype(dtype)
+  chol, x = linalg.solve_linear_system(a, b)
+  inv, ldh = linalg.spd_inverse(a)
+  a64 = a.astype(np.float64)
+  cref = spla.cholesky(a64, lower=True)
+  assert chol.dtype == dtype and np.array_equal(np.triu(chol, 1), np.zeros_like(chol))
+  assert helpers.rel_err(chol, cref) < tol * 10
+  assert helpers.rel_err(x, spla.cho_solve((cref, True), b.astype(np.float64))) < tol * 100
+  assert helpers.rel_err(inv, np.linalg.inv(a64)) < tol * 100
+  assert abs(ldh - np.sum(np.log(np.diag(cref)))) < tol * 100 * n
+
+
+def test_not_positive_definite_gives_nan_not_exception(gpu_ctx):
+  defs, linalg, _, gp, kernel, mean, objectives, utils = _native()
+  chol, x = linalg.solve_linear_system(-np.eye(6), np.ones((6, 1)))
+  assert np.isnan(chol).all() and np.isnan(x).all()
+  a = np.eye(200); a[150, 150] = -1.0   # fails in the second diagonal block
+  chol, x = linalg.solve_linear_system(a, np.ones((200, 1)))
+  assert np.isnan(chol).all()
+  # duplicated inputs, zero noise, dot-product kernel, eps=... -> NLL NaN like the reference
+  rng = np.random.default_rng(0)
+  x1 = np.repeat(rng.uniform(size=(4, 2)), 40, axis=0)
+  model = {'dot_prod_sigma': np.array(1.0), 'dot_prod_bias': np.array(0.0), 'noise_variance': np.array(-1e-6)}
+  p = defs.GPParams(model=model)
+  v = objectives.neg_log_marginal_likelihood(mean.zero, kernel.dot_product, p, {0: defs.SubDataset(x1, x1[:, :1])})
+  assert np.isnan(v)
+
+
+# ---- Gram / mean ------------------------------------------------------------------------------
+@pytest.mark.parametrize('kname', helpers.KERNELS)
+@pytest.mark.parametrize('mlp', [False, True])
+@pytest.mark.parametrize('dtype,tol', [(np.float64, 1e-13), (np.float32, 2e-5)])
+def test_gram_vs_oracle(gpu_ctx, kname, mlp, dtype, tol):
+  defs, _, _, _, kernel, _, _, utils = _native()
+  rng = np.random.default_rng(1)
+  d = 3
+  model = helpers.make_model(rng, 'zero', mlp, d, dtype)
+  po, pn = _pair(model)
+  ko = getattr(o, kname + ('_mlp' if mlp else '')); kn = getattr(kernel, kname + ('_mlp' if mlp else ''))
+  x1 = rng.uniform(size=(150, d)).astype(dtype); x2 = rng.uniform(size=(37, d)).astype(dtype)
+  model64 = helpers.unflatten_like(model, helpers.flatten(model))
+  po64 = o.GPParams(model=model64, config=po.config)
+  g = kn(pn, x1, warp_func=utils.DEFAULT_WARP_FUNC)
+  assert g.shape == (150, 150) and g.dtype == dtype
+  assert helpers.rel_err(g, ko(po64, x1.astype(np.float64), warp_func=WFO)) < tol
+  c = kn(pn, x1, x2, warp_func=utils.DEFAULT_WARP_FUNC)
+  assert c.shape == (150, 37)
+  assert helpers.rel_err(c, ko(po64, x1.astype(np.float64), x2.astype(np.float64), warp_func=WFO)) < tol
+  dg = kn(pn, x1, warp_func=utils.DEFAULT_WARP_FUNC, diag=True)
+  assert dg.shape == (150,)
+  assert helpers.rel_err(dg, np.diag(ko(po64, x1.astype(np.float64), warp_func=WFO))) < tol
+  # symmetric PSD (kernel_test.py:146-150)
+  np.testing.assert_allclose(g, g.T, atol=tol)
+  assert np.linalg.eigvalsh(g.astype(np.float64)).min() > -1e-5
+  assert kn(pn, np.zeros((0, d), dtype), warp_func=utils.DEFAULT_WARP_FUNC).shape == (0, 0)
+
+
+@pytest.mark.parametrize('mname', helpers.MEANS)
+def test_mean_vs_oracle(gpu_ctx, mname):
+  defs, _, _, _, _, mean, _, utils = _native()
+  rng = np.random.default_rng(2)
+  model = helpers.make_model(rng, mname, False, 3)
+  po, pn = _pair(model)
+  x = rng.uniform(size=(50, 3))
+  mu = getattr(mean, mname)(pn, x, warp_func=utils.DEFAULT_WARP_FUNC)
+  assert mu.shape == (50, 1)
+  np.testing.assert_allclose(mu, getattr(o, mname)(po, x, warp_func=WFO), rtol=1e-13, atol=1e-15)
+
+
+# ---- NLL and its gradient ----------------------------------------------------------------------
+def _ragged_dataset(rng, d):
+  dso = {0: o.SubDataset(*helpers.synthetic_task(rng, 140, d)), 1: o.SubDataset(*helpers.synthetic_task(rng, 300, d)),
+         2: o.SubDataset(*helpers.synthetic_task(rng, 20, d, m=3), aligned=1), 3: o.SubDataset(np.zeros((0, d)), np.zeros((0, 1))),
+         4: o.SubDataset(*helpers.synthetic_task(rng, 128, d))}
+  return dso
+
+
+@pytest.mark.parametrize('kname', helpers.KERNELS)
+@pytest.mark.parametrize('mname', ['zero', 'constant', 'linear'])
+@pytest.mark.parametrize('exclude_aligned', [True, False])
+def test_nll_value_and_grad_vs_oracle_fp64(gpu_ctx, kname, mname, exclude_aligned):
+  defs, _, _, _, kernel, mean, objectives, utils = _native()
+  rng = np.random.default_rng(3)
+  d = 3
+  model = helpers.make_model(rng, mname, False, d)
+  po, pn = _pair(model)
+  dso = _ragged_dataset(rng, d)
+  dsn = {k: defs.SubDataset(v.x, v.y, v.aligned) for k, v in dso.items()}
+  vo, go = o.nll_value_and_grad(getattr(o, mname), getattr(o, kname), po, dso, WFO, exclude_aligned=exclude_aligned)
+  vn, gn = objectives.nll_value_and_grad(getattr(mean, mname), getattr(kernel, kname), pn, dsn,
+                                         utils.DEFAULT_WARP_FUNC, exclude_aligned=exclude_aligned)
+  assert abs(vn - vo) <= 1e-10 * abs(vo)
+  fo, fn = helpers.flatten(go), helpers.flatten(gn)
+  assert np.max(np.abs(fo - fn)) <= 1e-8 * np.max(np.abs(fo))
+  v2, k2 = objectives.neg_log_marginal_likelihood(getattr(mean, mname), getattr(kernel, kname), pn, dsn,
+                                                  utils.DEFAULT_WARP_FUNC, exclude_aligned=exclude_aligned,
+                                                  return_key2nll=True)
+  _, k2o = o.neg_log_marginal_likelihood(getattr(o, mname), getattr(o, kname), po, dso, WFO,
+                                         exclude_aligned=exclude_aligned, return_key2nll=True)
+  assert abs(v2 - vo) <= 1e-10 * abs(vo) and set(k2) == set(k2o)
+  for k in k2o:
+    assert abs(k2[k] - k2o[k]) <= 1e-10 * abs(k2o[k])
+
+
+def test_nll_with_priors_and_scalar_lengthscale(gpu_ctx):
+  defs, _, _, _, kernel, mean, objectives, utils = _native()
+  from hyperbo_amd.gp_utils import priors
+  rng = np.random.default_rng(5)
+  model = helpers.make_model(rng, 'constant', False, 4)
+  model['lengthscale'] = np.array([0.3])   # scalar lengthscale broadcast over 4 dims
+  cfgo = {'priors': o.DEFAULT_PRIORS}; cfgn = {'priors': priors.DEFAULT_PRIORS}
+  po, pn = o.GPParams(model=model, config=cfgo), defs.GPParams(model=model, config=cfgn)
+  dso = {i: o.SubDataset(*helpers.synthetic_task(rng, 60 + 30 * i, 4)) for i in range(3)}
+  dsn = {k: defs.SubDataset(v.x, v.y) for k, v in dso.items()}
+  vo, go = o.nll_value_and_grad(o.constant, o.matern52, po, dso, WFO, priors_grad=o.DEFAULT_PRIORS_GRAD)
+  vn, gn = objectives.nll_value_and_grad(mean.constant, kernel.matern52, pn, dsn, utils.DEFAULT_WARP_FUNC)
+  assert abs(vn - vo) <= 1e-10 * abs(vo)
+  np.testing.assert_allclose(helpers.flatten(gn), helpers.flatten(go), rtol=1e-7, atol=1e-9)
+  assert gn['lengthscale'].shape == (1,)
+
+
+def test_nll_fp32_vs_fp64_oracle(gpu_ctx):
+  defs, _, _, _, kernel, mean, objectives, utils = _native()
+  rng = np.random.default_rng(6)
+  model = helpers.make_model(rng, 'constant', False, 4, np.float32)
+  dsn = {i: defs.SubDataset(*helpers.synthetic_task(rng, 200 + 57 * i, 4, dtype=np.float32)) for i in range(3)}
+  dso = {k: o.SubDataset(v.x.astype(np.float64), v.y.astype(np.float64)) for k, v in dsn.items()}
+  po = o.GPParams(model=helpers.unflatten_like(model, helpers.flatten(model)))
+  vo, go = o.nll_value_and_grad(o.constant, o.matern32, po, dso, WFO)
+  vn, gn = objectives.nll_value_and_grad(mean.constant, kernel.matern32, defs.GPParams(model=model), dsn, utils.DEFAULT_WARP_FUNC)
+  assert abs(vn - vo) <= 2e-4 * abs(vo)
+  fo, fn = helpers.flatten(go), helpers.flatten(gn)
+  assert np.max(np.abs(fo - fn)) <= 5e-3 * np.max(np.abs(fo))
+
+
+# ---- factorisation, posterior, acquisition --------------------------------------------------------
+CASES = [('squared_exponential', False, 'constant'), ('matern52', True, 'linear_mlp'), ('matern32', False, 'linear'),
+         ('dot_product', True, 'zero')]
+
+
+@pytest.mark.parametrize('kname,mlp,mname', CASES)
+def test_factor_predict_acquisition_vs_oracle(gpu_ctx, kname, mlp, mname):
+  defs, linalg, acfun, gp, kernel, mean, _, utils = _native()
+  rng = np.random.default_rng(7)
+  d = 3
+  model = helpers.make_model(rng, mname, mlp, d)
+  po, pn = _pair(model)
+  ko = getattr(o, kname + ('_mlp' if mlp else '')); kn = getattr(kernel, kname + ('_mlp' if mlp else ''))
+  mo, mn = getattr(o, mname), getattr(mean, mname)
+  x, y = helpers.synthetic_task(rng, 200, d)
+  xq = rng.uniform(size=(70, d))
+  cho, kio, ymo = o.solve_gp_linear_system(mo, ko, po, x, y, WFO)
+  chn, kin, ymn = linalg.solve_gp_linear_system(mn, kn, pn, x, y, utils.DEFAULT_WARP_FUNC)
+  assert chn.shape == (200, 200) and kin.shape == (200, 1) and ymn.shape == (200, 1)
+  assert helpers.rel_err(chn, cho) < 1e-11 and helpers.rel_err(kin, kio) < 1e-9 and helpers.rel_err(ymn, ymo) < 1e-13
+  muo, varo = o.predict(mo, ko, po, x, y, xq, WFO)
+  mun, varn = gp.predict(mn, kn, pn, x, y, xq, utils.DEFAULT_WARP_FUNC)
+  assert mun.shape == (70, 1) and varn.shape == (70, 1)
+  assert helpers.rel_err(mun, muo) < 1e-9 and helpers.rel_err(varn, varo) < 1e-9
+  _, covo = o.predict(mo, ko, po, x, y, xq, WFO, full_cov=True)
+  mun2, covn = gp.predict(mn, kn, pn, x, y, xq, utils.DEFAULT_WARP_FUNC, full_cov=True)
+  assert covn.shape == (70, 70) and helpers.rel_err(covn, covo) < 1e-9
+  np.testing.assert_allclose(np.diag(covn), varn[:, 0], rtol=1e-8, atol=1e-12)   # gp_test.py:201-203
+  # GP object: cache, +noise, T/(T-1), acquisition functions
+  ds = {0: defs.SubDataset(x, y), 1: defs.SubDataset(x[:50], y[:50])}
+  model_n = gp.GP(ds, mn, kn, pn, utils.DEFAULT_WARP_FUNC)
+  mu_g, var_g = model_n.predict(xq, 0)
+  assert 0 in model_n.params.cache and not model_n.params.cache[0].needs_update   # gp_test.py:186-189
+  np.testing.assert_allclose(model_n.params.cache[0].chol, cho, rtol=1e-9, atol=1e-12)
+  dso = {k: o.SubDataset(v.x, v.y) for k, v in ds.items()}
+  mu_o, var_o = o.gp_predict_postprocess(po, dso, muo, varo, WFO, False, True, True)
+  assert helpers.rel_err(var_g, var_o) < 1e-9 and helpers.rel_err(mu_g, mu_o) < 1e-9
+  mu_nn, var_nn = model_n.predict(xq, 0, with_noise=False, unbiased=False)
+  assert helpers.rel_err(var_nn, varo) < 1e-9
+  for name, sub_o, par in [('expected_improvement', o.expected_improvement_sub, float(np.max(y))),
+                           ('probability_of_improvement', o.probability_of_improvement_sub, float(np.max(y)) + 0.1),
+                           ('pi2', o.probability_of_improvement_sub, float(np.max(y) + 0.1 * np.std(y))),
+                           ('pi3', o.probability_of_improvement_sub, float(np.max(y)) + 0.05),
+                           ('ucb', o.ucb_sub, 3.0), ('ucb2', o.ucb_sub, 2.0), ('ucb4', o.ucb_sub, 4.0)]:
+    an = getattr(acfun, name)(model=model_n, sub_dataset_key=0, x_queries=xq)
+    assert an.shape == (70, 1)
+    ao = sub_o(mu_o, np.sqrt(var_o), par)
+    assert helpers.rel_err(an, ao) < 1e-8, name
+  # prior path: key not in dataset (gp.py:584-593), EI target 0.0 (acfun.py:146-147)
+  mu_p, var_p = model_n.predict(xq, 'missing')
+  mu_po, var_po = o.predict(mo, ko, po, None, None, xq, WFO)
+  mu_po, var_po = o.gp_predict_postprocess(po, dso, mu_po, var_po, WFO, False, True, True)
+  np.testing.assert_allclose(mu_p, mu_po, rtol=1e-12, atol=1e-14)
+  np.testing.assert_allclose(var_p, var_po, rtol=1e-12)
+  ei_p = acfun.expected_improvement(model=model_n, sub_dataset_key='missing', x_queries=xq)
+  assert helpers.rel_err(ei_p, o.expected_improvement_sub(mu_po, np.sqrt(var_po), 0.0)) < 1e-9
+  # cache invalidation: append -> refactor from scratch (bayesopt.py:186-190)
+  model_n.update_sub_dataset((xq[:3], np.ones((3, 1))), 0, is_append=True)
+  assert model_n.params.cache[0].needs_update
+  mu_a, _ = model_n.predict(xq, 0)
+  mu_ao, _ = o.predict(mo, ko, po, np.vstack([x, xq[:3]]), np.vstack([y, np.ones((3, 1))]), xq, WFO)
+  assert helpers.rel_err(mu_a, mu_ao) < 1e-8
+
+
+def test_multi_column_y_factor(gpu_ctx):
+  defs, linalg, _, _, kernel, mean, _, utils = _native()
+  rng = np.random.default_rng(8)
+  model = helpers.make_model(rng, 'constant', False, 2)
+  po, pn = _pair(model)
+  x, y = helpers.synthetic_task(rng, 150, 2, m=4)
+  cho, kio, ymo = o.solve_gp_linear_system(o.constant, o.matern52, po, x, y, WFO)
+  chn, kin, ymn = linalg.solve_gp_linear_system(mean.constant, kernel.matern52, pn, x, y, utils.DEFAULT_WARP_FUNC)
+  assert kin.shape == (150, 4)
+  assert helpers.rel_err(kin, kio) < 1e-9 and helpers.rel_err(ymn, ymo) < 1e-13
+
+
+# ---- committed golden fixtures ---------------------------------------------------------------------
+def _golden_cases():
+  import importlib.util
+  spec = importlib.util.spec_from_file_location('make_golden', os.path.join(GOLDEN, 'make_golden.py'))
+  mg = importlib.util.module_from_spec(spec); spec.loader.exec_module(mg)
+  return mg.CASES
+
+
+@pytest.mark.parametrize('case', _golden_cases(), ids=lambda c: c[0])
+def test_against_golden_fixtures(gpu_ctx, case):
+  defs, linalg, acfun, gp, kernel, mean, objectives, utils = _native()
+  name, kname, mlp, mname, n, d, nq, seed = case
+  ref = np.load(os.path.join(GOLDEN, name + '.npz'))
+  rng = np.random.Generator(np.random.PCG64(seed))
+  model = helpers.unflatten_like(helpers.make_model(rng, mname, mlp, d), ref['model_flat'])
+  pn = defs.GPParams(model=model, config={'mlp_features': helpers.MLP_FEATURES})
+  kn = getattr(kernel, kname + ('_mlp' if mlp else '')); mn = getattr(mean, mname)
+  wf = utils.DEFAULT_WARP_FUNC
+  x, y, xq = ref['x'], ref['y'], ref['xq']
+  np.testing.assert_allclose(kn(pn, x, warp_func=wf), ref['gram'], rtol=1e-12, atol=1e-14)
+  np.testing.assert_allclose(kn(pn, x, xq, warp_func=wf), ref['cross'], rtol=1e-12, atol=1e-14)
+  np.testing.assert_allclose(mn(pn, x, warp_func=wf), ref['mean_x'], rtol=1e-12, atol=1e-14)
+  ds = {0: defs.SubDataset(x, y), 1: defs.SubDataset(ref['x2'], ref['y2'])}
+  nll, k2 = objectives.neg_log_marginal_likelihood(mn, kn, pn, ds, wf, return_key2nll=True)
+  assert abs(nll - float(ref['nll'])) <= 1e-10 * abs(float(ref['nll']))
+  assert abs(k2[0] - float(ref['nll0'])) <= 1e-10 * abs(float(ref['nll0']))
+  assert abs(k2[1] - float(ref['nll1'])) <= 1e-10 * abs(float(ref['nll1']))
+  assert abs(nll / float(ref['nll_svd']) - 1) < 1e-6          # objectives_test.py:168
+  if not mlp and mname != 'linear_mlp':
+    v, g = objectives.nll_value_and_grad(mn, kn, pn, ds, wf)
+    gf = helpers.flatten(g)
+    assert np.max(np.abs(gf - ref['grad_flat'])) <= 1e-8 * np.max(np.abs(ref['grad_flat']))
+  chol, kinvy, ymu = linalg.solve_gp_linear_system(mn, kn, pn, x, y, wf)
+  assert helpers.rel_err(chol, ref['chol']) < 1e-10 and helpers.rel_err(kinvy, ref['kinvy']) < 1e-8
+  mu, var = gp.predict(mn, kn, pn, x, y, xq, wf)
+  _, cov = gp.predict(mn, kn, pn, x, y, xq, wf, full_cov=True)
+  assert helpers.rel_err(mu, ref['mu']) < 1e-9 and helpers.rel_err(var, ref['var']) < 1e-8
+  assert helpers.rel_err(cov, ref['cov']) < 1e-8
+  m = gp.GP(ds, mn, kn, pn, wf)
+  for nm, key in (('expected_improvement', 'ei'), ('probability_of_improvement', 'pi'), ('ucb', 'ucb')):
+    a = getattr(acfun, nm)(model=m, sub_dataset_key=0, x_queries=xq)
+    assert helpers.rel_err(a, ref[key]) < 1e-7, nm
+
+
+# ---- BASELINE sizes: oracle where it still finishes in seconds, size-independent properties above --
+def _cfg2_like(rng, n, d=16):
+  x = rng.uniform(size=(n, d)); w = rng.normal(size=d)
+  y = np.sin(2 * np.pi * x @ w)[:, None] + 0.1 * rng.normal(size=(n, 1))
+  model = {'lengthscale': helpers.inv_softplus(np.full(d, np.sqrt(d) * 0.3)), 'signal_variance': helpers.inv_softplus(1.0),
+           'noise_variance': helpers.inv_softplus(1e-2), 'constant': np.array(0.0)}
+  return x, y, model
+
+
+def test_cfg2_shape_n2048_vs_oracle(gpu_ctx):
+  defs, _, _, _, kernel, mean, objectives, utils = _native()
+  x, y, model = _cfg2_like(np.random.default_rng(2), 2048)
+  vo, go = o.nll_value_and_grad(o.constant, o.squared_exponential, o.GPParams(model=model), {0: o.SubDataset(x, y)}, WFO)
+  vn, gn = objectives.nll_value_and_grad(mean.constant, kernel.squared_exponential, defs.GPParams(model=model),
+                                         {0: defs.SubDataset(x, y)}, utils.DEFAULT_WARP_FUNC)
+  assert abs(vn - vo) <= 1e-10 * abs(vo)
+  fo, fn = helpers.flatten(go), helpers.flatten(gn)
+  assert np.max(np.abs(fo - fn)) <= 1e-8 * np.max(np.abs(fo))
+
+
+def test_cfg2_full_size_properties(gpu_ctx):
+  """N=8192, D=16 fp64: (a) NLL agrees with LAPACK's Cholesky of the same Gram (value-only oracle,
+  seconds); (b) the analytic gradient matches a directional central difference of the GPU NLL."""
+  defs, _, _, _, kernel, mean, objectives, utils = _native()
+  rng = np.random.default_rng(2)
+  x, y, model = _cfg2_like(rng, 8192)
+  pn = defs.GPParams(model=model)
+  dev = objectives.DeviceDataset({0: defs.SubDataset(x, y)})
+  v, g = objectives.nll_value_and_grad(mean.constant, kernel.squared_exponential, pn, dev, utils.DEFAULT_WARP_FUNC)
+  vo = o.neg_log_marginal_likelihood(o.constant, o.squared_exponential, o.GPParams(model=model), {0: o.SubDataset(x, y)}, WFO)
+  assert abs(v - vo) <= 1e-10 * abs(vo)
+  x0 = helpers.flatten(model); gf = helpers.flatten(g)
+  direction = rng.normal(size=x0.size); direction /= np.linalg.norm(direction)
+  h = 1e-5
+  vals = []
+  for sgn in (+1, -1):
+    pm = defs.GPParams(model=helpers.unflatten_like(model, x0 + sgn * h * direction))
+    vals.append(objectives.neg_log_marginal_likelihood(mean.constant, kernel.squared_exponential, pm, dev, utils.DEFAULT_WARP_FUNC))
+  num = (vals[0] - vals[1]) / (2 * h)
+  assert abs(num - gf @ direction) <= 1e-5 * abs(num) + 1e-6
+  dev.close()
+
+
+def test_cfg4_like_ragged_multitask_vs_oracle(gpu_ctx):
+  defs, _, _, _, kernel, mean, objectives, utils = _native()
+  rng = np.random.default_rng(4)
+  d = 4
+  sizes = rng.integers(1600, 2401, size=6)
+  model = {'lengthscale': helpers.inv_softplus(np.full(d, 0.4)), 'signal_variance': helpers.inv_softplus(1.0),
+           'noise_variance': helpers.inv_softplus(1e-2), 'constant': np.array(0.1)}
+  dso = {i: o.SubDataset(*helpers.synthetic_task(rng, int(n), d)) for i, n in enumerate(sizes)}
+  dsn = {k: defs.SubDataset(v.x, v.y) for k, v in dso.items()}
+  vo, go = o.nll_value_and_grad(o.constant, o.squared_exponential, o.GPParams(model=model), dso, WFO)
+  vn, gn = objectives.nll_value_and_grad(mean.constant, kernel.squared_exponential, defs.GPParams(model=model), dsn, utils.DEFAULT_WARP_FUNC)
+  assert abs(vn - vo) <= 1e-10 * abs(vo)
+  fo, fn = helpers.flatten(go), helpers.flatten(gn)
+  assert np.max(np.abs(fo - fn)) <= 1e-8 * np.max(np.abs(fo))
+
+
+def test_cfg3_shape_fp32_ei_against_fp64(gpu_ctx):
+  """Matern-5/2 on tanh-MLP(32->64) features + linear_mlp mean, N=16384, fp32 factor + EI over 65536
+  candidates; checked against the same computation in fp64 on the GPU for a 4096-candidate subset
+  (and that against the oracle on 256 of them at N=2048)."""
+  defs, _, acfun, gp, kernel, mean, _, utils = _native()
+  rng = np.random.default_rng(3)
+  d, f = 32, 64
+  model = {'lengthscale': helpers.inv_softplus(np.ones(f)), 'signal_variance': helpers.inv_softplus(1.0),
+           'noise_variance': helpers.inv_softplus(1e-2),
+           'mlp_params': {'Dense_0': {'kernel': rng.normal(size=(d, f)) / np.sqrt(d), 'bias': np.zeros(f)}},
+           'linear_mean': {'kernel': rng.normal(size=(f, 1)) / np.sqrt(f), 'bias': np.zeros(1)}}
+  cfg = {'mlp_features': (f,)}
+  n, M = 16384, 65536
+  x = rng.uniform(size=(n, d)); y = np.sin(x[:, :4].sum(axis=1, keepdims=True) * 2.0) + 0.1 * rng.normal(size=(n, 1))
+  xq = rng.uniform(size=(M, d))
+  to32 = lambda t: {k: to32(v) for k, v in t.items()} if isinstance(t, dict) else np.asarray(t, dtype=np.float32)
+  g32 = gp.GP({0: defs.SubDataset(x.astype(np.float32), y.astype(np.float32))}, mean.linear_mlp, kernel.matern52_mlp,
+              defs.GPParams(model=to32(model), config=dict(cfg)), utils.DEFAULT_WARP_FUNC)
+  ei32 = acfun.expected_improvement(model=g32, sub_dataset_key=0, x_queries=xq.astype(np.float32))
+  assert ei32.shape == (M, 1) and ei32.dtype == np.float32 and np.isfinite(ei32).all() and (ei32 >= 0).all()
+  g64 = gp.GP({0: defs.SubDataset(x, y)}, mean.linear_mlp, kernel.matern52_mlp,
+              defs.GPParams(model=model, config=dict(cfg)), utils.DEFAULT_WARP_FUNC)
+  sub = slice(0, 4096)
+  ei64 = acfun.expected_improvement(model=g64, sub_dataset_key=0, x_queries=xq[sub])
+  mu32, var32 = g32.predict(xq[sub].astype(np.float32), 0)
+  mu64, var64 = g64.predict(xq[sub], 0)
+  assert np.max(np.abs(mu32 - mu64)) < 5e-3 * (1 + np.max(np.abs(mu64)))
+  assert np.max(np.abs(var32 - var64)) < 5e-3 * np.max(np.abs(var64))
+  assert np.max(np.abs(ei32[sub] - ei64)) < 5e-3 * (np.max(np.abs(ei64)) + 1e-3)
+  # fp64 path vs the oracle at a size it finishes in seconds
+  ns = 2048
+  gs = gp.GP({0: defs.SubDataset(x[:ns], y[:ns])}, mean.linear_mlp, kernel.matern52_mlp,
+             defs.GPParams(model=model, config=dict(cfg)), utils.DEFAULT_WARP_FUNC)
+  ei_s = acfun.expected_improvement(model=gs, sub_dataset_key=0, x_queries=xq[:256])
+  po = o.GPParams(model=model, config=dict(cfg))
+  mu_o, var_o = o.predict(o.linear_mlp, o.matern52_mlp, po, x[:ns], y[:ns], xq[:256], WFO)
+  mu_o, var_o = o.gp_predict_postprocess(po, {0: o.SubDataset(x[:ns], y[:ns])}, mu_o, var_o, WFO, False, True, True)
+  assert helpers.rel_err(ei_s, o.expected_improvement_sub(mu_o, np.sqrt(var_o), float(np.max(y[:ns])))) < 1e-7
+
+
+def test_cfg5_full_size_closed_form(gpu_ctx):
+  """N=65536 fp64 blocked Cholesky (32 GiB Gram, HBM-bound panels).  The dot-product kernel on 1-D
+  inputs gives K = x x^T / s^2 + b^2 + c I, whose log-determinant and quadratic form have closed
+  forms (matrix determinant lemma / Woodbury): a size-independent check of the whole pipeline."""
+  defs, _, _, _, kernel, mean, objectives, utils = _native()
+  rng = np.random.default_rng(5)
+  n = 65536
+  x = rng.uniform(-1, 1, size=(n, 1)); y = rng.normal(size=(n, 1))
+  sigma, bias, noise = 0.7, 0.3, 0.1
+  model = {'dot_prod_sigma': np.array(sigma), 'dot_prod_bias': np.array(bias), 'noise_variance': np.array(noise)}
+  v = objectives.neg_log_marginal_likelihood(mean.zero, kernel.dot_product, defs.GPParams(model=model), {0: defs.SubDataset(x, y)})
+  c = noise + 1e-6
+  U = np.hstack([x / sigma, np.full((n, 1), bias)])
+  cap = np.eye(2) + U.T @ U / c
+  logdet = n * np.log(c) + np.linalg.slogdet(cap)[1]
+  uty = U.T @ y
+  quad = (float(y.T @ y) - float(uty.T @ np.linalg.solve(cap, uty)) / c) / c
+  expect = 0.5 * quad + 0.5 * logdet + 0.5 * n * np.log(2 * np.pi)
+  assert abs(v - expect) <= 1e-9 * abs(expect)

@@ -1,0 +1,333 @@
+"""Pins for the CPU oracle (oracle/hyperbo_oracle.py).
+
+The JAX reference cannot be imported here and its own tests hold no golden values (SURVEY.md
+F0.2/F0.3), so the oracle is pinned by: 50-digit mpmath recomputation, central finite differences,
+an independent torch.autograd re-expression, the identities the reference's tests assert, and the
+NumPy-seeded inputs of hyperbo/basics/linalg_test.py.  All CPU, `-m "not gpu"`.
+"""
+import os
+
+import mpmath as mp
+import numpy as np
+import pytest
+import scipy.linalg as spla
+
+import helpers
+from oracle import hyperbo_oracle as o
+
+WF = o.DEFAULT_WARP_FUNC
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+def _params(model):
+  return o.GPParams(model=model, config={'mlp_features': helpers.MLP_FEATURES})
+
+
+# --- (1) mpmath 50-digit recomputation ------------------------------------------------------
+def _mp_kernel(kname, a, b, ls, sv, sigma, bias):
+  if kname == 'dot_product':
+    return sum(x * y for x, y in zip(a, b)) / sigma**2 + bias**2
+  u = sum(((x - y) / l)**2 for x, y, l in zip(a, b, ls))
+  if kname == 'squared_exponential':
+    return sv * mp.e**(-u / 2)
+  c = 3 if kname == 'matern32' else 5
+  r = mp.sqrt(c * u)
+  if kname == 'matern32':
+    return sv * (1 + r) * mp.e**(-r)
+  return sv * (1 + r + r**2 / 3) * mp.e**(-r)
+
+
+def _mp_softplus(v):
+  return mp.log(1 + mp.e**mp.mpf(float(v))) + mp.mpf('1e-10')
+
+
+@pytest.mark.parametrize('kname', helpers.KERNELS)
+@pytest.mark.parametrize('n', [4, 16, 48])
+def test_mpmath_nll_alpha_posterior_ei(kname, n):
+  mp.mp.dps = 50
+  rng = np.random.default_rng(100 + n)
+  d = 3
+  model = helpers.make_model(rng, 'constant', False, d)
+  x, y = helpers.synthetic_task(rng, n, d)
+  xq = rng.uniform(size=(3, d))
+  params = _params(model)
+  kern = getattr(o, kname)
+  ls = [_mp_softplus(v) for v in model['lengthscale']]
+  sv = _mp_softplus(model['signal_variance']); noise = _mp_softplus(model['noise_variance'])
+  sigma = _mp_softplus(model['dot_prod_sigma']); bias = mp.mpf(float(model['dot_prod_bias']))
+  const = mp.mpf(float(model['constant']))
+  X = [[mp.mpf(float(v)) for v in row] for row in x]
+  K = mp.matrix(n, n)
+  for i in range(n):
+    for j in range(n):
+      K[i, j] = _mp_kernel(kname, X[i], X[j], ls, sv, sigma, bias)
+    K[i, i] += noise + mp.mpf('1e-6')
+  r = mp.matrix([mp.mpf(float(v)) - const for v in y[:, 0]])
+  L = mp.cholesky(K)
+  alpha = mp.lu_solve(K, r)
+  nll = (r.T * alpha)[0] / 2 + sum(mp.log(L[i, i]) for i in range(n)) + mp.mpf(n) / 2 * mp.log(2 * mp.pi)
+  # oracle
+  nll_o = o.neg_log_marginal_likelihood(o.constant, kern, params, {0: o.SubDataset(x, y)}, WF)
+  chol_o, kinvy_o, _ = o.solve_gp_linear_system(o.constant, kern, params, x, y, WF)
+  cond = float(np.linalg.cond(np.array(K.tolist(), dtype=np.float64)))
+  assert abs(nll_o - float(nll)) <= 1e-13 * max(cond, 1.0) * abs(float(nll)) + 1e-12
+  np.testing.assert_allclose(kinvy_o[:, 0], [float(a) for a in alpha], rtol=1e-13 * cond, atol=1e-13 * cond)
+  np.testing.assert_allclose(np.diag(chol_o), [float(L[i, i]) for i in range(n)], rtol=1e-12)
+  # posterior at xq + EI
+  mu_o, var_o = o.predict(o.constant, kern, params, x, y, xq, WF)
+  for q in range(xq.shape[0]):
+    xqv = [mp.mpf(float(v)) for v in xq[q]]
+    kq = mp.matrix([_mp_kernel(kname, X[i], xqv, ls, sv, sigma, bias) for i in range(n)])
+    mu = (kq.T * alpha)[0] + const
+    var = _mp_kernel(kname, xqv, xqv, ls, sv, sigma, bias) - (kq.T * mp.lu_solve(K, kq))[0]
+    assert abs(mu_o[q, 0] - float(mu)) <= 1e-12 * cond * (1 + abs(float(mu)))
+    assert abs(var_o[q, 0] - float(var)) <= 1e-12 * cond * (1 + abs(float(var)))
+    sd = mp.sqrt(var + noise)
+    target = mp.mpf(float(np.max(y)))
+    g = (target - mu) / sd
+    ei = (mp.npdf(g) - g * (1 - mp.ncdf(g))) * sd
+    ei_o = o.expected_improvement_sub(mu_o[q, 0], np.sqrt(var_o[q, 0] + float(noise)), float(target))
+    assert abs(ei_o - float(ei)) <= 1e-10 * cond * (abs(float(ei)) + 1e-6)
+
+
+# --- (2) finite differences for every leaf, every kernel x mean x MLP -----------------------
+def _fd_check(kname, mlp, mname, exclude_aligned, rng):
+  d = 3
+  model = helpers.make_model(rng, mname, mlp, d)
+  params = _params(model)
+  kern = getattr(o, kname + ('_mlp' if mlp else ''))
+  mean = getattr(o, mname)
+  ds = {0: o.SubDataset(*helpers.synthetic_task(rng, 12, d)), 1: o.SubDataset(*helpers.synthetic_task(rng, 7, d)),
+        2: o.SubDataset(*helpers.synthetic_task(rng, 5, d, m=3), aligned=1),
+        3: o.SubDataset(np.zeros((0, d)), np.zeros((0, 1)))}
+  _, g = o.nll_value_and_grad(mean, kern, params, ds, WF, exclude_aligned=exclude_aligned)
+  x0 = helpers.flatten(model)
+  gf = helpers.flatten(g)
+  num = np.zeros_like(x0)
+  h = 1e-6
+  for i in range(x0.size):
+    vals = []
+    for sgn in (+1, -1):
+      xp = x0.copy(); xp[i] += sgn * h
+      vals.append(o.neg_log_marginal_likelihood(mean, kern, _params(helpers.unflatten_like(model, xp)), ds, WF,
+                                                exclude_aligned=exclude_aligned))
+    num[i] = (vals[0] - vals[1]) / (2 * h)
+  np.testing.assert_allclose(gf, num, rtol=1e-6 * 200, atol=1e-6)
+
+
+@pytest.mark.parametrize('kname', helpers.KERNELS)
+@pytest.mark.parametrize('mlp', [False, True])
+@pytest.mark.parametrize('mname', helpers.MEANS)
+def test_finite_difference_gradient(kname, mlp, mname):
+  rng = np.random.default_rng(abs(hash((kname, mlp, mname))) % 2**32)
+  _fd_check(kname, mlp, mname, True, rng)
+
+
+def test_finite_difference_gradient_multicolumn_quirk():
+  # y with m>1 columns is only reachable with exclude_aligned=False (objectives_test.py:160)
+  _fd_check('matern52', False, 'constant', False, np.random.default_rng(5))
+
+
+# --- (3) independent torch.autograd re-expression -------------------------------------------
+def _torch_nll(kname, mlp, mname, model_t, xs, ys, torch):
+  def warp(v):
+    return torch.nn.functional.softplus(v) + 1e-10
+  total = 0.
+  for x, y in zip(xs, ys):
+    feat = x
+    if mlp or mname == 'linear_mlp':
+      h = x
+      for l in range(len(model_t['mlp_params'])):
+        lay = model_t['mlp_params'][f'Dense_{l}']
+        h = torch.tanh(h @ lay['kernel'] + lay['bias'])
+      if mlp:
+        feat = h
+    if mname == 'zero':
+      mu = torch.zeros((x.shape[0], 1), dtype=x.dtype)
+    elif mname == 'constant':
+      mu = model_t['constant'] * torch.ones((x.shape[0], 1), dtype=x.dtype)
+    else:
+      inp = x if mname == 'linear' else h
+      mu = inp @ model_t['linear_mean']['kernel'] + model_t['linear_mean']['bias']
+    if kname == 'dot_product':
+      k = feat @ feat.T / warp(model_t['dot_prod_sigma'])**2 + model_t['dot_prod_bias']**2
+    else:
+      ls = warp(model_t['lengthscale'])
+      diff = (feat[:, None, :] - feat[None, :, :]) / ls
+      u = (diff**2).sum(-1)
+      sv = warp(model_t['signal_variance'])
+      if kname == 'squared_exponential':
+        k = sv * torch.exp(-u / 2)
+      else:
+        c = 3.0 if kname == 'matern32' else 5.0
+        # safe sqrt: gradient contribution 0 where u == 0 (hyperbo/basics/linalg.py:173-197)
+        r = torch.sqrt(c * torch.where(u > 0, u, torch.ones_like(u))) * (u > 0)
+        k = sv * (1 + r) * torch.exp(-r) if kname == 'matern32' else sv * (1 + r + r**2 / 3) * torch.exp(-r)
+    n = x.shape[0]
+    cov = k + torch.eye(n, dtype=x.dtype) * (warp(model_t['noise_variance']) + 1e-6)
+    chol = torch.linalg.cholesky(cov)
+    r_ = y - mu
+    alpha = torch.cholesky_solve(r_, chol)
+    total = total + (0.5 * (r_.T @ alpha) + torch.log(torch.diagonal(chol)).sum()
+                     + 0.5 * n * np.log(2 * np.pi)).sum()
+  return total / len(xs)
+
+
+@pytest.mark.parametrize('kname', helpers.KERNELS)
+@pytest.mark.parametrize('mlp,mname', [(False, 'constant'), (True, 'linear_mlp'), (False, 'linear'), (True, 'zero')])
+def test_torch_autograd_matches_oracle_gradient(kname, mlp, mname):
+  torch = pytest.importorskip('torch')
+  rng = np.random.default_rng(31)
+  d = 3
+  model = helpers.make_model(rng, mname, mlp, d)
+  tasks = [helpers.synthetic_task(rng, 15, d), helpers.synthetic_task(rng, 9, d)]
+  ds = {i: o.SubDataset(x, y) for i, (x, y) in enumerate(tasks)}
+
+  def to_t(t):
+    if isinstance(t, dict):
+      return {k: to_t(v) for k, v in t.items()}
+    return torch.tensor(np.asarray(t, dtype=np.float64), requires_grad=True)
+  model_t = to_t(model)
+  xs = [torch.tensor(x) for x, _ in tasks]
+  ys = [torch.tensor(y) for _, y in tasks]
+  loss = _torch_nll(kname, mlp, mname, model_t, xs, ys, torch)
+  loss.backward()
+  kern = getattr(o, kname + ('_mlp' if mlp else ''))
+  val, g = o.nll_value_and_grad(getattr(o, mname), kern, _params(model), ds, WF)
+  assert abs(val - loss.item()) <= 1e-10 * abs(val)
+
+  def grad_tree(t):
+    if isinstance(t, dict):
+      return {k: grad_tree(v) for k, v in t.items()}
+    return np.zeros(t.shape) if t.grad is None else t.grad.numpy()
+  gt = grad_tree(model_t)
+  np.testing.assert_allclose(helpers.flatten(g), helpers.flatten(gt), rtol=1e-8, atol=1e-10)
+
+
+# --- (4) identities the reference's tests assert ---------------------------------------------
+@pytest.mark.parametrize('kname', helpers.KERNELS)
+def test_svd_nll_equals_cholesky_nll(kname):  # objectives_test.py:168,185
+  rng = np.random.default_rng(7)
+  model = helpers.make_model(rng, 'constant', False, 2)
+  ds = {i: o.SubDataset(*helpers.synthetic_task(rng, 20, 2)) for i in range(3)}
+  a = o.neg_log_marginal_likelihood(o.constant, getattr(o, kname), _params(model), ds, WF)
+  b = o.neg_log_marginal_likelihood(o.constant, getattr(o, kname), _params(model), ds, WF, use_cholesky=False)
+  assert abs(a / b - 1) < 1e-9
+
+
+@pytest.mark.parametrize('kname', helpers.KERNELS)
+@pytest.mark.parametrize('mlp', [False, True])
+def test_gram_shape_symmetry_psd(kname, mlp):  # kernel_test.py:77-152
+  rng = np.random.default_rng(3)
+  model = helpers.make_model(rng, 'zero', mlp, 4)
+  kern = getattr(o, kname + ('_mlp' if mlp else ''))
+  x1, x2 = rng.uniform(size=(5, 4)), rng.uniform(size=(7, 4))
+  assert kern(_params(model), x1, x2, warp_func=WF).shape == (5, 7)
+  k = kern(_params(model), x1, warp_func=WF)
+  np.testing.assert_allclose(k, k.T, atol=1e-12)
+  assert np.linalg.eigvalsh(k).min() > -1e-10
+  np.testing.assert_allclose(kern(_params(model), x1, warp_func=WF, diag=True), np.diag(k), rtol=1e-12)
+
+
+def test_predict_self_consistency():  # gp_test.py:151-207
+  rng = np.random.default_rng(4)
+  model = helpers.make_model(rng, 'constant', False, 2)
+  x, y = helpers.synthetic_task(rng, 30, 2)
+  xq = rng.uniform(size=(9, 2))
+  p = _params(model)
+  mu, var = o.predict(o.constant, o.matern52, p, x, y, xq, WF)
+  mu2, cov = o.predict(o.constant, o.matern52, p, x, y, xq, WF, full_cov=True)
+  assert mu.shape == (9, 1) and var.shape == (9, 1) and cov.shape == (9, 9)
+  np.testing.assert_allclose(np.diag(cov), var[:, 0], rtol=1e-9, atol=1e-12)
+  ds = {0: o.SubDataset(x, y)}
+  _, var_n = o.gp_predict_postprocess(p, ds, mu, var, WF, False, True, True)
+  noise = float(o.default_softplus(model['noise_variance']))
+  np.testing.assert_allclose(var_n, var + noise)
+  # unbiased scaling counts every non-aligned sub-dataset (gp.py:615-619)
+  ds3 = {0: o.SubDataset(x, y), 1: o.SubDataset(x, y), 2: o.SubDataset(x, y, aligned=1)}
+  _, var_s = o.gp_predict_postprocess(p, ds3, mu, var, WF, False, False, True)
+  np.testing.assert_allclose(var_s, var * 2.0)
+  # prior branch (gp.py:275-282) and near-noiseless interpolation
+  mu_p, var_p = o.predict(o.constant, o.matern52, p, None, None, xq, WF)
+  np.testing.assert_allclose(mu_p, np.full((9, 1), 0.4))
+  np.testing.assert_allclose(var_p, np.full((9, 1), float(o.default_softplus(model['signal_variance']))))
+  model2 = dict(model); model2['noise_variance'] = np.array(-40.0)
+  ys = np.sin(x.sum(axis=1, keepdims=True))  # smooth target: the jitter-only GP interpolates it
+  mu_i, var_i = o.predict(o.constant, o.matern32, _params(model2), x, ys, x[:5], WF)
+  np.testing.assert_allclose(mu_i, ys[:5], atol=1e-4)
+  assert (np.abs(var_i) < 1e-4).all()
+
+
+def test_acquisition_properties():
+  mu = np.array([[0.1], [0.5], [-0.3]]); sd = np.array([[0.2], [1e-9], [0.7]])
+  ei = o.expected_improvement_sub(mu, sd, 0.2)
+  assert (ei >= 0).all()
+  # acfun.py:108-110 is (phi(g) - g (1 - Phi(g))) sd with g = (target - mu)/sd : as sd -> 0 it
+  # tends to max(mu - target, 0)... for the *minimising* sign convention of gamma:
+  assert abs(ei[1, 0] - 0.0) < 1e-6 or abs(ei[1, 0] - 0.3) < 1e-6
+  np.testing.assert_allclose(o.ucb_sub(mu, sd, 2.0) + o.ucb_sub(mu, sd, 4.0), 2 * o.ucb_sub(mu, sd, 3.0))
+  np.testing.assert_allclose(o.probability_of_improvement_sub(mu, sd, 0.2), -(0.2 - mu) / sd)
+  assert o.ei_callback_default({}, 0) == 0.0  # acfun.py:146-147
+
+
+def test_retrieve_params_and_selection_rules():
+  p = o.GPParams(model={'lengthscale': np.array([0.0]), 'constant': np.array(2.0)})
+  with pytest.raises(ValueError):
+    o.retrieve_params(p, ['signal_variance'])
+  ls, c = o.retrieve_params(p, ['lengthscale', 'constant'], WF)
+  np.testing.assert_allclose(ls, np.log(2.0) + 1e-10)
+  assert c == 2.0
+  assert o.retrieve_params(p, ['lengthscale'], None)[0] == 0.0
+  ds = {0: o.SubDataset(np.zeros((0, 2)), np.zeros((0, 1))), 1: o.SubDataset(np.ones((3, 2)), np.ones((3, 1)), aligned=1)}
+  assert o.neg_log_marginal_likelihood(o.zero, o.squared_exponential,
+                                       o.GPParams(model=helpers.make_model(np.random.default_rng(0), 'zero', False, 2)), ds, WF) == 0.
+
+
+# --- (5) hyperbo/basics/linalg_test.py:57-110 -- NumPy-seeded SPD systems ---------------------
+def test_reference_linalg_test_inputs():
+  np.random.seed(1)
+  dim, noise = 10, 1e-3
+  for _ in range(10):
+    matrix = np.random.randn(dim, dim)
+    spd = matrix.T.dot(matrix) + noise * np.eye(dim)
+    x = np.random.randn(dim)
+    chol, kinvx = o.solve_linear_system(spd, x[:, None])
+    np.testing.assert_allclose(chol @ chol.T, spd, rtol=1e-10, atol=1e-10)
+    np.testing.assert_allclose(spd @ kinvx[:, 0], x, rtol=1e-6, atol=1e-8)
+    # the custom VJP of x^T K^-1 x (linalg.py:157-167): dK = -outer(K^-1 x, K^-1 x) vs central FD
+    vec = np.random.randn(dim, dim); vec = 0.5 * (vec + vec.T); vec /= np.linalg.norm(vec)
+    eps = 1e-5
+    f = lambda m: float(x @ np.linalg.solve(m, x))
+    num = (f(spd + eps / 2 * vec) - f(spd - eps / 2 * vec)) / eps
+    exact = float(np.vdot(-np.outer(kinvx, kinvx), vec))
+    assert abs(num - exact) <= 1e-4 * abs(exact) + 1e-6
+  # non-PD -> NaN, never an exception (JAX cholesky semantics)
+  chol, sol = o.solve_linear_system(-np.eye(3), np.ones((3, 1)))
+  assert np.isnan(chol).all() and np.isnan(sol).all()
+
+
+# --- golden fixtures stay reproducible ---------------------------------------------------------
+def test_golden_fixtures_reproduce():
+  import importlib.util
+  spec = importlib.util.spec_from_file_location('make_golden', os.path.join(GOLDEN, 'make_golden.py'))
+  mg = importlib.util.module_from_spec(spec)
+  spec.loader.exec_module(mg)
+  for case in mg.CASES:
+    name, out = mg.build(case)
+    ref = np.load(os.path.join(GOLDEN, name + '.npz'))
+    for k in out:
+      np.testing.assert_allclose(out[k], ref[k], rtol=1e-9, atol=1e-11, err_msg=f'{name}:{k}')
+
+
+def test_cpu_baseline_port_matches_oracle():
+  from oracle import cpu_baseline
+  rng = np.random.default_rng(9)
+  d = 5
+  x, y = helpers.synthetic_task(rng, 300, d)
+  raw = {'lengthscale': helpers.inv_softplus(np.full(d, 0.6)), 'signal_variance': helpers.inv_softplus(1.0),
+         'noise_variance': helpers.inv_softplus(1e-2), 'constant': np.array(0.2)}
+  v, g = cpu_baseline.nll_and_grad_se_ard_constant(x, y, raw)
+  vo, go = o.nll_value_and_grad(o.constant, o.squared_exponential, o.GPParams(model=raw), {0: o.SubDataset(x, y)}, WF)
+  assert abs(v - vo) <= 1e-10 * abs(vo)
+  for k in go:
+    np.testing.assert_allclose(g[k], go[k], rtol=1e-6, atol=1e-8)
