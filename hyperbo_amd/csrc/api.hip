@@ -58,6 +58,9 @@ static int fail(hbo_ctx* ctx, int code, const std::string& msg) {
 }
 static inline size_t esize(int dtype) { return dtype == HBO_F64 ? 8 : 4; }
 static inline int round_up(int64_t n, int q) { return (int)(((n + q - 1) / q) * q); }
+// leading dimension: padded extent + 128 bytes, so that rows do not sit at a power-of-two stride
+// (a 64 KiB row stride maps every row of a k-contiguous tile onto the same L2/HBM channel)
+static inline int64_t padded_ld(int64_t extent, int dtype) { return extent + 128 / (int64_t)esize(dtype); }
 
 // ---- profiling ---------------------------------------------------------------------------
 struct ProfScope {
@@ -307,8 +310,8 @@ static void run_trtri(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks
     const int ngroups = (max_nblk + 2 * s - 1) / (2 * s);
     GemmArgs a = {}; a.tasks = d_tasks; a.p0 = s;
     { ProfScope ps(c, "trtri_gemm", 2);
-      a.mode = GEMM_TRTRI_A; launch_gemm(dtype, a, dim3(s, ngroups * s, ntasks), st);
-      a.mode = GEMM_TRTRI_B; launch_gemm(dtype, a, dim3(s, ngroups * s, ntasks), st); }
+      a.mode = GEMM_TRTRI_A; launch_gemm(dtype, a, dim3(ngroups * s, s, ntasks), st);
+      a.mode = GEMM_TRTRI_B; launch_gemm(dtype, a, dim3(ngroups * s, s, ntasks), st); }
   }
 }
 static void run_lauum(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, int max_nblk) {
@@ -319,7 +322,7 @@ static void run_lauum(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks
 
 // ---- datasets ----------------------------------------------------------------------------
 struct TaskHost {
-  int64_t n = 0; int m = 0; int npad = 0, nblk = 0;
+  int64_t n = 0; int m = 0; int npad = 0, nblk = 0; int64_t ld = 0;
   void* X = nullptr; void* ysum = nullptr;
   void* A = nullptr; void* W = nullptr; void* S = nullptr; void* svec = nullptr;
   FeatBuf feat;
@@ -366,7 +369,7 @@ extern "C" int hbo_dataset_create(hbo_ctx* c, int dtype, int input_dim, const hb
     if (tk.m <= 0 || !tk.x || !tk.y) { hbo_dataset_free(c, ds); return fail(c, HBO_ERR_ARG, "hbo_dataset_create: bad task"); }
     TaskHost* t = new TaskHost();
     ds->tasks.push_back(t);
-    t->n = tk.n; t->m = tk.m; t->npad = round_up(tk.n, HBO_TILE); t->nblk = t->npad / HBO_TILE;
+    t->n = tk.n; t->m = tk.m; t->npad = round_up(tk.n, HBO_TILE); t->nblk = t->npad / HBO_TILE; t->ld = padded_ld(t->npad, dtype);
     // ysum on the host (sum over columns, in double then cast)
     std::vector<unsigned char> ys((size_t)tk.n * es);
     for (int64_t i = 0; i < tk.n; ++i) {
@@ -390,7 +393,7 @@ extern "C" int hbo_dataset_create(hbo_ctx* c, int dtype, int input_dim, const hb
 
 static int ensure_task_workspace(hbo_ctx* c, int dtype, TaskHost* t, bool need_S, int naug_cols) {
   const size_t es = esize(dtype);
-  const size_t ld = t->npad;
+  const size_t ld = (size_t)t->ld;
   if (!t->A) HIPCHK(c, hipMalloc(&t->A, (size_t)(t->npad + HBO_TILE) * ld * es));
   if (!t->W) { HIPCHK(c, hipMalloc(&t->W, (size_t)t->npad * ld * es)); HIPCHK(c, hipMemsetAsync(t->W, 0, (size_t)t->npad * ld * es, c->stream)); }
   if (need_S && !t->S) HIPCHK(c, hipMalloc(&t->S, (size_t)t->npad * ld * es));
@@ -401,7 +404,7 @@ static int ensure_task_workspace(hbo_ctx* c, int dtype, TaskHost* t, bool need_S
 static void fill_desc(TaskDesc& d, TaskHost* t, const hbo_model* m, int dtype) {
   memset(&d, 0, sizeof d);
   d.A = t->A; d.W = t->W; d.S = t->S; d.X = t->X; d.ysum = t->ysum; d.svec = t->svec;
-  d.n = (int)t->n; d.npad = t->npad; d.nblk = t->nblk; d.m = t->m; d.ld = t->npad;
+  d.n = (int)t->n; d.npad = t->npad; d.nblk = t->nblk; d.m = t->m; d.ld = t->ld;
   const void* last = needs_mlp(m) ? t->feat.acts[m->n_layers - 1] : nullptr;
   d.F = m->kernel_uses_mlp ? last : t->X;
   d.fdim = feature_dim(m);
@@ -541,7 +544,7 @@ extern "C" int hbo_factor(hbo_ctx* c, const hbo_model* m, const void* x, int64_t
   hbo_cache* k = new hbo_cache();
   k->dtype = dtype; k->D = m->input_dim; k->m = mcols;
   TaskHost* t = k->t = new TaskHost();
-  t->n = n; t->m = mcols; t->npad = round_up(n, HBO_TILE); t->nblk = t->npad / HBO_TILE;
+  t->n = n; t->m = mcols; t->npad = round_up(n, HBO_TILE); t->nblk = t->npad / HBO_TILE; t->ld = padded_ld(t->npad, dtype);
   auto bail = [&](int code) { hbo_cache_free(c, k); return code; };
 #define HIPCHK_K(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) { c->err = std::string(#call " failed: ") + hipGetErrorString(e__); return bail(HBO_ERR_HIP); } } while (0)
   HIPCHK_K(hipMalloc(&t->X, (size_t)n * m->input_dim * es));
@@ -566,7 +569,7 @@ extern "C" int hbo_factor(hbo_ctx* c, const hbo_model* m, const void* x, int64_t
   { ProfScope ps(c, "features", 1);
     if (needs_mlp(m)) run_mlp(c, m, t->X, n, t->feat.acts.data());
     launch_aug_rows(dtype, k->d_desc, 1, t->npad, c->d_model, mcols, 0, st); }
-  HIPCHK_K(hipMemcpyAsync(k->resid, (char*)t->A + (size_t)t->npad * t->npad * es, (size_t)mcols * t->npad * es, hipMemcpyDeviceToDevice, st));
+  HIPCHK_K(hipMemcpy2DAsync(k->resid, (size_t)t->npad * es, (char*)t->A + (size_t)t->npad * t->ld * es, (size_t)t->ld * es, (size_t)t->npad * es, mcols, hipMemcpyDeviceToDevice, st));
   { ProfScope ps(c, "gram", 1);
     GramArgs g = {}; g.tasks = k->d_desc; g.fdim = feature_dim(m); g.symmetric = 1; g.padded = 1;
     launch_gram(dtype, g, c->d_model, dim3(t->nblk, t->nblk, 1), st); }
@@ -600,7 +603,7 @@ extern "C" int hbo_cache_export(hbo_ctx* c, hbo_cache* k, void* chol_out, void* 
     else {
       void* tmp = nullptr;
       HIPCHK(c, hipMalloc(&tmp, (size_t)n * n * es));
-      launch_extract_lower(k->dtype, t->A, t->npad, n, tmp, c->stream);
+      launch_extract_lower(k->dtype, t->A, t->ld, n, tmp, c->stream);
       hipError_t e = hipMemcpyAsync(chol_out, tmp, (size_t)n * n * es, hipMemcpyDeviceToHost, c->stream);
       if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
       hipFree(tmp);
@@ -639,6 +642,7 @@ static int posterior(hbo_ctx* c, const hbo_model* m, hbo_cache* k, const void* x
   const int64_t CH = 65536;  // candidates per pass (bounds the cross-Gram workspace)
   const int64_t mc_max = std::min<int64_t>(M, CH);
   const int mpad_max = round_up(mc_max, HBO_TILE);
+  const int64_t ldq_max = padded_ld(mpad_max, dtype);
   void *d_xq = nullptr, *d_mu0 = nullptr, *d_kd = nullptr, *d_mu = nullptr, *d_var = nullptr, *d_acq = nullptr;
   void *d_K = nullptr, *d_colsq = nullptr, *d_V = nullptr, *d_Kqq = nullptr, *d_cov = nullptr;
   FeatBuf fq;
@@ -655,9 +659,9 @@ static int posterior(hbo_ctx* c, const hbo_model* m, hbo_cache* k, const void* x
   if (needs_mlp(m)) { rc = fq.ensure(c, m, mc_max); if (rc) { cleanup(); return rc; } }
   TaskHost* t = k ? k->t : nullptr;
   if (k) {
-    HIPCHK_P(hipMalloc(&d_K, (size_t)t->npad * mpad_max * es));
-    HIPCHK_P(hipMalloc(&d_colsq, (size_t)t->nblk * mpad_max * es));
-    if (full_cov) HIPCHK_P(hipMalloc(&d_V, (size_t)t->npad * mpad_max * es));
+    HIPCHK_P(hipMalloc(&d_K, (size_t)t->npad * ldq_max * es));
+    HIPCHK_P(hipMalloc(&d_colsq, (size_t)t->nblk * ldq_max * es));
+    if (full_cov) HIPCHK_P(hipMalloc(&d_V, (size_t)t->npad * ldq_max * es));
   }
   if (full_cov) { HIPCHK_P(hipMalloc(&d_Kqq, (size_t)M * M * es)); HIPCHK_P(hipMalloc(&d_cov, (size_t)M * M * es)); }
   const bool bad = k && k->info != INT_MAX;
@@ -665,6 +669,7 @@ static int posterior(hbo_ctx* c, const hbo_model* m, hbo_cache* k, const void* x
   for (int64_t q0 = 0; q0 < M; q0 += CH) {
     const int64_t mc = std::min<int64_t>(CH, M - q0);
     const int mpad = round_up(mc, HBO_TILE);
+    const int64_t ldq = padded_ld(mpad, dtype);
     HIPCHK_P(hipMemcpyAsync(d_xq, (const char*)xq + (size_t)q0 * m->input_dim * es, (size_t)mc * m->input_dim * es, hipMemcpyHostToDevice, st));
     const void* fq_last = nullptr;
     { ProfScope ps(c, "features", 1);
@@ -683,7 +688,7 @@ static int posterior(hbo_ctx* c, const hbo_model* m, hbo_cache* k, const void* x
         HIPCHK_P(hipMemcpyAsync((char*)var_out + (size_t)q0 * es, d_kd, (size_t)mc * es, hipMemcpyDeviceToHost, st));
       }
       if (acq_out) {   // acquisition on the prior
-        PostArgs pa = {}; pa.Kxq = nullptr; pa.n = 0; pa.nblk = 0; pa.ldq = mpad; pa.alpha = nullptr; pa.colsq = nullptr;
+        PostArgs pa = {}; pa.Kxq = nullptr; pa.n = 0; pa.nblk = 0; pa.ldq = ldq; pa.alpha = nullptr; pa.colsq = nullptr;
         pa.kdiag = d_kd; pa.muq = d_mu0; pa.acq_out = d_acq; pa.M = mc; pa.acq_id = acq_id; pa.param = param; pa.add_noise = add_noise; pa.scale = scale;
         launch_post_epilogue(dtype, pa, st);
         HIPCHK_P(hipMemcpyAsync((char*)acq_out + (size_t)q0 * es, d_acq, (size_t)mc * es, hipMemcpyDeviceToHost, st));
@@ -692,14 +697,14 @@ static int posterior(hbo_ctx* c, const hbo_model* m, hbo_cache* k, const void* x
       continue;
     }
     { ProfScope ps(c, "cross_gram", 1);
-      GramArgs g = {}; g.x1 = k->h_desc.F; g.x2 = Fq; g.out = d_K; g.n1 = t->n; g.n2 = mc; g.ldo = mpad;
+      GramArgs g = {}; g.x1 = k->h_desc.F; g.x2 = Fq; g.out = d_K; g.n1 = t->n; g.n2 = mc; g.ldo = ldq;
       g.n1pad = t->npad; g.n2pad = mpad; g.fdim = fdim; g.symmetric = 0; g.padded = 1;
       launch_gram(dtype, g, c->d_model, dim3(mpad / HBO_TILE, t->nblk, 1), st); }
     { ProfScope ps(c, "post_gemm", 1);
-      GemmArgs a = {}; a.tasks = k->d_desc; a.mode = GEMM_POST; a.B = d_K; a.ldb = mpad; a.V = full_cov ? d_V : nullptr; a.colsq = d_colsq;
+      GemmArgs a = {}; a.tasks = k->d_desc; a.mode = GEMM_POST; a.B = d_K; a.ldb = ldq; a.V = full_cov ? d_V : nullptr; a.colsq = d_colsq;
       launch_gemm(dtype, a, dim3(mpad / HBO_TILE, t->nblk, 1), st); }
     { ProfScope ps(c, "post_epilogue", 1);
-      PostArgs pa = {}; pa.Kxq = d_K; pa.ldq = mpad; pa.npad = t->npad; pa.n = (int)t->n; pa.nblk = t->nblk; pa.alpha = t->svec; pa.colsq = d_colsq;
+      PostArgs pa = {}; pa.Kxq = d_K; pa.ldq = ldq; pa.npad = t->npad; pa.n = (int)t->n; pa.nblk = t->nblk; pa.alpha = t->svec; pa.colsq = d_colsq;
       pa.kdiag = d_kd; pa.muq = d_mu0; pa.mu_out = d_mu; pa.var_out = d_var; pa.acq_out = d_acq; pa.M = mc;
       pa.acq_id = acq_id; pa.param = param; pa.add_noise = add_noise; pa.scale = scale;
       launch_post_epilogue(dtype, pa, st); }
@@ -707,7 +712,7 @@ static int posterior(hbo_ctx* c, const hbo_model* m, hbo_cache* k, const void* x
     if (full_cov) {
       GramArgs g = {}; g.x1 = Fq; g.x2 = Fq; g.out = d_Kqq; g.n1 = mc; g.n2 = mc; g.ldo = mc; g.fdim = fdim;
       launch_gram(dtype, g, c->d_model, dim3((unsigned)((mc + 127) / 128), (unsigned)((mc + 127) / 128), 1), st);
-      launch_fullcov(dtype, d_V, mpad, t->npad, d_Kqq, mc, d_cov, st);
+      launch_fullcov(dtype, d_V, ldq, t->npad, d_Kqq, mc, d_cov, st);
       if (var_out) HIPCHK_P(hipMemcpyAsync(var_out, d_cov, (size_t)M * M * es, hipMemcpyDeviceToHost, st));
     } else if (var_out) {
       HIPCHK_P(hipMemcpyAsync((char*)var_out + (size_t)q0 * es, d_var, (size_t)mc * es, hipMemcpyDeviceToHost, st));
@@ -822,7 +827,7 @@ extern "C" int hbo_spd_solve(hbo_ctx* c, int dtype, const void* a, int64_t n, co
   const size_t es = esize(dtype);
   hipStream_t st = c->stream;
   TaskHost* t = new TaskHost();
-  t->n = n; t->m = b ? mcols : 1; t->npad = round_up(n, HBO_TILE); t->nblk = t->npad / HBO_TILE;
+  t->n = n; t->m = b ? mcols : 1; t->npad = round_up(n, HBO_TILE); t->nblk = t->npad / HBO_TILE; t->ld = padded_ld(t->npad, dtype);
   void *d_a = nullptr, *d_b = nullptr, *d_tmp = nullptr; TaskDesc* d_desc = nullptr; int* d_info = nullptr;
   auto cleanup = [&]() { free_task(t); for (void* p : {d_a, d_b, d_tmp, (void*)d_desc, (void*)d_info}) if (p) hipFree(p); };
 #define HIPCHK_S(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) { c->err = std::string(#call " failed: ") + hipGetErrorString(e__); cleanup(); return HBO_ERR_HIP; } } while (0)
@@ -831,10 +836,10 @@ extern "C" int hbo_spd_solve(hbo_ctx* c, int dtype, const void* a, int64_t n, co
   HIPCHK_S(hipMalloc(&d_a, (size_t)n * n * es));
   HIPCHK_S(hipMemcpyAsync(d_a, a, (size_t)n * n * es, hipMemcpyHostToDevice, st));
   if (b) { HIPCHK_S(hipMalloc(&d_b, (size_t)n * mcols * es)); HIPCHK_S(hipMemcpyAsync(d_b, b, (size_t)n * mcols * es, hipMemcpyHostToDevice, st)); }
-  launch_fill_spd(dtype, d_a, n, t->A, t->npad, t->npad, st);
-  launch_set_aug(dtype, d_b, n, b ? mcols : 0, t->A, t->npad, t->npad, st);
+  launch_fill_spd(dtype, d_a, n, t->A, t->ld, t->npad, st);
+  launch_set_aug(dtype, d_b, n, b ? mcols : 0, t->A, t->ld, t->npad, st);
   TaskDesc h; memset(&h, 0, sizeof h);
-  h.A = t->A; h.W = t->W; h.S = t->S; h.svec = t->svec; h.n = (int)n; h.npad = t->npad; h.nblk = t->nblk; h.m = t->m; h.ld = t->npad;
+  h.A = t->A; h.W = t->W; h.S = t->S; h.svec = t->svec; h.n = (int)n; h.npad = t->npad; h.nblk = t->nblk; h.m = t->m; h.ld = t->ld;
   HIPCHK_S(hipMalloc((void**)&d_desc, sizeof h));
   HIPCHK_S(hipMalloc((void**)&d_info, sizeof(int)));
   int inf = INT_MAX;
@@ -851,7 +856,7 @@ extern "C" int hbo_spd_solve(hbo_ctx* c, int dtype, const void* a, int64_t n, co
   HIPCHK_S(hipMalloc(&d_tmp, (size_t)n * n * es));
   std::vector<unsigned char> hchol;
   if (chol_out || logdet_half) {
-    launch_extract_lower(dtype, t->A, t->npad, n, d_tmp, st);
+    launch_extract_lower(dtype, t->A, t->ld, n, d_tmp, st);
     void* dst = chol_out;
     if (!dst) { hchol.resize((size_t)n * n * es); dst = hchol.data(); }
     HIPCHK_S(hipMemcpyAsync(dst, d_tmp, (size_t)n * n * es, hipMemcpyDeviceToHost, st));
@@ -859,7 +864,7 @@ extern "C" int hbo_spd_solve(hbo_ctx* c, int dtype, const void* a, int64_t n, co
     if (logdet_half) { double s = 0; for (int64_t i = 0; i < n; ++i) s += log(host_elem(dst, dtype, i * n + i)); *logdet_half = s; }
   }
   if (inv_out) {
-    launch_symmetrize_from_lower(dtype, t->S, t->npad, n, d_tmp, st);
+    launch_symmetrize_from_lower(dtype, t->S, t->ld, n, d_tmp, st);
     HIPCHK_S(hipMemcpyAsync(inv_out, d_tmp, (size_t)n * n * es, hipMemcpyDeviceToHost, st));
   }
   HIPCHK_S(hipStreamSynchronize(st));

@@ -29,17 +29,34 @@ template <> struct Mma<float> {
 constexpr int NB = HBO_TILE;   // 128
 constexpr int LS = NB + 1;     // LDS row stride of the potf2 block (odd -> conflict-free columns)
 
+__device__ __forceinline__ double readlane_t(double v, int lane) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_readlane(lo, lane);
+  hi = __builtin_amdgcn_readlane(hi, lane);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ float readlane_t(float v, int lane) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+
+// LDS-resident factorisation of one 128x128 diagonal block, blocked by 16 columns:
+//   (A) wave 0 factors the 16x16 leaf in registers (lane = row, cross-lane broadcasts via readlane),
+//   (B) one thread per remaining row solves its 16 unknowns against the leaf (forward substitution),
+//   (C) all four waves apply the rank-16 update to the trailing tiles with MFMA.
+// Finally the eight leaf inverses are written to W (used by trsm_kernel and the trtri base case).
 template <typename T>
 __global__ __launch_bounds__(256) void potf2_kernel(const TaskDesc* tasks, int p, int* info) {
+  typedef typename Mma<T>::acc_t acc_t;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   T* sL = reinterpret_cast<T*>(smem);       // [128][129]
-  T* sD = sL + NB * LS;                     // [128] diagonal of L
+  T* sDinv = sL + NB * LS;                  // [128] 1 / diag(L)
   const TaskDesc& t = tasks[blockIdx.x];
   if (p >= t.nblk) return;
   const int64_t ld = t.ld;
   T* Ab = static_cast<T*>(t.A) + (int64_t)p * NB * ld + (int64_t)p * NB;
   T* Wb = static_cast<T*>(t.W) + (int64_t)p * NB * ld + (int64_t)p * NB;
-  const int tid = threadIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, lq = lane >> 4;
 
   for (int idx = tid; idx < NB * NB; idx += 256) {
     const int r = idx >> 7, c = idx & 127;
@@ -47,25 +64,75 @@ __global__ __launch_bounds__(256) void potf2_kernel(const TaskDesc* tasks, int p
   }
   __syncthreads();
 
-  const int r = tid & 127, h = tid >> 7;
-  bool bad_seen = false;
-  for (int j = 0; j < NB; ++j) {
-    T d = sL[j * LS + j];
-    if (!(d > (T)0)) {  // not positive definite (or NaN): propagate NaN like jax's cholesky
-      if (!bad_seen && tid == 0) atomicMin(&info[blockIdx.x], p * NB + j + 1);
-      bad_seen = true;
-      d = (T)NAN;
-    }
-    const T ljj = sqrt(d);
-    const T inv = (T)1 / ljj;
-    if (tid < NB) {
-      if (tid > j) sL[tid * LS + j] *= inv;
-      else if (tid == j) sD[j] = ljj;
+  for (int jb = 0; jb < 8; ++jb) {
+    const int o = jb * 16;
+    // ---- (A) leaf Cholesky, wave 0, lanes 0..15 hold one row each --------------------------
+    if (wave == 0) {
+      T a[16];
+      const int row = o + l15;
+#pragma unroll
+      for (int c = 0; c < 16; ++c) a[c] = (lane < 16 && c <= l15) ? sL[row * LS + o + c] : (T)0;
+      T myinv = (T)0;
+      int bad_col = -1;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        T d = readlane_t(a[j], j);
+        if (!(d > (T)0)) {   // not PD (or NaN): propagate NaN like jax.scipy.linalg.cholesky
+          if (bad_col < 0) bad_col = j;
+          d = (T)NAN;
+        }
+        const T inv = rsqrt(d);
+        if (l15 == j) { a[j] = d * inv; myinv = inv; }
+        else a[j] = a[j] * inv;
+#pragma unroll
+        for (int c = j + 1; c < 16; ++c) {
+          const T lcj = readlane_t(a[j], c);
+          a[c] -= a[j] * lcj;
+        }
+      }
+      if (bad_col >= 0 && lane == 0) atomicMin(&info[blockIdx.x], p * NB + o + bad_col + 1);
+      if (lane < 16) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c)
+          if (c <= l15) sL[row * LS + o + c] = a[c];
+        sDinv[row] = myinv;
+      }
     }
     __syncthreads();
-    if (r > j) {
-      const T lr = sL[r * LS + j];
-      for (int c = j + 1 + h; c <= r; c += 2) sL[r * LS + c] -= lr * sL[c * LS + j];
+    // ---- (B) panel rows below the leaf: x L_leaf^T = a -------------------------------------
+    if (tid < NB && tid >= o + 16) {
+      T x[16];
+#pragma unroll
+      for (int c = 0; c < 16; ++c) {
+        T s = sL[tid * LS + o + c];
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+          if (k < c) s -= x[k] * sL[(o + c) * LS + o + k];
+        x[c] = s * sDinv[o + c];
+      }
+#pragma unroll
+      for (int c = 0; c < 16; ++c) sL[tid * LS + o + c] = x[c];
+    }
+    __syncthreads();
+    // ---- (C) trailing update C[I][J] -= X_I X_J^T on MFMA -----------------------------------
+    const int m = 7 - jb;               // remaining 16-blocks
+    const int ntiles = m * (m + 1) / 2;
+    for (int tix = wave; tix < ntiles; tix += 4) {
+      int ii = 0;
+      while ((ii + 1) * (ii + 2) / 2 <= tix) ++ii;
+      const int jj = tix - ii * (ii + 1) / 2;
+      const int I = jb + 1 + ii, J = jb + 1 + jj;
+      acc_t acc;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[r] = sL[(I * 16 + Mma<T>::crow(lane, r)) * LS + J * 16 + l15];
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        const T af = -sL[(I * 16 + l15) * LS + o + kk * 4 + lq];
+        const T bf = sL[(J * 16 + l15) * LS + o + kk * 4 + lq];
+        acc = Mma<T>::mma(af, bf, acc);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sL[(I * 16 + Mma<T>::crow(lane, r)) * LS + J * 16 + l15] = acc[r];
     }
     __syncthreads();
   }
@@ -73,8 +140,7 @@ __global__ __launch_bounds__(256) void potf2_kernel(const TaskDesc* tasks, int p
   // write L (lower, zeros above the diagonal inside the block)
   for (int idx = tid; idx < NB * NB; idx += 256) {
     const int rr = idx >> 7, c = idx & 127;
-    T v = (c < rr) ? sL[rr * LS + c] : (c == rr ? sD[rr] : (T)0);
-    Ab[(int64_t)rr * ld + c] = v;
+    Ab[(int64_t)rr * ld + c] = (c <= rr) ? sL[rr * LS + c] : (T)0;
   }
   // inverses of the eight 16x16 diagonal leaves: thread = (leaf b, column c), forward substitution
   if (tid < NB) {
@@ -86,7 +152,7 @@ __global__ __launch_bounds__(256) void potf2_kernel(const TaskDesc* tasks, int p
 #pragma unroll
       for (int k = 0; k < 16; ++k)
         if (k < i) s -= sL[(b * 16 + i) * LS + b * 16 + k] * w[k];
-      w[i] = s / sD[b * 16 + i];
+      w[i] = s * sDinv[b * 16 + i];
     }
 #pragma unroll
     for (int i = 0; i < 16; ++i) Wb[(int64_t)(b * 16 + i) * ld + b * 16 + c] = w[i];

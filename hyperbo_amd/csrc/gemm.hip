@@ -35,9 +35,13 @@ template <> struct Mma<float> {
 // LDS strides (elements).  k-contiguous operand: [128][SKC]; m-contiguous operand: [BKE][SMC].
 //   f64: SKC = 18 (== 2 mod 32 -> conflict-free ds_read_b64 fragment reads), f32: SKC = 36.
 //   SMC = 144 (== 16 mod 32) for both.  Both layouts take 18432 bytes per operand stage.
+#ifdef HBO_SKC17
+template <typename T> __device__ __host__ constexpr int skc() { return sizeof(T) == 8 ? 17 : 36; }
+#else
 template <typename T> __device__ __host__ constexpr int skc() { return sizeof(T) == 8 ? 18 : 36; }
+#endif
 constexpr int SMC = 144;
-constexpr int OPERAND_BYTES = 18432;
+constexpr int OPERAND_BYTES = 18432;  // >= 128*skc*sizeof(T) and BKE*SMC*sizeof(T)
 constexpr int GEMM_LDS_BYTES = 4 * OPERAND_BYTES;  // A,B x 2 stages
 
 template <typename T, bool KC>
@@ -50,14 +54,14 @@ __device__ __forceinline__ void stage_load(const T* __restrict__ g, int64_t ld, 
     const int c = tid & 7, row = tid >> 3;
     const T* p = g + (int64_t)row * ld + (int64_t)kt * BKE + c * VEC;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) r[q] = *reinterpret_cast<const vec_t*>(p + (int64_t)(32 * q) * ld);
+    for (int q = 0; q < 4; ++q) r[q] = gld(reinterpret_cast<const vec_t*>(p + (int64_t)(32 * q) * ld));
   } else {
     constexpr int CPR = 128 / VEC;  // 16-byte chunks per 128-element row
     constexpr int RPP = 256 / CPR;  // k rows per pass
     const int c = tid % CPR, kr = tid / CPR;
     const T* p = g + ((int64_t)kt * BKE + kr) * ld + c * VEC;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) r[q] = *reinterpret_cast<const vec_t*>(p + (int64_t)(RPP * q) * ld);
+    for (int q = 0; q < 4; ++q) r[q] = gld(reinterpret_cast<const vec_t*>(p + (int64_t)(RPP * q) * ld));
   }
 }
 
@@ -68,7 +72,14 @@ __device__ __forceinline__ void stage_store(T* s, const typename Mma<T>::vec_t (
   if (KC) {
     const int c = tid & 7, row = tid >> 3;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) *reinterpret_cast<vec_t*>(s + (row + 32 * q) * skc<T>() + c * VEC) = r[q];
+    for (int q = 0; q < 4; ++q) {
+      if ((skc<T>() * sizeof(T)) % 16 == 0) {
+        *reinterpret_cast<vec_t*>(s + (row + 32 * q) * skc<T>() + c * VEC) = r[q];
+      } else {
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) s[(row + 32 * q) * skc<T>() + c * VEC + e] = r[q][e];
+      }
+    }
   } else {
     constexpr int CPR = 128 / VEC;
     constexpr int RPP = 256 / CPR;
@@ -105,7 +116,7 @@ __device__ __forceinline__ bool decode_job(const GemmArgs& g, TileJob<T>& j) {
     case GEMM_SYRK: {
       const int c = g.c_lo + (int)blockIdx.y;
       const int r = g.c_lo + (int)blockIdx.x;
-      const int nrt = nblk + (g.aug ? 1 : 0);
+      const int nrt = nblk + ((g.aug & 1) ? 1 : 0);
       const int chi = g.c_hi < nblk ? g.c_hi : nblk;
       if (c >= chi || r < c || r >= nrt) return false;
       T* Am = static_cast<T*>(t.A);
@@ -115,14 +126,22 @@ __device__ __forceinline__ bool decode_job(const GemmArgs& g, TileJob<T>& j) {
       j.lda = j.ldb = j.ldc = ld;
       j.ksteps = g.kt * HBO_TILE / BKE;
       j.alpha = (T)-1; j.beta = 1;
+#ifdef HBO_GEMM_DEBUG
+      if (g.aug & 2) j.beta = 0;
+      if (g.aug & 4) j.C = nullptr;
+#endif
       return true;
     }
     case GEMM_TRTRI_A:
     case GEMM_TRTRI_B: {
+      // blockIdx.y carries the index that fixes the K length, ordered longest first, so that the
+      // dispatcher hands out tiles in longest-processing-time order (x runs over groups x tiles).
       const int s = g.p0;
-      const int jt = blockIdx.x;            // column tile inside the first half
-      const int grp = (int)blockIdx.y / s;
-      const int it = (int)blockIdx.y % s;   // row tile inside the second half
+      const int grp = (int)blockIdx.x / s;
+      const int inner = (int)blockIdx.x % s;
+      int jt, it;
+      if (g.mode == GEMM_TRTRI_A) { jt = blockIdx.y; it = inner; }            // K = s - jt
+      else { it = s - 1 - (int)blockIdx.y; jt = inner; }                      // K = it + 1
       const int o = grp * 2 * s;
       const int R = o + s + it;
       if (R >= nblk) return false;
@@ -150,6 +169,8 @@ __device__ __forceinline__ bool decode_job(const GemmArgs& g, TileJob<T>& j) {
       return true;
     }
     case GEMM_LAUUM: {
+      // x = row tile i (K = nblk - i), y = column tile: concurrently running tiles share the
+      // column panel W[:, jt] through L2 (measured faster than a strict longest-first order).
       const int i = blockIdx.x, jt = blockIdx.y;
       if (i >= nblk || jt > i) return false;
       const T* W = static_cast<const T*>(t.W);
@@ -183,7 +204,11 @@ __device__ __forceinline__ bool decode_job(const GemmArgs& g, TileJob<T>& j) {
 }
 
 template <typename T, bool AKC, bool BKC>
+#ifdef HBO_LB1
+__global__ __launch_bounds__(256, 1) void gemm_kernel(GemmArgs g) {
+#else
 __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
+#endif
   typedef typename Mma<T>::acc_t acc_t;
   typedef typename Mma<T>::vec_t vec_t;
   constexpr int BKE = 128 / sizeof(T);
@@ -207,6 +232,14 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
 #pragma unroll
     for (int b = 0; b < 4; ++b) acc[a][b] = (acc_t){0, 0, 0, 0};
 
+#if defined(HBO_PRIO_SLOT)
+  // co-resident workgroups (2 per CU) otherwise run phase-locked and stall on the same barriers;
+  // giving the wave in the even hardware slot of each SIMD priority makes one workgroup the
+  // MFMA owner and the other the gap filler.
+  if (__builtin_amdgcn_s_getreg(6148) & 1) __builtin_amdgcn_s_setprio(1);   // HW_REG_HW_ID.WAVE_ID
+#elif defined(HBO_PRIO_PARITY)
+  if ((blockIdx.x + blockIdx.y) & 1) __builtin_amdgcn_s_setprio(1);
+#endif
   vec_t ra[4], rb[4];
   const int nk = job.ksteps;
   stage_load<T, AKC>(job.A, job.lda, 0, ra, tid);
@@ -235,29 +268,52 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
       for (int a = 0; a < 4; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = Mma<T>::mma(af[a], bf[b], acc[a][b]);
+#ifdef HBO_MID_STORE
+      if (kk == BKE / 4 - 2 && more) {
+        __builtin_amdgcn_sched_barrier(0);
+        stage_store<T, AKC>((kt & 1) ? sA0 : sA1, ra, tid);
+        stage_store<T, BKC>((kt & 1) ? sB0 : sB1, rb, tid);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#endif
     }
+#ifndef HBO_MID_STORE
     if (more) {
       stage_store<T, AKC>((kt & 1) ? sA0 : sA1, ra, tid);
       stage_store<T, BKC>((kt & 1) ? sB0 : sB1, rb, tid);
     }
+#endif
     __syncthreads();
   }
 
-  // epilogue
+  // epilogue: C read-modify-write in four chunks of 16 values per lane, all loads of a chunk in
+  // flight before the first dependent store (a load->store chain per element costs one HBM round
+  // trip per element).
   if (job.C) {
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < 4; ++a) {
+      T cv[4][4];
+      if (job.beta) {
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = wm * 64 + a * 16 + Mma<T>::crow(lane, r);
+            const int col = wn * 64 + b * 16 + l15;
+            cv[b][r] = gld(job.C + (int64_t)row * job.ldc + col);
+          }
+      }
 #pragma unroll
       for (int b = 0; b < 4; ++b)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int row = wm * 64 + a * 16 + Mma<T>::crow(lane, r);
           const int col = wn * 64 + b * 16 + l15;
-          T* p = job.C + (int64_t)row * job.ldc + col;
           T v = job.alpha * acc[a][b][r];
-          if (job.beta) v += *p;
-          *p = v;
+          if (job.beta) v += cv[b][r];
+          gst(job.C + (int64_t)row * job.ldc + col, v);
         }
+    }
   }
   if (job.colsq) {
     // sum over this tile's 128 rows of acc^2, per column
@@ -283,7 +339,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
     if (tid < 128) {
       const int wn2 = tid >> 6, c = tid & 63;
       // waves (wm=0,wn2) and (wm=1,wn2)
-      job.colsq[wn2 * 64 + c] = red[(0 * 2 + wn2) * 64 + c] + red[(1 * 2 + wn2) * 64 + c];
+      gst(job.colsq + wn2 * 64 + c, red[(0 * 2 + wn2) * 64 + c] + red[(1 * 2 + wn2) * 64 + c]);
     }
   }
 }

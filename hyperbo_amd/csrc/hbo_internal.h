@@ -4,6 +4,13 @@
 #include <stdint.h>
 #include "../../include/hbo.h"
 
+// Pointers fetched from descriptor structs are generic ("flat") to the compiler; flat loads count on
+// lgkmcnt as well as vmcnt, so every LDS wait would also drain the global prefetch.  These helpers
+// force global_load / global_store (address space 1).
+#define HBO_GLOBAL __attribute__((address_space(1)))
+template <typename V> __device__ __forceinline__ V gld(const V* p) { return *(const HBO_GLOBAL V*)(p); }
+template <typename V> __device__ __forceinline__ void gst(V* p, V v) { *(HBO_GLOBAL V*)(p) = v; }
+
 #define HBO_TILE 128     // square tile / panel width of every blocked algorithm
 #define HBO_LEAF 16      // MFMA tile edge (v_mfma_*_16x16x4)
 

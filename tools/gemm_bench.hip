@@ -1,0 +1,62 @@
+// Micro-benchmark of the tile-GEMM modes (links the library objects directly).
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/gemm_bench.hip hyperbo_amd/csrc/gemm.o -o tools/gemm_bench
+#include "../hyperbo_amd/csrc/hbo_internal.h"
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
+
+__global__ void fill(double* p, size_t n, unsigned seed) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) { unsigned h = (unsigned)(i * 2654435761u) ^ seed; h ^= h >> 13; h *= 0x5bd1e995; h ^= h >> 15; p[i] = ((h & 0xffff) / 65536.0 - 0.5) * 0.01; }
+}
+
+int main(int argc, char** argv) {
+  int n = argc > 1 ? atoi(argv[1]) : 8192;
+  int nblk = n / 128; int64_t ld = n + 16;
+  double *A, *W, *S;
+  size_t na = (size_t)(n + 128) * ld;
+  CK(hipMalloc(&A, na * 8)); CK(hipMalloc(&W, na * 8)); CK(hipMalloc(&S, na * 8));
+  fill<<<(na + 255) / 256, 256>>>(A, na, 1); fill<<<(na + 255) / 256, 256>>>(W, na, 2); fill<<<(na + 255) / 256, 256>>>(S, na, 3);
+  TaskDesc h = {}; h.A = A; h.W = W; h.S = S; h.n = n; h.npad = n; h.nblk = nblk; h.m = 1; h.ld = ld;
+  TaskDesc* d; CK(hipMalloc(&d, sizeof h)); CK(hipMemcpy(d, &h, sizeof h, hipMemcpyHostToDevice));
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  auto timeit = [&](const char* name, GemmArgs a, dim3 grid, double flops) {
+    launch_gemm(HBO_F64, a, grid, 0); CK(hipDeviceSynchronize());
+    CK(hipEventRecord(e0));
+    const int reps = 5;
+    for (int i = 0; i < reps; ++i) launch_gemm(HBO_F64, a, grid, 0);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
+    printf("%-28s %8.3f ms  %6.1f TFLOP/s (algorithmic)\n", name, ms, flops / ms / 1e9);
+  };
+  if (argc > 2) {  // single-kernel mode for PMC runs: syrk K=1024 without C traffic
+    GemmArgs a = {}; a.tasks = d; a.mode = GEMM_SYRK; a.p0 = 0; a.kt = 8; a.c_lo = 8; a.c_hi = nblk; a.aug = 1 | 4;
+    double m = nblk - 8;
+    timeit("syrk K=1024 dbg=4", a, dim3(nblk + 1 - 8, nblk - 8, 1), m * (m + 1) / 2 * 128.0 * 128 * 2 * 128 * 8);
+    return 0;
+  }
+  for (int dbg : {0, 2, 4})
+  for (int kt : {1, 2, 4, 8}) {
+    GemmArgs a = {}; a.tasks = d; a.mode = GEMM_SYRK; a.p0 = 0; a.kt = kt; a.c_lo = kt; a.c_hi = nblk; a.aug = 1 | dbg;
+    double m = nblk - kt;
+    char nm[64]; snprintf(nm, 64, "syrk K=%d dbg=%d", kt * 128, dbg);
+    timeit(nm, a, dim3(nblk + 1 - kt, nblk - kt, 1), m * (m + 1) / 2 * 128.0 * 128 * 2 * 128 * kt);
+  }
+  { GemmArgs a = {}; a.tasks = d; a.mode = GEMM_LAUUM;
+    timeit("lauum", a, dim3(nblk, nblk, 1), (double)n * n * n / 3); }
+  { double tot = 0; float msum = 0;
+    for (int s = 1; s < nblk; s *= 2) {
+      int ng = (nblk + 2 * s - 1) / (2 * s);
+      GemmArgs a = {}; a.tasks = d; a.p0 = s;
+      for (int mode : {GEMM_TRTRI_A, GEMM_TRTRI_B}) {
+        a.mode = mode;
+        launch_gemm(HBO_F64, a, dim3(ng * s, s, 1), 0); CK(hipDeviceSynchronize());
+        CK(hipEventRecord(e0)); launch_gemm(HBO_F64, a, dim3(ng * s, s, 1), 0); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1)); msum += ms;
+        printf("  trtri s=%2d mode %d: %.3f ms\n", s, mode, ms);
+      }
+    }
+    printf("%-28s %8.3f ms  %6.1f TFLOP/s (algorithmic, N^3/3 minus diag blocks)\n", "trtri levels", msum, (double)n * n * n / 3 / msum / 1e9); }
+  return 0;
+}

@@ -139,6 +139,25 @@ int main() {
       printf("f64 valu fma waves/CU=%d: %.3f ms, %.1f TFLOP/s\n", wpc, ms, fl / ms / 1e9);
     }
   }
+  // sustained fp64 MFMA throughput (DVFS): back-to-back launches for ~0.5 s, report per-window TF
+  {
+    int blocks = cus * 2, threads = 256;  // 2 waves per SIMD
+    int it2 = 20000;                      // ~ 20000*4*64 cycles = 2.1 ms per launch at 2.4 GHz
+    hipEvent_t ev[64]; for (int i = 0; i < 64; ++i) CK(hipEventCreate(&ev[i]));
+    CK(hipEventRecord(ev[0]));
+    for (int w = 1; w < 64; ++w) {
+      for (int r = 0; r < 4; ++r) bench_f64<4><<<blocks, threads>>>(out, it2);
+      CK(hipEventRecord(ev[w]));
+    }
+    CK(hipDeviceSynchronize());
+    printf("sustained f64 mfma (TF per ~10ms window):");
+    for (int w = 1; w < 64; ++w) {
+      float ms; CK(hipEventElapsedTime(&ms, ev[w - 1], ev[w]));
+      double fl = 4.0 * blocks * (threads / 64) * (double)it2 * 4 * 2048.0;
+      if (w % 4 == 1) printf(" %.1f", fl / ms / 1e9);
+    }
+    printf("\n");
+  }
   // simple HBM copy bandwidth
   {
     size_t n = (size_t)1 << 30; double *a, *b; CK(hipMalloc(&a, n)); CK(hipMalloc(&b, n));
