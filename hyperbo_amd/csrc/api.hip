@@ -20,6 +20,11 @@ struct ProfEntry { std::string name; hipEvent_t e0, e1; };
 struct hbo_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
+  hipStream_t stream2 = nullptr;   // panel stream of the look-ahead Cholesky (high priority)
+  hipStream_t stream3 = nullptr;   // bulk trailing updates, CU-masked so the panel chain always finds free CUs
+  int opt_reserve_cus = 0;   // >0: keep that many CUs free of bulk updates (measured: no gain)
+  std::vector<hipEvent_t> ev_pool;
+  int opt_lookahead = 1;
   std::string err;
   ModelDev h_model;
   ModelDev* d_model = nullptr;
@@ -64,16 +69,17 @@ static inline int64_t padded_ld(int64_t extent, int dtype) { return extent + 128
 
 // ---- profiling ---------------------------------------------------------------------------
 struct ProfScope {
-  hbo_ctx* c; bool on; ProfEntry e;
-  ProfScope(hbo_ctx* ctx, const char* name, int level) : c(ctx), on(ctx->prof_level >= level) {
+  hbo_ctx* c; bool on; ProfEntry e; hipStream_t st;
+  ProfScope(hbo_ctx* ctx, const char* name, int level, hipStream_t stream = nullptr)
+      : c(ctx), on(ctx->prof_level >= level), st(stream ? stream : ctx->stream) {
     if (!on) return;
     e.name = name;
     hipEventCreate(&e.e0); hipEventCreate(&e.e1);
-    hipEventRecord(e.e0, c->stream);
+    hipEventRecord(e.e0, st);
   }
   ~ProfScope() {
     if (!on) return;
-    hipEventRecord(e.e1, c->stream);
+    hipEventRecord(e.e1, st);
     c->prof_pending.push_back(e);
   }
 };
@@ -116,6 +122,7 @@ extern "C" int hbo_ctx_create(int device, hbo_ctx** out) {
   hbo_ctx* nullctx = nullptr;
   hipError_t e = hipSetDevice(device);
   if (e == hipSuccess) e = hipStreamCreate(&c->stream);
+  if (e == hipSuccess) e = hipStreamCreate(&c->stream2);
   if (e == hipSuccess) e = hipMalloc((void**)&c->d_model, sizeof(ModelDev));
   if (e != hipSuccess) {
     g_err = std::string("hbo_ctx_create: ") + hipGetErrorString(e);
@@ -134,6 +141,9 @@ extern "C" int hbo_ctx_destroy(hbo_ctx* c) {
   prof_begin(c);
   for (int l = 0; l < HBO_MAX_MLP_LAYERS; ++l) { if (c->d_mlp_w[l]) hipFree(c->d_mlp_w[l]); if (c->d_mlp_b[l]) hipFree(c->d_mlp_b[l]); }
   if (c->d_model) hipFree(c->d_model);
+  for (hipEvent_t ev : c->ev_pool) hipEventDestroy(ev);
+  if (c->stream3) hipStreamDestroy(c->stream3);
+  if (c->stream2) hipStreamDestroy(c->stream2);
   if (c->stream) hipStreamDestroy(c->stream);
   delete c;
   return HBO_OK;
@@ -141,6 +151,13 @@ extern "C" int hbo_ctx_destroy(hbo_ctx* c) {
 extern "C" int hbo_set_option(hbo_ctx* c, const char* name, int64_t value) {
   if (!c || !name) return HBO_ERR_ARG;
   if (!strcmp(name, "potrf_group")) { if (value < 1 || value > 8) return fail(c, HBO_ERR_ARG, "potrf_group in 1..8"); c->opt_group = (int)value; return HBO_OK; }
+  if (!strcmp(name, "lookahead")) { c->opt_lookahead = value ? 1 : 0; return HBO_OK; }
+  if (!strcmp(name, "reserve_cus")) {
+    if (value < 0 || value > 128) return fail(c, HBO_ERR_ARG, "reserve_cus in 0..128");
+    c->opt_reserve_cus = (int)value;
+    if (c->stream3) { hipStreamDestroy(c->stream3); c->stream3 = nullptr; }
+    return HBO_OK;
+  }
   return fail(c, HBO_ERR_ARG, std::string("unknown option ") + name);
 }
 extern "C" int hbo_profile_enable(hbo_ctx* c, int level) { if (!c) return HBO_ERR_ARG; c->prof_level = level; return HBO_OK; }
@@ -282,24 +299,93 @@ struct FeatBuf {   // device activations of one input matrix
 };
 
 // ---- blocked factorisation drivers -----------------------------------------------------------
+// stream for the bulk trailing updates: all CUs except `opt_reserve_cus` (spread evenly), so that the
+// single-workgroup potf2 (132 KB LDS) and the panel trsm never wait for a GEMM tile to drain
+static hipStream_t bulk_stream(hbo_ctx* c) {
+  if (c->stream3) return c->stream3;
+  if (c->opt_reserve_cus > 0) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, c->device) == hipSuccess) {
+      const int ncu = prop.multiProcessorCount;
+      std::vector<uint32_t> mask((ncu + 31) / 32, 0xffffffffu);
+      if (ncu % 32) mask.back() = (1u << (ncu % 32)) - 1;
+      const int step = ncu / c->opt_reserve_cus;
+      for (int i = 0; i < c->opt_reserve_cus; ++i) { const int cu = i * step; mask[cu / 32] &= ~(1u << (cu % 32)); }
+      if (hipExtStreamCreateWithCUMask(&c->stream3, (uint32_t)mask.size(), mask.data()) == hipSuccess) return c->stream3;
+      c->stream3 = nullptr;
+    }
+  }
+  (void)hipGetLastError();
+  hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking);
+  return c->stream3;
+}
+
+static hipEvent_t pool_event(hbo_ctx* c, size_t i) {
+  while (c->ev_pool.size() <= i) {
+    hipEvent_t ev;
+    hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+    c->ev_pool.push_back(ev);
+  }
+  return c->ev_pool[i];
+}
+
+// Right-looking blocked Cholesky with look-ahead.  Panels are 128 wide; `group` consecutive panels
+// are factored left-looking (the later ones first receive the group's earlier panels: syrk_col),
+// then one trailing update with K = 128*group is applied.  The trailing update is split in two
+// launches: F1 updates only the NEXT group's block columns, F2 the rest; the next group's panel
+// work (potf2 -> trsm, the serial chain) runs on a second stream as soon as F1 is done, so F2
+// -- the bulk of the flops -- overlaps it.
 static void run_potrf(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, int max_nblk, int* d_info) {
   const int q = c->opt_group;
-  hipStream_t st = c->stream;
+  hipStream_t sm = c->stream;
+  hipStream_t sp = c->opt_lookahead ? c->stream2 : c->stream;
+  const bool la = c->opt_lookahead != 0;
+  hipStream_t sb = (la && c->opt_reserve_cus > 0) ? bulk_stream(c) : sm;
+  size_t evi = 0;
+  if (la) { hipEvent_t e = pool_event(c, evi++); hipEventRecord(e, sm); hipStreamWaitEvent(sp, e, 0); }
+  hipEvent_t ev_f1 = nullptr;
   for (int g0 = 0; g0 < max_nblk; g0 += q) {
     const int g1 = std::min(g0 + q, max_nblk);
+    const int g2 = std::min(g1 + q, max_nblk);
+    if (la && ev_f1) hipStreamWaitEvent(sp, ev_f1, 0);
     for (int p = g0; p < g1; ++p) {
       if (p > g0) {  // left-looking update of block column p with the group's earlier panels
-        ProfScope ps(c, "syrk_col", 2);
-        GemmArgs a = {}; a.tasks = d_tasks; a.mode = GEMM_SYRK; a.p0 = g0; a.kt = p - g0; a.c_lo = p; a.c_hi = p + 1; a.aug = 1;
-        launch_gemm(dtype, a, dim3(max_nblk + 1 - p, 1, ntasks), st);
+        ProfScope ps(c, "syrk_col", 2, sp);
+        GemmArgs a = {}; a.tasks = d_tasks; a.mode = GEMM_SYRK; a.p0 = g0; a.kt = p - g0; a.c_lo = p; a.c_hi = p + 1; a.aug = 1; a.small_tiles = 1;
+        launch_gemm(dtype, a, dim3(max_nblk + 1 - p, 1, ntasks), sp);
       }
-      { ProfScope ps(c, "potf2", 2); launch_potf2(dtype, d_tasks, ntasks, p, d_info, st); }
-      { ProfScope ps(c, "trsm", 2); launch_trsm(dtype, d_tasks, ntasks, p, max_nblk, st); }
+      { ProfScope ps(c, "potf2", 2, sp); launch_potf2(dtype, d_tasks, ntasks, p, d_info, sp); }
+      { ProfScope ps(c, "trsm", 2, sp); launch_trsm(dtype, d_tasks, ntasks, p, max_nblk, sp); }
     }
+    if (la) { hipEvent_t e = pool_event(c, evi++); hipEventRecord(e, sp); hipStreamWaitEvent(sm, e, 0); }
     if (g1 < max_nblk) {
-      ProfScope ps(c, "syrk_trailing", 1);
-      GemmArgs a = {}; a.tasks = d_tasks; a.mode = GEMM_SYRK; a.p0 = g0; a.kt = g1 - g0; a.c_lo = g1; a.c_hi = max_nblk; a.aug = 1;
-      launch_gemm(dtype, a, dim3(max_nblk + 1 - g1, max_nblk - g1, ntasks), st);
+      GemmArgs a = {}; a.tasks = d_tasks; a.mode = GEMM_SYRK; a.p0 = g0; a.kt = g1 - g0; a.aug = 1;
+      {
+        ProfScope ps(c, "syrk_trailing", 1, sm);
+        a.c_lo = g1; a.c_hi = la ? g2 : max_nblk;
+        // few tiles (one group's block columns, or a small remainder): 64x64 tiles for latency
+        a.small_tiles = (int64_t)(max_nblk + 1 - a.c_lo) * (a.c_hi - a.c_lo) * ntasks < 600;
+        launch_gemm(dtype, a, dim3(max_nblk + 1 - a.c_lo, a.c_hi - a.c_lo, ntasks), sm);
+      }
+      if (la) {
+        ev_f1 = pool_event(c, evi++);
+        hipEventRecord(ev_f1, sm);
+        if (g2 < max_nblk) {
+          // F2 on the CU-masked bulk stream: after F1(g) (same C columns are not shared, but F2(g)
+          // must precede F1(g+1)/F2(g+1) which accumulate into the same tiles)
+          hipStreamWaitEvent(sb, ev_f1, 0);
+          {
+            ProfScope ps(c, "syrk_trailing", 1, sb);
+            a.c_lo = g2; a.c_hi = max_nblk;
+            const int64_t m = max_nblk - g2;
+            a.small_tiles = m * (m + 1) / 2 * ntasks < 600;
+            launch_gemm(dtype, a, dim3(max_nblk + 1 - a.c_lo, a.c_hi - a.c_lo, ntasks), sb);
+          }
+          hipEvent_t e2 = pool_event(c, evi++);
+          hipEventRecord(e2, sb);
+          hipStreamWaitEvent(sm, e2, 0);   // later F1 / final consumers on the main stream
+        }
+      }
     }
   }
 }
@@ -325,6 +411,7 @@ struct TaskHost {
   int64_t n = 0; int m = 0; int npad = 0, nblk = 0; int64_t ld = 0;
   void* X = nullptr; void* ysum = nullptr;
   void* A = nullptr; void* W = nullptr; void* S = nullptr; void* svec = nullptr;
+  double* dF = nullptr; double* dtmp = nullptr; size_t dF_elems = 0;   // MLP backward workspaces
   FeatBuf feat;
 };
 struct hbo_dataset {
@@ -336,12 +423,13 @@ struct hbo_dataset {
   double* d_nll = nullptr;
   double* d_partials = nullptr; size_t partials_bytes = 0;
   double* d_gradout = nullptr; size_t gradout_bytes = 0;
+  double* d_mlpgrad = nullptr; size_t mlpgrad_elems = 0;
   bool has_S = false;
 };
 
 static void free_task(TaskHost* t) {
   if (!t) return;
-  for (void* p : {t->X, t->ysum, t->A, t->W, t->S, t->svec}) if (p) hipFree(p);
+  for (void* p : {t->X, t->ysum, t->A, t->W, t->S, t->svec, (void*)t->dF, (void*)t->dtmp}) if (p) hipFree(p);
   delete t;
 }
 
@@ -349,7 +437,7 @@ extern "C" int hbo_dataset_free(hbo_ctx* c, hbo_dataset* ds) {
   if (!ds) return HBO_OK;
   if (c) hipSetDevice(c->device);
   for (TaskHost* t : ds->tasks) free_task(t);
-  for (void* p : {(void*)ds->d_desc, (void*)ds->d_info, (void*)ds->d_nll, (void*)ds->d_partials, (void*)ds->d_gradout}) if (p) hipFree(p);
+  for (void* p : {(void*)ds->d_desc, (void*)ds->d_info, (void*)ds->d_nll, (void*)ds->d_partials, (void*)ds->d_gradout, (void*)ds->d_mlpgrad}) if (p) hipFree(p);
   delete ds;
   return HBO_OK;
 }
@@ -410,6 +498,7 @@ static void fill_desc(TaskDesc& d, TaskHost* t, const hbo_model* m, int dtype) {
   d.fdim = feature_dim(m);
   d.fmean = mean_feature_dim(m);
   d.Fm = (m->mean_id == HBO_MEAN_LINEAR) ? t->X : (m->mean_id == HBO_MEAN_LINEAR_MLP ? last : nullptr);
+  d.dF = t->dF;
   (void)dtype;
 }
 
@@ -423,7 +512,6 @@ extern "C" int hbo_nll(hbo_ctx* c, const hbo_model* m, hbo_dataset* ds, double* 
   hbo_grad_layout lay;
   hbo_grad_layout_of(m, &lay);
   const bool want_grad = grad_sum != nullptr;
-  if (want_grad && needs_mlp(m)) return fail(c, HBO_ERR_UNSUPPORTED, "hbo_nll: gradients through the MLP basis are not implemented yet");
   *nll_sum = 0;
   if (want_grad) for (int i = 0; i < lay.total; ++i) grad_sum[i] = 0;
   const int T = ds->ntasks;
@@ -441,6 +529,19 @@ extern "C" int hbo_nll(hbo_ctx* c, const hbo_model* m, hbo_dataset* ds, double* 
     rc = ensure_task_workspace(c, dtype, t, want_grad, 1);
     if (rc) return rc;
     if (needs_mlp(m)) { rc = t->feat.ensure(c, m, t->n); if (rc) return rc; }
+    if (needs_mlp(m) && want_grad) {
+      int maxf = m->input_dim;
+      for (int l = 0; l < m->n_layers; ++l) maxf = std::max(maxf, (int)m->features[l]);
+      const size_t need = (size_t)t->n * maxf;
+      if (t->dF_elems < need) {
+        if (t->dF) hipFree(t->dF);
+        if (t->dtmp) hipFree(t->dtmp);
+        t->dF = t->dtmp = nullptr;
+        HIPCHK(c, hipMalloc((void**)&t->dF, need * sizeof(double)));
+        HIPCHK(c, hipMalloc((void**)&t->dtmp, need * sizeof(double)));
+        t->dF_elems = need;
+      }
+    }
     fill_desc(ds->h_desc[k], t, m, dtype);
   }
   if (!ds->d_desc) HIPCHK(c, hipMalloc((void**)&ds->d_desc, sizeof(TaskDesc) * T));
@@ -479,11 +580,40 @@ extern "C" int hbo_nll(hbo_ctx* c, const hbo_model* m, hbo_dataset* ds, double* 
     { ProfScope ps(c, "grad_contract", 1);
       launch_grad_contract(dtype, ds->d_desc, T, max_nblk, c->d_model, m->kernel_id, fdim, ds->d_partials, stride_task, st);
       launch_grad_finalize(dtype, ds->d_desc, T, c->d_model, m->kernel_id, fdim, ds->d_partials, stride_task, ds->d_gradout, out_stride, st); }
+    if (needs_mlp(m)) {
+      // d nll / d features -> MLP backward (hyperbo/gp_utils/basis_functions.py:24-36), summed over tasks
+      ProfScope ps(c, "mlp_backward", 1);
+      const int L = m->n_layers, flast = m->features[L - 1];
+      size_t tot = 0; int fin0 = m->input_dim;
+      std::vector<size_t> woff(L), boff(L);
+      for (int l = 0; l < L; ++l) { woff[l] = tot; tot += (size_t)fin0 * m->features[l]; boff[l] = tot; tot += m->features[l]; fin0 = m->features[l]; }
+      if (ds->mlpgrad_elems < tot) { if (ds->d_mlpgrad) hipFree(ds->d_mlpgrad); HIPCHK(c, hipMalloc((void**)&ds->d_mlpgrad, tot * sizeof(double))); ds->mlpgrad_elems = tot; }
+      HIPCHK(c, hipMemsetAsync(ds->d_mlpgrad, 0, tot * sizeof(double), st));
+      for (int k = 0; k < T; ++k) HIPCHK(c, hipMemsetAsync(ds->tasks[k]->dF, 0, (size_t)ds->tasks[k]->n * flast * sizeof(double), st));
+      if (m->kernel_uses_mlp) launch_grad_feat(dtype, ds->d_desc, T, max_nblk, c->d_model, flast, st);
+      if (m->mean_id == HBO_MEAN_LINEAR_MLP) launch_grad_feat_mean(dtype, ds->d_desc, T, (int64_t)max_npad, c->d_model, flast, st);
+      for (int k = 0; k < T; ++k) {
+        TaskHost* t = ds->tasks[k];
+        double* cur = t->dF; double* other = t->dtmp;
+        for (int l = L - 1; l >= 0; --l) {
+          const int fin = l ? m->features[l - 1] : m->input_dim;
+          const void* in = l ? t->feat.acts[l - 1] : t->X;
+          launch_dense_bwd(dtype, in, t->feat.acts[l], c->d_mlp_w[l], cur, l ? other : nullptr,
+                           ds->d_mlpgrad + woff[l], ds->d_mlpgrad + boff[l], t->n, fin, m->features[l], st);
+          std::swap(cur, other);
+        }
+      }
+    }
   }
   std::vector<double> h_nll(T), h_grad(want_grad ? (size_t)out_stride * T : 0);
   HIPCHK(c, hipMemcpyAsync(h_nll.data(), ds->d_nll, sizeof(double) * T, hipMemcpyDeviceToHost, st));
   HIPCHK(c, hipMemcpyAsync(h_info.data(), ds->d_info, sizeof(int) * T, hipMemcpyDeviceToHost, st));
   if (want_grad) HIPCHK(c, hipMemcpyAsync(h_grad.data(), ds->d_gradout, sizeof(double) * out_stride * T, hipMemcpyDeviceToHost, st));
+  std::vector<double> h_mlp;
+  if (want_grad && needs_mlp(m)) {
+    h_mlp.resize(ds->mlpgrad_elems);
+    HIPCHK(c, hipMemcpyAsync(h_mlp.data(), ds->d_mlpgrad, sizeof(double) * ds->mlpgrad_elems, hipMemcpyDeviceToHost, st));
+  }
   HIPCHK(c, hipStreamSynchronize(st));
   HIPCHK(c, hipGetLastError());
   prof_collect(c);
@@ -507,6 +637,16 @@ extern "C" int hbo_nll(hbo_ctx* c, const hbo_model* m, hbo_dataset* ds, double* 
       add(lay.dot_prod_bias, o[n_ls + 4]);
       for (int d = 0; d < fm; ++d) add(lay.linear_kernel + d, o[n_ls + 5 + d]);
       add(lay.linear_bias, o[n_ls + 5 + fm]);
+    }
+    if (needs_mlp(m)) {
+      size_t pos = 0; int fin0 = m->input_dim;
+      for (int l = 0; l < m->n_layers; ++l) {
+        const size_t wn = (size_t)fin0 * m->features[l], bn = m->features[l];
+        for (size_t i = 0; i < wn; ++i) grad_sum[lay.mlp_kernel[l] + i] = notpd ? NAN : h_mlp[pos + i];
+        pos += wn;
+        for (size_t i = 0; i < bn; ++i) grad_sum[lay.mlp_bias[l] + i] = notpd ? NAN : h_mlp[pos + i];
+        pos += bn; fin0 = m->features[l];
+      }
     }
   }
   return notpd ? HBO_NOT_PD : HBO_OK;

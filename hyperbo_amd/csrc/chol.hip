@@ -27,7 +27,6 @@ template <> struct Mma<float> {
 };
 
 constexpr int NB = HBO_TILE;   // 128
-constexpr int LS = NB + 1;     // LDS row stride of the potf2 block (odd -> conflict-free columns)
 
 __device__ __forceinline__ double readlane_t(double v, int lane) {
   int lo = __double2loint(v), hi = __double2hiint(v);
@@ -39,17 +38,61 @@ __device__ __forceinline__ float readlane_t(float v, int lane) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
 
-// LDS-resident factorisation of one 128x128 diagonal block, blocked by 16 columns:
-//   (A) wave 0 factors the 16x16 leaf in registers (lane = row, cross-lane broadcasts via readlane),
-//   (B) one thread per remaining row solves its 16 unknowns against the leaf (forward substitution),
-//   (C) all four waves apply the rank-16 update to the trailing tiles with MFMA.
+// packed 16x16 tiles, row stride 17
+constexpr int TS = 17;
+constexpr int TILE_ELEMS = 16 * TS;                 // 272
+__device__ __forceinline__ int tri_index(int I, int J) { return I * (I + 1) / 2 + J; }
+
+
+template <typename T>
+constexpr int potf2_lds_bytes() { return (36 * TILE_ELEMS + NB) * (int)sizeof(T); }
+
+// 16x16 Cholesky of a symmetric tile held in the MFMA accumulator layout (one wave).  Column j:
+// pivot by readlane, rsqrt, scale column j (lanes with col == j), and one rank-1 MFMA update
+// acc -= f f^T with f_c = S[j][c]/sqrt(d) for c > j (taken from row j by symmetry, zero elsewhere,
+// so finished columns are never touched).  Returns the first failing column or -1.
+template <typename T>
+__device__ __forceinline__ int leaf_cholesky(typename Mma<T>::acc_t& acc, T* dinv_out, int lane) {
+  const int l15 = lane & 15, lq = lane >> 4;
+  int bad_col = -1;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    constexpr int dummy = 0; (void)dummy;
+    // element (j,j): f64 layout row = lq + 4 reg ; f32 layout row = 4 lq + reg
+    const int pr = Mma<T>::crow(0, 0) == 0 && Mma<T>::crow(16, 0) == 1 ? (j >> 2) : (j & 3);   // reg index
+    const int pq = Mma<T>::crow(16, 0) == 1 ? (j & 3) : (j >> 2);                                // lq of the holder
+    T d = readlane_t(acc[pr], j + 16 * pq);
+    if (!(d > (T)0)) {   // not PD (or NaN): propagate NaN like jax.scipy.linalg.cholesky
+      if (bad_col < 0) bad_col = j;
+      d = (T)NAN;
+    }
+    const T inv = rsqrt(d);
+    if (lane == 0) dinv_out[j] = inv;
+    // f_c for c = l15 > j, from row j (lanes with lq == pq hold S[j][l15] in reg pr)
+    const T f = (lq == pq && l15 > j) ? acc[pr] * inv : (T)0;
+    if (l15 == j) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[r] *= inv;   // column j of L (rows >= j are the meaningful ones)
+    }
+    acc = Mma<T>::mma(-f, f, acc);
+  }
+  return bad_col;
+}
+
+// LDS-resident factorisation of one 128x128 diagonal block as 36 packed 16x16 lower tiles (78 KB
+// for fp64, so the workgroup fits on a CU next to a running GEMM workgroup):
+//   leaf   : wave 0 factors the symmetric diagonal tile on MFMA (leaf_cholesky),
+//   (B)    : one thread per remaining row solves its 16 unknowns against the leaf,
+//   (C)    : rank-16 MFMA update of the trailing tiles; wave 0 takes the next diagonal tile first and
+//            factors it while waves 1-3 finish the rest (the leaf chain is the critical path).
 // Finally the eight leaf inverses are written to W (used by trsm_kernel and the trtri base case).
 template <typename T>
 __global__ __launch_bounds__(256) void potf2_kernel(const TaskDesc* tasks, int p, int* info) {
   typedef typename Mma<T>::acc_t acc_t;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  T* sL = reinterpret_cast<T*>(smem);       // [128][129]
-  T* sDinv = sL + NB * LS;                  // [128] 1 / diag(L)
+  __builtin_amdgcn_s_setprio(3);            // critical path: outrank co-resident GEMM waves
+  T* sT = reinterpret_cast<T*>(smem);       // 36 tiles [16][17]
+  T* sDinv = sT + 36 * TILE_ELEMS;          // [128] 1 / diag(L)
   const TaskDesc& t = tasks[blockIdx.x];
   if (p >= t.nblk) return;
   const int64_t ld = t.ld;
@@ -57,123 +100,128 @@ __global__ __launch_bounds__(256) void potf2_kernel(const TaskDesc* tasks, int p
   T* Wb = static_cast<T*>(t.W) + (int64_t)p * NB * ld + (int64_t)p * NB;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, lq = lane >> 4;
+  const int ei = tid >> 4, ej = tid & 15;    // element of a tile owned by this thread for I/O
 
-  for (int idx = tid; idx < NB * NB; idx += 256) {
-    const int r = idx >> 7, c = idx & 127;
-    sL[r * LS + c] = (c <= r) ? Ab[(int64_t)r * ld + c] : (T)0;
+  // load: one element of every lower tile per thread; diagonal tiles are mirrored to full symmetry
+  {
+    T v[36];
+    int tile = 0;
+#pragma unroll
+    for (int I = 0; I < 8; ++I)
+#pragma unroll
+      for (int J = 0; J <= I; ++J, ++tile) {
+        int r = ei, c = ej;
+        if (I == J && ej > ei) { r = ej; c = ei; }
+        v[tile] = gld(Ab + (int64_t)(I * 16 + r) * ld + J * 16 + c);
+      }
+#pragma unroll
+    for (int k = 0; k < 36; ++k) sT[k * TILE_ELEMS + ei * TS + ej] = v[k];
   }
   __syncthreads();
 
+  auto factor_leaf = [&](int jb) {   // wave 0 only
+    T* dt = sT + tri_index(jb, jb) * TILE_ELEMS;
+    acc_t acc;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = dt[Mma<T>::crow(lane, r) * TS + l15];
+    const int bad = leaf_cholesky<T>(acc, sDinv + jb * 16, lane);
+    if (bad >= 0 && lane == 0) atomicMin(&info[blockIdx.x], p * NB + jb * 16 + bad + 1);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dt[Mma<T>::crow(lane, r) * TS + l15] = acc[r];
+  };
+  auto update_tile = [&](int jb, int I, int J) {   // C[I][J] -= X_I X_J^T (K = 16)
+    T* ct = sT + tri_index(I, J) * TILE_ELEMS;
+    const T* at = sT + tri_index(I, jb) * TILE_ELEMS;
+    const T* bt = sT + tri_index(J, jb) * TILE_ELEMS;
+    acc_t acc;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] = ct[Mma<T>::crow(lane, r) * TS + l15];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) acc = Mma<T>::mma(-at[l15 * TS + kk * 4 + lq], bt[l15 * TS + kk * 4 + lq], acc);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ct[Mma<T>::crow(lane, r) * TS + l15] = acc[r];
+  };
+
+  if (wave == 0) factor_leaf(0);
+  __syncthreads();
   for (int jb = 0; jb < 8; ++jb) {
-    const int o = jb * 16;
-    // ---- (A) leaf Cholesky, wave 0, lanes 0..15 hold one row each --------------------------
-    if (wave == 0) {
-      T a[16];
-      const int row = o + l15;
-#pragma unroll
-      for (int c = 0; c < 16; ++c) a[c] = (lane < 16 && c <= l15) ? sL[row * LS + o + c] : (T)0;
-      T myinv = (T)0;
-      int bad_col = -1;
-#pragma unroll
-      for (int j = 0; j < 16; ++j) {
-        T d = readlane_t(a[j], j);
-        if (!(d > (T)0)) {   // not PD (or NaN): propagate NaN like jax.scipy.linalg.cholesky
-          if (bad_col < 0) bad_col = j;
-          d = (T)NAN;
-        }
-        const T inv = rsqrt(d);
-        if (l15 == j) { a[j] = d * inv; myinv = inv; }
-        else a[j] = a[j] * inv;
-#pragma unroll
-        for (int c = j + 1; c < 16; ++c) {
-          const T lcj = readlane_t(a[j], c);
-          a[c] -= a[j] * lcj;
-        }
-      }
-      if (bad_col >= 0 && lane == 0) atomicMin(&info[blockIdx.x], p * NB + o + bad_col + 1);
-      if (lane < 16) {
-#pragma unroll
-        for (int c = 0; c < 16; ++c)
-          if (c <= l15) sL[row * LS + o + c] = a[c];
-        sDinv[row] = myinv;
-      }
-    }
-    __syncthreads();
-    // ---- (B) panel rows below the leaf: x L_leaf^T = a -------------------------------------
-    if (tid < NB && tid >= o + 16) {
+    // ---- (B) rows below the leaf: x L_leaf^T = a ; thread = row --------------------------
+    if (tid < NB && tid >= jb * 16 + 16) {
+      const T* lt = sT + tri_index(jb, jb) * TILE_ELEMS;
+      T* xt = sT + tri_index(tid >> 4, jb) * TILE_ELEMS + (tid & 15) * TS;
       T x[16];
 #pragma unroll
       for (int c = 0; c < 16; ++c) {
-        T s = sL[tid * LS + o + c];
+        T s = xt[c];
 #pragma unroll
         for (int k = 0; k < 16; ++k)
-          if (k < c) s -= x[k] * sL[(o + c) * LS + o + k];
-        x[c] = s * sDinv[o + c];
+          if (k < c) s -= x[k] * lt[c * TS + k];
+        x[c] = s * sDinv[jb * 16 + c];
       }
 #pragma unroll
-      for (int c = 0; c < 16; ++c) sL[tid * LS + o + c] = x[c];
+      for (int c = 0; c < 16; ++c) xt[c] = x[c];
     }
     __syncthreads();
-    // ---- (C) trailing update C[I][J] -= X_I X_J^T on MFMA -----------------------------------
-    const int m = 7 - jb;               // remaining 16-blocks
-    const int ntiles = m * (m + 1) / 2;
-    for (int tix = wave; tix < ntiles; tix += 4) {
-      int ii = 0;
-      while ((ii + 1) * (ii + 2) / 2 <= tix) ++ii;
-      const int jj = tix - ii * (ii + 1) / 2;
-      const int I = jb + 1 + ii, J = jb + 1 + jj;
-      acc_t acc;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) acc[r] = sL[(I * 16 + Mma<T>::crow(lane, r)) * LS + J * 16 + l15];
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        const T af = -sL[(I * 16 + l15) * LS + o + kk * 4 + lq];
-        const T bf = sL[(J * 16 + l15) * LS + o + kk * 4 + lq];
-        acc = Mma<T>::mma(af, bf, acc);
+    if (jb == 7) break;
+    // ---- (C) trailing update; wave 0 owns the next diagonal tile and factors it right away ----
+    if (wave == 0) {
+      update_tile(jb, jb + 1, jb + 1);
+      factor_leaf(jb + 1);
+    } else {
+      const int m = 7 - jb;
+      const int ntiles = m * (m + 1) / 2;
+      for (int tix = wave; tix < ntiles; tix += 3) {   // tix 0 is the (jb+1,jb+1) tile: skipped
+        int ii = 0;
+        while ((ii + 1) * (ii + 2) / 2 <= tix) ++ii;
+        const int jj = tix - ii * (ii + 1) / 2;
+        update_tile(jb, jb + 1 + ii, jb + 1 + jj);
       }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) sL[(I * 16 + Mma<T>::crow(lane, r)) * LS + J * 16 + l15] = acc[r];
     }
     __syncthreads();
   }
 
-  // write L (lower, zeros above the diagonal inside the block)
-  for (int idx = tid; idx < NB * NB; idx += 256) {
-    const int rr = idx >> 7, c = idx & 127;
-    Ab[(int64_t)rr * ld + c] = (c <= rr) ? sL[rr * LS + c] : (T)0;
+  // write L (lower; zeros above the diagonal inside the diagonal tiles)
+  {
+    int tile = 0;
+#pragma unroll
+    for (int I = 0; I < 8; ++I)
+#pragma unroll
+      for (int J = 0; J <= I; ++J, ++tile) {
+        T v = sT[tile * TILE_ELEMS + ei * TS + ej];
+        if (I == J && ej > ei) v = (T)0;
+        gst(Ab + (int64_t)(I * 16 + ei) * ld + J * 16 + ej, v);
+      }
   }
   // inverses of the eight 16x16 diagonal leaves: thread = (leaf b, column c), forward substitution
   if (tid < NB) {
     const int b = tid >> 4, c = tid & 15;
+    const T* lt = sT + tri_index(b, b) * TILE_ELEMS;
     T w[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
       T s = (i == c) ? (T)1 : (T)0;
 #pragma unroll
       for (int k = 0; k < 16; ++k)
-        if (k < i) s -= sL[(b * 16 + i) * LS + b * 16 + k] * w[k];
+        if (k < i) s -= lt[i * TS + k] * w[k];
       w[i] = s * sDinv[b * 16 + i];
     }
 #pragma unroll
-    for (int i = 0; i < 16; ++i) Wb[(int64_t)(b * 16 + i) * ld + b * 16 + c] = w[i];
+    for (int i = 0; i < 16; ++i) gst(Wb + (int64_t)(b * 16 + i) * ld + b * 16 + c, w[i]);
   }
 }
 
-// packed 16x16 tiles, row stride 17
-constexpr int TS = 17;
-constexpr int TILE_ELEMS = 16 * TS;                 // 272
-__device__ __forceinline__ int tri_index(int I, int J) { return I * (I + 1) / 2 + J; }
-
 template <typename T>
-constexpr int trsm_lds_bytes() { return (36 + 8 + 4) * TILE_ELEMS * (int)sizeof(T); }
+constexpr int trsm_lds_bytes() { return (28 + 8 + 4) * TILE_ELEMS * (int)sizeof(T); }   // 87 KB fp64: fits beside one GEMM workgroup
+__device__ __forceinline__ int strict_index(int I, int J) { return I * (I - 1) / 2 + J; }
 
 // grid.x = 64-row group, grid.y = (IDENT ? diagonal block p : unused), grid.z = task
 template <typename T, bool IDENT>
 __global__ __launch_bounds__(256) void trsm_kernel(const TaskDesc* tasks, int p_arg) {
   typedef typename Mma<T>::acc_t acc_t;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  T* sLt = reinterpret_cast<T*>(smem);          // 36 packed lower tiles of L_pp
-  T* sWi = sLt + 36 * TILE_ELEMS;               // 8 leaf inverses
+  __builtin_amdgcn_s_setprio(3);                // critical path: outrank co-resident GEMM waves
+  T* sLt = reinterpret_cast<T*>(smem);          // 28 packed strictly-lower tiles of L_pp
+  T* sWi = sLt + 28 * TILE_ELEMS;               // 8 leaf inverses (stand in for the diagonal tiles)
   T* sSc = sWi + 8 * TILE_ELEMS;                // 4 per-wave scratch tiles
   const TaskDesc& t = tasks[blockIdx.z];
   const int p = IDENT ? (int)blockIdx.y : p_arg;
@@ -194,54 +242,62 @@ __global__ __launch_bounds__(256) void trsm_kernel(const TaskDesc* tasks, int p_
   const T* Lb = static_cast<const T*>(t.A) + (int64_t)p * NB * ld + (int64_t)p * NB;
   const T* Wb = static_cast<const T*>(t.W) + (int64_t)p * NB * ld + (int64_t)p * NB;
 
-  // stage L_pp (lower tiles) and the leaf inverses
-  for (int idx = tid; idx < 36 * 256; idx += 256) {
-    const int tile = idx >> 8, e = idx & 255, i = e >> 4, j = e & 15;
-    // tile -> (I,J)
-    int I = 0;
-    while ((I + 1) * (I + 2) / 2 <= tile) ++I;
-    const int J = tile - I * (I + 1) / 2;
-    sLt[tile * TILE_ELEMS + i * TS + j] = Lb[(int64_t)(I * 16 + i) * ld + J * 16 + j];
-  }
-  for (int idx = tid; idx < 8 * 256; idx += 256) {
-    const int b = idx >> 8, e = idx & 255, i = e >> 4, j = e & 15;
-    sWi[b * TILE_ELEMS + i * TS + j] = Wb[(int64_t)(b * 16 + i) * ld + b * 16 + j];
-  }
-  __syncthreads();
-
-  T* sc = sSc + wave * TILE_ELEMS;
   const int64_t wrow0 = row0 + wave * 16;                 // this wave's 16 rows
   const int rg = IDENT ? (int)((wrow0 - (int64_t)p * NB) >> 4) : 0;  // row group inside the block
   T* Ap = IDENT ? nullptr : static_cast<T*>(t.A) + wrow0 * ld + (int64_t)p * NB;
   T* Wout = IDENT ? static_cast<T*>(t.W) + (int64_t)p * NB * ld + (int64_t)p * NB : nullptr;
 
-  T xneg[8][4];  // -X in A-operand layout, per 16-column block
+  // the wave's 16 x 128 panel rows, all eight tiles in flight before L_pp is staged
+  acc_t areg[8];
 #pragma unroll
-  for (int jb = 0; jb < 8; ++jb) {
-    acc_t acc;
+  for (int jb = 0; jb < 8; ++jb)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = Mma<T>::crow(lane, r);
-      if (IDENT) acc[r] = (rg == jb && row == l15) ? (T)1 : (T)0;
-      else acc[r] = Ap[(int64_t)row * ld + jb * 16 + l15];
+      if (IDENT) areg[jb][r] = (rg == jb && row == l15) ? (T)1 : (T)0;
+      else areg[jb][r] = gld(Ap + (int64_t)row * ld + jb * 16 + l15);
     }
-    // acc -= sum_{kb<jb} X[:,kb] * L[jb,kb]^T
+  // stage L_pp (lower tiles) and the leaf inverses: thread = one element of each 16x16 tile
+  {
+    const int i = tid >> 4, j = tid & 15;
+    int tile = 0;
+#pragma unroll
+    for (int I = 1; I < 8; ++I)
+#pragma unroll
+      for (int J = 0; J < I; ++J, ++tile)
+        sLt[tile * TILE_ELEMS + i * TS + j] = gld(Lb + (int64_t)(I * 16 + i) * ld + J * 16 + j);
+#pragma unroll
+    for (int b = 0; b < 8; ++b)
+      sWi[b * TILE_ELEMS + i * TS + j] = gld(Wb + (int64_t)(b * 16 + i) * ld + b * 16 + j);
+  }
+  __syncthreads();
+
+  T* sc = sSc + wave * TILE_ELEMS;   // wave-private: LDS ops of one wave execute in order
+  T xneg[8][4];                      // -X in A-operand layout, per 16-column block
+#pragma unroll
+  for (int jb = 0; jb < 8; ++jb) {
+    // acc = A[:,jb] - sum_{kb<jb} X[:,kb] * L[jb,kb]^T   (two accumulators: shorter MFMA chain)
+    acc_t acc = areg[jb];
+    acc_t acc2 = (acc_t){0, 0, 0, 0};
 #pragma unroll
     for (int kb = 0; kb < 8; ++kb) {
       if (kb < jb) {
-        const T* lt = sLt + tri_index(jb, kb) * TILE_ELEMS;
+        const T* lt = sLt + strict_index(jb, kb) * TILE_ELEMS;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
           const T bfrag = lt[l15 * TS + kk * 4 + lq];   // B[k][j] = L[jb*16+j][kb*16+k]
-          acc = Mma<T>::mma(xneg[kb][kk], bfrag, acc);
+          if (kb & 1) acc2 = Mma<T>::mma(xneg[kb][kk], bfrag, acc2);
+          else acc = Mma<T>::mma(xneg[kb][kk], bfrag, acc);
         }
       }
     }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) acc[r] += acc2[r];
     // T (C layout) -> scratch -> A layout
-    __syncthreads();
+    __builtin_amdgcn_wave_barrier();
 #pragma unroll
     for (int r = 0; r < 4; ++r) sc[Mma<T>::crow(lane, r) * TS + l15] = acc[r];
-    __syncthreads();
+    __builtin_amdgcn_wave_barrier();
     T ta[4];
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) ta[kk] = sc[l15 * TS + kk * 4 + lq];
@@ -259,18 +315,20 @@ __global__ __launch_bounds__(256) void trsm_kernel(const TaskDesc* tasks, int p_
       const int row = Mma<T>::crow(lane, r);
       if (IDENT) {
         // W = X^T ; the diagonal leaves were already written by potf2
-        if (rg != jb) Wout[(int64_t)(jb * 16 + l15) * ld + rg * 16 + row] = x[r];
+        if (rg != jb) gst(Wout + (int64_t)(jb * 16 + l15) * ld + rg * 16 + row, x[r]);
       } else {
-        Ap[(int64_t)row * ld + jb * 16 + l15] = x[r];
+        gst(Ap + (int64_t)row * ld + jb * 16 + l15, x[r]);
       }
     }
-    // X (C layout) -> scratch -> negated A layout for later column blocks
-    __syncthreads();
+    if (jb < 7) {
+      // X (C layout) -> scratch -> negated A layout for later column blocks
+      __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int r = 0; r < 4; ++r) sc[Mma<T>::crow(lane, r) * TS + l15] = x[r];
-    __syncthreads();
+      for (int r = 0; r < 4; ++r) sc[Mma<T>::crow(lane, r) * TS + l15] = x[r];
+      __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) xneg[jb][kk] = -sc[l15 * TS + kk * 4 + lq];
+      for (int kk = 0; kk < 4; ++kk) xneg[jb][kk] = -sc[l15 * TS + kk * 4 + lq];
+    }
   }
 }
 
@@ -279,7 +337,7 @@ void set_attrs() {
   static bool done = false;
   if (done) return;
   hipFuncSetAttribute(reinterpret_cast<const void*>(&potf2_kernel<T>),
-                      hipFuncAttributeMaxDynamicSharedMemorySize, (NB * LS + NB) * (int)sizeof(T));
+                      hipFuncAttributeMaxDynamicSharedMemorySize, potf2_lds_bytes<T>());
   hipFuncSetAttribute(reinterpret_cast<const void*>(&trsm_kernel<T, false>),
                       hipFuncAttributeMaxDynamicSharedMemorySize, trsm_lds_bytes<T>());
   hipFuncSetAttribute(reinterpret_cast<const void*>(&trsm_kernel<T, true>),
@@ -290,7 +348,7 @@ void set_attrs() {
 template <typename T>
 void potf2_t(const TaskDesc* tasks, int ntasks, int p, int* info, hipStream_t st) {
   set_attrs<T>();
-  hipLaunchKernelGGL((potf2_kernel<T>), dim3(ntasks), dim3(256), (NB * LS + NB) * sizeof(T), st, tasks, p, info);
+  hipLaunchKernelGGL((potf2_kernel<T>), dim3(ntasks), dim3(256), potf2_lds_bytes<T>(), st, tasks, p, info);
 }
 template <typename T>
 void trsm_t(const TaskDesc* tasks, int ntasks, int p, int max_nblk, hipStream_t st) {

@@ -40,13 +40,15 @@ template <typename T> __device__ __host__ constexpr int skc() { return sizeof(T)
 #else
 template <typename T> __device__ __host__ constexpr int skc() { return sizeof(T) == 8 ? 18 : 36; }
 #endif
-constexpr int SMC = 144;
+template <int TM> __device__ __host__ constexpr int smc() { return TM + 16; }   // == 16 mod 32
 constexpr int OPERAND_BYTES = 18432;  // >= 128*skc*sizeof(T) and BKE*SMC*sizeof(T)
-constexpr int GEMM_LDS_BYTES = 4 * OPERAND_BYTES;  // A,B x 2 stages
+constexpr int OPERAND_BYTES_64 = 10240;   // 64-tiles: max(64*skc, BKE*80) elements
+constexpr int GEMM_LDS_BYTES_64 = 4 * OPERAND_BYTES_64;
+constexpr int GEMM_LDS_BYTES = 4 * OPERAND_BYTES;  // A,B x 2 stages (128-tiles; 64-tiles use half)
 
-template <typename T, bool KC>
+template <typename T, bool KC, int TM>
 __device__ __forceinline__ void stage_load(const T* __restrict__ g, int64_t ld, int kt,
-                                           typename Mma<T>::vec_t (&r)[4], int tid) {
+                                           typename Mma<T>::vec_t (&r)[TM / 32], int tid) {
   typedef typename Mma<T>::vec_t vec_t;
   constexpr int VEC = 16 / sizeof(T);
   constexpr int BKE = 128 / sizeof(T);
@@ -54,25 +56,25 @@ __device__ __forceinline__ void stage_load(const T* __restrict__ g, int64_t ld, 
     const int c = tid & 7, row = tid >> 3;
     const T* p = g + (int64_t)row * ld + (int64_t)kt * BKE + c * VEC;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) r[q] = gld(reinterpret_cast<const vec_t*>(p + (int64_t)(32 * q) * ld));
+    for (int q = 0; q < TM / 32; ++q) r[q] = gld(reinterpret_cast<const vec_t*>(p + (int64_t)(32 * q) * ld));
   } else {
-    constexpr int CPR = 128 / VEC;  // 16-byte chunks per 128-element row
+    constexpr int CPR = TM / VEC;   // 16-byte chunks per TM-element row
     constexpr int RPP = 256 / CPR;  // k rows per pass
     const int c = tid % CPR, kr = tid / CPR;
     const T* p = g + ((int64_t)kt * BKE + kr) * ld + c * VEC;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) r[q] = gld(reinterpret_cast<const vec_t*>(p + (int64_t)(RPP * q) * ld));
+    for (int q = 0; q < TM / 32; ++q) r[q] = gld(reinterpret_cast<const vec_t*>(p + (int64_t)(RPP * q) * ld));
   }
 }
 
-template <typename T, bool KC>
-__device__ __forceinline__ void stage_store(T* s, const typename Mma<T>::vec_t (&r)[4], int tid) {
+template <typename T, bool KC, int TM>
+__device__ __forceinline__ void stage_store(T* s, const typename Mma<T>::vec_t (&r)[TM / 32], int tid) {
   typedef typename Mma<T>::vec_t vec_t;
   constexpr int VEC = 16 / sizeof(T);
   if (KC) {
     const int c = tid & 7, row = tid >> 3;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int q = 0; q < TM / 32; ++q) {
       if ((skc<T>() * sizeof(T)) % 16 == 0) {
         *reinterpret_cast<vec_t*>(s + (row + 32 * q) * skc<T>() + c * VEC) = r[q];
       } else {
@@ -81,17 +83,17 @@ __device__ __forceinline__ void stage_store(T* s, const typename Mma<T>::vec_t (
       }
     }
   } else {
-    constexpr int CPR = 128 / VEC;
+    constexpr int CPR = TM / VEC;
     constexpr int RPP = 256 / CPR;
     const int c = tid % CPR, kr = tid / CPR;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) *reinterpret_cast<vec_t*>(s + (kr + RPP * q) * SMC + c * VEC) = r[q];
+    for (int q = 0; q < TM / 32; ++q) *reinterpret_cast<vec_t*>(s + (kr + RPP * q) * smc<TM>() + c * VEC) = r[q];
   }
 }
 
-template <typename T, bool KC>
+template <typename T, bool KC, int TM>
 __device__ __forceinline__ T frag_read(const T* s, int mn, int k) {
-  return KC ? s[mn * skc<T>() + k] : s[k * SMC + mn];
+  return KC ? s[mn * skc<T>() + k] : s[k * smc<TM>() + mn];
 }
 
 template <typename T>
@@ -105,7 +107,7 @@ struct TileJob {
   int beta;                  // 0: C = alpha*acc ; 1: C += alpha*acc
 };
 
-template <typename T>
+template <typename T, int TM>
 __device__ __forceinline__ bool decode_job(const GemmArgs& g, TileJob<T>& j) {
   constexpr int BKE = 128 / sizeof(T);
   const TaskDesc& t = g.tasks[blockIdx.z];
@@ -114,15 +116,17 @@ __device__ __forceinline__ bool decode_job(const GemmArgs& g, TileJob<T>& j) {
   j.colsq = nullptr;
   switch (g.mode) {
     case GEMM_SYRK: {
-      const int c = g.c_lo + (int)blockIdx.y;
-      const int r = g.c_lo + (int)blockIdx.x;
-      const int nrt = nblk + ((g.aug & 1) ? 1 : 0);
-      const int chi = g.c_hi < nblk ? g.c_hi : nblk;
+      // tile coordinates in units of TM (128 or 64); c_lo/c_hi/p0/kt are in 128-units
+      constexpr int U = HBO_TILE / TM;
+      const int c = g.c_lo * U + (int)blockIdx.y;
+      const int r = g.c_lo * U + (int)blockIdx.x;
+      const int nrt = (nblk + ((g.aug & 1) ? 1 : 0)) * U;
+      const int chi = (g.c_hi < nblk ? g.c_hi : nblk) * U;
       if (c >= chi || r < c || r >= nrt) return false;
       T* Am = static_cast<T*>(t.A);
-      j.A = Am + (int64_t)r * HBO_TILE * ld + (int64_t)g.p0 * HBO_TILE;
-      j.B = Am + (int64_t)c * HBO_TILE * ld + (int64_t)g.p0 * HBO_TILE;
-      j.C = Am + (int64_t)r * HBO_TILE * ld + (int64_t)c * HBO_TILE;
+      j.A = Am + (int64_t)r * TM * ld + (int64_t)g.p0 * HBO_TILE;
+      j.B = Am + (int64_t)c * TM * ld + (int64_t)g.p0 * HBO_TILE;
+      j.C = Am + (int64_t)r * TM * ld + (int64_t)c * TM;
       j.lda = j.ldb = j.ldc = ld;
       j.ksteps = g.kt * HBO_TILE / BKE;
       j.alpha = (T)-1; j.beta = 1;
@@ -203,49 +207,40 @@ __device__ __forceinline__ bool decode_job(const GemmArgs& g, TileJob<T>& j) {
   return false;
 }
 
-template <typename T, bool AKC, bool BKC>
-#ifdef HBO_LB1
-__global__ __launch_bounds__(256, 1) void gemm_kernel(GemmArgs g) {
-#else
+template <typename T, bool AKC, bool BKC, int TM>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
-#endif
   typedef typename Mma<T>::acc_t acc_t;
   typedef typename Mma<T>::vec_t vec_t;
   constexpr int BKE = 128 / sizeof(T);
+  constexpr int MI = TM / 32;            // 16x16 MFMA tiles per wave and dimension (wave tile TM/2)
+  constexpr int WT = TM / 2;             // wave tile edge
+  constexpr int OPB = TM == 128 ? OPERAND_BYTES : OPERAND_BYTES_64;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
   TileJob<T> job;
-  if (!decode_job<T>(g, job)) return;
+  if (!decode_job<T, TM>(g, job)) return;
 
   T* sA0 = reinterpret_cast<T*>(smem);
-  T* sA1 = reinterpret_cast<T*>(smem + OPERAND_BYTES);
-  T* sB0 = reinterpret_cast<T*>(smem + 2 * OPERAND_BYTES);
-  T* sB1 = reinterpret_cast<T*>(smem + 3 * OPERAND_BYTES);
+  T* sA1 = reinterpret_cast<T*>(smem + OPB);
+  T* sB0 = reinterpret_cast<T*>(smem + 2 * OPB);
+  T* sB1 = reinterpret_cast<T*>(smem + 3 * OPB);
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int l15 = lane & 15, lq = lane >> 4;
 
-  acc_t acc[4][4];
+  acc_t acc[MI][MI];
 #pragma unroll
-  for (int a = 0; a < 4; ++a)
+  for (int a = 0; a < MI; ++a)
 #pragma unroll
-    for (int b = 0; b < 4; ++b) acc[a][b] = (acc_t){0, 0, 0, 0};
+    for (int b = 0; b < MI; ++b) acc[a][b] = (acc_t){0, 0, 0, 0};
 
-#if defined(HBO_PRIO_SLOT)
-  // co-resident workgroups (2 per CU) otherwise run phase-locked and stall on the same barriers;
-  // giving the wave in the even hardware slot of each SIMD priority makes one workgroup the
-  // MFMA owner and the other the gap filler.
-  if (__builtin_amdgcn_s_getreg(6148) & 1) __builtin_amdgcn_s_setprio(1);   // HW_REG_HW_ID.WAVE_ID
-#elif defined(HBO_PRIO_PARITY)
-  if ((blockIdx.x + blockIdx.y) & 1) __builtin_amdgcn_s_setprio(1);
-#endif
-  vec_t ra[4], rb[4];
+  vec_t ra[MI], rb[MI];
   const int nk = job.ksteps;
-  stage_load<T, AKC>(job.A, job.lda, 0, ra, tid);
-  stage_load<T, BKC>(job.B, job.ldb, 0, rb, tid);
-  stage_store<T, AKC>(sA0, ra, tid);
-  stage_store<T, BKC>(sB0, rb, tid);
+  stage_load<T, AKC, TM>(job.A, job.lda, 0, ra, tid);
+  stage_load<T, BKC, TM>(job.B, job.ldb, 0, rb, tid);
+  stage_store<T, AKC, TM>(sA0, ra, tid);
+  stage_store<T, BKC, TM>(sB0, rb, tid);
   __syncthreads();
 
   for (int kt = 0; kt < nk; ++kt) {
@@ -253,77 +248,70 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
     const T* cB = (kt & 1) ? sB1 : sB0;
     const bool more = (kt + 1 < nk);
     if (more) {
-      stage_load<T, AKC>(job.A, job.lda, kt + 1, ra, tid);
-      stage_load<T, BKC>(job.B, job.ldb, kt + 1, rb, tid);
+      stage_load<T, AKC, TM>(job.A, job.lda, kt + 1, ra, tid);
+      stage_load<T, BKC, TM>(job.B, job.ldb, kt + 1, rb, tid);
     }
 #pragma unroll
     for (int kk = 0; kk < BKE / 4; ++kk) {
       const int k = kk * 4 + lq;
-      T af[4], bf[4];
+      T af[MI], bf[MI];
 #pragma unroll
-      for (int a = 0; a < 4; ++a) af[a] = frag_read<T, AKC>(cA, wm * 64 + a * 16 + l15, k);
+      for (int a = 0; a < MI; ++a) af[a] = frag_read<T, AKC, TM>(cA, wm * WT + a * 16 + l15, k);
 #pragma unroll
-      for (int b = 0; b < 4; ++b) bf[b] = frag_read<T, BKC>(cB, wn * 64 + b * 16 + l15, k);
+      for (int b = 0; b < MI; ++b) bf[b] = frag_read<T, BKC, TM>(cB, wn * WT + b * 16 + l15, k);
 #pragma unroll
-      for (int a = 0; a < 4; ++a)
+      for (int a = 0; a < MI; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = Mma<T>::mma(af[a], bf[b], acc[a][b]);
-#ifdef HBO_MID_STORE
+        for (int b = 0; b < MI; ++b) acc[a][b] = Mma<T>::mma(af[a], bf[b], acc[a][b]);
+      // the LDS stores of the prefetched slab go in the middle of the MFMA stream
       if (kk == BKE / 4 - 2 && more) {
         __builtin_amdgcn_sched_barrier(0);
-        stage_store<T, AKC>((kt & 1) ? sA0 : sA1, ra, tid);
-        stage_store<T, BKC>((kt & 1) ? sB0 : sB1, rb, tid);
+        stage_store<T, AKC, TM>((kt & 1) ? sA0 : sA1, ra, tid);
+        stage_store<T, BKC, TM>((kt & 1) ? sB0 : sB1, rb, tid);
         __builtin_amdgcn_sched_barrier(0);
       }
-#endif
     }
-#ifndef HBO_MID_STORE
-    if (more) {
-      stage_store<T, AKC>((kt & 1) ? sA0 : sA1, ra, tid);
-      stage_store<T, BKC>((kt & 1) ? sB0 : sB1, rb, tid);
-    }
-#endif
     __syncthreads();
   }
 
-  // epilogue: C read-modify-write in four chunks of 16 values per lane, all loads of a chunk in
-  // flight before the first dependent store (a load->store chain per element costs one HBM round
-  // trip per element).
+  // epilogue: C read-modify-write in chunks of one MFMA row block, all loads of a chunk in flight
+  // before the first dependent store (a load->store chain per element costs one HBM round trip
+  // per element).
   if (job.C) {
 #pragma unroll
-    for (int a = 0; a < 4; ++a) {
-      T cv[4][4];
+    for (int a = 0; a < MI; ++a) {
+      T cv[MI][4];
       if (job.beta) {
 #pragma unroll
-        for (int b = 0; b < 4; ++b)
+        for (int b = 0; b < MI; ++b)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
-            const int row = wm * 64 + a * 16 + Mma<T>::crow(lane, r);
-            const int col = wn * 64 + b * 16 + l15;
+            const int row = wm * WT + a * 16 + Mma<T>::crow(lane, r);
+            const int col = wn * WT + b * 16 + l15;
             cv[b][r] = gld(job.C + (int64_t)row * job.ldc + col);
           }
       }
 #pragma unroll
-      for (int b = 0; b < 4; ++b)
+      for (int b = 0; b < MI; ++b)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int row = wm * 64 + a * 16 + Mma<T>::crow(lane, r);
-          const int col = wn * 64 + b * 16 + l15;
+          const int row = wm * WT + a * 16 + Mma<T>::crow(lane, r);
+          const int col = wn * WT + b * 16 + l15;
           T v = job.alpha * acc[a][b][r];
           if (job.beta) v += cv[b][r];
           gst(job.C + (int64_t)row * job.ldc + col, v);
         }
     }
   }
-  if (job.colsq) {
+  if (TM == 128 && job.colsq) {
     // sum over this tile's 128 rows of acc^2, per column
     T* red = reinterpret_cast<T*>(smem);  // [4 waves][64]
-    T part[4];
+    T part[MI];
 #pragma unroll
-    for (int b = 0; b < 4; ++b) {
+    for (int b = 0; b < MI; ++b) {
       T s = 0;
 #pragma unroll
-      for (int a = 0; a < 4; ++a)
+      for (int a = 0; a < MI; ++a)
 #pragma unroll
         for (int r = 0; r < 4; ++r) s += acc[a][b][r] * acc[a][b][r];
       s += __shfl_xor(s, 16);
@@ -333,7 +321,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
     // (the k-loop ended with a barrier, so smem is free)
     if (lq == 0) {
 #pragma unroll
-      for (int b = 0; b < 4; ++b) red[wave * 64 + b * 16 + l15] = part[b];
+      for (int b = 0; b < MI; ++b) red[wave * 64 + b * 16 + l15] = part[b];
     }
     __syncthreads();
     if (tid < 128) {
@@ -348,25 +336,32 @@ template <typename T>
 void launch_gemm_t(const GemmArgs& a, dim3 grid, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T, true, true>),
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T, true, true, 128>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T, true, false>),
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T, true, false, 128>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T, false, false>),
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T, false, false, 128>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
     attr_set = true;
   }
   switch (a.mode) {
     case GEMM_SYRK:
-      hipLaunchKernelGGL((gemm_kernel<T, true, true>), grid, dim3(256), GEMM_LDS_BYTES, st, a);
+      if (a.small_tiles) {
+        // 64x64 tiles: 4x the workgroups, a quarter of the per-tile latency -- for the skinny
+        // updates on the critical path (next block column) and small trailing matrices
+        dim3 g2(grid.x * 2, grid.y * 2, grid.z);
+        hipLaunchKernelGGL((gemm_kernel<T, true, true, 64>), g2, dim3(256), GEMM_LDS_BYTES_64, st, a);
+      } else {
+        hipLaunchKernelGGL((gemm_kernel<T, true, true, 128>), grid, dim3(256), GEMM_LDS_BYTES, st, a);
+      }
       break;
     case GEMM_TRTRI_A:
     case GEMM_TRTRI_B:
     case GEMM_POST:
-      hipLaunchKernelGGL((gemm_kernel<T, true, false>), grid, dim3(256), GEMM_LDS_BYTES, st, a);
+      hipLaunchKernelGGL((gemm_kernel<T, true, false, 128>), grid, dim3(256), GEMM_LDS_BYTES, st, a);
       break;
     case GEMM_LAUUM:
-      hipLaunchKernelGGL((gemm_kernel<T, false, false>), grid, dim3(256), GEMM_LDS_BYTES, st, a);
+      hipLaunchKernelGGL((gemm_kernel<T, false, false, 128>), grid, dim3(256), GEMM_LDS_BYTES, st, a);
       break;
   }
 }

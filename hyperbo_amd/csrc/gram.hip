@@ -400,6 +400,174 @@ __global__ __launch_bounds__(256) void grad_contract_kernel(const TaskDesc* task
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// d nll / d features for MLP-basis kernels (hyperbo/gp_utils/kernel.py:148-183): per lower tile
+//   dF[a][d] += c_d * sum_j g_aj (fs_a - fs_j)_d        (rows of the tile)
+//   dF[j][d] -= c_d * sum_a g_aj (fs_a - fs_j)_d        (columns, off-diagonal tiles only)
+// with g = G * dk/du, c_d = 4/ls_d (SE / Matern);  dot product: dF[a] += 2/sigma^2 sum_j G_aj f_j.
+// Accumulated with fp64 atomics into tasks[t].dF (n x fdim doubles, zeroed by the caller).
+// ---------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void grad_feat_kernel(const TaskDesc* tasks, const ModelDev* __restrict__ md,
+                                                        int fdim) {
+  __shared__ T sA[DC * SXS];
+  __shared__ T sB[DC * SXS];
+  const TaskDesc& t = tasks[blockIdx.z];
+  const int ti = blockIdx.x, tj = blockIdx.y;
+  if (ti >= t.nblk || tj > ti) return;
+  constexpr int VEC = 16 / sizeof(T);
+  const int kid = md->kernel_id;
+  const bool is_dot = (kid == HBO_KERNEL_DOT);
+  const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+  const int64_t r0 = (int64_t)ti * HBO_TILE, c0 = (int64_t)tj * HBO_TILE;
+  const T* F = static_cast<const T*>(t.F);
+  const T* S = static_cast<const T*>(t.S);
+  const T* sv_ = static_cast<const T*>(t.svec);
+  double* dF = static_cast<double*>(t.dF);
+  const int64_t n = t.n;
+
+  T acc[8][8];
+#pragma unroll
+  for (int a = 0; a < 8; ++a)
+#pragma unroll
+    for (int b = 0; b < 8; ++b) acc[a][b] = (T)0;
+  for (int d0 = 0; d0 < fdim; d0 += DC) {
+    __syncthreads();
+    stage_x<T>(sA, F, n, fdim, r0, d0, md->inv_ls, !is_dot, tid);
+    stage_x<T>(sB, F, n, fdim, c0, d0, md->inv_ls, !is_dot, tid);
+    __syncthreads();
+    const int dlim = (fdim - d0) < DC ? (fdim - d0) : DC;
+    for (int dd = 0; dd < dlim; ++dd) {
+      T av[8], bv[8];
+#pragma unroll
+      for (int a = 0; a < 8; ++a) av[a] = sA[dd * SXS + ty + 16 * a];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) bv[q] = sB[dd * SXS + 16 * VEC * (q / VEC) + VEC * tx + (q % VEC)];
+#pragma unroll
+      for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          if (is_dot) acc[a][q] += av[a] * bv[q];
+          else { const T df = av[a] - bv[q]; acc[a][q] += df * df; }
+        }
+    }
+  }
+  const T sv = (T)md->sv;
+  const T inv_sigma2 = (T)(1.0 / (md->dot_sigma * md->dot_sigma));
+  const T bias2 = (T)(md->dot_bias * md->dot_bias);
+  const T m2 = (T)((double)t.m * t.m);
+  // g[a][q] = G_ij * dk/du (SE/Matern) or G_ij (dot)
+#pragma unroll
+  for (int a = 0; a < 8; ++a) {
+    const int64_t row = r0 + ty + 16 * a;
+    const T si = row < n ? sv_[row] : (T)0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int64_t col = c0 + 16 * VEC * (q / VEC) + VEC * tx + (q % VEC);
+      T g = (T)0;
+      if (row < n && col < n) {
+        const T u = acc[a][q];
+        const T G = (T)0.5 * (m2 * S[row * t.ld + col] - si * sv_[col]);
+        if (is_dot) g = G;
+        else { const T k = kfun<T>(kid, u, sv, inv_sigma2, bias2); g = G * dk_du<T>(kid, u, k, sv); }
+      }
+      acc[a][q] = g;
+    }
+  }
+  const bool offdiag = (ti != tj);
+  for (int d0 = 0; d0 < fdim; d0 += DC) {
+    __syncthreads();
+    stage_x<T>(sA, F, n, fdim, r0, d0, md->inv_ls, !is_dot, tid);
+    stage_x<T>(sB, F, n, fdim, c0, d0, md->inv_ls, !is_dot, tid);
+    __syncthreads();
+    const int dlim = (fdim - d0) < DC ? (fdim - d0) : DC;
+    for (int dd = 0; dd < dlim; ++dd) {
+      const int d = d0 + dd;
+      const double cd = is_dot ? 2.0 / (md->dot_sigma * md->dot_sigma) : 4.0 * md->inv_ls[d];
+      T av[8], bv[8];
+#pragma unroll
+      for (int a = 0; a < 8; ++a) av[a] = sA[dd * SXS + ty + 16 * a];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) bv[q] = sB[dd * SXS + 16 * VEC * (q / VEC) + VEC * tx + (q % VEC)];
+      double rs[8], cs[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) cs[q] = 0;
+#pragma unroll
+      for (int a = 0; a < 8; ++a) {
+        double s = 0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          if (is_dot) { s += (double)(acc[a][q] * bv[q]); cs[q] += (double)(acc[a][q] * av[a]); }
+          else { const T w = acc[a][q] * (av[a] - bv[q]); s += (double)w; cs[q] -= (double)w; }
+        }
+        rs[a] = s;
+      }
+      // rows: reduce over the 16 tx lanes (consecutive lanes of a wave)
+#pragma unroll
+      for (int a = 0; a < 8; ++a) {
+        double s = rs[a];
+        s += __shfl_xor(s, 1); s += __shfl_xor(s, 2); s += __shfl_xor(s, 4); s += __shfl_xor(s, 8);
+        const int64_t row = r0 + ty + 16 * a;
+        if (tx == 0 && row < n) atomicAdd(&dF[row * fdim + d], cd * s);
+      }
+      if (offdiag) {
+        // columns: reduce over the 4 ty values inside the wave, one atomic per wave and column
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          double s = cs[q];
+          s += __shfl_xor(s, 16); s += __shfl_xor(s, 32);
+          const int64_t col = c0 + 16 * VEC * (q / VEC) + VEC * tx + (q % VEC);
+          if ((tid & 63) < 16 && col < n) atomicAdd(&dF[col * fdim + d], cd * s);
+        }
+      }
+    }
+  }
+}
+
+// dF[i][d] += -m s_i w_lin[d]   (mean.linear_mlp: d nll / d mu_i = -m s_i, mu = feat . w + b)
+template <typename T>
+__global__ void grad_feat_mean_kernel(const TaskDesc* tasks, const ModelDev* __restrict__ md, int fdim) {
+  const TaskDesc& t = tasks[blockIdx.z];
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)t.n * fdim) return;
+  const int64_t i = idx / fdim; const int d = (int)(idx % fdim);
+  static_cast<double*>(t.dF)[idx] += -(double)t.m * (double)static_cast<const T*>(t.svec)[i] * md->lin_w[d];
+}
+
+// MLP backward, one dense+tanh layer:  dz = dout * (1 - out^2) (in place, double)
+template <typename T>
+__global__ void dense_bwd_dz_kernel(double* __restrict__ dout, const T* __restrict__ out, int64_t count) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= count) return;
+  const double o = (double)out[idx];
+  dout[idx] *= (1.0 - o * o);
+}
+// dW[k][o] += sum_i in[i][k] dz[i][o] ; db[o] += sum_i dz[i][o]   (grid.x = k in 0..fin (fin = bias row),
+// grid.y = row chunk; threads over o)
+template <typename T>
+__global__ void dense_bwd_w_kernel(const T* __restrict__ in, const double* __restrict__ dz, int64_t n, int fin,
+                                   int fout, double* dW, double* db, int rows_per_block) {
+  const int k = blockIdx.x;
+  const int64_t i0 = (int64_t)blockIdx.y * rows_per_block;
+  int64_t i1 = i0 + rows_per_block; if (i1 > n) i1 = n;
+  for (int o = threadIdx.x; o < fout; o += blockDim.x) {
+    double s = 0;
+    if (k < fin) { for (int64_t i = i0; i < i1; ++i) s += (double)in[i * fin + k] * dz[i * fout + o]; atomicAdd(&dW[(int64_t)k * fout + o], s); }
+    else { for (int64_t i = i0; i < i1; ++i) s += dz[i * fout + o]; atomicAdd(&db[o], s); }
+  }
+}
+// din[i][k] = sum_o dz[i][o] w[k][o]
+template <typename T>
+__global__ void dense_bwd_in_kernel(const double* __restrict__ dz, const T* __restrict__ w, int64_t n, int fin,
+                                    int fout, double* din) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n * fin) return;
+  const int64_t i = idx / fin; const int k = (int)(idx % fin);
+  double s = 0;
+  for (int o = 0; o < fout; ++o) s += dz[i * fout + o] * (double)w[(int64_t)k * fout + o];
+  din[idx] = s;
+}
+
 // per task: reduce tile partials and apply the chain-rule factors; also mean-parameter grads.
 // out layout per task (doubles): [lengthscale(n_ls)] [signal_variance] [noise_variance] [constant]
 //                                [dot_prod_sigma] [dot_prod_bias] [linear_kernel(fmean)] [linear_bias]
@@ -641,6 +809,36 @@ void launch_grad_finalize(int dtype, const TaskDesc* tasks, int ntasks, const Mo
   const int nacc = grad_nacc(kernel_id, fdim);
   if (dtype == HBO_F64) hipLaunchKernelGGL((grad_finalize_kernel<double>), dim3(ntasks), dim3(256), 0, st, tasks, md, fdim, nacc, partials, stride_task, out, out_stride);
   else hipLaunchKernelGGL((grad_finalize_kernel<float>), dim3(ntasks), dim3(256), 0, st, tasks, md, fdim, nacc, partials, stride_task, out, out_stride);
+}
+void launch_grad_feat(int dtype, const TaskDesc* tasks, int ntasks, int max_nblk, const ModelDev* md, int fdim,
+                      hipStream_t st) {
+  dim3 grid(max_nblk, max_nblk, ntasks);
+  if (dtype == HBO_F64) hipLaunchKernelGGL((grad_feat_kernel<double>), grid, dim3(256), 0, st, tasks, md, fdim);
+  else hipLaunchKernelGGL((grad_feat_kernel<float>), grid, dim3(256), 0, st, tasks, md, fdim);
+}
+void launch_grad_feat_mean(int dtype, const TaskDesc* tasks, int ntasks, int64_t max_n, const ModelDev* md,
+                           int fdim, hipStream_t st) {
+  dim3 grid((unsigned)((max_n * fdim + 255) / 256), 1, ntasks);
+  if (dtype == HBO_F64) hipLaunchKernelGGL((grad_feat_mean_kernel<double>), grid, dim3(256), 0, st, tasks, md, fdim);
+  else hipLaunchKernelGGL((grad_feat_mean_kernel<float>), grid, dim3(256), 0, st, tasks, md, fdim);
+}
+// one layer of the MLP backward pass for one task; dout (n x fout, double) is turned into dz in place
+void launch_dense_bwd(int dtype, const void* in, const void* out, const void* w, double* dout, double* din,
+                      double* dW, double* db, int64_t n, int fin, int fout, hipStream_t st) {
+  if (n <= 0) return;
+  const int64_t cnt = n * fout;
+  const int rpb = 256;
+  dim3 gw(fin + 1, (unsigned)((n + rpb - 1) / rpb));
+  const int thr = fout < 64 ? 64 : (fout > 256 ? 256 : ((fout + 63) / 64) * 64);
+  if (dtype == HBO_F64) {
+    hipLaunchKernelGGL((dense_bwd_dz_kernel<double>), dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, dout, (const double*)out, cnt);
+    hipLaunchKernelGGL((dense_bwd_w_kernel<double>), gw, dim3(thr), 0, st, (const double*)in, dout, n, fin, fout, dW, db, rpb);
+    if (din) hipLaunchKernelGGL((dense_bwd_in_kernel<double>), dim3((unsigned)((n * fin + 255) / 256)), dim3(256), 0, st, dout, (const double*)w, n, fin, fout, din);
+  } else {
+    hipLaunchKernelGGL((dense_bwd_dz_kernel<float>), dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, st, dout, (const float*)out, cnt);
+    hipLaunchKernelGGL((dense_bwd_w_kernel<float>), gw, dim3(thr), 0, st, (const float*)in, dout, n, fin, fout, dW, db, rpb);
+    if (din) hipLaunchKernelGGL((dense_bwd_in_kernel<float>), dim3((unsigned)((n * fin + 255) / 256)), dim3(256), 0, st, dout, (const float*)w, n, fin, fout, din);
+  }
 }
 void launch_post_epilogue(int dtype, const PostArgs& a, hipStream_t st) {
   if (a.M <= 0) return;

@@ -57,6 +57,7 @@ struct GemmArgs {
   int c_lo;      // SYRK: first updated tile column
   int c_hi;      // SYRK: end (exclusive) of updated tile columns
   int aug;       // SYRK: 1 -> include the augmented tile-row
+  int small_tiles;  // SYRK: 1 -> 64x64 output tiles (grid is given in 128-tile units)
   void* B;       // POST: Kxq (npad x ldb)
   int64_t ldb;
   void* V;       // POST: optional V output (npad x ldb), may be null
@@ -99,6 +100,12 @@ void launch_grad_contract(int dtype, const TaskDesc* tasks, int ntasks, int max_
 void launch_grad_finalize(int dtype, const TaskDesc* tasks, int ntasks, const ModelDev* md, int kernel_id,
                           int fdim, const double* partials, int64_t stride_task, double* out, int out_stride,
                           hipStream_t st);
+void launch_grad_feat(int dtype, const TaskDesc* tasks, int ntasks, int max_nblk, const ModelDev* md, int fdim,
+                      hipStream_t st);
+void launch_grad_feat_mean(int dtype, const TaskDesc* tasks, int ntasks, int64_t max_n, const ModelDev* md,
+                           int fdim, hipStream_t st);
+void launch_dense_bwd(int dtype, const void* in, const void* out, const void* w, double* dout, double* din,
+                      double* dW, double* db, int64_t n, int fin, int fout, hipStream_t st);
 struct PostArgs {
   const void* Kxq; int64_t ldq; int npad; int n; int nblk;   // cross Gram (npad x ldq)
   const void* alpha;    // kinvy [npad] (first column)

@@ -119,26 +119,29 @@ def _ragged_dataset(rng, d):
 
 
 @pytest.mark.parametrize('kname', helpers.KERNELS)
-@pytest.mark.parametrize('mname', ['zero', 'constant', 'linear'])
+@pytest.mark.parametrize('mlp', [False, True])
+@pytest.mark.parametrize('mname', helpers.MEANS)
 @pytest.mark.parametrize('exclude_aligned', [True, False])
-def test_nll_value_and_grad_vs_oracle_fp64(gpu_ctx, kname, mname, exclude_aligned):
+def test_nll_value_and_grad_vs_oracle_fp64(gpu_ctx, kname, mlp, mname, exclude_aligned):
   defs, _, _, _, kernel, mean, objectives, utils = _native()
   rng = np.random.default_rng(3)
   d = 3
-  model = helpers.make_model(rng, mname, False, d)
+  model = helpers.make_model(rng, mname, mlp, d)
   po, pn = _pair(model)
   dso = _ragged_dataset(rng, d)
   dsn = {k: defs.SubDataset(v.x, v.y, v.aligned) for k, v in dso.items()}
-  vo, go = o.nll_value_and_grad(getattr(o, mname), getattr(o, kname), po, dso, WFO, exclude_aligned=exclude_aligned)
-  vn, gn = objectives.nll_value_and_grad(getattr(mean, mname), getattr(kernel, kname), pn, dsn,
+  ko = getattr(o, kname + ('_mlp' if mlp else '')); kn = getattr(kernel, kname + ('_mlp' if mlp else ''))
+  vo, go = o.nll_value_and_grad(getattr(o, mname), ko, po, dso, WFO, exclude_aligned=exclude_aligned)
+  vn, gn = objectives.nll_value_and_grad(getattr(mean, mname), kn, pn, dsn,
                                          utils.DEFAULT_WARP_FUNC, exclude_aligned=exclude_aligned)
+  assert set(gn) == set(go)
   assert abs(vn - vo) <= 1e-10 * abs(vo)
   fo, fn = helpers.flatten(go), helpers.flatten(gn)
   assert np.max(np.abs(fo - fn)) <= 1e-8 * np.max(np.abs(fo))
-  v2, k2 = objectives.neg_log_marginal_likelihood(getattr(mean, mname), getattr(kernel, kname), pn, dsn,
+  v2, k2 = objectives.neg_log_marginal_likelihood(getattr(mean, mname), kn, pn, dsn,
                                                   utils.DEFAULT_WARP_FUNC, exclude_aligned=exclude_aligned,
                                                   return_key2nll=True)
-  _, k2o = o.neg_log_marginal_likelihood(getattr(o, mname), getattr(o, kname), po, dso, WFO,
+  _, k2o = o.neg_log_marginal_likelihood(getattr(o, mname), ko, po, dso, WFO,
                                          exclude_aligned=exclude_aligned, return_key2nll=True)
   assert abs(v2 - vo) <= 1e-10 * abs(vo) and set(k2) == set(k2o)
   for k in k2o:
@@ -160,6 +163,31 @@ def test_nll_with_priors_and_scalar_lengthscale(gpu_ctx):
   assert abs(vn - vo) <= 1e-10 * abs(vo)
   np.testing.assert_allclose(helpers.flatten(gn), helpers.flatten(go), rtol=1e-7, atol=1e-9)
   assert gn['lengthscale'].shape == (1,)
+
+
+def test_nll_grad_mlp_fp32_and_feature_dim_gt_chunk(gpu_ctx):
+  """MLP-basis gradient with a feature dimension above the 16-wide LDS chunk, fp64 and fp32."""
+  defs, _, _, _, kernel, mean, objectives, utils = _native()
+  rng = np.random.default_rng(16)
+  d, f = 6, 40
+  model = {'lengthscale': rng.uniform(0.5, 1.5, size=f), 'signal_variance': np.array(0.3), 'noise_variance': np.array(-2.0),
+           'mlp_params': {'Dense_0': {'kernel': rng.normal(size=(d, f)) / np.sqrt(d), 'bias': rng.normal(size=f) * 0.1}},
+           'linear_mean': {'kernel': rng.normal(size=(f, 1)) / np.sqrt(f), 'bias': np.zeros(1)}}
+  cfg = {'mlp_features': (f,)}
+  dso = {i: o.SubDataset(*helpers.synthetic_task(rng, 150 + 40 * i, d)) for i in range(2)}
+  dsn = {k: defs.SubDataset(v.x, v.y) for k, v in dso.items()}
+  vo, go = o.nll_value_and_grad(o.linear_mlp, o.matern52_mlp, o.GPParams(model=model, config=cfg), dso, WFO)
+  vn, gn = objectives.nll_value_and_grad(mean.linear_mlp, kernel.matern52_mlp, defs.GPParams(model=model, config=dict(cfg)),
+                                         dsn, utils.DEFAULT_WARP_FUNC)
+  assert abs(vn - vo) <= 1e-10 * abs(vo)
+  fo, fn = helpers.flatten(go), helpers.flatten(gn)
+  assert np.max(np.abs(fo - fn)) <= 1e-8 * np.max(np.abs(fo))
+  to32 = lambda t: {k: to32(v) for k, v in t.items()} if isinstance(t, dict) else np.asarray(t, dtype=np.float32)
+  ds32 = {k: defs.SubDataset(v.x.astype(np.float32), v.y.astype(np.float32)) for k, v in dso.items()}
+  v32, g32 = objectives.nll_value_and_grad(mean.linear_mlp, kernel.matern52_mlp, defs.GPParams(model=to32(model), config=dict(cfg)),
+                                           ds32, utils.DEFAULT_WARP_FUNC)
+  assert abs(v32 - vo) <= 2e-4 * abs(vo)
+  assert np.max(np.abs(helpers.flatten(g32) - fo)) <= 5e-3 * np.max(np.abs(fo))
 
 
 def test_nll_fp32_vs_fp64_oracle(gpu_ctx):
@@ -280,10 +308,9 @@ def test_against_golden_fixtures(gpu_ctx, case):
   assert abs(k2[0] - float(ref['nll0'])) <= 1e-10 * abs(float(ref['nll0']))
   assert abs(k2[1] - float(ref['nll1'])) <= 1e-10 * abs(float(ref['nll1']))
   assert abs(nll / float(ref['nll_svd']) - 1) < 1e-6          # objectives_test.py:168
-  if not mlp and mname != 'linear_mlp':
-    v, g = objectives.nll_value_and_grad(mn, kn, pn, ds, wf)
-    gf = helpers.flatten(g)
-    assert np.max(np.abs(gf - ref['grad_flat'])) <= 1e-8 * np.max(np.abs(ref['grad_flat']))
+  v, g = objectives.nll_value_and_grad(mn, kn, pn, ds, wf)
+  gf = helpers.flatten(g)
+  assert np.max(np.abs(gf - ref['grad_flat'])) <= 1e-8 * np.max(np.abs(ref['grad_flat']))
   chol, kinvy, ymu = linalg.solve_gp_linear_system(mn, kn, pn, x, y, wf)
   assert helpers.rel_err(chol, ref['chol']) < 1e-10 and helpers.rel_err(kinvy, ref['kinvy']) < 1e-8
   mu, var = gp.predict(mn, kn, pn, x, y, xq, wf)
