@@ -22,7 +22,9 @@ struct hbo_ctx {
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;   // panel stream of the look-ahead Cholesky (high priority)
   hipStream_t stream3 = nullptr;   // bulk trailing updates, CU-masked so the panel chain always finds free CUs
-  int opt_reserve_cus = 0;   // >0: keep that many CUs free of bulk updates (measured: no gain)
+  int opt_reserve_cus = 0;   // >0: CU-masked bulk stream (measured: no gain)
+  int opt_persist_free = 32; // bulk trailing update runs as 2*(CUs - this) persistent workgroups
+  int n_cus = 256;
   std::vector<hipEvent_t> ev_pool;
   int opt_lookahead = 1;
   std::string err;
@@ -32,7 +34,7 @@ struct hbo_ctx {
   void* d_mlp_b[HBO_MAX_MLP_LAYERS] = {nullptr};
   size_t mlp_w_bytes[HBO_MAX_MLP_LAYERS] = {0};
   size_t mlp_b_bytes[HBO_MAX_MLP_LAYERS] = {0};
-  int opt_group = 2;         // 128-wide panels per trailing update (K = 128*group)
+  int opt_group = 4;         // 128-wide panels per trailing update (K = 128*group)
   int prof_level = 0;
   std::vector<ProfEntry> prof_pending;
   std::vector<std::string> prof_names;
@@ -130,6 +132,7 @@ extern "C" int hbo_ctx_create(int device, hbo_ctx** out) {
     (void)nullctx;
     return HBO_ERR_HIP;
   }
+  { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_cus = prop.multiProcessorCount; }
   *out = c;
   return HBO_OK;
 }
@@ -152,6 +155,7 @@ extern "C" int hbo_set_option(hbo_ctx* c, const char* name, int64_t value) {
   if (!c || !name) return HBO_ERR_ARG;
   if (!strcmp(name, "potrf_group")) { if (value < 1 || value > 8) return fail(c, HBO_ERR_ARG, "potrf_group in 1..8"); c->opt_group = (int)value; return HBO_OK; }
   if (!strcmp(name, "lookahead")) { c->opt_lookahead = value ? 1 : 0; return HBO_OK; }
+  if (!strcmp(name, "persist_free")) { if (value < 0 || value > 200) return fail(c, HBO_ERR_ARG, "persist_free in 0..200"); c->opt_persist_free = (int)value; return HBO_OK; }
   if (!strcmp(name, "reserve_cus")) {
     if (value < 0 || value > 128) return fail(c, HBO_ERR_ARG, "reserve_cus in 0..128");
     c->opt_reserve_cus = (int)value;
@@ -379,7 +383,12 @@ static void run_potrf(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks
             a.c_lo = g2; a.c_hi = max_nblk;
             const int64_t m = max_nblk - g2;
             a.small_tiles = m * (m + 1) / 2 * ntasks < 600;
+            // persistent form (single task, enough tiles to fill the machine): leave CUs for the panel chain
+            const int64_t ntiles = (m * (m + 1) / 2 + m) * (a.small_tiles ? 4 : 1);
+            const int pblocks = 2 * (c->n_cus - c->opt_persist_free);
+            a.persistent = (ntasks == 1 && c->opt_persist_free > 0 && ntiles > pblocks) ? pblocks : 0;
             launch_gemm(dtype, a, dim3(max_nblk + 1 - a.c_lo, a.c_hi - a.c_lo, ntasks), sb);
+            a.persistent = 0;
           }
           hipEvent_t e2 = pool_event(c, evi++);
           hipEventRecord(e2, sb);

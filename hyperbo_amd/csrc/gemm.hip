@@ -173,17 +173,19 @@ __device__ __forceinline__ bool decode_job(const GemmArgs& g, TileJob<T>& j) {
       return true;
     }
     case GEMM_LAUUM: {
-      // x = row tile i (K = nblk - i), y = column tile: concurrently running tiles share the
-      // column panel W[:, jt] through L2 (measured faster than a strict longest-first order).
+      // x = row tile i (K = nblk - i), y = column tile: concurrently running tiles share the column
+      // panel W[:, jt] through L2.  (Measured alternatives that were slower: strict longest-first
+      // order, 1.4x; XCD-aware 4x16 super-tiles streaming K in lockstep, 2x -- hot L2 channels.)
       const int i = blockIdx.x, jt = blockIdx.y;
       if (i >= nblk || jt > i) return false;
+      const int k0 = i;
       const T* W = static_cast<const T*>(t.W);
       // C[i,j] = sum_{k >= i*128} W[k, i-tile]^T W[k, j-tile]
-      j.A = W + (int64_t)i * HBO_TILE * ld + (int64_t)i * HBO_TILE;
-      j.B = W + (int64_t)i * HBO_TILE * ld + (int64_t)jt * HBO_TILE;
+      j.A = W + (int64_t)k0 * HBO_TILE * ld + (int64_t)i * HBO_TILE;
+      j.B = W + (int64_t)k0 * HBO_TILE * ld + (int64_t)jt * HBO_TILE;
       j.C = static_cast<T*>(t.S) + (int64_t)i * HBO_TILE * ld + (int64_t)jt * HBO_TILE;
       j.lda = j.ldb = j.ldc = ld;
-      j.ksteps = (nblk - i) * HBO_TILE / BKE;
+      j.ksteps = (nblk - k0) * HBO_TILE / BKE;
       j.alpha = (T)1; j.beta = 0;
       return true;
     }
@@ -208,17 +210,13 @@ __device__ __forceinline__ bool decode_job(const GemmArgs& g, TileJob<T>& j) {
 }
 
 template <typename T, bool AKC, bool BKC, int TM>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
+__device__ __forceinline__ void gemm_tile(const TileJob<T>& job, unsigned char* smem) {
   typedef typename Mma<T>::acc_t acc_t;
   typedef typename Mma<T>::vec_t vec_t;
   constexpr int BKE = 128 / sizeof(T);
   constexpr int MI = TM / 32;            // 16x16 MFMA tiles per wave and dimension (wave tile TM/2)
   constexpr int WT = TM / 2;             // wave tile edge
   constexpr int OPB = TM == 128 ? OPERAND_BYTES : OPERAND_BYTES_64;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-
-  TileJob<T> job;
-  if (!decode_job<T, TM>(g, job)) return;
 
   T* sA0 = reinterpret_cast<T*>(smem);
   T* sA1 = reinterpret_cast<T*>(smem + OPB);
@@ -332,6 +330,46 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
   }
 }
 
+// SYRK tiles by linear index (column-major over the trapezoid c in [c_lo,c_hi), r in [c,nrt)): used by
+// the persistent form of the bulk trailing update, whose grid is smaller than the machine so that
+// the panel kernels of the look-ahead (potf2 / trsm / next-column update) always find free CUs.
+template <typename T, int TM>
+__device__ __forceinline__ bool decode_syrk_linear(const GemmArgs& g, int tix, TileJob<T>& j) {
+  constexpr int BKE = 128 / sizeof(T);
+  constexpr int U = HBO_TILE / TM;
+  const TaskDesc& t = g.tasks[blockIdx.z];
+  const int nblk = t.nblk;
+  const int nrt = (nblk + ((g.aug & 1) ? 1 : 0)) * U;
+  const int chi = (g.c_hi < nblk ? g.c_hi : nblk) * U;
+  int c = g.c_lo * U;
+  while (c < chi && tix >= nrt - c) { tix -= nrt - c; ++c; }
+  if (c >= chi) return false;
+  const int r = c + tix;
+  const int64_t ld = t.ld;
+  T* Am = static_cast<T*>(t.A);
+  j.A = Am + (int64_t)r * TM * ld + (int64_t)g.p0 * HBO_TILE;
+  j.B = Am + (int64_t)c * TM * ld + (int64_t)g.p0 * HBO_TILE;
+  j.C = Am + (int64_t)r * TM * ld + (int64_t)c * TM;
+  j.lda = j.ldb = j.ldc = ld;
+  j.colsq = nullptr;
+  j.ksteps = g.kt * HBO_TILE / BKE;
+  j.alpha = (T)-1; j.beta = 1;
+  return true;
+}
+
+template <typename T, bool AKC, bool BKC, int TM>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  TileJob<T> job;
+  if (AKC && BKC && g.persistent) {
+    for (int tix = blockIdx.x; decode_syrk_linear<T, TM>(g, tix, job); tix += gridDim.x)
+      gemm_tile<T, AKC, BKC, TM>(job, smem);
+    return;
+  }
+  if (!decode_job<T, TM>(g, job)) return;
+  gemm_tile<T, AKC, BKC, TM>(job, smem);
+}
+
 template <typename T>
 void launch_gemm_t(const GemmArgs& a, dim3 grid, hipStream_t st) {
   static bool attr_set = false;
@@ -346,7 +384,11 @@ void launch_gemm_t(const GemmArgs& a, dim3 grid, hipStream_t st) {
   }
   switch (a.mode) {
     case GEMM_SYRK:
-      if (a.small_tiles) {
+      if (a.persistent > 0) {
+        dim3 gp(a.persistent, 1, grid.z);
+        if (a.small_tiles) hipLaunchKernelGGL((gemm_kernel<T, true, true, 64>), gp, dim3(256), GEMM_LDS_BYTES_64, st, a);
+        else hipLaunchKernelGGL((gemm_kernel<T, true, true, 128>), gp, dim3(256), GEMM_LDS_BYTES, st, a);
+      } else if (a.small_tiles) {
         // 64x64 tiles: 4x the workgroups, a quarter of the per-tile latency -- for the skinny
         // updates on the critical path (next block column) and small trailing matrices
         dim3 g2(grid.x * 2, grid.y * 2, grid.z);

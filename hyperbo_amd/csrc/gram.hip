@@ -54,21 +54,26 @@ constexpr int DC = 16;     // feature chunk staged in LDS
 constexpr int SXS = 132;   // LDS row stride of a staged [DC][128] block
 
 // stage rows [r0, r0+128) x features [d0, d0+DC) of x (n x fdim) into s[dd][row], scaled
-template <typename T>
+template <typename T, int NQ = 8>
 __device__ __forceinline__ void stage_x(T* s, const T* __restrict__ x, int64_t n, int fdim, int64_t r0,
                                         int d0, const double* inv_ls, bool scale, int tid) {
   const int dd = tid & 15, rr0 = tid >> 4;
   const int d = d0 + dd;
   const T sc = (scale && d < fdim) ? (T)inv_ls[d] : (T)1;
 #pragma unroll
-  for (int q = 0; q < 8; ++q) {
+  for (int q = 0; q < NQ; ++q) {
     const int rr = rr0 + 16 * q;
     const int64_t row = r0 + rr;
     T v = (T)0;
-    if (row < n && d < fdim) v = x[row * fdim + d] * sc;
+    if (row < n && d < fdim) v = gld(x + row * fdim + d) * sc;
     s[dd * SXS + rr] = v;
   }
 }
+
+// tile = 64 rows x 128 columns per 256-thread workgroup, 4x8 register micro-tile per thread
+// (an 8x8 micro-tile needs 256 VGPRs in fp64 -> 1 wave/SIMD and exposed exp/store latency).
+constexpr int GRA = 4;            // rows per thread
+constexpr int GTR = 16 * GRA;     // tile rows
 
 template <typename T, bool PADDED>
 __global__ __launch_bounds__(256) void gram_kernel(GramArgs g, const ModelDev* __restrict__ md) {
@@ -76,11 +81,11 @@ __global__ __launch_bounds__(256) void gram_kernel(GramArgs g, const ModelDev* _
   constexpr int VEC = 16 / sizeof(T);
   __shared__ T sA[DC * SXS];
   __shared__ T sB[DC * SXS];
-  const int ti = blockIdx.y, tj = blockIdx.x;
+  const int ti = blockIdx.y, tj = blockIdx.x;   // ti in units of GTR rows, tj in units of 128 columns
   const T* x1; const T* x2; T* out; int64_t n1, n2, ldo; int64_t e1, e2;  // e*: padded extents
   if (g.tasks) {
     const TaskDesc& t = g.tasks[blockIdx.z];
-    if (ti >= t.nblk || tj >= t.nblk) return;
+    if ((int64_t)ti * GTR >= t.npad || tj >= t.nblk) return;
     x1 = x2 = static_cast<const T*>(t.F);
     out = static_cast<T*>(t.A);
     n1 = n2 = t.n; ldo = t.ld; e1 = e2 = t.npad;
@@ -88,39 +93,39 @@ __global__ __launch_bounds__(256) void gram_kernel(GramArgs g, const ModelDev* _
     x1 = static_cast<const T*>(g.x1); x2 = static_cast<const T*>(g.x2); out = static_cast<T*>(g.out);
     n1 = g.n1; n2 = g.n2; ldo = g.ldo; e1 = PADDED ? g.n1pad : g.n1; e2 = PADDED ? g.n2pad : g.n2;
   }
-  if (g.symmetric && tj > ti) return;
+  const int64_t r0 = (int64_t)ti * GTR, c0 = (int64_t)tj * HBO_TILE;
+  if (g.symmetric && c0 > r0 + GTR - 1) return;   // entirely above the diagonal
   const int fdim = g.fdim;
   const int kid = md->kernel_id;
   const bool is_dot = (kid == HBO_KERNEL_DOT);
   const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
-  const int64_t r0 = (int64_t)ti * HBO_TILE, c0 = (int64_t)tj * HBO_TILE;
 
-  T acc[8][8];
+  T acc[GRA][8];
 #pragma unroll
-  for (int a = 0; a < 8; ++a)
+  for (int a = 0; a < GRA; ++a)
 #pragma unroll
     for (int b = 0; b < 8; ++b) acc[a][b] = (T)0;
 
   for (int d0 = 0; d0 < fdim; d0 += DC) {
     __syncthreads();
-    stage_x<T>(sA, x1, n1, fdim, r0, d0, md->inv_ls, !is_dot, tid);
-    stage_x<T>(sB, x2, n2, fdim, c0, d0, md->inv_ls, !is_dot, tid);
+    stage_x<T, GRA>(sA, x1, n1, fdim, r0, d0, md->inv_ls, !is_dot, tid);
+    stage_x<T, 8>(sB, x2, n2, fdim, c0, d0, md->inv_ls, !is_dot, tid);
     __syncthreads();
     const int dlim = (fdim - d0) < DC ? (fdim - d0) : DC;
     for (int dd = 0; dd < dlim; ++dd) {
-      T av[8], bv[8];
+      T av[GRA], bv[8];
 #pragma unroll
-      for (int a = 0; a < 8; ++a) av[a] = sA[dd * SXS + ty + 16 * a];
+      for (int a = 0; a < GRA; ++a) av[a] = sA[dd * SXS + ty + 16 * a];
 #pragma unroll
       for (int q = 0; q < 8; ++q) bv[q] = sB[dd * SXS + 16 * VEC * (q / VEC) + VEC * tx + (q % VEC)];
       if (is_dot) {
 #pragma unroll
-        for (int a = 0; a < 8; ++a)
+        for (int a = 0; a < GRA; ++a)
 #pragma unroll
           for (int q = 0; q < 8; ++q) acc[a][q] += av[a] * bv[q];
       } else {
 #pragma unroll
-        for (int a = 0; a < 8; ++a)
+        for (int a = 0; a < GRA; ++a)
 #pragma unroll
           for (int q = 0; q < 8; ++q) { const T df = av[a] - bv[q]; acc[a][q] += df * df; }
       }
@@ -132,7 +137,7 @@ __global__ __launch_bounds__(256) void gram_kernel(GramArgs g, const ModelDev* _
   const T bias2 = (T)(md->dot_bias * md->dot_bias);
   const T diag_add = (T)(md->noise + md->eps);
 #pragma unroll
-  for (int a = 0; a < 8; ++a) {
+  for (int a = 0; a < GRA; ++a) {
     const int64_t row = r0 + ty + 16 * a;
     if (row >= e1) continue;
 #pragma unroll
@@ -155,11 +160,11 @@ __global__ __launch_bounds__(256) void gram_kernel(GramArgs g, const ModelDev* _
         vec_t vv;
 #pragma unroll
         for (int e = 0; e < VEC; ++e) vv[e] = vals[e];
-        *reinterpret_cast<vec_t*>(out + row * ldo + col0) = vv;
+        gst(reinterpret_cast<vec_t*>(out + row * ldo + col0), vv);
       } else {
 #pragma unroll
         for (int e = 0; e < VEC; ++e)
-          if (col0 + e < e2) out[row * ldo + col0 + e] = vals[e];
+          if (col0 + e < e2) gst(out + row * ldo + col0 + e, vals[e]);
       }
     }
   }
@@ -351,10 +356,26 @@ __global__ __launch_bounds__(256) void grad_contract_kernel(const TaskDesc* task
   const T wt = (ti == tj) ? (T)1 : (T)2;   // off-diagonal tiles stand for their mirror image too
   double a_gk = 0, a_tr = 0, a_g = 0;
   // gw[a][q] = weight * G_ij * dk/du  (re-uses acc storage)
+  typedef typename V16<T>::type vec_t;
+  // s_j for this thread's 8 columns (svec is zero-padded to npad, S has full padded tiles)
+  T sj[8];
+#pragma unroll
+  for (int qb = 0; qb < 8 / VEC; ++qb) {
+    const vec_t v = gld(reinterpret_cast<const vec_t*>(sv_ + c0 + 16 * VEC * qb + VEC * tx));
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) sj[qb * VEC + e] = v[e];
+  }
 #pragma unroll
   for (int a = 0; a < 8; ++a) {
     const int64_t row = r0 + ty + 16 * a;
-    const T si = row < n ? sv_[row] : (T)0;
+    const T si = gld(sv_ + row);
+    T kinv_row[8];
+#pragma unroll
+    for (int qb = 0; qb < 8 / VEC; ++qb) {
+      const vec_t v = gld(reinterpret_cast<const vec_t*>(S + row * t.ld + c0 + 16 * VEC * qb + VEC * tx));
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) kinv_row[qb * VEC + e] = v[e];
+    }
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       const int64_t col = c0 + 16 * VEC * (q / VEC) + VEC * tx + (q % VEC);
@@ -362,8 +383,8 @@ __global__ __launch_bounds__(256) void grad_contract_kernel(const TaskDesc* task
       if (row < n && col < n) {
         const T u = acc[a][q];
         const T k = kfun<T>(kid, u, sv, inv_sigma2, bias2);
-        const T kinv = S[row * t.ld + col];
-        const T G = (T)0.5 * (m2 * kinv - si * sv_[col]) * wt;
+        const T kinv = kinv_row[q];
+        const T G = (T)0.5 * (m2 * kinv - si * sj[q]) * wt;
         if (is_dot) { a_gk += (double)(G * u); a_g += (double)G; }
         else { a_gk += (double)(G * k); gw = G * dk_du<T>(kid, u, k, sv); }
         if (row == col) a_tr += (double)G;
@@ -741,6 +762,7 @@ __global__ __launch_bounds__(256) void tri_matvec_kernel(const T* __restrict__ W
 
 template <typename T>
 void launch_gram_t(const GramArgs& a, const ModelDev* md, dim3 grid, hipStream_t st) {
+  grid.y *= HBO_TILE / GTR;   // callers size the grid in 128x128 tiles; the kernel tiles rows by GTR
   if (a.padded || a.tasks) hipLaunchKernelGGL((gram_kernel<T, true>), grid, dim3(256), 0, st, a, md);
   else hipLaunchKernelGGL((gram_kernel<T, false>), grid, dim3(256), 0, st, a, md);
 }
