@@ -23,6 +23,7 @@ struct hbo_ctx {
   hipStream_t stream2 = nullptr;   // panel stream of the look-ahead Cholesky (high priority)
   hipStream_t stream3 = nullptr;   // bulk trailing updates, CU-masked so the panel chain always finds free CUs
   int opt_reserve_cus = 0;   // >0: CU-masked bulk stream (measured: no gain)
+  int opt_small_nblk = 32;   // matrices up to this many 128-blocks use 64x64 GEMM tiles in trtri / lauum
   int opt_persist_free = 32; // bulk trailing update runs as 2*(CUs - this) persistent workgroups
   int n_cus = 256;
   std::vector<hipEvent_t> ev_pool;
@@ -155,6 +156,7 @@ extern "C" int hbo_set_option(hbo_ctx* c, const char* name, int64_t value) {
   if (!c || !name) return HBO_ERR_ARG;
   if (!strcmp(name, "potrf_group")) { if (value < 1 || value > 8) return fail(c, HBO_ERR_ARG, "potrf_group in 1..8"); c->opt_group = (int)value; return HBO_OK; }
   if (!strcmp(name, "lookahead")) { c->opt_lookahead = value ? 1 : 0; return HBO_OK; }
+  if (!strcmp(name, "small_nblk")) { c->opt_small_nblk = (int)value; return HBO_OK; }
   if (!strcmp(name, "persist_free")) { if (value < 0 || value > 200) return fail(c, HBO_ERR_ARG, "persist_free in 0..200"); c->opt_persist_free = (int)value; return HBO_OK; }
   if (!strcmp(name, "reserve_cus")) {
     if (value < 0 || value > 128) return fail(c, HBO_ERR_ARG, "reserve_cus in 0..128");
@@ -404,6 +406,9 @@ static void run_trtri(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks
   for (int s = 1; s < max_nblk; s *= 2) {
     const int ngroups = (max_nblk + 2 * s - 1) / (2 * s);
     GemmArgs a = {}; a.tasks = d_tasks; a.p0 = s;
+    // few or short tiles (small levels, small / batched matrices): 64x64 tiles -- a lone 128-tile runs
+    // its K loop latency-bound, four 64-tiles expose 4x the parallelism for the same flops
+    a.small_tiles = (max_nblk <= c->opt_small_nblk) || ((int64_t)ngroups * s * s * ntasks < 600);
     { ProfScope ps(c, "trtri_gemm", 2);
       a.mode = GEMM_TRTRI_A; launch_gemm(dtype, a, dim3(ngroups * s, s, ntasks), st);
       a.mode = GEMM_TRTRI_B; launch_gemm(dtype, a, dim3(ngroups * s, s, ntasks), st); }
@@ -412,6 +417,7 @@ static void run_trtri(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks
 static void run_lauum(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, int max_nblk) {
   ProfScope ps(c, "lauum", 2);
   GemmArgs a = {}; a.tasks = d_tasks; a.mode = GEMM_LAUUM;
+  a.small_tiles = max_nblk <= c->opt_small_nblk;
   launch_gemm(dtype, a, dim3(max_nblk, max_nblk, ntasks), c->stream);
 }
 

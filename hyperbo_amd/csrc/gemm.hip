@@ -138,34 +138,37 @@ __device__ __forceinline__ bool decode_job(const GemmArgs& g, TileJob<T>& j) {
     }
     case GEMM_TRTRI_A:
     case GEMM_TRTRI_B: {
+      // Tile coordinates in units of TM (128, or 64 for small / batched problems); s is in 128-units.
       // blockIdx.y carries the index that fixes the K length, ordered longest first, so that the
       // dispatcher hands out tiles in longest-processing-time order (x runs over groups x tiles).
-      const int s = g.p0;
-      const int grp = (int)blockIdx.x / s;
-      const int inner = (int)blockIdx.x % s;
+      constexpr int U = HBO_TILE / TM;
+      const int s = g.p0, su = s * U;
+      const int grp = (int)blockIdx.x / su;
+      const int inner = (int)blockIdx.x % su;
       int jt, it;
-      if (g.mode == GEMM_TRTRI_A) { jt = blockIdx.y; it = inner; }            // K = s - jt
-      else { it = s - 1 - (int)blockIdx.y; jt = inner; }                      // K = it + 1
-      const int o = grp * 2 * s;
-      const int R = o + s + it;
-      if (R >= nblk) return false;
-      const int Cc = o + jt;
+      if (g.mode == GEMM_TRTRI_A) { jt = blockIdx.y; it = inner; }            // K = s*128 - jt*TM
+      else { it = su - 1 - (int)blockIdx.y; jt = inner; }                     // K = (it+1)*TM
+      const int64_t o = (int64_t)grp * 2 * s * HBO_TILE;                      // element offsets from here on
+      const int64_t R = o + (int64_t)s * HBO_TILE + (int64_t)it * TM;
+      if (R >= (int64_t)nblk * HBO_TILE) return false;
+      const int64_t Cc = o + (int64_t)jt * TM;
       const T* L = static_cast<const T*>(t.A);
       T* W = static_cast<T*>(t.W);
       T* S = static_cast<T*>(t.S);
       if (g.mode == GEMM_TRTRI_A) {
-        // S21 = L21 * W11 ; W11 lower-triangular => k >= column tile jt
-        j.A = L + (int64_t)R * HBO_TILE * ld + (int64_t)(o + jt) * HBO_TILE;
-        j.B = W + (int64_t)(o + jt) * HBO_TILE * ld + (int64_t)Cc * HBO_TILE;
-        j.C = S + (int64_t)R * HBO_TILE * ld + (int64_t)Cc * HBO_TILE;
-        j.ksteps = (s - jt) * HBO_TILE / BKE;
+        // S21 = L21 * W11 ; W11 lower-triangular => k >= column tile start
+        j.A = L + R * ld + Cc;
+        j.B = W + Cc * ld + Cc;
+        j.C = S + R * ld + Cc;
+        j.ksteps = (s * HBO_TILE - jt * TM) / BKE;
         j.alpha = (T)1;
       } else {
-        // W21 = -W22 * S21 ; W22 lower-triangular => k <= row tile it
-        j.A = W + (int64_t)R * HBO_TILE * ld + (int64_t)(o + s) * HBO_TILE;
-        j.B = S + (int64_t)(o + s) * HBO_TILE * ld + (int64_t)Cc * HBO_TILE;
-        j.C = W + (int64_t)R * HBO_TILE * ld + (int64_t)Cc * HBO_TILE;
-        j.ksteps = (it + 1) * HBO_TILE / BKE;
+        // W21 = -W22 * S21 ; W22 lower-triangular => k < row tile end
+        const int64_t o2 = o + (int64_t)s * HBO_TILE;
+        j.A = W + R * ld + o2;
+        j.B = S + o2 * ld + Cc;
+        j.C = W + R * ld + Cc;
+        j.ksteps = (it + 1) * TM / BKE;
         j.alpha = (T)-1;
       }
       j.lda = j.ldb = j.ldc = ld;
@@ -173,19 +176,22 @@ __device__ __forceinline__ bool decode_job(const GemmArgs& g, TileJob<T>& j) {
       return true;
     }
     case GEMM_LAUUM: {
-      // x = row tile i (K = nblk - i), y = column tile: concurrently running tiles share the column
+      // x = row tile i (K = npad - i*TM), y = column tile: concurrently running tiles share the column
       // panel W[:, jt] through L2.  (Measured alternatives that were slower: strict longest-first
       // order, 1.4x; XCD-aware 4x16 super-tiles streaming K in lockstep, 2x -- hot L2 channels.)
+      // With 64-tiles the tile right of an even diagonal tile is computed too, so that every
+      // 128x128 block on the diagonal is complete (the contraction kernel reads whole 128-blocks).
+      constexpr int U = HBO_TILE / TM;
       const int i = blockIdx.x, jt = blockIdx.y;
-      if (i >= nblk || jt > i) return false;
-      const int k0 = i;
+      if (i >= nblk * U || jt > (U == 1 ? i : (i | 1))) return false;
+      const int64_t k0 = (int64_t)i * TM;
       const T* W = static_cast<const T*>(t.W);
-      // C[i,j] = sum_{k >= i*128} W[k, i-tile]^T W[k, j-tile]
-      j.A = W + (int64_t)k0 * HBO_TILE * ld + (int64_t)i * HBO_TILE;
-      j.B = W + (int64_t)k0 * HBO_TILE * ld + (int64_t)jt * HBO_TILE;
-      j.C = static_cast<T*>(t.S) + (int64_t)i * HBO_TILE * ld + (int64_t)jt * HBO_TILE;
+      // C[i,j] = sum_{k >= i*TM} W[k, i-tile]^T W[k, j-tile]   (rows of W[:,j] above j*TM are zero)
+      j.A = W + k0 * ld + (int64_t)i * TM;
+      j.B = W + k0 * ld + (int64_t)jt * TM;
+      j.C = static_cast<T*>(t.S) + (int64_t)i * TM * ld + (int64_t)jt * TM;
       j.lda = j.ldb = j.ldc = ld;
-      j.ksteps = (nblk - k0) * HBO_TILE / BKE;
+      j.ksteps = (int)(((int64_t)nblk * HBO_TILE - k0) / BKE);
       j.alpha = (T)1; j.beta = 0;
       return true;
     }
@@ -233,8 +239,8 @@ __device__ __forceinline__ void gemm_tile(const TileJob<T>& job, unsigned char* 
 #pragma unroll
     for (int b = 0; b < MI; ++b) acc[a][b] = (acc_t){0, 0, 0, 0};
 
-  vec_t ra[MI], rb[MI];
   const int nk = job.ksteps;
+  vec_t ra[MI], rb[MI];
   stage_load<T, AKC, TM>(job.A, job.lda, 0, ra, tid);
   stage_load<T, BKC, TM>(job.B, job.ldb, 0, rb, tid);
   stage_store<T, AKC, TM>(sA0, ra, tid);
@@ -399,11 +405,23 @@ void launch_gemm_t(const GemmArgs& a, dim3 grid, hipStream_t st) {
       break;
     case GEMM_TRTRI_A:
     case GEMM_TRTRI_B:
+      if (a.small_tiles) {
+        dim3 g2(grid.x * 2, grid.y * 2, grid.z);
+        hipLaunchKernelGGL((gemm_kernel<T, true, false, 64>), g2, dim3(256), GEMM_LDS_BYTES_64, st, a);
+      } else {
+        hipLaunchKernelGGL((gemm_kernel<T, true, false, 128>), grid, dim3(256), GEMM_LDS_BYTES, st, a);
+      }
+      break;
     case GEMM_POST:
       hipLaunchKernelGGL((gemm_kernel<T, true, false, 128>), grid, dim3(256), GEMM_LDS_BYTES, st, a);
       break;
     case GEMM_LAUUM:
-      hipLaunchKernelGGL((gemm_kernel<T, false, false, 128>), grid, dim3(256), GEMM_LDS_BYTES, st, a);
+      if (a.small_tiles) {
+        dim3 g2(grid.x * 2, grid.y * 2, grid.z);
+        hipLaunchKernelGGL((gemm_kernel<T, false, false, 64>), g2, dim3(256), GEMM_LDS_BYTES_64, st, a);
+      } else {
+        hipLaunchKernelGGL((gemm_kernel<T, false, false, 128>), grid, dim3(256), GEMM_LDS_BYTES, st, a);
+      }
       break;
   }
 }

@@ -57,7 +57,7 @@ struct GemmArgs {
   int c_lo;      // SYRK: first updated tile column
   int c_hi;      // SYRK: end (exclusive) of updated tile columns
   int aug;       // SYRK: 1 -> include the augmented tile-row
-  int small_tiles;  // SYRK: 1 -> 64x64 output tiles (grid is given in 128-tile units)
+  int small_tiles;  // 1 -> 64x64 output tiles (SYRK / TRTRI / LAUUM; grid is given in 128-tile units)
   int persistent;   // SYRK: >0 -> that many persistent workgroups loop over the tiles
   void* B;       // POST: Kxq (npad x ldb)
   int64_t ldb;

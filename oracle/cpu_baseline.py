@@ -60,3 +60,61 @@ def nll_and_grad_se_ard_constant(x, y, raw, eps=1e-6):
       'constant': np.asarray(-float(alpha.sum())),
   }
   return nll, grad
+
+
+
+# ---- OpenMP + LAPACK port (the baseline bench.py reports) -----------------------------------------
+_LIB = None
+
+
+def _lib():
+  global _LIB
+  if _LIB is None:
+    import ctypes as C
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'libcpu_port.so')
+    if not os.path.exists(path):
+      raise RuntimeError(f'{path} missing: run __graft_entry__.build() (gcc -fopenmp oracle/cpu_port.c)')
+    lib = C.CDLL(path)
+    dp = C.POINTER(C.c_double)
+    lib.hbo_cpu_gram_se.argtypes = [dp, C.c_int64, C.c_int64, C.c_double, C.c_double, dp]
+    lib.hbo_cpu_contract_se.argtypes = [dp, C.c_int64, C.c_int64, C.c_double, dp, dp, dp]
+    lib.hbo_cpu_gram_se.restype = lib.hbo_cpu_contract_se.restype = None
+    _LIB = lib
+  return _LIB
+
+
+def nll_and_grad_se_ard_constant_omp(x, y, raw, eps=1e-6):
+  """Same algorithm as above; the O(N^2 D) Gram build and gradient contraction run in C/OpenMP
+  (oracle/cpu_port.c) over all host cores, potrf/potri in LAPACK (SciPy/OpenBLAS threads)."""
+  import ctypes as C
+  dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+  n, d = x.shape
+  assert d <= 64
+  sp = lambda v: np.logaddexp(np.asarray(v, dtype=np.float64), 0.0) + 1e-10
+  ls, sv, noise = sp(raw['lengthscale']), float(sp(raw['signal_variance'])), float(sp(raw['noise_variance']))
+  const = float(np.asarray(raw['constant']))
+  xs = np.ascontiguousarray(x / ls)
+  k = np.empty((n, n))
+  _lib().hbo_cpu_gram_se(dp(xs), n, d, sv, noise + eps, dp(k))
+  r = y - const
+  # symmetric => the C-ordered buffer is also a valid Fortran-ordered matrix: no copies in LAPACK
+  c, info = lapack.dpotrf(k.T, lower=0, overwrite_a=1)     # upper in Fortran order == lower in C order
+  if info != 0:
+    return float('nan'), None
+  alpha, info = lapack.dpotrs(c, np.asfortranarray(r), lower=0)
+  nll = float(0.5 * (r.T @ alpha)[0, 0] + np.sum(np.log(np.diagonal(c))) + 0.5 * n * np.log(2 * np.pi))
+  kinv, info = lapack.dpotri(c, lower=0, overwrite_c=1)
+  kinv_c = kinv.T                                            # C-order view: triangle row >= col valid
+  out = np.zeros(2 + d)
+  a1 = np.ascontiguousarray(alpha[:, 0])
+  assert kinv_c.flags.c_contiguous
+  _lib().hbo_cpu_contract_se(dp(xs), n, d, sv, dp(kinv_c), dp(a1), dp(out))
+  sig = spsp.expit
+  grad = {
+      'lengthscale': (-0.5) * out[2:] * (-2.0 / ls) * sig(np.asarray(raw['lengthscale'], dtype=np.float64)),
+      'signal_variance': np.asarray(out[0] / sv * sig(float(raw['signal_variance']))),
+      'noise_variance': np.asarray(out[1] * sig(float(raw['noise_variance']))),
+      'constant': np.asarray(-float(alpha.sum())),
+  }
+  return nll, grad

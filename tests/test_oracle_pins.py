@@ -331,3 +331,8 @@ def test_cpu_baseline_port_matches_oracle():
   assert abs(v - vo) <= 1e-10 * abs(vo)
   for k in go:
     np.testing.assert_allclose(g[k], go[k], rtol=1e-6, atol=1e-8)
+  # C/OpenMP + LAPACK port (what bench.py times); needs oracle/libcpu_port.so from build()
+  v2, g2 = cpu_baseline.nll_and_grad_se_ard_constant_omp(x, y, raw)
+  assert abs(v2 - vo) <= 1e-10 * abs(vo)
+  for k in go:
+    np.testing.assert_allclose(g2[k], go[k], rtol=1e-8, atol=1e-10)
