@@ -1,0 +1,25 @@
+"""Per-task sub-sampling iterator -- hyperbo/basics/data_utils.py:72-100 with a NumPy Generator
+in place of the JAX PRNG key (the reference's threefry streams cannot be reproduced without jax)."""
+import numpy as np
+
+from hyperbo_amd.basics import definitions as defs
+
+SubDataset = defs.SubDataset
+
+
+def sub_sample_dataset_iterator(key, dataset, batch_size):
+  """Yields batches in which every sub-dataset has at most batch_size rows (random subset)."""
+  rng = key if isinstance(key, np.random.Generator) else np.random.default_rng(key)
+  while True:
+    sub_sampled_dataset = {}
+    for i, (sub_dataset_key, sub_dataset) in enumerate(dataset.items()):
+      if sub_dataset.x.shape[0] >= batch_size:
+        indices = rng.permutation(sub_dataset.x.shape[0])[:batch_size]
+        new_sub_dataset = SubDataset(x=sub_dataset.x[indices, :], y=sub_dataset.y[indices, :],
+                                     aligned=sub_dataset.aligned)
+      else:
+        new_sub_dataset = sub_dataset
+      if isinstance(new_sub_dataset.aligned, str):   # data_utils.py:95-98
+        new_sub_dataset = SubDataset(x=new_sub_dataset.x, y=new_sub_dataset.y, aligned=i)
+      sub_sampled_dataset[sub_dataset_key] = new_sub_dataset
+    yield sub_sampled_dataset

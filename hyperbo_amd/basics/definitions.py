@@ -5,13 +5,43 @@ from typing import Any, Callable, Dict, List, NamedTuple, Optional, Tuple, Union
 import numpy as np
 
 
-@dataclasses.dataclass
 class GPCache:
-  """Cached factorisation.  chol/kinvy are NumPy views; `handle` keeps the device copy."""
-  chol: np.ndarray
-  kinvy: np.ndarray
-  needs_update: bool
-  handle: Any = None
+  """Cached factorisation (hyperbo/basics/definitions.py:23-28: chol, kinvy, needs_update).
+
+  With a device `handle` (hyperbo_amd.basics.linalg.CacheHandle) the factor lives in HBM and
+  `chol` / `kinvy` are exported over PCIe only when somebody reads them (N^2 elements: 0.5 GiB at
+  N=8192), so the BO loop's predict / acquisition calls never pay for the copy.
+  """
+
+  def __init__(self, chol=None, kinvy=None, needs_update=False, handle=None):
+    self._chol, self._kinvy = chol, kinvy
+    self.needs_update = needs_update
+    self.handle = handle
+
+  def _export(self):
+    if self.handle is not None and (self._chol is None or self._kinvy is None):
+      self._chol, self._kinvy, _ = self.handle.export()
+
+  @property
+  def chol(self):
+    self._export()
+    return self._chol
+
+  @chol.setter
+  def chol(self, v):
+    self._chol = v
+
+  @property
+  def kinvy(self):
+    self._export()
+    return self._kinvy
+
+  @kinvy.setter
+  def kinvy(self, v):
+    self._kinvy = v
+
+  def __repr__(self):
+    return f'GPCache(needs_update={self.needs_update}, device={self.handle is not None})'
 
 
 class SubDataset(NamedTuple):

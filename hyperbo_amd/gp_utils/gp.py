@@ -1,8 +1,8 @@
 """GP model object and posterior -- hyperbo/gp_utils/gp.py:242-305 (predict), :308-620 (GP).
 
 Same method names / arguments / cache semantics as the reference; factorisation, posterior and
-NLL run on the GPU.  `GP.train` (the Adam / L-BFGS host loop, gp.py:53-195) is listed as the next
-row in SURVEY.md 8(f) and is provided by hyperbo_amd.gp_utils.train once built.
+NLL run on the GPU; `infer_parameters` / `GP.train` (gp.py:53-195, 454-485) are the host loops
+(Adam, L-BFGS) around the native value_and_grad.
 """
 import ctypes as C
 from typing import Any, Callable, Dict, List, Tuple, Union
@@ -20,6 +20,108 @@ retrieve_params = params_utils.retrieve_params
 GPCache = defs.GPCache
 SubDataset = defs.SubDataset
 GPParams = defs.GPParams
+
+
+class _Adam:
+  """optax.adam(learning_rate) defaults: b1=0.9, b2=0.999, eps=1e-8 (used at gp.py:124-144)."""
+
+  def __init__(self, lr, b1=0.9, b2=0.999, eps=1e-8):
+    self.lr, self.b1, self.b2, self.eps = lr, b1, b2, eps
+    self.m = self.v = None
+    self.t = 0
+
+  def step(self, x, g):
+    if self.m is None:
+      self.m, self.v = np.zeros_like(x), np.zeros_like(x)
+    self.t += 1
+    self.m = self.b1 * self.m + (1 - self.b1) * g
+    self.v = self.b2 * self.v + (1 - self.b2) * g * g
+    mhat = self.m / (1 - self.b1**self.t)
+    vhat = self.v / (1 - self.b2**self.t)
+    return x - self.lr * mhat / (np.sqrt(vhat) + self.eps)
+
+
+def _value_and_grad_of(objective):
+  """The companion of an objective that returns (value, grads): native NLL, or `.value_and_grad`."""
+  if objective is obj.neg_log_marginal_likelihood or objective is obj.nll:
+    return obj.nll_value_and_grad
+  vg = getattr(objective, 'value_and_grad', None)
+  if vg is None:
+    raise NotImplementedError(
+        f'objective {objective!r} has no native value_and_grad (only the NLL is on the GPU path; '
+        'EKL/Euclid objectives are a later row of SURVEY.md 8(f))')
+  return vg
+
+
+def infer_parameters(mean_func, cov_func, init_params, dataset, warp_func=None,
+                     objective=obj.neg_log_marginal_likelihood, key=None, get_params_path=None, callback=None):
+  """Posterior inference for a meta GP -- the training driver of hyperbo/gp_utils/gp.py:53-195.
+
+  Host loop (Adam on per-step sub-sampled batches, or L-BFGS on one sub-sample) around the native
+  `nll_value_and_grad`.  `key`: numpy Generator or seed (JAX PRNG keys are not reproducible here).
+  NaN at step 0 raises, a non-finite loss later stops and keeps the last finite parameters
+  (gp.py:135-142); the cache is cleared on return (gp.py:194).
+  """
+  from hyperbo_amd.basics import data_utils, lbfgs as lbfgs_lib
+  if not dataset:
+    return init_params
+  rng = key if isinstance(key, np.random.Generator) else np.random.default_rng(0 if key is None else key)
+  params = init_params
+  method = params.config['method']
+  batch_size = params.config['batch_size']
+  max_training_step = params.config['max_training_step']
+  if max_training_step <= 0 and method != 'slice_sample':
+    return init_params
+  vg = _value_and_grad_of(objective)
+
+  def loss_and_grad(model_params, batch):
+    p = GPParams(model=model_params, config=init_params.config)
+    return vg(mean_func=mean_func, cov_func=cov_func, params=p, dataset=batch, warp_func=warp_func)
+
+  def make_device(batch):
+    return obj.DeviceDataset(batch) if vg is obj.nll_value_and_grad else batch
+
+  if method == 'adam':
+    needs_resample = any(s.x.shape[0] >= batch_size for s in dataset.values())
+    dataset_iter = data_utils.sub_sample_dataset_iterator(rng, dataset, batch_size)
+    x, unflatten = lbfgs_lib.tree_flatten(params.model)
+    opt = _Adam(params.config['learning_rate'])
+    dev = None
+    current_loss = None
+    for i in range(max_training_step):
+      if dev is None or needs_resample:
+        if dev is not None and hasattr(dev, 'close'):
+          dev.close()
+        dev = make_device(next(dataset_iter))
+      current_loss, grads = loss_and_grad(unflatten(x), dev)
+      if np.isnan(current_loss) and i == 0:
+        raise ValueError(f'Encountered NaN in loss function. current_loss = {current_loss}, grads = {grads}.')
+      if np.isfinite(current_loss):
+        params.model = unflatten(x)
+      else:
+        break
+      gvec, _ = lbfgs_lib.tree_flatten(grads)
+      x = opt.step(x, gvec)
+      if callback:
+        callback(i, params.model, current_loss)
+    if dev is not None:
+      final_loss, _ = loss_and_grad(unflatten(x), dev)
+      if np.isfinite(final_loss):
+        params.model = unflatten(x)
+      if hasattr(dev, 'close'):
+        dev.close()
+  elif method == 'lbfgs':
+    batch = next(data_utils.sub_sample_dataset_iterator(rng, dataset, batch_size))   # gp.py:102-107
+    dev = make_device(batch)
+    alpha = params.config.get('alpha', 1.0)
+    _, params.model, _ = lbfgs_lib.lbfgs(None, params.model, steps=max_training_step, alpha=alpha,
+                                         val_and_grad_fn=lambda mp: loss_and_grad(mp, dev), callback=callback)
+    if hasattr(dev, 'close'):
+      dev.close()
+  else:
+    raise ValueError(f'Optimization method {method} is not supported.')
+  params.cache = {}
+  return params
 
 
 def _predict_native(mean_func, cov_func, params, x_query, warp_func, full_cov, handle, input_dim):
@@ -141,6 +243,19 @@ class GP:
     if sub_dataset_key in self.params.cache:
       self.params.cache[sub_dataset_key].needs_update = True
 
+  def train(self, key=None, get_params_path=None, callback=None) -> GPParams:
+    """Fit the GP hyper-parameters to the dataset (gp.py:454-485)."""
+    if key is None:
+      if self.rng is None:
+        self.rng = np.random.default_rng(0)
+      key = self.rng
+    self._drop_cache()
+    self.params = infer_parameters(
+        mean_func=self.mean_func, cov_func=self.cov_func, init_params=self.params, dataset=self.dataset,
+        warp_func=self.warp_func, objective=self.params.config['objective'], key=key,
+        get_params_path=get_params_path, callback=callback)
+    return self.params
+
   def neg_log_marginal_likelihood(self):
     """Total nll and key->nll dict (gp.py:487-497).  NB the reference uses the SVD variant here;
     the Cholesky variant agrees with it to ~2 decimals in the reference's own tests
@@ -163,8 +278,7 @@ class GP:
       old.handle.close()
     sd = self.dataset[sub_dataset_key]
     handle = linalg.factor(self.mean_func, self.cov_func, self.params, sd.x, sd.y, self.warp_func)
-    chol, kinvy, _ = handle.export()
-    self.params.cache[sub_dataset_key] = GPCache(chol=chol, kinvy=kinvy, needs_update=False, handle=handle)
+    self.params.cache[sub_dataset_key] = GPCache(needs_update=False, handle=handle)   # chol/kinvy exported lazily
 
   def predict(self, queried_inputs, sub_dataset_key: Union[int, str] = 0, full_cov: bool = False,
               with_noise: bool = True, unbiased: bool = True) -> Tuple[np.ndarray, np.ndarray]:

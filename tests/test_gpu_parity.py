@@ -441,3 +441,52 @@ def test_cfg5_full_size_closed_form(gpu_ctx):
   quad = (float(y.T @ y) - float(uty.T @ np.linalg.solve(cap, uty)) / c) / c
   expect = 0.5 * quad + 0.5 * logdet + 0.5 * n * np.log(2 * np.pi)
   assert abs(v - expect) <= 1e-9 * abs(expect)
+
+
+# ---- training driver on the native objective (gp_test.py:58-148, objectives_test.py:206-324) -------
+@pytest.mark.parametrize('method,steps,lr', [('adam', 10, 1e-2), ('lbfgs', 3, None)])
+@pytest.mark.parametrize('kname,mname', [('squared_exponential', 'constant'), ('matern32', 'zero'),
+                                         ('matern52_mlp', 'linear_mlp'), ('dot_product_mlp', 'linear')])
+def test_gp_train_reduces_nll(gpu_ctx, method, steps, lr, kname, mname):
+  defs, _, _, gp, kernel, mean, objectives, utils = _native()
+  rng = np.random.default_rng(21)
+  d = 1
+  mlp = kname.endswith('_mlp')
+  model = helpers.make_model(rng, mname, mlp, d)
+  ds = {i: defs.SubDataset(*helpers.synthetic_task(rng, 100, d)) for i in range(10)}   # 10 tasks x n=100, d=1
+  ds['aligned'] = defs.SubDataset(*helpers.synthetic_task(rng, 30, d, m=5), aligned=1)  # ignored by the NLL
+  cfg = {'method': method, 'batch_size': 50 if method == 'adam' else 300, 'max_training_step': steps,
+         'learning_rate': lr, 'mlp_features': helpers.MLP_FEATURES}
+  model_n = gp.GP(ds, getattr(mean, mname), getattr(kernel, kname), defs.GPParams(model=model, config=cfg),
+                  utils.DEFAULT_WARP_FUNC)
+  init_nll, _ = model_n.neg_log_marginal_likelihood()
+  seen = []
+  model_n.train(key=0, callback=lambda *a, **k: seen.append(1))
+  nll, key2nll = model_n.neg_log_marginal_likelihood()
+  assert np.isfinite(nll) and nll < init_nll
+  assert 'aligned' not in key2nll and len(key2nll) == 10 and seen
+  assert model_n.params.cache == {}
+
+
+def test_simulated_bo_iteration(gpu_ctx):
+  """One step of hyperbo/bo_utils/bayesopt.py:164-190: acquisition over all candidates -> argmax ->
+  append (cache goes stale) -> next acquisition re-factorises; checked against the oracle."""
+  defs, _, acfun, gp, kernel, mean, _, utils = _native()
+  rng = np.random.default_rng(22)
+  d = 5
+  model = helpers.make_model(rng, 'constant', False, d)
+  x, y = helpers.synthetic_task(rng, 40, d)
+  cand_x, cand_y = helpers.synthetic_task(rng, 30, d)
+  ds = {0: defs.SubDataset(x, y), 1: defs.SubDataset(x[:10], y[:10])}
+  m = gp.GP(ds, mean.constant, kernel.matern52, defs.GPParams(model=model), utils.DEFAULT_WARP_FUNC)
+  po = o.GPParams(model=model)
+  for it in range(3):
+    ev = acfun.expected_improvement(model=m, sub_dataset_key=0, x_queries=cand_x)
+    sd = m.dataset[0]
+    mu, var = o.predict(o.constant, o.matern52, po, sd.x, sd.y, cand_x, WFO)
+    mu, var = o.gp_predict_postprocess(po, {k: o.SubDataset(v.x, v.y) for k, v in m.dataset.items()}, mu, var, WFO, False, True, True)
+    ref = o.expected_improvement_sub(mu, np.sqrt(var), float(np.max(sd.y)))
+    assert helpers.rel_err(ev, ref) < 1e-7 and int(np.argmax(ev)) == int(np.argmax(ref))
+    sel = int(np.argmax(ev))
+    m.update_sub_dataset((cand_x[sel:sel + 1], cand_y[sel:sel + 1]), 0, is_append=True)
+    assert m.params.cache[0].needs_update and m.dataset[0].x.shape[0] == 41 + it
