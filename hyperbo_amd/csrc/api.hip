@@ -388,7 +388,8 @@ static void run_potrf(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks
             // persistent form (single task, enough tiles to fill the machine): leave CUs for the panel chain
             const int64_t ntiles = (m * (m + 1) / 2 + m) * (a.small_tiles ? 4 : 1);
             const int pblocks = 2 * (c->n_cus - c->opt_persist_free);
-            a.persistent = (ntasks == 1 && c->opt_persist_free > 0 && ntiles > pblocks) ? pblocks : 0;
+            // (for large trailing matrices the bulk update dominates and gets the whole machine)
+            a.persistent = (ntasks == 1 && c->opt_persist_free > 0 && ntiles > pblocks && m <= 96) ? pblocks : 0;
             launch_gemm(dtype, a, dim3(max_nblk + 1 - a.c_lo, a.c_hi - a.c_lo, ntasks), sb);
             a.persistent = 0;
           }
