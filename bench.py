@@ -64,15 +64,18 @@ def perturb(raw, step, rank):
   return out
 
 
-def trailing_update_flops(n, group):
-  """Algorithmic flops of every trailing-update launch: lower triangle (incl. diagonal tiles) of the
-  trailing block, K = 128*group panel columns: sum over entries of 2K."""
+def bulk_update_flops(n, group):
+  """Algorithmic flops of every BULK trailing-update launch (gemm_kernel<double,true,true,128>): with
+  look-ahead the update of panel group g is split into F1 (next group's block columns, 64x64 tiles,
+  latency-critical) and F2 (the remaining m = nblk - g2 tile columns); F2 runs on 128x128 tiles while
+  m(m+1)/2 >= 600 (hyperbo_amd/csrc/api.hip run_potrf).  Lower triangle incl. diagonal tiles, K = 128*group."""
   nblk = (n + 127) // 128
   out = []
   for g0 in range(0, nblk, group):
     g1 = min(g0 + group, nblk)
-    m = nblk - g1
-    if m > 0:
+    g2 = min(g1 + group, nblk)
+    m = nblk - g2
+    if g1 < nblk and g2 < nblk and m * (m + 1) // 2 >= 600:
       out.append(m * (m + 1) / 2 * 128 * 128 * 2.0 * 128 * (g1 - g0))
   return out
 
@@ -150,17 +153,30 @@ def main():
   value = world * args.steps / elapsed
 
   group = 4   # libhbo default potrf_group (K = 512 trailing updates)
-  fl = trailing_update_flops(args.n, group)
+  fl = bulk_update_flops(args.n, group)
   roofline = None
-  if 'syrk_trailing' in prof and prof['syrk_trailing'][1] > 0:
-    tot_ms, launches = prof['syrk_trailing']
+  if 'syrk_bulk' in prof and prof['syrk_bulk'][1] > 0 and fl:
+    tot_ms, launches = prof['syrk_bulk']
+    assert launches == len(fl) * args.steps, (launches, len(fl), args.steps)
     flops_total = sum(fl) * args.steps
     achieved = flops_total / (tot_ms * 1e-3) / 1e12
-    roofline = {'bound': 'mfma', 'kernel': 'gemm_kernel<double,true,true> (Cholesky trailing update, syrk)',
+    roofline = {'bound': 'mfma', 'kernel': 'gemm_kernel<double,true,true,128> (bulk Cholesky trailing update, syrk K=512)',
                 'achieved': round(achieved, 3), 'peak': FP64_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': round(achieved / FP64_MFMA_PEAK_TFLOPS, 4), 'traffic': None,
                 'launches': launches, 'avg_launch_ms': round(tot_ms / launches, 4),
-                'algorithmic_gflop_per_launch': round(sum(fl) / len(fl) / 1e9, 3)}
+                'algorithmic_gflop_per_launch': round(sum(fl) / len(fl) / 1e9, 3),
+                'note': 'HIP events around each launch on its own stream inside the timed region; the launches '
+                        'overlap with the look-ahead panel chain and the early triangular inverse on other streams'}
+  if roofline is not None:
+    # HBM traffic per launch from committed rocprofv3 PMC passes of this same command (separate
+    # --pmc FETCH_SIZE / WRITE_SIZE runs; FETCH_SIZE doubled per MI355X_MICROARCH.md: on gfx950 it
+    # reports half the bytes of wide coalesced streaming reads).  bench.py cannot run rocprof itself.
+    pmc_path = os.path.join(ROOT, 'profiles', 'r01_pmc_hbm.json')
+    if os.path.exists(pmc_path):
+      pmc = json.load(open(pmc_path)).get('gemm_kernel<double, true, true, 128>')
+      if pmc:
+        roofline['traffic'] = int((2 * pmc['FETCH_SIZE_KB'] + pmc['WRITE_SIZE_KB']) * 1024)
+        roofline['traffic_note'] = 'bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024, profiles/r01_pmc_hbm.json'
   stages = {k: round(v[0] / args.steps, 4) for k, v in prof.items()}
   ctx.profile_enable(0)
 

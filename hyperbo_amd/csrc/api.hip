@@ -21,6 +21,7 @@ struct hbo_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;   // panel stream of the look-ahead Cholesky (high priority)
+  hipStream_t stream4 = nullptr;   // early part of trtri, overlapped with the tail of potrf
   hipStream_t stream3 = nullptr;   // bulk trailing updates, CU-masked so the panel chain always finds free CUs
   int opt_reserve_cus = 0;   // >0: CU-masked bulk stream (measured: no gain)
   int opt_small_nblk = 32;   // matrices up to this many 128-blocks use 64x64 GEMM tiles in trtri / lauum
@@ -28,6 +29,7 @@ struct hbo_ctx {
   int n_cus = 256;
   std::vector<hipEvent_t> ev_pool;
   int opt_lookahead = 1;
+  int opt_overlap_trtri = 1;
   std::string err;
   ModelDev h_model;
   ModelDev* d_model = nullptr;
@@ -126,6 +128,7 @@ extern "C" int hbo_ctx_create(int device, hbo_ctx** out) {
   hipError_t e = hipSetDevice(device);
   if (e == hipSuccess) e = hipStreamCreate(&c->stream);
   if (e == hipSuccess) e = hipStreamCreate(&c->stream2);
+  if (e == hipSuccess) e = hipStreamCreate(&c->stream4);
   if (e == hipSuccess) e = hipMalloc((void**)&c->d_model, sizeof(ModelDev));
   if (e != hipSuccess) {
     g_err = std::string("hbo_ctx_create: ") + hipGetErrorString(e);
@@ -146,6 +149,7 @@ extern "C" int hbo_ctx_destroy(hbo_ctx* c) {
   for (int l = 0; l < HBO_MAX_MLP_LAYERS; ++l) { if (c->d_mlp_w[l]) hipFree(c->d_mlp_w[l]); if (c->d_mlp_b[l]) hipFree(c->d_mlp_b[l]); }
   if (c->d_model) hipFree(c->d_model);
   for (hipEvent_t ev : c->ev_pool) hipEventDestroy(ev);
+  if (c->stream4) hipStreamDestroy(c->stream4);
   if (c->stream3) hipStreamDestroy(c->stream3);
   if (c->stream2) hipStreamDestroy(c->stream2);
   if (c->stream) hipStreamDestroy(c->stream);
@@ -155,6 +159,7 @@ extern "C" int hbo_ctx_destroy(hbo_ctx* c) {
 extern "C" int hbo_set_option(hbo_ctx* c, const char* name, int64_t value) {
   if (!c || !name) return HBO_ERR_ARG;
   if (!strcmp(name, "potrf_group")) { if (value < 1 || value > 8) return fail(c, HBO_ERR_ARG, "potrf_group in 1..8"); c->opt_group = (int)value; return HBO_OK; }
+  if (!strcmp(name, "overlap_trtri")) { c->opt_overlap_trtri = value ? 1 : 0; return HBO_OK; }
   if (!strcmp(name, "lookahead")) { c->opt_lookahead = value ? 1 : 0; return HBO_OK; }
   if (!strcmp(name, "small_nblk")) { c->opt_small_nblk = (int)value; return HBO_OK; }
   if (!strcmp(name, "persist_free")) { if (value < 0 || value > 200) return fail(c, HBO_ERR_ARG, "persist_free in 0..200"); c->opt_persist_free = (int)value; return HBO_OK; }
@@ -326,6 +331,9 @@ static hipStream_t bulk_stream(hbo_ctx* c) {
   return c->stream3;
 }
 
+static void run_trtri_early(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, int max_nblk, int H,
+                            hipStream_t st);
+
 static hipEvent_t pool_event(hbo_ctx* c, size_t i) {
   while (c->ev_pool.size() <= i) {
     hipEvent_t ev;
@@ -341,7 +349,8 @@ static hipEvent_t pool_event(hbo_ctx* c, size_t i) {
 // launches: F1 updates only the NEXT group's block columns, F2 the rest; the next group's panel
 // work (potf2 -> trsm, the serial chain) runs on a second stream as soon as F1 is done, so F2
 // -- the bulk of the flops -- overlaps it.
-static void run_potrf(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, int max_nblk, int* d_info) {
+static void run_potrf(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, int max_nblk, int* d_info,
+                      int early_H = 0) {
   const int q = c->opt_group;
   hipStream_t sm = c->stream;
   hipStream_t sp = c->opt_lookahead ? c->stream2 : c->stream;
@@ -362,6 +371,14 @@ static void run_potrf(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks
       }
       { ProfScope ps(c, "potf2", 2, sp); launch_potf2(dtype, d_tasks, ntasks, p, d_info, sp); }
       { ProfScope ps(c, "trsm", 2, sp); launch_trsm(dtype, d_tasks, ntasks, p, max_nblk, sp); }
+      if (early_H > 0 && p == early_H - 1) {
+        // the first H block columns of L are final: start the early part of the inverse on a side stream
+        hipEvent_t e = pool_event(c, evi++);
+        hipEventRecord(e, sp);
+        hipStreamWaitEvent(c->stream4, e, 0);
+        ProfScope ps(c, "trtri_early", 1, c->stream4);
+        run_trtri_early(c, dtype, d_tasks, ntasks, max_nblk, early_H, c->stream4);
+      }
     }
     if (la) { hipEvent_t e = pool_event(c, evi++); hipEventRecord(e, sp); hipStreamWaitEvent(sm, e, 0); }
     if (g1 < max_nblk) {
@@ -381,10 +398,11 @@ static void run_potrf(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks
           // must precede F1(g+1)/F2(g+1) which accumulate into the same tiles)
           hipStreamWaitEvent(sb, ev_f1, 0);
           {
-            ProfScope ps(c, "syrk_trailing", 1, sb);
             a.c_lo = g2; a.c_hi = max_nblk;
             const int64_t m = max_nblk - g2;
             a.small_tiles = m * (m + 1) / 2 * ntasks < 600;
+            // "syrk_bulk" = the 128x128-tile bulk trailing update (the roofline kernel of bench.py)
+            ProfScope ps(c, a.small_tiles ? "syrk_trailing" : "syrk_bulk", 1, sb);
             // persistent form (single task, enough tiles to fill the machine): leave CUs for the panel chain
             const int64_t ntiles = (m * (m + 1) / 2 + m) * (a.small_tiles ? 4 : 1);
             const int pblocks = 2 * (c->n_cus - c->opt_persist_free);
@@ -400,20 +418,57 @@ static void run_potrf(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks
       }
     }
   }
+  if (early_H > 0) {   // the late part of the inverse (main stream) needs the early part
+    hipEvent_t e = pool_event(c, evi++);
+    hipEventRecord(e, c->stream4);
+    hipStreamWaitEvent(sm, e, 0);
+  }
+}
+// One level of the recursive inverse restricted to the groups [grp_lo, grp_hi) (a group = 2s blocks):
+//   mode A: S21 = L21 W11,  mode B: W21 = -W22 S21.
+static void trtri_level(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, int max_nblk, int s,
+                        int grp_lo, int grp_hi, bool do_a, bool do_b, hipStream_t st) {
+  const int ngroups = grp_hi - grp_lo;
+  if (ngroups <= 0) return;
+  GemmArgs a = {}; a.tasks = d_tasks; a.p0 = s; a.grp_lo = grp_lo;
+  // few or short tiles (small levels, small / batched matrices): 64x64 tiles -- a lone 128-tile runs
+  // its K loop latency-bound, four 64-tiles expose 4x the parallelism for the same flops
+  a.small_tiles = (max_nblk <= c->opt_small_nblk) || ((int64_t)ngroups * s * s * ntasks < 600);
+  ProfScope ps(c, "trtri_gemm", 2, st);
+  if (do_a) { a.mode = GEMM_TRTRI_A; launch_gemm(dtype, a, dim3(ngroups * s, s, ntasks), st); }
+  if (do_b) { a.mode = GEMM_TRTRI_B; launch_gemm(dtype, a, dim3(ngroups * s, s, ntasks), st); }
+}
+
+// W = L^-1 by recursive doubling.  The tree is cut at H = the largest power of two below the block
+// count: everything that only needs the first H block columns of L -- the inverse of the leading H
+// blocks and the top-level product S21 = L21 W11 -- is "early" work that run_potrf can enqueue on a
+// side stream as soon as panel H-1 is final (the second half of the factorisation is bound by the
+// serial panel chain and leaves most CUs idle); the rest is "late".
+static int trtri_split(int max_nblk) {
+  int h = 1;
+  while (h * 2 < max_nblk) h *= 2;
+  return max_nblk >= 4 ? h : 0;
+}
+static void run_trtri_early(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, int max_nblk, int H,
+                            hipStream_t st) {
+  { ProfScope ps(c, "trtri_diag", 2, st); launch_trtri_diag(dtype, d_tasks, ntasks, 0, H, st); }
+  for (int s = 1; s < H; s *= 2) trtri_level(c, dtype, d_tasks, ntasks, max_nblk, s, 0, H / (2 * s), true, true, st);
+  trtri_level(c, dtype, d_tasks, ntasks, max_nblk, H, 0, 1, true, false, st);
+}
+static void run_trtri_late(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, int max_nblk, int H,
+                           hipStream_t st) {
+  { ProfScope ps(c, "trtri_diag", 2, st); launch_trtri_diag(dtype, d_tasks, ntasks, H, max_nblk, st); }
+  for (int s = 1; s < H; s *= 2) {
+    const int glo = H / (2 * s), ghi = (max_nblk + 2 * s - 1) / (2 * s);
+    trtri_level(c, dtype, d_tasks, ntasks, max_nblk, s, glo, ghi, true, true, st);
+  }
+  trtri_level(c, dtype, d_tasks, ntasks, max_nblk, H, 0, 1, false, true, st);
 }
 static void run_trtri(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, int max_nblk) {
   hipStream_t st = c->stream;
-  { ProfScope ps(c, "trtri_diag", 2); launch_trtri_diag(dtype, d_tasks, ntasks, max_nblk, st); }
-  for (int s = 1; s < max_nblk; s *= 2) {
-    const int ngroups = (max_nblk + 2 * s - 1) / (2 * s);
-    GemmArgs a = {}; a.tasks = d_tasks; a.p0 = s;
-    // few or short tiles (small levels, small / batched matrices): 64x64 tiles -- a lone 128-tile runs
-    // its K loop latency-bound, four 64-tiles expose 4x the parallelism for the same flops
-    a.small_tiles = (max_nblk <= c->opt_small_nblk) || ((int64_t)ngroups * s * s * ntasks < 600);
-    { ProfScope ps(c, "trtri_gemm", 2);
-      a.mode = GEMM_TRTRI_A; launch_gemm(dtype, a, dim3(ngroups * s, s, ntasks), st);
-      a.mode = GEMM_TRTRI_B; launch_gemm(dtype, a, dim3(ngroups * s, s, ntasks), st); }
-  }
+  { ProfScope ps(c, "trtri_diag", 2); launch_trtri_diag(dtype, d_tasks, ntasks, 0, max_nblk, st); }
+  for (int s = 1; s < max_nblk; s *= 2)
+    trtri_level(c, dtype, d_tasks, ntasks, max_nblk, s, 0, (max_nblk + 2 * s - 1) / (2 * s), true, true, st);
 }
 static void run_lauum(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, int max_nblk) {
   ProfScope ps(c, "lauum", 2);
@@ -579,7 +634,8 @@ extern "C" int hbo_nll(hbo_ctx* c, const hbo_model* m, hbo_dataset* ds, double* 
     GramArgs g = {}; g.tasks = ds->d_desc; g.fdim = feature_dim(m); g.symmetric = 1; g.padded = 1;
     launch_gram(dtype, g, c->d_model, dim3(max_nblk, max_nblk, T), st);
   }
-  { ProfScope ps(c, "potrf", 1); run_potrf(c, dtype, ds->d_desc, T, max_nblk, ds->d_info); }
+  const int early_H = (want_grad && c->opt_lookahead && c->opt_overlap_trtri) ? trtri_split(max_nblk) : 0;
+  { ProfScope ps(c, "potrf", 1); run_potrf(c, dtype, ds->d_desc, T, max_nblk, ds->d_info, early_H); }
   { ProfScope ps(c, "nll_reduce", 1); launch_nll_reduce(dtype, ds->d_desc, T, ds->d_info, ds->d_nll, st); }
 
   const int fdim = feature_dim(m);
@@ -590,7 +646,9 @@ extern "C" int hbo_nll(hbo_ctx* c, const hbo_model* m, hbo_dataset* ds, double* 
     const size_t pb = sizeof(double) * stride_task * T, gb = sizeof(double) * out_stride * T;
     if (ds->partials_bytes < pb) { if (ds->d_partials) hipFree(ds->d_partials); HIPCHK(c, hipMalloc((void**)&ds->d_partials, pb)); ds->partials_bytes = pb; }
     if (ds->gradout_bytes < gb) { if (ds->d_gradout) hipFree(ds->d_gradout); HIPCHK(c, hipMalloc((void**)&ds->d_gradout, gb)); ds->gradout_bytes = gb; }
-    { ProfScope ps(c, "trtri", 1); run_trtri(c, dtype, ds->d_desc, T, max_nblk); }
+    { ProfScope ps(c, "trtri", 1);
+      if (early_H) run_trtri_late(c, dtype, ds->d_desc, T, max_nblk, early_H, st);
+      else run_trtri(c, dtype, ds->d_desc, T, max_nblk); }
     { ProfScope ps(c, "wt_z", 1); launch_wt_z(dtype, ds->d_desc, T, max_nblk, 0, 0, max_npad, st); }
     { ProfScope ps(c, "lauum", 1); run_lauum(c, dtype, ds->d_desc, T, max_nblk); }
     { ProfScope ps(c, "grad_contract", 1);

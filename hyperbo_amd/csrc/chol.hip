@@ -224,7 +224,7 @@ __global__ __launch_bounds__(256) void trsm_kernel(const TaskDesc* tasks, int p_
   T* sWi = sLt + 28 * TILE_ELEMS;               // 8 leaf inverses (stand in for the diagonal tiles)
   T* sSc = sWi + 8 * TILE_ELEMS;                // 4 per-wave scratch tiles
   const TaskDesc& t = tasks[blockIdx.z];
-  const int p = IDENT ? (int)blockIdx.y : p_arg;
+  const int p = IDENT ? p_arg + (int)blockIdx.y : p_arg;   // IDENT: p_arg = first diagonal block
   if (p >= t.nblk) return;
   const int64_t ld = t.ld;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -359,10 +359,11 @@ void trsm_t(const TaskDesc* tasks, int ntasks, int p, int max_nblk, hipStream_t 
                      tasks, p);
 }
 template <typename T>
-void trtri_diag_t(const TaskDesc* tasks, int ntasks, int max_nblk, hipStream_t st) {
+void trtri_diag_t(const TaskDesc* tasks, int ntasks, int p_lo, int p_hi, hipStream_t st) {
   set_attrs<T>();
-  hipLaunchKernelGGL((trsm_kernel<T, true>), dim3(2, max_nblk, ntasks), dim3(256), trsm_lds_bytes<T>(), st,
-                     tasks, 0);
+  if (p_hi <= p_lo) return;
+  hipLaunchKernelGGL((trsm_kernel<T, true>), dim3(2, p_hi - p_lo, ntasks), dim3(256), trsm_lds_bytes<T>(), st,
+                     tasks, p_lo);
 }
 
 }  // namespace
@@ -375,7 +376,7 @@ void launch_trsm(int dtype, const TaskDesc* tasks, int ntasks, int p, int max_nb
   if (dtype == HBO_F64) trsm_t<double>(tasks, ntasks, p, max_nblk, st);
   else trsm_t<float>(tasks, ntasks, p, max_nblk, st);
 }
-void launch_trtri_diag(int dtype, const TaskDesc* tasks, int ntasks, int max_nblk, hipStream_t st) {
-  if (dtype == HBO_F64) trtri_diag_t<double>(tasks, ntasks, max_nblk, st);
-  else trtri_diag_t<float>(tasks, ntasks, max_nblk, st);
+void launch_trtri_diag(int dtype, const TaskDesc* tasks, int ntasks, int p_lo, int p_hi, hipStream_t st) {
+  if (dtype == HBO_F64) trtri_diag_t<double>(tasks, ntasks, p_lo, p_hi, st);
+  else trtri_diag_t<float>(tasks, ntasks, p_lo, p_hi, st);
 }

@@ -146,7 +146,7 @@ __device__ __forceinline__ bool decode_job(const GemmArgs& g, TileJob<T>& j) {
       // dispatcher hands out tiles in longest-processing-time order (x runs over groups x tiles).
       constexpr int U = HBO_TILE / TM;
       const int s = g.p0, su = s * U;
-      const int grp = (int)blockIdx.x / su;
+      const int grp = g.grp_lo + (int)blockIdx.x / su;
       const int inner = (int)blockIdx.x % su;
       int jt, it;
       if (g.mode == GEMM_TRTRI_A) { jt = blockIdx.y; it = inner; }            // K = s*128 - jt*TM

@@ -59,6 +59,7 @@ struct GemmArgs {
   int aug;       // SYRK: 1 -> include the augmented tile-row
   int small_tiles;  // 1 -> 64x64 output tiles (SYRK / TRTRI / LAUUM; grid is given in 128-tile units)
   int persistent;   // SYRK: >0 -> that many persistent workgroups loop over the tiles
+  int grp_lo;       // TRTRI: first group (of size 2s blocks) handled by this launch
   void* B;       // POST: Kxq (npad x ldb)
   int64_t ldb;
   void* V;       // POST: optional V output (npad x ldb), may be null
@@ -70,7 +71,8 @@ void launch_gemm(int dtype, const GemmArgs& a, dim3 grid, hipStream_t st);
 
 void launch_potf2(int dtype, const TaskDesc* tasks, int ntasks, int p, int* info, hipStream_t st);
 void launch_trsm(int dtype, const TaskDesc* tasks, int ntasks, int p, int max_nblk, hipStream_t st);
-void launch_trtri_diag(int dtype, const TaskDesc* tasks, int ntasks, int max_nblk, hipStream_t st);
+// inverses of the diagonal blocks p in [p_lo, p_hi)
+void launch_trtri_diag(int dtype, const TaskDesc* tasks, int ntasks, int p_lo, int p_hi, hipStream_t st);
 
 struct GramArgs {
   const TaskDesc* tasks;   // batched symmetric mode (tasks != null): out = tasks[z].A, x = tasks[z].F
