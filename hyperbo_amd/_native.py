@@ -78,6 +78,7 @@ SIGNATURES = {
     'hbo_factor': (C.c_int, [_P, C.POINTER(Model), _P, C.c_int64, _P, C.c_int32, C.POINTER(_P)]),
     'hbo_cache_export': (C.c_int, [_P, _P, _P, _P, _P]),
     'hbo_cache_free': (C.c_int, [_P, _P]),
+    'hbo_cache_append': (C.c_int, [_P, C.POINTER(Model), _P, _P, C.c_int64, _P]),
     'hbo_predict': (C.c_int, [_P, C.POINTER(Model), _P, _P, C.c_int64, C.c_int, _P, _P]),
     'hbo_acq': (C.c_int, [_P, C.POINTER(Model), _P, _P, C.c_int64, C.c_int, C.c_double, C.c_double,
                           C.c_double, _P]),

@@ -17,6 +17,10 @@ class GPCache:
     self._chol, self._kinvy = chol, kinvy
     self.needs_update = needs_update
     self.handle = handle
+    self.pending = []     # observations appended since the factorisation ([] / list of (x, y)); None = replaced
+
+  def invalidate_arrays(self):
+    self._chol = self._kinvy = None
 
   def _export(self):
     if self.handle is not None and (self._chol is None or self._kinvy is None):

@@ -58,6 +58,7 @@ class CacheHandle:
     self.dtype = x.dtype
     self.n, self.m = y.shape
     self._h = C.c_void_p()
+    self._spec = (mean_func, cov_func, warp_func, eps, x.shape[1])
     bm = _model.BuiltModel(mean_func, cov_func, params, warp_func, x.dtype, x.shape[1], eps=eps)
     self.status = ctx.check(nat.lib().hbo_factor(ctx.handle, bm.ref(), nat.ptr(x), x.shape[0], nat.ptr(y),
                                                  y.shape[1], C.byref(self._h)))
@@ -69,6 +70,24 @@ class CacheHandle:
     self.ctx.check(nat.lib().hbo_cache_export(self.ctx.handle, self._h, nat.ptr(chol), nat.ptr(kinvy),
                                               nat.ptr(ymu)))
     return chol, kinvy, ymu
+
+  def append(self, params, x_new, y_new):
+    """O(N^2) in-place append of observations (hbo_cache_append); `params` must hold the SAME
+    hyper-parameters the cache was built with.  Returns False when the padded capacity is exhausted
+    (the caller re-factorises), True otherwise."""
+    mean_func, cov_func, warp_func, eps, d = self._spec
+    x_new = np.ascontiguousarray(np.asarray(x_new), dtype=self.dtype).reshape(-1, d)
+    y_new = np.ascontiguousarray(np.asarray(y_new), dtype=self.dtype).reshape(x_new.shape[0], -1)
+    if y_new.shape[1] != self.m:
+      raise ValueError(f'y has {y_new.shape[1]} columns, the cache was built with {self.m}')
+    bm = _model.BuiltModel(mean_func, cov_func, params, warp_func, self.dtype, d, eps=eps)
+    rc = nat.lib().hbo_cache_append(self.ctx.handle, bm.ref(), self._h, nat.ptr(x_new), x_new.shape[0],
+                                    nat.ptr(y_new))
+    if rc == nat.HBO_ERR_UNSUPPORTED:
+      return False
+    self.status = self.ctx.check(rc)
+    self.n += x_new.shape[0]
+    return True
 
   @property
   def handle(self):

@@ -733,13 +733,14 @@ struct hbo_cache {
   TaskDesc h_desc; TaskDesc* d_desc = nullptr;
   int* d_info = nullptr; int info = INT_MAX;
   void* resid = nullptr;   // m x npad : y - mu
+  void* zvec = nullptr;    // m x npad : z = L^-1 (y - mu), kept for O(N^2) row appends
 };
 
 extern "C" int hbo_cache_free(hbo_ctx* c, hbo_cache* k) {
   if (!k) return HBO_OK;
   if (c) hipSetDevice(c->device);
   free_task(k->t);
-  for (void* p : {(void*)k->d_desc, (void*)k->d_info, k->resid}) if (p) hipFree(p);
+  for (void* p : {(void*)k->d_desc, (void*)k->d_info, k->resid, k->zvec}) if (p) hipFree(p);
   delete k;
   return HBO_OK;
 }
@@ -761,7 +762,7 @@ extern "C" int hbo_factor(hbo_ctx* c, const hbo_model* m, const void* x, int64_t
   t->n = n; t->m = mcols; t->npad = round_up(n, HBO_TILE); t->nblk = t->npad / HBO_TILE; t->ld = padded_ld(t->npad, dtype);
   auto bail = [&](int code) { hbo_cache_free(c, k); return code; };
 #define HIPCHK_K(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) { c->err = std::string(#call " failed: ") + hipGetErrorString(e__); return bail(HBO_ERR_HIP); } } while (0)
-  HIPCHK_K(hipMalloc(&t->X, (size_t)n * m->input_dim * es));
+  HIPCHK_K(hipMalloc(&t->X, (size_t)t->npad * m->input_dim * es));   // capacity npad rows (row appends)
   HIPCHK_K(hipMemcpy(t->X, x, (size_t)n * m->input_dim * es, hipMemcpyHostToDevice));
   // y^T (m x n) so that aug row a = column a of y
   std::vector<unsigned char> yt((size_t)n * mcols * es);
@@ -771,11 +772,12 @@ extern "C" int hbo_factor(hbo_ctx* c, const hbo_model* m, const void* x, int64_t
   HIPCHK_K(hipMemcpy(t->ysum, yt.data(), (size_t)n * mcols * es, hipMemcpyHostToDevice));
   rc = ensure_task_workspace(c, dtype, t, true, mcols);
   if (rc) return bail(rc);
-  if (needs_mlp(m)) { rc = t->feat.ensure(c, m, n); if (rc) return bail(rc); }
+  if (needs_mlp(m)) { rc = t->feat.ensure(c, m, t->npad); if (rc) return bail(rc); }
   fill_desc(k->h_desc, t, m, dtype);
   HIPCHK_K(hipMalloc((void**)&k->d_desc, sizeof(TaskDesc)));
   HIPCHK_K(hipMalloc((void**)&k->d_info, sizeof(int)));
   HIPCHK_K(hipMalloc(&k->resid, (size_t)mcols * t->npad * es));
+  HIPCHK_K(hipMalloc(&k->zvec, (size_t)mcols * t->npad * es));
   HIPCHK_K(hipMemcpy(k->d_desc, &k->h_desc, sizeof(TaskDesc), hipMemcpyHostToDevice));
   int inf = INT_MAX;
   HIPCHK_K(hipMemcpy(k->d_info, &inf, sizeof(int), hipMemcpyHostToDevice));
@@ -788,6 +790,7 @@ extern "C" int hbo_factor(hbo_ctx* c, const hbo_model* m, const void* x, int64_t
     GramArgs g = {}; g.tasks = k->d_desc; g.fdim = feature_dim(m); g.symmetric = 1; g.padded = 1;
     launch_gram(dtype, g, c->d_model, dim3(t->nblk, t->nblk, 1), st); }
   { ProfScope ps(c, "potrf", 1); run_potrf(c, dtype, k->d_desc, 1, t->nblk, k->d_info); }
+  HIPCHK_K(hipMemcpy2DAsync(k->zvec, (size_t)t->npad * es, (char*)t->A + (size_t)t->npad * t->ld * es, (size_t)t->ld * es, (size_t)t->npad * es, mcols, hipMemcpyDeviceToDevice, st));
   { ProfScope ps(c, "trtri", 1); run_trtri(c, dtype, k->d_desc, 1, t->nblk); }
   { ProfScope ps(c, "wt_z", 1);
     for (int a = 0; a < mcols; ++a) launch_wt_z(dtype, k->d_desc, 1, t->nblk, a, a, t->npad, st); }
@@ -798,6 +801,112 @@ extern "C" int hbo_factor(hbo_ctx* c, const hbo_model* m, const void* x, int64_t
 #undef HIPCHK_K
   *out = k;
   return k->info != INT_MAX ? HBO_NOT_PD : HBO_OK;
+}
+
+// O(N^2) row append (the reference re-factorises from scratch after every BO
+// observation, hyperbo/bo_utils/bayesopt.py:186-190, and notes "One can potentially support rank-1
+// updates", hyperbo/gp_utils/gp.py:284).  For each new point (x*, y*), with W = L^-1 resident:
+//   l = W k(X,x*),  d = sqrt(k(x*,x*) + sigma^2 + eps - l.l),  L' = [[L,0],[l^T,d]],
+//   W' = [[W,0],[-(l^T W)/d, 1/d]],  z' = [z; (r* - l.z)/d],  alpha' = [alpha + w' z'_n ; z'_n/d].
+// Two triangular mat-vecs on the device, O(n) arithmetic on the host.  Returns HBO_ERR_UNSUPPORTED
+// when the padded capacity (npad) is exhausted -- the caller then re-factorises.
+extern "C" int hbo_cache_append(hbo_ctx* c, const hbo_model* m, hbo_cache* k, const void* x_new, int64_t n_new,
+                                const void* y_new) {
+  if (!c || !k || !x_new || !y_new) return fail(c, HBO_ERR_ARG, "hbo_cache_append: null argument");
+  if (n_new <= 0) return HBO_OK;
+  HIPCHK(c, hipSetDevice(c->device));
+  TaskHost* t = k->t;
+  if (k->dtype != m->dtype || k->D != m->input_dim) return fail(c, HBO_ERR_ARG, "hbo_cache_append: cache/model mismatch");
+  if (k->info != INT_MAX) return HBO_NOT_PD;
+  if (t->n + n_new > t->npad) return fail(c, HBO_ERR_UNSUPPORTED, "hbo_cache_append: capacity exhausted (re-factorise)");
+  int rc = upload_model(c, m);
+  if (rc) return rc;
+  const int dtype = k->dtype; const size_t es = esize(dtype);
+  hipStream_t st = c->stream;
+  const int fdim = feature_dim(m), fm = mean_feature_dim(m), mc = k->m;
+  void *d_kx = nullptr, *d_l = nullptr, *d_w = nullptr, *d_mu = nullptr, *d_kd = nullptr;
+  auto cleanup = [&]() { for (void* p : {d_kx, d_l, d_w, d_mu, d_kd}) if (p) hipFree(p); };
+#define HIPCHK_A(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) { c->err = std::string(#call " failed: ") + hipGetErrorString(e__); cleanup(); return HBO_ERR_HIP; } } while (0)
+  HIPCHK_A(hipMalloc(&d_kx, (size_t)t->npad * es)); HIPCHK_A(hipMalloc(&d_l, (size_t)t->npad * es));
+  HIPCHK_A(hipMalloc(&d_w, (size_t)t->npad * es)); HIPCHK_A(hipMalloc(&d_mu, es)); HIPCHK_A(hipMalloc(&d_kd, es));
+  std::vector<double> l(t->npad), w(t->npad), z((size_t)mc * t->npad), al((size_t)mc * t->npad);
+  std::vector<unsigned char> buf((size_t)t->npad * es * std::max(mc, 1));
+  auto to_host = [&](const void* dev, std::vector<double>& out, size_t count) -> hipError_t {
+    hipError_t e = hipMemcpy(buf.data(), dev, count * es, hipMemcpyDeviceToHost);
+    for (size_t i = 0; i < count; ++i) out[i] = host_elem(buf.data(), dtype, (int64_t)i);
+    return e;
+  };
+  auto to_dev = [&](void* dev, const double* src, size_t count) -> hipError_t {
+    for (size_t i = 0; i < count; ++i) { if (dtype == HBO_F64) ((double*)buf.data())[i] = src[i]; else ((float*)buf.data())[i] = (float)src[i]; }
+    return hipMemcpy(dev, buf.data(), count * es, hipMemcpyHostToDevice);
+  };
+  HIPCHK_A(to_host(k->zvec, z, (size_t)mc * t->npad));
+  HIPCHK_A(to_host(t->svec, al, (size_t)mc * t->npad));
+  int status = HBO_OK;
+  for (int64_t q = 0; q < n_new && status == HBO_OK; ++q) {
+    const int64_t n = t->n;
+    // new input row -> X[n], features -> acts[.][n]
+    void* xrow = (char*)t->X + (size_t)n * m->input_dim * es;
+    HIPCHK_A(hipMemcpyAsync(xrow, (const char*)x_new + (size_t)q * m->input_dim * es, (size_t)m->input_dim * es, hipMemcpyHostToDevice, st));
+    const void* flast = nullptr;
+    if (needs_mlp(m)) {
+      void* rows[HBO_MAX_MLP_LAYERS];
+      for (int lyr = 0; lyr < m->n_layers; ++lyr) rows[lyr] = (char*)t->feat.acts[lyr] + (size_t)n * m->features[lyr] * es;
+      run_mlp(c, m, xrow, 1, rows);
+      flast = rows[m->n_layers - 1];
+    }
+    const void* Fq = m->kernel_uses_mlp ? flast : xrow;
+    const void* Fmq = (m->mean_id == HBO_MEAN_LINEAR) ? xrow : (m->mean_id == HBO_MEAN_LINEAR_MLP ? flast : nullptr);
+    launch_mean(dtype, Fmq, 1, fm, c->d_model, d_mu, st);
+    launch_kdiag(dtype, Fq, 1, fdim, c->d_model, d_kd, st);
+    // k(X, x*)  (n x 1), zero-padded to npad
+    HIPCHK_A(hipMemsetAsync(d_kx, 0, (size_t)t->npad * es, st));
+    { GramArgs g = {}; g.x1 = k->h_desc.F; g.x2 = Fq; g.out = d_kx; g.n1 = n; g.n2 = 1; g.ldo = 1; g.fdim = fdim;
+      launch_gram(dtype, g, c->d_model, dim3(1, (unsigned)((n + 127) / 128), 1), st); }
+    // l = W kx ; wl = W^T l
+    launch_tri_matvec(dtype, t->W, t->ld, t->npad, d_kx, t->npad, 1, 0, d_l, t->npad, st);
+    launch_tri_matvec(dtype, t->W, t->ld, t->npad, d_l, t->npad, 1, 1, d_w, t->npad, st);
+    HIPCHK_A(hipStreamSynchronize(st));
+    HIPCHK_A(to_host(d_l, l, (size_t)t->npad));
+    HIPCHK_A(to_host(d_w, w, (size_t)t->npad));
+    std::vector<double> one(1);
+    HIPCHK_A(to_host(d_mu, one, 1)); const double mu_new = one[0];
+    HIPCHK_A(to_host(d_kd, one, 1)); const double kappa = one[0] + m->noise_variance + m->eps;
+    double ll = 0;
+    for (int64_t i = 0; i < n; ++i) ll += l[i] * l[i];
+    const double d2 = kappa - ll;
+    if (!(d2 > 0)) { status = HBO_NOT_PD; k->info = (int)n + 1; break; }
+    const double d = sqrt(d2);
+    for (int64_t i = 0; i < n; ++i) w[i] = -w[i] / d;      // new row of W (columns < n)
+    // write row n of L and of W (identity padding row is overwritten)
+    l[n] = d; w[n] = 1.0 / d;
+    HIPCHK_A(to_dev((char*)t->A + (size_t)n * t->ld * es, l.data(), (size_t)n + 1));
+    HIPCHK_A(to_dev((char*)t->W + (size_t)n * t->ld * es, w.data(), (size_t)n + 1));
+    for (int a = 0; a < mc; ++a) {
+      double* za = z.data() + (size_t)a * t->npad; double* aa = al.data() + (size_t)a * t->npad;
+      const double r_new = host_elem(y_new, dtype, q * mc + a) - mu_new;
+      double lz = 0;
+      for (int64_t i = 0; i < n; ++i) lz += l[i] * za[i];
+      const double zn = (r_new - lz) / d;
+      za[n] = zn;
+      for (int64_t i = 0; i < n; ++i) aa[i] += w[i] * zn;
+      aa[n] = zn / d;
+      // residual buffer (y - mu) gains the new entry
+      double rr = r_new;
+      HIPCHK_A(to_dev((char*)k->resid + ((size_t)a * t->npad + n) * es, &rr, 1));
+    }
+    t->n = n + 1;
+    k->h_desc.n = (int)t->n;
+  }
+  if (status == HBO_OK || status == HBO_NOT_PD) {
+    HIPCHK_A(to_dev(k->zvec, z.data(), (size_t)mc * t->npad));
+    HIPCHK_A(to_dev(t->svec, al.data(), (size_t)mc * t->npad));
+    HIPCHK_A(hipMemcpy(k->d_desc, &k->h_desc, sizeof(TaskDesc), hipMemcpyHostToDevice));
+  }
+  HIPCHK_A(hipGetLastError());
+#undef HIPCHK_A
+  cleanup();
+  return status;
 }
 
 static void fill_nan(void* p, size_t count, int dtype) {

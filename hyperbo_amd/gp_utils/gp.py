@@ -241,7 +241,14 @@ class GP:
     else:
       self.dataset[sub_dataset_key] = sub_dataset
     if sub_dataset_key in self.params.cache:
-      self.params.cache[sub_dataset_key].needs_update = True
+      cache = self.params.cache[sub_dataset_key]
+      cache.needs_update = True
+      # remember what was appended so that setup_predictor can update the factor in O(N^2)
+      pending = getattr(cache, 'pending', None)
+      if is_append and pending is not None:
+        pending.append((np.asarray(sub_dataset.x), np.asarray(sub_dataset.y)))
+      elif hasattr(cache, 'pending'):
+        cache.pending = None
 
   def train(self, key=None, get_params_path=None, callback=None) -> GPParams:
     """Fit the GP hyper-parameters to the dataset (gp.py:454-485)."""
@@ -274,6 +281,20 @@ class GP:
     if sub_dataset_key in self.params.cache and not self.params.cache[sub_dataset_key].needs_update:
       return
     old = self.params.cache.get(sub_dataset_key)
+    if (old is not None and getattr(old, 'handle', None) is not None and getattr(old, 'pending', None)
+        and self.params.config.get('incremental_cache', True)):
+      # rows were only appended since the factorisation: O(N^2) update instead of the reference's
+      # O(N^3) re-factorisation (same result up to rounding; gp.py:284 anticipates it)
+      ok = True
+      for xa, ya in old.pending:
+        ok = ok and old.handle.append(self.params, xa, ya)
+        if not ok:
+          break
+      if ok:
+        old.pending = []
+        old.needs_update = False
+        old.invalidate_arrays()
+        return
     if old is not None and getattr(old, 'handle', None) is not None:
       old.handle.close()
     sd = self.dataset[sub_dataset_key]

@@ -134,6 +134,12 @@ int hbo_factor(hbo_ctx* ctx, const hbo_model* model, const void* x, int64_t n, c
 int hbo_cache_export(hbo_ctx* ctx, hbo_cache* cache, void* chol_out, void* kinvy_out,
                      void* y_minus_mu_out);
 int hbo_cache_free(hbo_ctx* ctx, hbo_cache* cache);
+/* O(N^2) in-place append of n_new observations (x_new [n_new, D], y_new [n_new, m]) to a cache built with the
+ * SAME hyper-parameters -- what GP.update_sub_dataset(is_append=True) + setup_predictor recompute from
+ * scratch in the reference (gp.py:426-452,540-560; "One can potentially support rank-1 updates", gp.py:284).
+ * HBO_ERR_UNSUPPORTED: padded capacity exhausted, re-factorise with hbo_factor. */
+int hbo_cache_append(hbo_ctx* ctx, const hbo_model* model, hbo_cache* cache, const void* x_new, int64_t n_new,
+                     const void* y_new);
 
 /* ---- gp.py:242-305 predict ------------------------------------------------------------- */
 /* cache == NULL -> prior branch (gp.py:275-282).  mu_out [M,1]; var_out [M,1] or [M,M] if

@@ -490,3 +490,37 @@ def test_simulated_bo_iteration(gpu_ctx):
     sel = int(np.argmax(ev))
     m.update_sub_dataset((cand_x[sel:sel + 1], cand_y[sel:sel + 1]), 0, is_append=True)
     assert m.params.cache[0].needs_update and m.dataset[0].x.shape[0] == 41 + it
+
+
+@pytest.mark.parametrize('kname,mlp,mname', CASES)
+def test_incremental_cache_append_matches_refactorisation(gpu_ctx, kname, mlp, mname):
+  """O(N^2) row append (hbo_cache_append) vs the reference behaviour (re-factorise from scratch)."""
+  defs, linalg, acfun, gp, kernel, mean, _, utils = _native()
+  rng = np.random.default_rng(23)
+  d = 3
+  model = helpers.make_model(rng, mname, mlp, d)
+  po, pn = _pair(model)
+  ko = getattr(o, kname + ('_mlp' if mlp else '')); kn = getattr(kernel, kname + ('_mlp' if mlp else ''))
+  mo, mn = getattr(o, mname), getattr(mean, mname)
+  x, y = helpers.synthetic_task(rng, 120, d)
+  xa, ya = helpers.synthetic_task(rng, 11, d)
+  xq = rng.uniform(size=(40, d))
+  m = gp.GP({0: defs.SubDataset(x, y)}, mn, kn, pn, utils.DEFAULT_WARP_FUNC)
+  m.predict(xq, 0)
+  h0 = m.params.cache[0].handle
+  for i in range(0, 11, 4):                     # appends of 4, 4, 3 rows (crosses the 128-row tile edge)
+    m.update_sub_dataset((xa[i:i + 4], ya[i:i + 4]), 0, is_append=True)
+    mu, var = m.predict(xq, 0)
+    assert m.params.cache[0].handle is h0 or m.dataset[0].x.shape[0] > 128   # updated in place while capacity lasts
+    xs, ys = m.dataset[0].x, m.dataset[0].y
+    mu_o, var_o = o.predict(mo, ko, po, xs, ys, xq, WFO)
+    mu_o, var_o = o.gp_predict_postprocess(po, {0: o.SubDataset(xs, ys)}, mu_o, var_o, WFO, False, True, True)
+    assert helpers.rel_err(mu, mu_o) < 1e-8 and helpers.rel_err(var, var_o) < 1e-8
+    cho, kio, _ = o.solve_gp_linear_system(mo, ko, po, xs, ys, WFO)
+    assert helpers.rel_err(m.params.cache[0].chol, cho) < 1e-9 and helpers.rel_err(m.params.cache[0].kinvy, kio) < 1e-8
+  assert m.dataset[0].x.shape[0] == 131          # 120 + 11 > 128: the last append re-factorised
+  # a replace (not append) always re-factorises
+  m.update_sub_dataset((x[:50], y[:50]), 0)
+  mu, _ = m.predict(xq, 0)
+  mu_o, _ = o.predict(mo, ko, po, x[:50], y[:50], xq, WFO)
+  assert helpers.rel_err(mu, mu_o) < 1e-8
