@@ -28,6 +28,7 @@ struct hbo_ctx {
   int opt_persist_free = 32; // bulk trailing update runs as 2*(CUs - this) persistent workgroups
   int n_cus = 256;
   std::vector<hipEvent_t> ev_pool;
+  std::map<int, std::pair<void*, size_t>> ws;   // grow-only device scratch buffers by slot (no per-call hipMalloc/hipFree)
   int opt_lookahead = 1;
   int opt_overlap_trtri = 1;
   std::string err;
@@ -71,6 +72,21 @@ static inline int round_up(int64_t n, int q) { return (int)(((n + q - 1) / q) * 
 // leading dimension: padded extent + 128 bytes, so that rows do not sit at a power-of-two stride
 // (a 64 KiB row stride maps every row of a k-contiguous tile onto the same L2/HBM channel)
 static inline int64_t padded_ld(int64_t extent, int dtype) { return extent + 128 / (int64_t)esize(dtype); }
+
+// grow-only scratch buffer for `slot`; nullptr on allocation failure (ctx->err is set)
+enum WsSlot { WS_XQ = 1, WS_MU0, WS_KD, WS_MU, WS_VAR, WS_ACQ, WS_K, WS_COLSQ, WS_V, WS_KQQ, WS_COV,
+              WS_AP_KX, WS_AP_L, WS_AP_W, WS_AP_MU, WS_AP_KD, WS_FQ0 /* + layer */ };
+static void* ws_get(hbo_ctx* c, int slot, size_t bytes) {
+  auto& e = c->ws[slot];
+  if (e.second < bytes || !e.first) {
+    if (e.first) hipFree(e.first);
+    e.first = nullptr; e.second = 0;
+    hipError_t err = hipMalloc(&e.first, bytes ? bytes : 16);
+    if (err != hipSuccess) { c->err = std::string("hipMalloc failed: ") + hipGetErrorString(err); e.first = nullptr; return nullptr; }
+    e.second = bytes;
+  }
+  return e.first;
+}
 
 // ---- profiling ---------------------------------------------------------------------------
 struct ProfScope {
@@ -148,6 +164,7 @@ extern "C" int hbo_ctx_destroy(hbo_ctx* c) {
   prof_begin(c);
   for (int l = 0; l < HBO_MAX_MLP_LAYERS; ++l) { if (c->d_mlp_w[l]) hipFree(c->d_mlp_w[l]); if (c->d_mlp_b[l]) hipFree(c->d_mlp_b[l]); }
   if (c->d_model) hipFree(c->d_model);
+  for (auto& kv : c->ws) if (kv.second.first) hipFree(kv.second.first);
   for (hipEvent_t ev : c->ev_pool) hipEventDestroy(ev);
   if (c->stream4) hipStreamDestroy(c->stream4);
   if (c->stream3) hipStreamDestroy(c->stream3);
@@ -825,10 +842,11 @@ extern "C" int hbo_cache_append(hbo_ctx* c, const hbo_model* m, hbo_cache* k, co
   hipStream_t st = c->stream;
   const int fdim = feature_dim(m), fm = mean_feature_dim(m), mc = k->m;
   void *d_kx = nullptr, *d_l = nullptr, *d_w = nullptr, *d_mu = nullptr, *d_kd = nullptr;
-  auto cleanup = [&]() { for (void* p : {d_kx, d_l, d_w, d_mu, d_kd}) if (p) hipFree(p); };
+  auto cleanup = [&]() {};   // ctx-owned scratch
 #define HIPCHK_A(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) { c->err = std::string(#call " failed: ") + hipGetErrorString(e__); cleanup(); return HBO_ERR_HIP; } } while (0)
-  HIPCHK_A(hipMalloc(&d_kx, (size_t)t->npad * es)); HIPCHK_A(hipMalloc(&d_l, (size_t)t->npad * es));
-  HIPCHK_A(hipMalloc(&d_w, (size_t)t->npad * es)); HIPCHK_A(hipMalloc(&d_mu, es)); HIPCHK_A(hipMalloc(&d_kd, es));
+  d_kx = ws_get(c, WS_AP_KX, (size_t)t->npad * es); d_l = ws_get(c, WS_AP_L, (size_t)t->npad * es);
+  d_w = ws_get(c, WS_AP_W, (size_t)t->npad * es); d_mu = ws_get(c, WS_AP_MU, 16); d_kd = ws_get(c, WS_AP_KD, 16);
+  if (!d_kx || !d_l || !d_w || !d_mu || !d_kd) return HBO_ERR_HIP;
   std::vector<double> l(t->npad), w(t->npad), z((size_t)mc * t->npad), al((size_t)mc * t->npad);
   std::vector<unsigned char> buf((size_t)t->npad * es * std::max(mc, 1));
   auto to_host = [&](const void* dev, std::vector<double>& out, size_t count) -> hipError_t {
@@ -865,7 +883,7 @@ extern "C" int hbo_cache_append(hbo_ctx* c, const hbo_model* m, hbo_cache* k, co
       launch_gram(dtype, g, c->d_model, dim3(1, (unsigned)((n + 127) / 128), 1), st); }
     // l = W kx ; wl = W^T l
     launch_tri_matvec(dtype, t->W, t->ld, t->npad, d_kx, t->npad, 1, 0, d_l, t->npad, st);
-    launch_tri_matvec(dtype, t->W, t->ld, t->npad, d_l, t->npad, 1, 1, d_w, t->npad, st);
+    launch_wt_z(dtype, k->d_desc, 1, t->nblk, 0, 0, t->npad, st, d_l, d_w);   // W^T l (two-stage, uses S as scratch)
     HIPCHK_A(hipStreamSynchronize(st));
     HIPCHK_A(to_host(d_l, l, (size_t)t->npad));
     HIPCHK_A(to_host(d_w, w, (size_t)t->npad));
@@ -968,25 +986,25 @@ static int posterior(hbo_ctx* c, const hbo_model* m, hbo_cache* k, const void* x
   const int64_t ldq_max = padded_ld(mpad_max, dtype);
   void *d_xq = nullptr, *d_mu0 = nullptr, *d_kd = nullptr, *d_mu = nullptr, *d_var = nullptr, *d_acq = nullptr;
   void *d_K = nullptr, *d_colsq = nullptr, *d_V = nullptr, *d_Kqq = nullptr, *d_cov = nullptr;
-  FeatBuf fq;
+  void* fq_acts[HBO_MAX_MLP_LAYERS] = {nullptr};
   std::vector<void*> to_free;
-  auto cleanup = [&]() { for (void* p : {d_xq, d_mu0, d_kd, d_mu, d_var, d_acq, d_K, d_colsq, d_V, d_Kqq, d_cov}) if (p) hipFree(p); };
+  auto cleanup = [&]() {};   // buffers are ctx-owned scratch (ws_get)
 #define HIPCHK_P(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) { c->err = std::string(#call " failed: ") + hipGetErrorString(e__); cleanup(); return HBO_ERR_HIP; } } while (0)
   if (full_cov && M > CH) { return fail(c, HBO_ERR_UNSUPPORTED, "posterior: full_cov limited to 65536 queries"); }
-  HIPCHK_P(hipMalloc(&d_xq, (size_t)mc_max * m->input_dim * es));
-  HIPCHK_P(hipMalloc(&d_mu0, (size_t)mc_max * es));
-  HIPCHK_P(hipMalloc(&d_kd, (size_t)mc_max * es));
-  HIPCHK_P(hipMalloc(&d_mu, (size_t)mc_max * es));
-  HIPCHK_P(hipMalloc(&d_var, (size_t)mc_max * es));
-  if (acq_out) HIPCHK_P(hipMalloc(&d_acq, (size_t)mc_max * es));
-  if (needs_mlp(m)) { rc = fq.ensure(c, m, mc_max); if (rc) { cleanup(); return rc; } }
+  { d_xq = ws_get(c, WS_XQ, (size_t)mc_max * m->input_dim * es); if (!d_xq) return HBO_ERR_HIP; }
+  { d_mu0 = ws_get(c, WS_MU0, (size_t)mc_max * es); if (!d_mu0) return HBO_ERR_HIP; }
+  { d_kd = ws_get(c, WS_KD, (size_t)mc_max * es); if (!d_kd) return HBO_ERR_HIP; }
+  { d_mu = ws_get(c, WS_MU, (size_t)mc_max * es); if (!d_mu) return HBO_ERR_HIP; }
+  { d_var = ws_get(c, WS_VAR, (size_t)mc_max * es); if (!d_var) return HBO_ERR_HIP; }
+  if (acq_out) { d_acq = ws_get(c, WS_ACQ, (size_t)mc_max * es); if (!d_acq) return HBO_ERR_HIP; }
+  if (needs_mlp(m)) for (int l = 0; l < m->n_layers; ++l) { fq_acts[l] = ws_get(c, WS_FQ0 + l, (size_t)mc_max * m->features[l] * es); if (!fq_acts[l]) return HBO_ERR_HIP; }
   TaskHost* t = k ? k->t : nullptr;
   if (k) {
-    HIPCHK_P(hipMalloc(&d_K, (size_t)t->npad * ldq_max * es));
-    HIPCHK_P(hipMalloc(&d_colsq, (size_t)t->nblk * ldq_max * es));
-    if (full_cov) HIPCHK_P(hipMalloc(&d_V, (size_t)t->npad * ldq_max * es));
+    { d_K = ws_get(c, WS_K, (size_t)t->npad * ldq_max * es); if (!d_K) return HBO_ERR_HIP; }
+    { d_colsq = ws_get(c, WS_COLSQ, (size_t)t->nblk * ldq_max * es); if (!d_colsq) return HBO_ERR_HIP; }
+    if (full_cov) { d_V = ws_get(c, WS_V, (size_t)t->npad * ldq_max * es); if (!d_V) return HBO_ERR_HIP; }
   }
-  if (full_cov) { HIPCHK_P(hipMalloc(&d_Kqq, (size_t)M * M * es)); HIPCHK_P(hipMalloc(&d_cov, (size_t)M * M * es)); }
+  if (full_cov) { { d_Kqq = ws_get(c, WS_KQQ, (size_t)M * M * es); if (!d_Kqq) return HBO_ERR_HIP; } { d_cov = ws_get(c, WS_COV, (size_t)M * M * es); if (!d_cov) return HBO_ERR_HIP; } }
   const bool bad = k && k->info != INT_MAX;
 
   for (int64_t q0 = 0; q0 < M; q0 += CH) {
@@ -996,7 +1014,7 @@ static int posterior(hbo_ctx* c, const hbo_model* m, hbo_cache* k, const void* x
     HIPCHK_P(hipMemcpyAsync(d_xq, (const char*)xq + (size_t)q0 * m->input_dim * es, (size_t)mc * m->input_dim * es, hipMemcpyHostToDevice, st));
     const void* fq_last = nullptr;
     { ProfScope ps(c, "features", 1);
-      if (needs_mlp(m)) { run_mlp(c, m, d_xq, mc, fq.acts.data()); fq_last = fq.acts[m->n_layers - 1]; } }
+      if (needs_mlp(m)) { run_mlp(c, m, d_xq, mc, fq_acts); fq_last = fq_acts[m->n_layers - 1]; } }
     const void* Fq = m->kernel_uses_mlp ? fq_last : d_xq;
     const void* Fmq = (m->mean_id == HBO_MEAN_LINEAR) ? d_xq : (m->mean_id == HBO_MEAN_LINEAR_MLP ? fq_last : nullptr);
     launch_mean(dtype, Fmq, mc, fm, c->d_model, d_mu0, st);

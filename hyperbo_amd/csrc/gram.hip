@@ -261,7 +261,7 @@ __global__ __launch_bounds__(256) void nll_reduce_kernel(const TaskDesc* tasks, 
 
 // s = W^T z, stage 1: partial[rc][col] over 512-row chunks, stored in the scratch matrix S.
 template <typename T>
-__global__ __launch_bounds__(256) void wtz_partial_kernel(const TaskDesc* tasks, int aug_row) {
+__global__ __launch_bounds__(256) void wtz_partial_kernel(const TaskDesc* tasks, int aug_row, const T* xover) {
   __shared__ T sred[256];
   const TaskDesc& t = tasks[blockIdx.z];
   const int cb = blockIdx.x, rc = blockIdx.y;
@@ -273,7 +273,7 @@ __global__ __launch_bounds__(256) void wtz_partial_kernel(const TaskDesc* tasks,
   T acc = (T)0;
   if (row_lo + 512 > (int64_t)cb * HBO_TILE) {  // chunk reaches the lower triangle
     const T* W = static_cast<const T*>(t.W);
-    const T* z = static_cast<const T*>(t.A) + ((int64_t)t.npad + aug_row) * t.ld;
+    const T* z = xover ? xover : static_cast<const T*>(t.A) + ((int64_t)t.npad + aug_row) * t.ld;
     int64_t r_begin = row_lo + half * 256, r_end = r_begin + 256;
     if (r_end > t.npad) r_end = t.npad;
     const int64_t diag0 = (int64_t)cb * HBO_TILE;
@@ -285,7 +285,7 @@ __global__ __launch_bounds__(256) void wtz_partial_kernel(const TaskDesc* tasks,
   if (half == 0) part[col] = sred[col] + sred[col + 128];
 }
 template <typename T>
-__global__ void wtz_final_kernel(const TaskDesc* tasks, int out_col, int out_ld) {
+__global__ void wtz_final_kernel(const TaskDesc* tasks, int out_col, int out_ld, T* oover) {
   const TaskDesc& t = tasks[blockIdx.z];
   const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= t.npad) return;
@@ -293,7 +293,8 @@ __global__ void wtz_final_kernel(const TaskDesc* tasks, int out_col, int out_ld)
   const int nrc = (t.npad + 511) / 512;
   T s = (T)0;
   for (int rc = 0; rc < nrc; ++rc) s += part[(int64_t)rc * t.ld + j];
-  static_cast<T*>(t.svec)[(int64_t)out_col * out_ld + j] = s;
+  if (oover) oover[j] = s;
+  else static_cast<T*>(t.svec)[(int64_t)out_col * out_ld + j] = s;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -805,16 +806,16 @@ void launch_nll_reduce(int dtype, const TaskDesc* tasks, int ntasks, const int* 
   else hipLaunchKernelGGL((nll_reduce_kernel<float>), dim3(ntasks), dim3(256), 0, st, tasks, info, out);
 }
 void launch_wt_z(int dtype, const TaskDesc* tasks, int ntasks, int max_nblk, int aug_row, int out_col,
-                 int out_ld, hipStream_t st) {
+                 int out_ld, hipStream_t st, const void* xover, void* oover) {
   const int max_npad = max_nblk * HBO_TILE;
   dim3 g1(max_nblk, (max_npad + 511) / 512, ntasks);
   dim3 g2((max_npad + 255) / 256, 1, ntasks);
   if (dtype == HBO_F64) {
-    hipLaunchKernelGGL((wtz_partial_kernel<double>), g1, dim3(256), 0, st, tasks, aug_row);
-    hipLaunchKernelGGL((wtz_final_kernel<double>), g2, dim3(256), 0, st, tasks, out_col, out_ld);
+    hipLaunchKernelGGL((wtz_partial_kernel<double>), g1, dim3(256), 0, st, tasks, aug_row, (const double*)xover);
+    hipLaunchKernelGGL((wtz_final_kernel<double>), g2, dim3(256), 0, st, tasks, out_col, out_ld, (double*)oover);
   } else {
-    hipLaunchKernelGGL((wtz_partial_kernel<float>), g1, dim3(256), 0, st, tasks, aug_row);
-    hipLaunchKernelGGL((wtz_final_kernel<float>), g2, dim3(256), 0, st, tasks, out_col, out_ld);
+    hipLaunchKernelGGL((wtz_partial_kernel<float>), g1, dim3(256), 0, st, tasks, aug_row, (const float*)xover);
+    hipLaunchKernelGGL((wtz_final_kernel<float>), g2, dim3(256), 0, st, tasks, out_col, out_ld, (float*)oover);
   }
 }
 int grad_nacc(int kernel_id, int fdim) { return kernel_id == HBO_KERNEL_DOT ? 3 : 2 + fdim; }

@@ -95,8 +95,9 @@ void launch_aug_rows(int dtype, const TaskDesc* tasks, int ntasks, int max_npad,
 void launch_nll_reduce(int dtype, const TaskDesc* tasks, int ntasks, const int* info, double* out,
                        hipStream_t st);
 // s = W^T z_a (z_a = augmented row a of A) -> tasks[t].svec[out_col*out_ld + j]; uses S as scratch
+// xover / oover (single task only): explicit input vector [npad] / output vector [npad]
 void launch_wt_z(int dtype, const TaskDesc* tasks, int ntasks, int max_nblk, int aug_row, int out_col,
-                 int out_ld, hipStream_t st);
+                 int out_ld, hipStream_t st, const void* xover = nullptr, void* oover = nullptr);
 int grad_nacc(int kernel_id, int fdim);
 void launch_grad_contract(int dtype, const TaskDesc* tasks, int ntasks, int max_nblk, const ModelDev* md,
                           int kernel_id, int fdim, double* partials, int64_t stride_task, hipStream_t st);
