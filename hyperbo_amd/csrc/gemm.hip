@@ -135,7 +135,7 @@ __device__ __forceinline__ bool decode_job(const GemmArgs& g, TileJob<T>& j) {
       j.alpha = (T)-1; j.beta = 1;
 #ifdef HBO_GEMM_DEBUG
       if (g.aug & 2) j.beta = 0;
-      if (g.aug & 4) j.C = nullptr;
+      if (g.aug & 4) { j.C = nullptr; j.beta = 0; }
 #endif
       return true;
     }
@@ -236,11 +236,27 @@ __device__ __forceinline__ void gemm_tile(const TileJob<T>& job, unsigned char* 
   const int wm = wave >> 1, wn = wave & 1;
   const int l15 = lane & 15, lq = lane >> 4;
 
+  // accumulators start from C/alpha when the tile is accumulated into C (beta = 1): the C tile is
+  // fetched together with the first operand slabs instead of in a read-modify-write epilogue
   acc_t acc[MI][MI];
+  if (job.beta) {
+    const T inv_alpha = (T)1 / job.alpha;
 #pragma unroll
-  for (int a = 0; a < MI; ++a)
+    for (int a = 0; a < MI; ++a)
 #pragma unroll
-    for (int b = 0; b < MI; ++b) acc[a][b] = (acc_t){0, 0, 0, 0};
+      for (int b = 0; b < MI; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = wm * WT + a * 16 + Mma<T>::crow(lane, r);
+          const int col = wn * WT + b * 16 + l15;
+          acc[a][b][r] = gld(job.C + (int64_t)row * job.ldc + col) * inv_alpha;
+        }
+  } else {
+#pragma unroll
+    for (int a = 0; a < MI; ++a)
+#pragma unroll
+      for (int b = 0; b < MI; ++b) acc[a][b] = (acc_t){0, 0, 0, 0};
+  }
 
   const int nk = job.ksteps;
   vec_t ra[MI], rb[MI];
@@ -281,34 +297,18 @@ __device__ __forceinline__ void gemm_tile(const TileJob<T>& job, unsigned char* 
     __syncthreads();
   }
 
-  // epilogue: C read-modify-write in chunks of one MFMA row block, all loads of a chunk in flight
-  // before the first dependent store (a load->store chain per element costs one HBM round trip
-  // per element).
+  // epilogue: C = alpha * acc (the old C, if any, is already inside acc)
   if (job.C) {
 #pragma unroll
-    for (int a = 0; a < MI; ++a) {
-      T cv[MI][4];
-      if (job.beta) {
-#pragma unroll
-        for (int b = 0; b < MI; ++b)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int row = wm * WT + a * 16 + Mma<T>::crow(lane, r);
-            const int col = wn * WT + b * 16 + l15;
-            cv[b][r] = gld(job.C + (int64_t)row * job.ldc + col);
-          }
-      }
+    for (int a = 0; a < MI; ++a)
 #pragma unroll
       for (int b = 0; b < MI; ++b)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int row = wm * WT + a * 16 + Mma<T>::crow(lane, r);
           const int col = wn * WT + b * 16 + l15;
-          T v = job.alpha * acc[a][b][r];
-          if (job.beta) v += cv[b][r];
-          gst(job.C + (int64_t)row * job.ldc + col, v);
+          gst(job.C + (int64_t)row * job.ldc + col, job.alpha * acc[a][b][r]);
         }
-    }
   }
   if (TM == 128 && job.colsq) {
     // sum over this tile's 128 rows of acc^2, per column
