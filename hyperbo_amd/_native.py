@@ -75,6 +75,8 @@ SIGNATURES = {
     'hbo_dataset_free': (C.c_int, [_P, _P]),
     'hbo_nll': (C.c_int, [_P, C.POINTER(Model), _P, C.POINTER(C.c_double), C.POINTER(C.c_double),
                           C.POINTER(C.c_double)]),
+    'hbo_objective': (C.c_int, [_P, C.POINTER(Model), _P, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                C.POINTER(C.c_double)]),
     'hbo_factor': (C.c_int, [_P, C.POINTER(Model), _P, C.c_int64, _P, C.c_int32, C.POINTER(_P)]),
     'hbo_cache_export': (C.c_int, [_P, _P, _P, _P, _P]),
     'hbo_cache_free': (C.c_int, [_P, _P]),

@@ -39,6 +39,29 @@ def spd_inverse(coeff):
   return inv, logdet_half.value
 
 
+def inverse_spdmatrix_vector_product(spd_matrix, x, cached_cholesky=None):
+  """linalg.py:140-145: spd_matrix^-1 x.  `cached_cholesky` is accepted for signature parity; the device
+  re-factorises (the factor is not kept resident for this array-level entry point)."""
+  del cached_cholesky
+  return solve_linear_system(spd_matrix, x)[1]
+
+
+def svd_matrix_sqrt(cov):
+  """linalg.py:113-126: A with A A^T = cov, columns truncated to the numerical rank (host LAPACK; only used
+  by the non-partial KL, outside the device hot path)."""
+  cov = np.asarray(cov)
+  u, s, _ = np.linalg.svd(cov)
+  factor_ = u * np.sqrt(s[..., None, :])
+  tol = s.max() * np.finfo(s.dtype).eps / 2. * np.sqrt(2 * cov.shape[0] + 1.)
+  rank = np.count_nonzero(s > tol)
+  return factor_[:, :rank]
+
+
+def safe_l2norm(x):
+  """linalg.py:194-197: l2 norm (its custom gradient -- 0 at x = 0 -- lives in the device kernels)."""
+  return float(np.sqrt(np.sum(np.asarray(x, dtype=np.float64)**2)))
+
+
 def factor(mean_func, cov_func, params, x, y, warp_func=None, eps=1e-6, ctx=None):
   """Device-resident factorisation (hbo_cache handle wrapper)."""
   x = np.asarray(x)

@@ -498,7 +498,9 @@ static void run_lauum(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks
 struct TaskHost {
   int64_t n = 0; int m = 0; int npad = 0, nblk = 0; int64_t ld = 0;
   void* X = nullptr; void* ysum = nullptr;
-  void* A = nullptr; void* W = nullptr; void* S = nullptr; void* svec = nullptr;
+  void* ydiv = nullptr;   // (m+1) x n rows for the divergence objectives: (y_a - mean_a y)/sqrt(m), then -mean_a y
+  void* A = nullptr; void* W = nullptr; void* S = nullptr; void* svec = nullptr; int svec_cols = 0;
+  double* dmu = nullptr; double* fnorm = nullptr;
   double* dF = nullptr; double* dtmp = nullptr; size_t dF_elems = 0;   // MLP backward workspaces
   FeatBuf feat;
 };
@@ -517,7 +519,7 @@ struct hbo_dataset {
 
 static void free_task(TaskHost* t) {
   if (!t) return;
-  for (void* p : {t->X, t->ysum, t->A, t->W, t->S, t->svec, (void*)t->dF, (void*)t->dtmp}) if (p) hipFree(p);
+  for (void* p : {t->X, t->ysum, t->ydiv, t->A, t->W, t->S, t->svec, (void*)t->dmu, (void*)t->fnorm, (void*)t->dF, (void*)t->dtmp}) if (p) hipFree(p);
   delete t;
 }
 
@@ -557,6 +559,23 @@ extern "C" int hbo_dataset_create(hbo_ctx* c, int dtype, int input_dim, const hb
     if (e == hipSuccess) e = hipMalloc(&t->ysum, (size_t)tk.n * es);
     if (e == hipSuccess) e = hipMemcpy(t->X, tk.x, (size_t)tk.n * input_dim * es, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMemcpy(t->ysum, ys.data(), (size_t)tk.n * es, hipMemcpyHostToDevice);
+    if (e == hipSuccess && tk.m + 1 <= HBO_TILE) {
+      // sample statistics of objectives.py:57-58: mu_data = mean over the m aligned columns, cov_data =
+      // (1/m) sum_a yc_a yc_a^T (jnp.cov(bias=True)); kept as its m rank-1 factors.
+      std::vector<unsigned char> yd((size_t)(tk.m + 1) * tk.n * es);
+      const double rs = 1.0 / sqrt((double)tk.m);
+      for (int64_t i = 0; i < tk.n; ++i) {
+        double mu0 = 0;
+        for (int a = 0; a < tk.m; ++a) mu0 += host_elem(tk.y, dtype, i * tk.m + a);
+        mu0 /= tk.m;
+        for (int a = 0; a <= tk.m; ++a) {
+          const double v = a < tk.m ? (host_elem(tk.y, dtype, i * tk.m + a) - mu0) * rs : -mu0;
+          if (dtype == HBO_F64) ((double*)yd.data())[(size_t)a * tk.n + i] = v; else ((float*)yd.data())[(size_t)a * tk.n + i] = (float)v;
+        }
+      }
+      e = hipMalloc(&t->ydiv, yd.size());
+      if (e == hipSuccess) e = hipMemcpy(t->ydiv, yd.data(), yd.size(), hipMemcpyHostToDevice);
+    }
     if (e != hipSuccess) { hbo_dataset_free(c, ds); return fail(c, HBO_ERR_HIP, std::string("hbo_dataset_create: ") + hipGetErrorString(e)); }
     ds->max_nblk = std::max(ds->max_nblk, t->nblk);
   }
@@ -573,13 +592,39 @@ static int ensure_task_workspace(hbo_ctx* c, int dtype, TaskHost* t, bool need_S
   if (!t->A) HIPCHK(c, hipMalloc(&t->A, (size_t)(t->npad + HBO_TILE) * ld * es));
   if (!t->W) { HIPCHK(c, hipMalloc(&t->W, (size_t)t->npad * ld * es)); HIPCHK(c, hipMemsetAsync(t->W, 0, (size_t)t->npad * ld * es, c->stream)); }
   if (need_S && !t->S) HIPCHK(c, hipMalloc(&t->S, (size_t)t->npad * ld * es));
-  if (!t->svec) { HIPCHK(c, hipMalloc(&t->svec, (size_t)t->npad * es * naug_cols)); HIPCHK(c, hipMemsetAsync(t->svec, 0, (size_t)t->npad * es * naug_cols, c->stream)); }
+  if (t->svec_cols < naug_cols) {
+    if (t->svec) { HIPCHK(c, hipStreamSynchronize(c->stream)); hipFree(t->svec); t->svec = nullptr; }
+    HIPCHK(c, hipMalloc(&t->svec, (size_t)t->npad * es * naug_cols));
+    HIPCHK(c, hipMemsetAsync(t->svec, 0, (size_t)t->npad * es * naug_cols, c->stream));
+    t->svec_cols = naug_cols;
+  }
+  if (!t->dmu) { HIPCHK(c, hipMalloc((void**)&t->dmu, (size_t)t->npad * sizeof(double))); HIPCHK(c, hipMalloc((void**)&t->fnorm, 2 * sizeof(double))); }
   return HBO_OK;
 }
 
-static void fill_desc(TaskDesc& d, TaskHost* t, const hbo_model* m, int dtype) {
+// role of the augmented rows (see TaskDesc): the three training objectives + the posterior cache
+enum { ROLE_FACTOR = 100 };
+
+static void fill_desc(TaskDesc& d, TaskHost* t, const hbo_model* m, int dtype, int role) {
   memset(&d, 0, sizeof d);
   d.A = t->A; d.W = t->W; d.S = t->S; d.X = t->X; d.ysum = t->ysum; d.svec = t->svec;
+  d.dmu = t->dmu; d.fnorm = t->fnorm;
+  const double mm = (double)t->m;
+  switch (role) {
+    case OBJ_NLL:   // objectives.py:144-156 incl. the (m,m)+scalar broadcast for m > 1
+      d.naug = 1; d.e_last = -mm; d.coef_c = 0.5; d.coef_lh = 0.5 * mm * mm;
+      d.coef_const = mm * mm * 0.5 * (double)t->n * log(2.0 * M_PI);
+      break;
+    case OBJ_EKL:   // utils.py:84-106 partial KL: tr(K1^-1 C0) + d^T K1^-1 d + logdet K1
+      d.ysum = t->ydiv; d.naug = t->m + 1; d.e_last = 1.0; d.coef_c = 1.0; d.coef_lh = 1.0;
+      break;
+    case OBJ_EUC:   // utils.py:151-173 |mu0 - mu1| + |C0 - K1|_F  (no factorisation)
+      d.ysum = t->ydiv; d.naug = t->m + 1; d.e_last = 1.0;
+      break;
+    default:        // posterior cache: rows y_a - mu
+      d.naug = t->m; d.e_all = -1.0; d.coef_c = 0.5; d.coef_lh = 0.5;
+      break;
+  }
   d.n = (int)t->n; d.npad = t->npad; d.nblk = t->nblk; d.m = t->m; d.ld = t->ld;
   const void* last = needs_mlp(m) ? t->feat.acts[m->n_layers - 1] : nullptr;
   d.F = m->kernel_uses_mlp ? last : t->X;
@@ -592,11 +637,22 @@ static void fill_desc(TaskDesc& d, TaskHost* t, const hbo_model* m, int dtype) {
 
 extern "C" int hbo_nll(hbo_ctx* c, const hbo_model* m, hbo_dataset* ds, double* nll_sum, double* nll_per_task,
                        double* grad_sum) {
-  if (!c || !ds || !nll_sum) return fail(c, HBO_ERR_ARG, "hbo_nll: null argument");
+  return hbo_objective(c, m, ds, HBO_OBJ_NLL, nll_sum, nll_per_task, grad_sum);
+}
+
+extern "C" int hbo_objective(hbo_ctx* c, const hbo_model* m_in, hbo_dataset* ds, int objective, double* nll_sum,
+                             double* nll_per_task, double* grad_sum) {
+  if (!c || !ds || !nll_sum || !m_in) return fail(c, HBO_ERR_ARG, "hbo_objective: null argument");
+  if (objective != HBO_OBJ_NLL && objective != HBO_OBJ_EKL && objective != HBO_OBJ_EUC) return fail(c, HBO_ERR_ARG, "hbo_objective: unknown objective id");
   HIPCHK(c, hipSetDevice(c->device));
+  hbo_model mcopy = *m_in;
+  if (objective != HBO_OBJ_NLL) mcopy.eps = 0.0;   // objectives.py:63-65: cov_model = K + noise I, no jitter
+  const hbo_model* m = &mcopy;
+  const int obj = objective;
+  const bool euc = obj == OBJ_EUC;
   int rc = validate_model(c, m);
   if (rc) return rc;
-  if (m->dtype != ds->dtype || m->input_dim != ds->D) return fail(c, HBO_ERR_ARG, "hbo_nll: model/dataset dtype or input_dim mismatch");
+  if (m->dtype != ds->dtype || m->input_dim != ds->D) return fail(c, HBO_ERR_ARG, "hbo_objective: model/dataset dtype or input_dim mismatch");
   hbo_grad_layout lay;
   hbo_grad_layout_of(m, &lay);
   const bool want_grad = grad_sum != nullptr;
@@ -604,6 +660,7 @@ extern "C" int hbo_nll(hbo_ctx* c, const hbo_model* m, hbo_dataset* ds, double* 
   if (want_grad) for (int i = 0; i < lay.total; ++i) grad_sum[i] = 0;
   const int T = ds->ntasks;
   if (T == 0) return HBO_OK;
+  if (obj != OBJ_NLL) for (TaskHost* t : ds->tasks) if (!t->ydiv) return fail(c, HBO_ERR_UNSUPPORTED, "hbo_objective: divergence objectives need m + 1 <= 128 aligned columns");
   const int dtype = ds->dtype;
   hipStream_t st = c->stream;
   prof_begin(c);
@@ -614,7 +671,7 @@ extern "C" int hbo_nll(hbo_ctx* c, const hbo_model* m, hbo_dataset* ds, double* 
   ds->h_desc.resize(T);
   for (int k = 0; k < T; ++k) {
     TaskHost* t = ds->tasks[k];
-    rc = ensure_task_workspace(c, dtype, t, want_grad, 1);
+    rc = ensure_task_workspace(c, dtype, t, want_grad && !euc, obj == OBJ_NLL ? 1 : t->m + 1);
     if (rc) return rc;
     if (needs_mlp(m)) { rc = t->feat.ensure(c, m, t->n); if (rc) return rc; }
     if (needs_mlp(m) && want_grad) {
@@ -630,7 +687,7 @@ extern "C" int hbo_nll(hbo_ctx* c, const hbo_model* m, hbo_dataset* ds, double* 
         t->dF_elems = need;
       }
     }
-    fill_desc(ds->h_desc[k], t, m, dtype);
+    fill_desc(ds->h_desc[k], t, m, dtype, obj);
   }
   if (!ds->d_desc) HIPCHK(c, hipMalloc((void**)&ds->d_desc, sizeof(TaskDesc) * T));
   if (!ds->d_info) HIPCHK(c, hipMalloc((void**)&ds->d_info, sizeof(int) * T));
@@ -644,33 +701,43 @@ extern "C" int hbo_nll(hbo_ctx* c, const hbo_model* m, hbo_dataset* ds, double* 
   {
     ProfScope ps(c, "features", 1);
     if (needs_mlp(m)) for (int k = 0; k < T; ++k) run_mlp(c, m, ds->tasks[k]->X, ds->tasks[k]->n, ds->tasks[k]->feat.acts.data());
-    launch_aug_rows(dtype, ds->d_desc, T, max_npad, c->d_model, 1, 1, st);
+    launch_aug_rows(dtype, ds->d_desc, T, max_npad, c->d_model, st);
   }
-  {
-    ProfScope ps(c, "gram", 1);
-    GramArgs g = {}; g.tasks = ds->d_desc; g.fdim = feature_dim(m); g.symmetric = 1; g.padded = 1;
-    launch_gram(dtype, g, c->d_model, dim3(max_nblk, max_nblk, T), st);
-  }
+  int max_naug = 1;
+  for (int k = 0; k < T; ++k) max_naug = std::max(max_naug, ds->h_desc[k].naug);
   const int early_H = (want_grad && c->opt_lookahead && c->opt_overlap_trtri) ? trtri_split(max_nblk) : 0;
-  { ProfScope ps(c, "potrf", 1); run_potrf(c, dtype, ds->d_desc, T, max_nblk, ds->d_info, early_H); }
-  { ProfScope ps(c, "nll_reduce", 1); launch_nll_reduce(dtype, ds->d_desc, T, ds->d_info, ds->d_nll, st); }
+  if (!euc) {
+    {
+      ProfScope ps(c, "gram", 1);
+      GramArgs g = {}; g.tasks = ds->d_desc; g.fdim = feature_dim(m); g.symmetric = 1; g.padded = 1;
+      launch_gram(dtype, g, c->d_model, dim3(max_nblk, max_nblk, T), st);
+    }
+    { ProfScope ps(c, "potrf", 1); run_potrf(c, dtype, ds->d_desc, T, max_nblk, ds->d_info, early_H); }
+    { ProfScope ps(c, "nll_reduce", 1); launch_nll_reduce(dtype, ds->d_desc, T, ds->d_info, ds->d_nll, st); }
+  }
 
   const int fdim = feature_dim(m);
   const int nacc = grad_nacc(m->kernel_id, fdim);
   const int out_stride = (m->kernel_id == HBO_KERNEL_DOT ? 0 : m->n_lengthscale) + 6 + mean_feature_dim(m);
   const int64_t stride_task = (int64_t)(max_nblk * (max_nblk + 1) / 2) * nacc;
-  if (want_grad) {
+  if (want_grad || euc) {   // EUC: the Frobenius norm of the value comes out of the contraction pass
     const size_t pb = sizeof(double) * stride_task * T, gb = sizeof(double) * out_stride * T;
     if (ds->partials_bytes < pb) { if (ds->d_partials) hipFree(ds->d_partials); HIPCHK(c, hipMalloc((void**)&ds->d_partials, pb)); ds->partials_bytes = pb; }
     if (ds->gradout_bytes < gb) { if (ds->d_gradout) hipFree(ds->d_gradout); HIPCHK(c, hipMalloc((void**)&ds->d_gradout, gb)); ds->gradout_bytes = gb; }
-    { ProfScope ps(c, "trtri", 1);
-      if (early_H) run_trtri_late(c, dtype, ds->d_desc, T, max_nblk, early_H, st);
-      else run_trtri(c, dtype, ds->d_desc, T, max_nblk); }
-    { ProfScope ps(c, "wt_z", 1); launch_wt_z(dtype, ds->d_desc, T, max_nblk, 0, 0, max_npad, st); }
-    { ProfScope ps(c, "lauum", 1); run_lauum(c, dtype, ds->d_desc, T, max_nblk); }
+    if (!euc) {
+      { ProfScope ps(c, "trtri", 1);
+        if (early_H) run_trtri_late(c, dtype, ds->d_desc, T, max_nblk, early_H, st);
+        else run_trtri(c, dtype, ds->d_desc, T, max_nblk); }
+      { ProfScope ps(c, "wt_z", 1);
+        for (int b = 0; b < max_naug; ++b) launch_wt_z(dtype, ds->d_desc, T, max_nblk, b, b, max_npad, st); }
+      { ProfScope ps(c, "lauum", 1); run_lauum(c, dtype, ds->d_desc, T, max_nblk); }
+    }
     { ProfScope ps(c, "grad_contract", 1);
-      launch_grad_contract(dtype, ds->d_desc, T, max_nblk, c->d_model, m->kernel_id, fdim, ds->d_partials, stride_task, st);
-      launch_grad_finalize(dtype, ds->d_desc, T, c->d_model, m->kernel_id, fdim, ds->d_partials, stride_task, ds->d_gradout, out_stride, st); }
+      launch_dmu(dtype, ds->d_desc, T, obj, st);
+      launch_grad_contract(dtype, ds->d_desc, T, max_nblk, c->d_model, m->kernel_id, fdim, obj, ds->d_partials, stride_task, st);
+      launch_grad_finalize(dtype, ds->d_desc, T, c->d_model, m->kernel_id, fdim, obj, ds->d_partials, stride_task, ds->d_gradout, out_stride, euc ? ds->d_nll : nullptr, st); }
+  }
+  if (want_grad) {
     if (needs_mlp(m)) {
       // d nll / d features -> MLP backward (hyperbo/gp_utils/basis_functions.py:24-36), summed over tasks
       ProfScope ps(c, "mlp_backward", 1);
@@ -681,7 +748,10 @@ extern "C" int hbo_nll(hbo_ctx* c, const hbo_model* m, hbo_dataset* ds, double* 
       if (ds->mlpgrad_elems < tot) { if (ds->d_mlpgrad) hipFree(ds->d_mlpgrad); HIPCHK(c, hipMalloc((void**)&ds->d_mlpgrad, tot * sizeof(double))); ds->mlpgrad_elems = tot; }
       HIPCHK(c, hipMemsetAsync(ds->d_mlpgrad, 0, tot * sizeof(double), st));
       for (int k = 0; k < T; ++k) HIPCHK(c, hipMemsetAsync(ds->tasks[k]->dF, 0, (size_t)ds->tasks[k]->n * flast * sizeof(double), st));
-      if (m->kernel_uses_mlp) launch_grad_feat(dtype, ds->d_desc, T, max_nblk, c->d_model, flast, st);
+      if (m->kernel_uses_mlp) {
+        launch_grad_feat(dtype, ds->d_desc, T, max_nblk, c->d_model, flast, obj, st);
+        if (euc) launch_scale_dF(ds->d_desc, T, (int64_t)max_npad, flast, st);
+      }
       if (m->mean_id == HBO_MEAN_LINEAR_MLP) launch_grad_feat_mean(dtype, ds->d_desc, T, (int64_t)max_npad, c->d_model, flast, st);
       for (int k = 0; k < T; ++k) {
         TaskHost* t = ds->tasks[k];
@@ -790,7 +860,7 @@ extern "C" int hbo_factor(hbo_ctx* c, const hbo_model* m, const void* x, int64_t
   rc = ensure_task_workspace(c, dtype, t, true, mcols);
   if (rc) return bail(rc);
   if (needs_mlp(m)) { rc = t->feat.ensure(c, m, t->npad); if (rc) return bail(rc); }
-  fill_desc(k->h_desc, t, m, dtype);
+  fill_desc(k->h_desc, t, m, dtype, ROLE_FACTOR);
   HIPCHK_K(hipMalloc((void**)&k->d_desc, sizeof(TaskDesc)));
   HIPCHK_K(hipMalloc((void**)&k->d_info, sizeof(int)));
   HIPCHK_K(hipMalloc(&k->resid, (size_t)mcols * t->npad * es));
@@ -801,7 +871,7 @@ extern "C" int hbo_factor(hbo_ctx* c, const hbo_model* m, const void* x, int64_t
 
   { ProfScope ps(c, "features", 1);
     if (needs_mlp(m)) run_mlp(c, m, t->X, n, t->feat.acts.data());
-    launch_aug_rows(dtype, k->d_desc, 1, t->npad, c->d_model, mcols, 0, st); }
+    launch_aug_rows(dtype, k->d_desc, 1, t->npad, c->d_model, st); }
   HIPCHK_K(hipMemcpy2DAsync(k->resid, (size_t)t->npad * es, (char*)t->A + (size_t)t->npad * t->ld * es, (size_t)t->ld * es, (size_t)t->npad * es, mcols, hipMemcpyDeviceToDevice, st));
   { ProfScope ps(c, "gram", 1);
     GramArgs g = {}; g.tasks = k->d_desc; g.fdim = feature_dim(m); g.symmetric = 1; g.padded = 1;
@@ -1181,6 +1251,7 @@ extern "C" int hbo_spd_solve(hbo_ctx* c, int dtype, const void* a, int64_t n, co
   launch_set_aug(dtype, d_b, n, b ? mcols : 0, t->A, t->ld, t->npad, st);
   TaskDesc h; memset(&h, 0, sizeof h);
   h.A = t->A; h.W = t->W; h.S = t->S; h.svec = t->svec; h.n = (int)n; h.npad = t->npad; h.nblk = t->nblk; h.m = t->m; h.ld = t->ld;
+  h.naug = t->m;
   HIPCHK_S(hipMalloc((void**)&d_desc, sizeof h));
   HIPCHK_S(hipMalloc((void**)&d_info, sizeof(int)));
   int inf = INT_MAX;

@@ -218,11 +218,9 @@ __global__ void mean_kernel(const T* __restrict__ fm, int64_t n, int fmean, cons
   out[i] = mean_at<T>(md, fm, fmean, i);
 }
 
-// augmented tile-row: row a < m' holds  ysum[a*n + j] - mult * mu_j ; everything else zero.
-// NLL path: one row, ysum = sum of y columns, mult = m.  Factor path: m rows, mult = 1.
+// augmented tile-row: row b < naug holds  aug_src[b*n + j] + e_b * mu_j  (see TaskDesc); everything else zero.
 template <typename T>
-__global__ void aug_rows_kernel(const TaskDesc* tasks, const ModelDev* __restrict__ md, int naug_rows,
-                                int mult_is_m) {
+__global__ void aug_rows_kernel(const TaskDesc* tasks, const ModelDev* __restrict__ md) {
   const TaskDesc& t = tasks[blockIdx.z];
   const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= t.npad) return;
@@ -230,15 +228,17 @@ __global__ void aug_rows_kernel(const TaskDesc* tasks, const ModelDev* __restric
   const T* ys = static_cast<const T*>(t.ysum);
   T mu = (T)0;
   if (j < t.n) mu = mean_at<T>(md, static_cast<const T*>(t.Fm), t.fmean, j);
-  const T mult = mult_is_m ? (T)t.m : (T)1;
   for (int a = 0; a < HBO_TILE; ++a) {
     T v = (T)0;
-    if (a < naug_rows && j < t.n) v = ys[(int64_t)a * t.n + j] - mult * mu;
+    if (a < t.naug && j < t.n) {
+      const T e = (T)(t.e_all + (a == t.naug - 1 ? t.e_last : 0.0));
+      v = ys[(int64_t)a * t.n + j] + e * mu;
+    }
     Ar[(int64_t)a * t.ld] = v;
   }
 }
 
-// nll_t = 0.5 |z|^2 + m^2 (sum log diag L + 0.5 n log 2 pi)     (objectives.py:153-155)
+// f_t = c * sum_b |z_b|^2 + 2 lh * sum log diag L + const   (NLL: objectives.py:153-155; EKL: utils.py:84-106)
 template <typename T>
 __global__ __launch_bounds__(256) void nll_reduce_kernel(const TaskDesc* tasks, const int* info, double* out) {
   __shared__ double sred[4];
@@ -247,13 +247,15 @@ __global__ __launch_bounds__(256) void nll_reduce_kernel(const TaskDesc* tasks, 
   double ld_sum = 0, q = 0;
   for (int64_t i = threadIdx.x; i < t.n; i += 256) {
     ld_sum += log((double)A[i * t.ld + i]);
-    const double z = (double)A[(int64_t)t.npad * t.ld + i];
-    q += z * z;
+    for (int b = 0; b < t.naug; ++b) {
+      const double z = (double)A[((int64_t)t.npad + b) * t.ld + i];
+      q += z * z;
+    }
   }
   ld_sum = block_sum(ld_sum, sred);
   q = block_sum(q, sred);
   if (threadIdx.x == 0) {
-    double v = 0.5 * q + (double)t.m * t.m * (ld_sum + 0.5 * t.n * log(2.0 * M_PI));
+    double v = t.coef_c * q + 2.0 * t.coef_lh * ld_sum + t.coef_const;
     if (info[blockIdx.x] != 0x7fffffff) v = NAN;
     out[blockIdx.x] = v;
   }
@@ -265,7 +267,7 @@ __global__ __launch_bounds__(256) void wtz_partial_kernel(const TaskDesc* tasks,
   __shared__ T sred[256];
   const TaskDesc& t = tasks[blockIdx.z];
   const int cb = blockIdx.x, rc = blockIdx.y;
-  if (cb >= t.nblk) return;
+  if (cb >= t.nblk || (!xover && aug_row >= t.naug)) return;
   const int64_t row_lo = (int64_t)rc * 512;
   if (row_lo >= t.npad) return;
   T* part = static_cast<T*>(t.S) + (int64_t)rc * t.ld + (int64_t)cb * HBO_TILE;
@@ -288,25 +290,40 @@ template <typename T>
 __global__ void wtz_final_kernel(const TaskDesc* tasks, int out_col, int out_ld, T* oover) {
   const TaskDesc& t = tasks[blockIdx.z];
   const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= t.npad) return;
+  if (j >= t.npad || (!oover && out_col >= t.naug)) return;
   const T* part = static_cast<const T*>(t.S);
   const int nrc = (t.npad + 511) / 512;
   T s = (T)0;
   for (int rc = 0; rc < nrc; ++rc) s += part[(int64_t)rc * t.ld + j];
   if (oover) oover[j] = s;
-  else static_cast<T*>(t.svec)[(int64_t)out_col * out_ld + j] = s;
+  else static_cast<T*>(t.svec)[(int64_t)out_col * t.npad + j] = s;   // per-task stride (ragged tasks)
 }
 
 // ---------------------------------------------------------------------------------------
-// gradient contraction over the lower tiles of S = K^-1:
-//   G_ij = 1/2 (m^2 Kinv_ij - s_i s_j),  partial sums of G_ij * dK_ij/dtheta per tile.
-// accumulators: SE/Matern: [0] sum G K, [1] tr G, [2+d] sum G dk/du ds_d^2
-//               dot      : [0] sum G <fi,fj>, [1] tr G, [2] sum G
+// gradient contraction over the lower tiles, G = d objective / d K1:
+//   NLL / EKL : G_ij = lh Kinv_ij - c sum_b alpha_b,i alpha_b,j   (S = K1^-1, alpha_b = K1^-1 row_b in svec)
+//   EUC       : G_ij = K1_ij - sum_{b<m} V_b,i V_b,j              (= K1 - C0, un-normalised; V = augmented rows;
+//               the 1/|C0-K1|_F factor is applied by grad_finalize from the Frobenius accumulator)
+// partial sums of G_ij * dK_ij/dtheta per tile.
+// accumulators: SE/Matern: [0] sum G K, [1] tr G, [2+d] sum G dk/du ds_d^2, [2+fdim] sum G^2
+//               dot      : [0] sum G <fi,fj>, [1] tr G, [2] sum G,          [3] sum G^2
 // ---------------------------------------------------------------------------------------
+// outer-product vectors of a task: (pointer, row stride, count)
 template <typename T>
+__device__ __forceinline__ const T* outer_vecs(const TaskDesc& t, int obj, int64_t& stride, int& count) {
+  if (obj == OBJ_EUC) {
+    stride = t.ld; count = t.naug - 1;
+    return static_cast<const T*>(t.A) + (int64_t)t.npad * t.ld;
+  }
+  stride = t.npad; count = t.naug;
+  return static_cast<const T*>(t.svec);
+}
+// MULTI = false: the NLL fast path (one outer-product vector, no Frobenius accumulator)
+template <typename T, bool MULTI>
 __global__ __launch_bounds__(256) void grad_contract_kernel(const TaskDesc* tasks, const ModelDev* __restrict__ md,
-                                                            int fdim, int nacc, double* partials,
+                                                            int fdim, int nacc, int obj_arg, double* partials,
                                                             int64_t stride_task) {
+  const int obj = MULTI ? obj_arg : (int)OBJ_NLL;
   __shared__ T sA[DC * SXS];
   __shared__ T sB[DC * SXS];
   __shared__ double sred[4];
@@ -320,7 +337,10 @@ __global__ __launch_bounds__(256) void grad_contract_kernel(const TaskDesc* task
   const int64_t r0 = (int64_t)ti * HBO_TILE, c0 = (int64_t)tj * HBO_TILE;
   const T* F = static_cast<const T*>(t.F);
   const T* S = static_cast<const T*>(t.S);
-  const T* sv_ = static_cast<const T*>(t.svec);
+  int64_t vstride; int nvec_rt;
+  const T* sv_ = outer_vecs<T>(t, obj, vstride, nvec_rt);
+  const int nvec = MULTI ? nvec_rt : 1;
+  const bool euc = MULTI && (obj == OBJ_EUC);
   const int64_t n = t.n;
   double* out = partials + (int64_t)blockIdx.z * stride_task + ((int64_t)ti * (ti + 1) / 2 + tj) * nacc;
 
@@ -353,29 +373,47 @@ __global__ __launch_bounds__(256) void grad_contract_kernel(const TaskDesc* task
   const T sv = (T)md->sv;
   const T inv_sigma2 = (T)(1.0 / (md->dot_sigma * md->dot_sigma));
   const T bias2 = (T)(md->dot_bias * md->dot_bias);
-  const T m2 = (T)((double)t.m * t.m);
+  const T lh = (T)t.coef_lh, cc = (T)t.coef_c, noise = (T)md->noise;
   const T wt = (ti == tj) ? (T)1 : (T)2;   // off-diagonal tiles stand for their mirror image too
-  double a_gk = 0, a_tr = 0, a_g = 0;
+  double a_gk = 0, a_tr = 0, a_g = 0, a_fro = 0;
   // gw[a][q] = weight * G_ij * dk/du  (re-uses acc storage)
   typedef typename V16<T>::type vec_t;
-  // s_j for this thread's 8 columns (svec is zero-padded to npad, S has full padded tiles)
+  // vector b = 0 for this thread's 8 columns (vectors are zero-padded to npad, S has full padded tiles)
   T sj[8];
 #pragma unroll
-  for (int qb = 0; qb < 8 / VEC; ++qb) {
-    const vec_t v = gld(reinterpret_cast<const vec_t*>(sv_ + c0 + 16 * VEC * qb + VEC * tx));
+  for (int q = 0; q < 8; ++q) sj[q] = (T)0;
+  if (nvec > 0) {
 #pragma unroll
-    for (int e = 0; e < VEC; ++e) sj[qb * VEC + e] = v[e];
+    for (int qb = 0; qb < 8 / VEC; ++qb) {
+      const vec_t v = gld(reinterpret_cast<const vec_t*>(sv_ + c0 + 16 * VEC * qb + VEC * tx));
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) sj[qb * VEC + e] = v[e];
+    }
   }
 #pragma unroll
   for (int a = 0; a < 8; ++a) {
     const int64_t row = r0 + ty + 16 * a;
-    const T si = gld(sv_ + row);
-    T kinv_row[8];
+    const T si = nvec > 0 ? gld(sv_ + row) : (T)0;
+    T kinv_row[8], outer[8];
 #pragma unroll
-    for (int qb = 0; qb < 8 / VEC; ++qb) {
-      const vec_t v = gld(reinterpret_cast<const vec_t*>(S + row * t.ld + c0 + 16 * VEC * qb + VEC * tx));
+    for (int q = 0; q < 8; ++q) { outer[q] = si * sj[q]; kinv_row[q] = (T)0; }
+    for (int b = 1; b < nvec; ++b) {   // EKL / EUC: further outer-product vectors
+      const T* vb = sv_ + (int64_t)b * vstride;
+      const T sib = gld(vb + row);
 #pragma unroll
-      for (int e = 0; e < VEC; ++e) kinv_row[qb * VEC + e] = v[e];
+      for (int qb = 0; qb < 8 / VEC; ++qb) {
+        const vec_t v = gld(reinterpret_cast<const vec_t*>(vb + c0 + 16 * VEC * qb + VEC * tx));
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) outer[qb * VEC + e] += sib * v[e];
+      }
+    }
+    if (!euc) {
+#pragma unroll
+      for (int qb = 0; qb < 8 / VEC; ++qb) {
+        const vec_t v = gld(reinterpret_cast<const vec_t*>(S + row * t.ld + c0 + 16 * VEC * qb + VEC * tx));
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) kinv_row[qb * VEC + e] = v[e];
+      }
     }
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
@@ -384,8 +422,9 @@ __global__ __launch_bounds__(256) void grad_contract_kernel(const TaskDesc* task
       if (row < n && col < n) {
         const T u = acc[a][q];
         const T k = kfun<T>(kid, u, sv, inv_sigma2, bias2);
-        const T kinv = kinv_row[q];
-        const T G = (T)0.5 * (m2 * kinv - si * sj[q]) * wt;
+        const T G0 = euc ? (k + (row == col ? noise : (T)0) - outer[q]) : (lh * kinv_row[q] - cc * outer[q]);
+        const T G = G0 * wt;
+        if (MULTI) a_fro += (double)(G0 * G);
         if (is_dot) { a_gk += (double)(G * u); a_g += (double)G; }
         else { a_gk += (double)(G * k); gw = G * dk_du<T>(kid, u, k, sv); }
         if (row == col) a_tr += (double)G;
@@ -396,7 +435,8 @@ __global__ __launch_bounds__(256) void grad_contract_kernel(const TaskDesc* task
   a_gk = block_sum(a_gk, sred);
   a_tr = block_sum(a_tr, sred);
   if (is_dot) a_g = block_sum(a_g, sred);
-  if (tid == 0) { out[0] = a_gk; out[1] = a_tr; if (is_dot) out[2] = a_g; }
+  if (MULTI) a_fro = block_sum(a_fro, sred);
+  if (tid == 0) { out[0] = a_gk; out[1] = a_tr; if (is_dot) out[2] = a_g; out[nacc - 1] = a_fro; }
   if (is_dot) return;
   // second pass over the features: sum gw * ds_d^2
   for (int d0 = 0; d0 < fdim; d0 += DC) {
@@ -431,7 +471,7 @@ __global__ __launch_bounds__(256) void grad_contract_kernel(const TaskDesc* task
 // ---------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void grad_feat_kernel(const TaskDesc* tasks, const ModelDev* __restrict__ md,
-                                                        int fdim) {
+                                                        int fdim, int obj) {
   __shared__ T sA[DC * SXS];
   __shared__ T sB[DC * SXS];
   const TaskDesc& t = tasks[blockIdx.z];
@@ -444,7 +484,9 @@ __global__ __launch_bounds__(256) void grad_feat_kernel(const TaskDesc* tasks, c
   const int64_t r0 = (int64_t)ti * HBO_TILE, c0 = (int64_t)tj * HBO_TILE;
   const T* F = static_cast<const T*>(t.F);
   const T* S = static_cast<const T*>(t.S);
-  const T* sv_ = static_cast<const T*>(t.svec);
+  int64_t vstride; int nvec;
+  const T* sv_ = outer_vecs<T>(t, obj, vstride, nvec);
+  const bool euc = (obj == OBJ_EUC);
   double* dF = static_cast<double*>(t.dF);
   const int64_t n = t.n;
 
@@ -477,21 +519,23 @@ __global__ __launch_bounds__(256) void grad_feat_kernel(const TaskDesc* tasks, c
   const T sv = (T)md->sv;
   const T inv_sigma2 = (T)(1.0 / (md->dot_sigma * md->dot_sigma));
   const T bias2 = (T)(md->dot_bias * md->dot_bias);
-  const T m2 = (T)((double)t.m * t.m);
-  // g[a][q] = G_ij * dk/du (SE/Matern) or G_ij (dot)
+  const T lh = (T)t.coef_lh, cc = (T)t.coef_c, noise = (T)md->noise;
+  // g[a][q] = G_ij * dk/du (SE/Matern) or G_ij (dot);  G as in grad_contract_kernel
 #pragma unroll
   for (int a = 0; a < 8; ++a) {
     const int64_t row = r0 + ty + 16 * a;
-    const T si = row < n ? sv_[row] : (T)0;
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       const int64_t col = c0 + 16 * VEC * (q / VEC) + VEC * tx + (q % VEC);
       T g = (T)0;
       if (row < n && col < n) {
         const T u = acc[a][q];
-        const T G = (T)0.5 * (m2 * S[row * t.ld + col] - si * sv_[col]);
+        const T k = kfun<T>(kid, u, sv, inv_sigma2, bias2);
+        T outer = (T)0;
+        for (int b = 0; b < nvec; ++b) outer += sv_[(int64_t)b * vstride + row] * sv_[(int64_t)b * vstride + col];
+        const T G = euc ? (k + (row == col ? noise : (T)0) - outer) : (lh * S[row * t.ld + col] - cc * outer);
         if (is_dot) g = G;
-        else { const T k = kfun<T>(kid, u, sv, inv_sigma2, bias2); g = G * dk_du<T>(kid, u, k, sv); }
+        else g = G * dk_du<T>(kid, u, k, sv);
       }
       acc[a][q] = g;
     }
@@ -546,14 +590,52 @@ __global__ __launch_bounds__(256) void grad_feat_kernel(const TaskDesc* tasks, c
   }
 }
 
-// dF[i][d] += -m s_i w_lin[d]   (mean.linear_mlp: d nll / d mu_i = -m s_i, mu = feat . w + b)
+// dF[i][d] += dmu_i w_lin[d]   (mean.linear_mlp: mu = feat . w + b)
 template <typename T>
 __global__ void grad_feat_mean_kernel(const TaskDesc* tasks, const ModelDev* __restrict__ md, int fdim) {
   const TaskDesc& t = tasks[blockIdx.z];
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (int64_t)t.n * fdim) return;
   const int64_t i = idx / fdim; const int d = (int)(idx % fdim);
-  static_cast<double*>(t.dF)[idx] += -(double)t.m * (double)static_cast<const T*>(t.svec)[i] * md->lin_w[d];
+  static_cast<double*>(t.dF)[idx] += static_cast<const double*>(t.dmu)[i] * md->lin_w[d];
+}
+
+// d objective / d mu_i.  NLL / EKL: 2 c sum_b e_b alpha_b,i.  EUC: d_i / |d| (0 at d = 0, utils.py safe_l2norm),
+// d = mu1 - mu0 = last augmented row; also stores |d| in fnorm[1].
+template <typename T>
+__global__ __launch_bounds__(256) void dmu_kernel(const TaskDesc* tasks, int obj) {
+  __shared__ double sred[4];
+  const TaskDesc& t = tasks[blockIdx.x];
+  double* dmu = static_cast<double*>(t.dmu);
+  if (obj == OBJ_EUC) {
+    const T* d = static_cast<const T*>(t.A) + ((int64_t)t.npad + t.naug - 1) * t.ld;
+    double q = 0;
+    for (int64_t i = threadIdx.x; i < t.n; i += 256) { const double v = (double)d[i]; q += v * v; }
+    q = block_sum(q, sred);
+    const double nd = sqrt(q);
+    if (threadIdx.x == 0) t.fnorm[1] = nd;
+    const double inv = nd > 0 ? 1.0 / nd : 0.0;
+    for (int64_t i = threadIdx.x; i < t.n; i += 256) dmu[i] = (double)d[i] * inv;
+    return;
+  }
+  const T* al = static_cast<const T*>(t.svec);
+  for (int64_t i = threadIdx.x; i < t.n; i += 256) {
+    double s = 0;
+    for (int b = 0; b < t.naug; ++b) {
+      const double e = t.e_all + (b == t.naug - 1 ? t.e_last : 0.0);
+      if (e != 0.0) s += e * (double)al[(int64_t)b * t.npad + i];
+    }
+    dmu[i] = 2.0 * t.coef_c * s;
+  }
+}
+
+// EUC with an MLP kernel: the kernel part of dF was accumulated with the un-normalised G
+__global__ void scale_dF_kernel(const TaskDesc* tasks, int fdim) {
+  const TaskDesc& t = tasks[blockIdx.z];
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)t.n * fdim) return;
+  const double f = t.fnorm[0];
+  static_cast<double*>(t.dF)[idx] *= (f > 0 ? 1.0 / f : 0.0);
 }
 
 // MLP backward, one dense+tanh layer:  dz = dout * (1 - out^2) (in place, double)
@@ -595,9 +677,11 @@ __global__ void dense_bwd_in_kernel(const double* __restrict__ dz, const T* __re
 //                                [dot_prod_sigma] [dot_prod_bias] [linear_kernel(fmean)] [linear_bias]
 template <typename T>
 __global__ __launch_bounds__(256) void grad_finalize_kernel(const TaskDesc* tasks, const ModelDev* __restrict__ md,
-                                                            int fdim, int nacc, const double* partials,
-                                                            int64_t stride_task, double* out, int out_stride) {
+                                                            int fdim, int nacc, int obj, const double* partials,
+                                                            int64_t stride_task, double* out, int out_stride,
+                                                            double* value_out) {
   __shared__ double sred[4];
+  __shared__ double s_scale;
   const TaskDesc& t = tasks[blockIdx.x];
   const double* part = partials + (int64_t)blockIdx.x * stride_task;
   double* o = out + (int64_t)blockIdx.x * out_stride;
@@ -606,10 +690,22 @@ __global__ __launch_bounds__(256) void grad_finalize_kernel(const TaskDesc* task
   const bool is_dot = (md->kernel_id == HBO_KERNEL_DOT);
   int pos = 0;
   double ls_total = 0;
-  for (int q = 0; q < nacc; ++q) {
+  {
+    // Frobenius slot first: EUC scales every kernel-parameter gradient by 1 / |C0 - K1|_F
+    double s = 0;
+    for (int tl = threadIdx.x; tl < ntile; tl += 256) s += part[(int64_t)tl * nacc + nacc - 1];
+    s = block_sum(s, sred);
+    if (threadIdx.x == 0) {
+      const double f = sqrt(s);
+      s_scale = (obj == OBJ_EUC) ? (f > 0 ? 1.0 / f : 0.0) : 1.0;
+      if (obj == OBJ_EUC) { t.fnorm[0] = f; if (value_out) value_out[blockIdx.x] = f + t.fnorm[1]; }
+    }
+    __syncthreads();
+  }
+  for (int q = 0; q < nacc - 1; ++q) {
     double s = 0;
     for (int tl = threadIdx.x; tl < ntile; tl += 256) s += part[(int64_t)tl * nacc + q];
-    s = block_sum(s, sred);
+    s = block_sum(s, sred) * s_scale;
     if (threadIdx.x == 0) {
       if (!is_dot) {
         if (q == 0) o[n_ls] = s / md->sv;                 // signal_variance
@@ -631,24 +727,24 @@ __global__ __launch_bounds__(256) void grad_finalize_kernel(const TaskDesc* task
     else { for (int d = 0; d < n_ls; ++d) o[d] = 0; o[n_ls] = 0; }
   }
   pos = n_ls + 2;
-  // mean parameters: d nll / d mu_i = -m s_i
-  const T* sv_ = static_cast<const T*>(t.svec);
+  // mean parameters from d objective / d mu_i (dmu_kernel)
+  const double* dmu = static_cast<const double*>(t.dmu);
   double ssum = 0;
-  for (int64_t i = threadIdx.x; i < t.n; i += 256) ssum += (double)sv_[i];
+  for (int64_t i = threadIdx.x; i < t.n; i += 256) ssum += dmu[i];
   ssum = block_sum(ssum, sred);
   if (threadIdx.x == 0) {
-    o[pos] = (md->mean_id == HBO_MEAN_CONSTANT) ? -(double)t.m * ssum : 0.0;     // constant
+    o[pos] = (md->mean_id == HBO_MEAN_CONSTANT) ? ssum : 0.0;     // constant
   }
   const int lin0 = n_ls + 5;
   const bool lin = (md->mean_id == HBO_MEAN_LINEAR || md->mean_id == HBO_MEAN_LINEAR_MLP);
   const T* fm = static_cast<const T*>(t.Fm);
   for (int d = 0; d < t.fmean; ++d) {
     double s = 0;
-    if (lin) for (int64_t i = threadIdx.x; i < t.n; i += 256) s += (double)sv_[i] * (double)fm[i * t.fmean + d];
+    if (lin) for (int64_t i = threadIdx.x; i < t.n; i += 256) s += dmu[i] * (double)fm[i * t.fmean + d];
     s = block_sum(s, sred);
-    if (threadIdx.x == 0) o[lin0 + d] = -(double)t.m * s;
+    if (threadIdx.x == 0) o[lin0 + d] = s;
   }
-  if (threadIdx.x == 0) o[lin0 + t.fmean] = lin ? -(double)t.m * ssum : 0.0;
+  if (threadIdx.x == 0) o[lin0 + t.fmean] = lin ? ssum : 0.0;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -795,11 +891,10 @@ void launch_mean(int dtype, const void* fm, int64_t n, int fmean, const ModelDev
   if (dtype == HBO_F64) hipLaunchKernelGGL((mean_kernel<double>), grid, dim3(256), 0, st, (const double*)fm, n, fmean, md, (double*)mu);
   else hipLaunchKernelGGL((mean_kernel<float>), grid, dim3(256), 0, st, (const float*)fm, n, fmean, md, (float*)mu);
 }
-void launch_aug_rows(int dtype, const TaskDesc* tasks, int ntasks, int max_npad, const ModelDev* md,
-                     int naug_rows, int mult_is_m, hipStream_t st) {
+void launch_aug_rows(int dtype, const TaskDesc* tasks, int ntasks, int max_npad, const ModelDev* md, hipStream_t st) {
   dim3 grid((max_npad + 255) / 256, 1, ntasks);
-  if (dtype == HBO_F64) hipLaunchKernelGGL((aug_rows_kernel<double>), grid, dim3(256), 0, st, tasks, md, naug_rows, mult_is_m);
-  else hipLaunchKernelGGL((aug_rows_kernel<float>), grid, dim3(256), 0, st, tasks, md, naug_rows, mult_is_m);
+  if (dtype == HBO_F64) hipLaunchKernelGGL((aug_rows_kernel<double>), grid, dim3(256), 0, st, tasks, md);
+  else hipLaunchKernelGGL((aug_rows_kernel<float>), grid, dim3(256), 0, st, tasks, md);
 }
 void launch_nll_reduce(int dtype, const TaskDesc* tasks, int ntasks, const int* info, double* out, hipStream_t st) {
   if (dtype == HBO_F64) hipLaunchKernelGGL((nll_reduce_kernel<double>), dim3(ntasks), dim3(256), 0, st, tasks, info, out);
@@ -818,26 +913,39 @@ void launch_wt_z(int dtype, const TaskDesc* tasks, int ntasks, int max_nblk, int
     hipLaunchKernelGGL((wtz_final_kernel<float>), g2, dim3(256), 0, st, tasks, out_col, out_ld, (float*)oover);
   }
 }
-int grad_nacc(int kernel_id, int fdim) { return kernel_id == HBO_KERNEL_DOT ? 3 : 2 + fdim; }
+int grad_nacc(int kernel_id, int fdim) { return (kernel_id == HBO_KERNEL_DOT ? 3 : 2 + fdim) + 1; }
 void launch_grad_contract(int dtype, const TaskDesc* tasks, int ntasks, int max_nblk, const ModelDev* md,
-                          int kernel_id, int fdim, double* partials, int64_t stride_task, hipStream_t st) {
+                          int kernel_id, int fdim, int obj, double* partials, int64_t stride_task, hipStream_t st) {
   dim3 grid(max_nblk, max_nblk, ntasks);
   const int nacc = grad_nacc(kernel_id, fdim);
-  if (dtype == HBO_F64) hipLaunchKernelGGL((grad_contract_kernel<double>), grid, dim3(256), 0, st, tasks, md, fdim, nacc, partials, stride_task);
-  else hipLaunchKernelGGL((grad_contract_kernel<float>), grid, dim3(256), 0, st, tasks, md, fdim, nacc, partials, stride_task);
+  if (obj == OBJ_NLL) {
+    if (dtype == HBO_F64) hipLaunchKernelGGL((grad_contract_kernel<double, false>), grid, dim3(256), 0, st, tasks, md, fdim, nacc, obj, partials, stride_task);
+    else hipLaunchKernelGGL((grad_contract_kernel<float, false>), grid, dim3(256), 0, st, tasks, md, fdim, nacc, obj, partials, stride_task);
+  } else {
+    if (dtype == HBO_F64) hipLaunchKernelGGL((grad_contract_kernel<double, true>), grid, dim3(256), 0, st, tasks, md, fdim, nacc, obj, partials, stride_task);
+    else hipLaunchKernelGGL((grad_contract_kernel<float, true>), grid, dim3(256), 0, st, tasks, md, fdim, nacc, obj, partials, stride_task);
+  }
+}
+void launch_dmu(int dtype, const TaskDesc* tasks, int ntasks, int obj, hipStream_t st) {
+  if (dtype == HBO_F64) hipLaunchKernelGGL((dmu_kernel<double>), dim3(ntasks), dim3(256), 0, st, tasks, obj);
+  else hipLaunchKernelGGL((dmu_kernel<float>), dim3(ntasks), dim3(256), 0, st, tasks, obj);
 }
 void launch_grad_finalize(int dtype, const TaskDesc* tasks, int ntasks, const ModelDev* md, int kernel_id,
-                          int fdim, const double* partials, int64_t stride_task, double* out, int out_stride,
-                          hipStream_t st) {
+                          int fdim, int obj, const double* partials, int64_t stride_task, double* out,
+                          int out_stride, double* value_out, hipStream_t st) {
   const int nacc = grad_nacc(kernel_id, fdim);
-  if (dtype == HBO_F64) hipLaunchKernelGGL((grad_finalize_kernel<double>), dim3(ntasks), dim3(256), 0, st, tasks, md, fdim, nacc, partials, stride_task, out, out_stride);
-  else hipLaunchKernelGGL((grad_finalize_kernel<float>), dim3(ntasks), dim3(256), 0, st, tasks, md, fdim, nacc, partials, stride_task, out, out_stride);
+  if (dtype == HBO_F64) hipLaunchKernelGGL((grad_finalize_kernel<double>), dim3(ntasks), dim3(256), 0, st, tasks, md, fdim, nacc, obj, partials, stride_task, out, out_stride, value_out);
+  else hipLaunchKernelGGL((grad_finalize_kernel<float>), dim3(ntasks), dim3(256), 0, st, tasks, md, fdim, nacc, obj, partials, stride_task, out, out_stride, value_out);
+}
+void launch_scale_dF(const TaskDesc* tasks, int ntasks, int64_t max_n, int fdim, hipStream_t st) {
+  dim3 grid((unsigned)((max_n * fdim + 255) / 256), 1, ntasks);
+  hipLaunchKernelGGL(scale_dF_kernel, grid, dim3(256), 0, st, tasks, fdim);
 }
 void launch_grad_feat(int dtype, const TaskDesc* tasks, int ntasks, int max_nblk, const ModelDev* md, int fdim,
-                      hipStream_t st) {
+                      int obj, hipStream_t st) {
   dim3 grid(max_nblk, max_nblk, ntasks);
-  if (dtype == HBO_F64) hipLaunchKernelGGL((grad_feat_kernel<double>), grid, dim3(256), 0, st, tasks, md, fdim);
-  else hipLaunchKernelGGL((grad_feat_kernel<float>), grid, dim3(256), 0, st, tasks, md, fdim);
+  if (dtype == HBO_F64) hipLaunchKernelGGL((grad_feat_kernel<double>), grid, dim3(256), 0, st, tasks, md, fdim, obj);
+  else hipLaunchKernelGGL((grad_feat_kernel<float>), grid, dim3(256), 0, st, tasks, md, fdim, obj);
 }
 void launch_grad_feat_mean(int dtype, const TaskDesc* tasks, int ntasks, int64_t max_n, const ModelDev* md,
                            int fdim, hipStream_t st) {

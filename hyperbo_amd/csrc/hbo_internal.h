@@ -31,7 +31,18 @@ struct TaskDesc {
   int n, npad, nblk, m;
   int64_t ld;
   int fdim, fmean;
+  // generalised objective  f = c * sum_b |z_b|^2 + 2*lh * sum_i log L_ii + const  over `naug` augmented
+  // rows  row_b = aug_src[b] + e_b * mu,  e_b = e_all + (b == naug-1 ? e_last : 0):
+  //   NLL (objectives.py:144-156): 1 row (sum of y columns), e_last = -m, c = 1/2, lh = m^2/2
+  //   EKL (objectives.py:29-101 with utils.partial_kl_mvn): rows yc_a/sqrt(m), last row -mu0, e_last = +1, c = 1, lh = 1
+  //   factor path: m rows y_a, e_all = -1
+  int naug;
+  double e_last, e_all, coef_c, coef_lh, coef_const;
+  void* dmu;         // npad doubles: d f / d mu_i
+  double* fnorm;     // 2 doubles: [0] |C0 - K1|_F, [1] |mu1 - mu0|  (EUC)
 };
+
+enum ObjectiveId { OBJ_NLL = 0, OBJ_EKL = 1, OBJ_EUC = 2 };
 
 // Device-side copy of the (already warped) model hyper-parameters.
 struct ModelDev {
@@ -90,22 +101,25 @@ void launch_dense_tanh(int dtype, const void* in, const void* w, const void* b, 
                        int fin, int fout, hipStream_t st);
 void launch_mean(int dtype, const void* fm, int64_t n, int fmean, const ModelDev* model, void* mu,
                  hipStream_t st);
-void launch_aug_rows(int dtype, const TaskDesc* tasks, int ntasks, int max_npad, const ModelDev* md,
-                     int naug_rows, int mult_is_m, hipStream_t st);
+void launch_aug_rows(int dtype, const TaskDesc* tasks, int ntasks, int max_npad, const ModelDev* md, hipStream_t st);
 void launch_nll_reduce(int dtype, const TaskDesc* tasks, int ntasks, const int* info, double* out,
                        hipStream_t st);
 // s = W^T z_a (z_a = augmented row a of A) -> tasks[t].svec[out_col*out_ld + j]; uses S as scratch
 // xover / oover (single task only): explicit input vector [npad] / output vector [npad]
 void launch_wt_z(int dtype, const TaskDesc* tasks, int ntasks, int max_nblk, int aug_row, int out_col,
                  int out_ld, hipStream_t st, const void* xover = nullptr, void* oover = nullptr);
-int grad_nacc(int kernel_id, int fdim);
+int grad_nacc(int kernel_id, int fdim);   // accumulators per tile (incl. the Frobenius slot)
 void launch_grad_contract(int dtype, const TaskDesc* tasks, int ntasks, int max_nblk, const ModelDev* md,
-                          int kernel_id, int fdim, double* partials, int64_t stride_task, hipStream_t st);
+                          int kernel_id, int fdim, int obj, double* partials, int64_t stride_task, hipStream_t st);
+// d f / d mu_i per task (tasks[t].dmu) -- needs svec (NLL/EKL) or the data rows (EUC)
+void launch_dmu(int dtype, const TaskDesc* tasks, int ntasks, int obj, hipStream_t st);
+// value_out (nullable, EUC): per-task objective value |mu1-mu0| + |C0-K1|_F
 void launch_grad_finalize(int dtype, const TaskDesc* tasks, int ntasks, const ModelDev* md, int kernel_id,
-                          int fdim, const double* partials, int64_t stride_task, double* out, int out_stride,
-                          hipStream_t st);
+                          int fdim, int obj, const double* partials, int64_t stride_task, double* out,
+                          int out_stride, double* value_out, hipStream_t st);
+void launch_scale_dF(const TaskDesc* tasks, int ntasks, int64_t max_n, int fdim, hipStream_t st);
 void launch_grad_feat(int dtype, const TaskDesc* tasks, int ntasks, int max_nblk, const ModelDev* md, int fdim,
-                      hipStream_t st);
+                      int obj, hipStream_t st);
 void launch_grad_feat_mean(int dtype, const TaskDesc* tasks, int ntasks, int64_t max_n, const ModelDev* md,
                            int fdim, hipStream_t st);
 void launch_dense_bwd(int dtype, const void* in, const void* out, const void* w, double* dout, double* din,

@@ -42,14 +42,12 @@ class _Adam:
 
 
 def _value_and_grad_of(objective):
-  """The companion of an objective that returns (value, grads): native NLL, or `.value_and_grad`."""
-  if objective is obj.neg_log_marginal_likelihood or objective is obj.nll:
-    return obj.nll_value_and_grad
+  """The `.value_and_grad` companion of an objective (native NLL / EKL / Euclid and their add / mul sums)."""
   vg = getattr(objective, 'value_and_grad', None)
   if vg is None:
     raise NotImplementedError(
-        f'objective {objective!r} has no native value_and_grad (only the NLL is on the GPU path; '
-        'EKL/Euclid objectives are a later row of SURVEY.md 8(f))')
+        f'objective {objective!r} has no value_and_grad companion: there is no autodiff on this path, '
+        'attach `objective.value_and_grad = fn(mean_func, cov_func, params, dataset, warp_func)`')
   return vg
 
 
@@ -79,7 +77,7 @@ def infer_parameters(mean_func, cov_func, init_params, dataset, warp_func=None,
     return vg(mean_func=mean_func, cov_func=cov_func, params=p, dataset=batch, warp_func=warp_func)
 
   def make_device(batch):
-    return obj.DeviceDataset(batch) if vg is obj.nll_value_and_grad else batch
+    return obj.DeviceBatch(batch) if getattr(vg, 'accepts_device_batch', False) else batch
 
   if method == 'adam':
     needs_resample = any(s.x.shape[0] >= batch_size for s in dataset.values())

@@ -1,9 +1,12 @@
-"""Training objectives -- hyperbo/gp_utils/objectives.py:109-210 on the GPU.
+"""Training objectives -- hyperbo/gp_utils/objectives.py:29-247 on the GPU.
 
-`neg_log_marginal_likelihood` keeps the reference signature.  Because there is no autodiff, the
-companion `nll_value_and_grad` returns what `jax.value_and_grad(loss_func)` returns at
-hyperbo/gp_utils/gp.py:134 / hyperbo/basics/lbfgs.py:238: (scalar, pytree shaped like params.model).
-`DeviceDataset` keeps the sub-datasets resident in HBM across evaluations (only theta changes).
+`neg_log_marginal_likelihood`, `multivariate_normal_divergence` (kl / ekl) and
+`multivariate_normal_euc_distance` (euc) keep the reference signatures.  Because there is no autodiff,
+every objective carries a `.value_and_grad` companion that returns what `jax.value_and_grad(loss_func)`
+returns at hyperbo/gp_utils/gp.py:134 / hyperbo/basics/lbfgs.py:238: (scalar, pytree shaped like
+params.model); `add` / `mul` (objectives.py:221-247) compose the companions too.
+`DeviceDataset` keeps the sub-datasets resident in HBM across evaluations (only theta changes);
+`DeviceBatch` holds the i.i.d. and the aligned selection of one training batch.
 """
 import ctypes as C
 import logging
@@ -17,11 +20,18 @@ from hyperbo_amd.basics import params_utils
 retrieve_params = params_utils.retrieve_params
 
 
-def included_sub_datasets(dataset, exclude_aligned=True):
-  """Selection rule of objectives.py:181-185: skip aligned (if asked) and empty sub-datasets."""
+OBJ_NLL, OBJ_EKL, OBJ_EUC = 0, 1, 2   # include/hbo.h hbo_objective_id
+
+
+def included_sub_datasets(dataset, exclude_aligned=True, only_aligned=False):
+  """Selection rules: objectives.py:181-185 (NLL: skip aligned if asked, skip empty) and
+  objectives.py:85-96 (divergences: aligned and non-empty only)."""
   out = []
   for k, s in dataset.items():
-    if exclude_aligned and s.aligned is not None:
+    if only_aligned:
+      if s.aligned is None:
+        continue
+    elif exclude_aligned and s.aligned is not None:
       continue
     if s.x.shape[0] == 0:
       continue
@@ -32,9 +42,10 @@ def included_sub_datasets(dataset, exclude_aligned=True):
 class DeviceDataset:
   """Sub-datasets uploaded once (hbo_dataset); tasks are independent given theta."""
 
-  def __init__(self, dataset, exclude_aligned=True, dtype=None, ctx=None, keys=None):
+  def __init__(self, dataset, exclude_aligned=True, dtype=None, ctx=None, keys=None, only_aligned=False):
     self.ctx = ctx or nat.default_context()
-    items = included_sub_datasets(dataset, exclude_aligned)
+    self.only_aligned = only_aligned
+    items = included_sub_datasets(dataset, exclude_aligned, only_aligned)
     if keys is not None:
       keyset = set(keys)
       items = [(k, s) for k, s in items if k in keyset]
@@ -44,10 +55,14 @@ class DeviceDataset:
     self.dtype = np.dtype(dtype)
     self._xs = [np.ascontiguousarray(np.asarray(s.x), dtype=self.dtype) for _, s in items]
     self._ys = [np.ascontiguousarray(np.asarray(s.y), dtype=self.dtype) for _, s in items]
-    for x, y in zip(self._xs, self._ys):
+    for (k, _), x, y in zip(items, self._xs, self._ys):
       if y.ndim != 2 or y.shape[0] != x.shape[0] or y.shape[1] == 0:
-        raise ValueError(f'sub-dataset x has shape {x.shape} but y has shape {y.shape}')
-    self.input_dim = self._xs[0].shape[1] if self._xs else 1
+        raise ValueError(f'dataset[{k}].x has shape {x.shape} but dataset[{k}].y has shape {y.shape}')
+    if self._xs:
+      self.input_dim = self._xs[0].shape[1]
+    else:   # nothing selected: keep the dataset's input dimension so that params still validate
+      dims = [np.shape(s.x)[1] for s in dataset.values() if np.ndim(s.x) == 2]
+      self.input_dim = dims[0] if dims else 1
     self.num_tasks = len(items)
     self._h = C.c_void_p()
     # device order: largest task first (stable) -- mirrors hbo_dataset_create
@@ -72,14 +87,15 @@ class DeviceDataset:
     except Exception:  # pylint: disable=broad-except
       pass
 
-  def evaluate(self, mean_func, cov_func, params, warp_func=None, want_grad=False, per_task=False):
-    """Returns (nll_sum, per_task dict or None, flat grad_sum (warped) or None, BuiltModel)."""
+  def evaluate(self, mean_func, cov_func, params, warp_func=None, want_grad=False, per_task=False,
+               objective=OBJ_NLL):
+    """Returns (value_sum, per_task dict or None, flat grad_sum (warped) or None, BuiltModel)."""
     bm = _model.BuiltModel(mean_func, cov_func, params, warp_func, self.dtype, self.input_dim)
     nll = C.c_double(0.0)
     pt = (C.c_double * max(self.num_tasks, 1))() if per_task else None
     g = (C.c_double * max(bm.layout.total, 1))() if want_grad else None
     if self.num_tasks:
-      self.ctx.check(nat.lib().hbo_nll(self.ctx.handle, bm.ref(), self._h, C.byref(nll), pt, g))
+      self.ctx.check(nat.lib().hbo_objective(self.ctx.handle, bm.ref(), self._h, objective, C.byref(nll), pt, g))
     key2nll = None
     if per_task:
       vals = dict(zip(self.device_order_keys, list(pt)[:self.num_tasks]))
@@ -88,10 +104,36 @@ class DeviceDataset:
     return nll.value, key2nll, grad, bm
 
 
-def _as_device(dataset, exclude_aligned, ctx=None):
+class DeviceBatch:
+  """One training batch resident in HBM: lazily uploaded selections of the same dataset dict --
+  'iid' (aligned excluded, the NLL's default), 'all' (NLL with exclude_aligned=False) and 'aligned'
+  (the divergence objectives)."""
+
+  def __init__(self, dataset, ctx=None):
+    self.dataset = dataset
+    self.ctx = ctx
+    self._dev = {}
+
+  def get(self, selection):
+    if selection not in self._dev:
+      self._dev[selection] = DeviceDataset(self.dataset, exclude_aligned=(selection == 'iid'),
+                                           only_aligned=(selection == 'aligned'), ctx=self.ctx)
+    return self._dev[selection]
+
+  def close(self):
+    for d in self._dev.values():
+      d.close()
+    self._dev = {}
+
+
+def _as_device(dataset, exclude_aligned, ctx=None, only_aligned=False):
   if isinstance(dataset, DeviceDataset):
+    if dataset.only_aligned != only_aligned:
+      raise ValueError('DeviceDataset was built with a different sub-dataset selection than this objective needs')
     return dataset, False
-  return DeviceDataset(dataset, exclude_aligned=exclude_aligned, ctx=ctx), True
+  if isinstance(dataset, DeviceBatch):
+    return dataset.get('aligned' if only_aligned else ('iid' if exclude_aligned else 'all')), False
+  return DeviceDataset(dataset, exclude_aligned=exclude_aligned, ctx=ctx, only_aligned=only_aligned), True
 
 
 def _apply_priors(total_nll, params, warp_func):
@@ -166,16 +208,119 @@ def nll_value_and_grad(mean_func, cov_func, params, dataset, warp_func=None, exc
   return value, grads
 
 
+neg_log_marginal_likelihood.value_and_grad = nll_value_and_grad
+nll_value_and_grad.accepts_device_batch = True
+
+
+def _divergence(objective_id, mean_func, cov_func, params, dataset, warp_func, want_grad, comm=None):
+  dev, owned = _as_device(dataset, True, only_aligned=True)
+  try:
+    total, _, grad, bm = dev.evaluate(mean_func, cov_func, params, warp_func, want_grad=want_grad,
+                                      objective=objective_id)
+    count = float(dev.num_tasks)
+  finally:
+    if owned:
+      dev.close()
+  if not want_grad:
+    return (0. if count == 0 else total / count), None
+  if comm is not None:
+    buf = comm.allreduce_sum(np.concatenate([[total, count], grad]))
+    total, count, grad = buf[0], buf[1], buf[2:]
+  if count > 0:
+    return total / count, bm.unflatten_grad(grad / count)
+  return 0., bm.unflatten_grad(grad * 0.)
+
+
+def multivariate_normal_divergence(mean_func, cov_func, params, dataset, warp_func=None, distance=None):
+  """objectives.py:29-101: mean over the aligned sub-datasets of distance(N(mean_a y, cov_a y), GP prior).
+
+  `distance`: None / utils.kl_multivariate_normal (partial KL, utils.py:109-148 defaults) or
+  utils.euclidean_multivariate_normal; both run natively (hbo_objective).  Other callables, or functools
+  partials that change weight / eps / partial, are not on the device path and raise.
+  """
+  from hyperbo_amd.gp_utils import utils as _utils
+  if distance is None or distance is _utils.kl_multivariate_normal:
+    oid = OBJ_EKL
+  elif distance is _utils.euclidean_multivariate_normal:
+    oid = OBJ_EUC
+  else:
+    raise NotImplementedError('multivariate_normal_divergence: only utils.kl_multivariate_normal (partial, '
+                              'eps=0) and utils.euclidean_multivariate_normal run on the device')
+  return _divergence(oid, mean_func, cov_func, params, dataset, warp_func, False)[0]
+
+
+def multivariate_normal_euc_distance(mean_func, cov_func, params, dataset, warp_func=None):
+  """objectives.py:104-106."""
+  return _divergence(OBJ_EUC, mean_func, cov_func, params, dataset, warp_func, False)[0]
+
+
+def ekl_value_and_grad(mean_func, cov_func, params, dataset, warp_func=None, comm=None):
+  """(value, grads w.r.t. raw params.model) of multivariate_normal_divergence (partial KL)."""
+  return _divergence(OBJ_EKL, mean_func, cov_func, params, dataset, warp_func, True, comm)
+
+
+def euc_value_and_grad(mean_func, cov_func, params, dataset, warp_func=None, comm=None):
+  """(value, grads w.r.t. raw params.model) of multivariate_normal_euc_distance."""
+  return _divergence(OBJ_EUC, mean_func, cov_func, params, dataset, warp_func, True, comm)
+
+
+multivariate_normal_divergence.value_and_grad = ekl_value_and_grad
+multivariate_normal_euc_distance.value_and_grad = euc_value_and_grad
+ekl_value_and_grad.accepts_device_batch = True
+euc_value_and_grad.accepts_device_batch = True
+
 nll = neg_log_marginal_likelihood
+kl = multivariate_normal_divergence
+ekl = kl
+euc = multivariate_normal_euc_distance
+regkl = kl
+regeuc = euc
+
+
+def _tree_combine(fn, *trees):
+  first = trees[0]
+  if isinstance(first, dict):
+    return {k: _tree_combine(fn, *[t[k] for t in trees]) for k in first}
+  if isinstance(first, (list, tuple)):
+    return type(first)(_tree_combine(fn, *parts) for parts in zip(*trees))
+  return fn(*trees)
 
 
 def add(*objectives):
+  """objectives.py:221-226; the sum also carries the summed value_and_grad when every term has one."""
   def added_objective(*args, **kwargs):
     return sum([obj(*args, **kwargs) for obj in objectives])
+  if all(getattr(o, 'value_and_grad', None) is not None for o in objectives):
+    def added_value_and_grad(*args, **kwargs):
+      pairs = [o.value_and_grad(*args, **kwargs) for o in objectives]
+      return sum(v for v, _ in pairs), _tree_combine(lambda *g: sum(np.asarray(x) for x in g), *[g for _, g in pairs])
+    added_value_and_grad.accepts_device_batch = all(
+        getattr(o.value_and_grad, 'accepts_device_batch', False) for o in objectives)
+    added_objective.value_and_grad = added_value_and_grad
   return added_objective
 
 
 def mul(c, obj):
+  """objectives.py:229-234."""
   def multiplied_objective(*args, **kwargs):
     return c * obj(*args, **kwargs)
+  if getattr(obj, 'value_and_grad', None) is not None:
+    def multiplied_value_and_grad(*args, **kwargs):
+      v, g = obj.value_and_grad(*args, **kwargs)
+      return c * v, _tree_combine(lambda x: c * np.asarray(x), g)
+    multiplied_value_and_grad.accepts_device_batch = getattr(obj.value_and_grad, 'accepts_device_batch', False)
+    multiplied_objective.value_and_grad = multiplied_value_and_grad
   return multiplied_objective
+
+
+# objectives.py:237-247 (the regeuc01 / regeuc10 aliases use regkl there too)
+nll_regkl = lambda c: add(nll, mul(c, regkl))
+nll_regeuc = lambda c: add(nll, mul(c, regeuc))
+
+nll_regkl1 = nll_regkl(1.)
+nll_regeuc1 = nll_regeuc(1.)
+nll_regkl01 = nll_regkl(.1)
+nll_regeuc01 = nll_regkl(.1)
+
+nll_regkl10 = nll_regkl(10.)
+nll_regeuc10 = nll_regkl(10.)

@@ -73,7 +73,7 @@ typedef struct hbo_model {
   const void* linear_kernel;                     /* [Fin] (linear_mean['kernel'][:,0]) */
 } hbo_model;
 
-/* Flat layout (in doubles) of the gradient w.r.t. the WARPED parameters written by hbo_nll.
+/* Flat layout (in doubles) of the gradient w.r.t. the WARPED parameters written by hbo_nll / hbo_objective.
  * Offsets of absent parameters are -1.  total = number of doubles. */
 typedef struct hbo_grad_layout {
   int32_t lengthscale;      /* n_lengthscale entries */
@@ -125,6 +125,18 @@ int hbo_dataset_free(hbo_ctx* ctx, hbo_dataset* ds);
  * d nll_task / d warped-parameter.  Returns HBO_NOT_PD if any task failed (its values are NaN). */
 int hbo_nll(hbo_ctx* ctx, const hbo_model* model, hbo_dataset* ds, double* nll_sum,
             double* nll_per_task, double* grad_sum);
+
+/* ---- objectives.py:29-106 multivariate_normal_divergence (+ jax.value_and_grad) over the ALIGNED
+ *      sub-datasets of `ds`: distance between N(mean_a y, cov_a y) of the m aligned columns and the GP prior
+ *      N(mean_func(x), cov_func(x,x) + noise I) -- no jitter, model->eps is ignored.
+ *        HBO_OBJ_NLL  = hbo_nll
+ *        HBO_OBJ_EKL  utils.py:84-148 kl_multivariate_normal(partial=True, eps=0, weight=1)  ('ekl' / 'kl')
+ *        HBO_OBJ_EUC  utils.py:151-173 euclidean_multivariate_normal(mean_weight=cov_weight=1) ('euc')
+ *      Same output convention as hbo_nll (sums over tasks; the caller divides by the task count,
+ *      objectives.py:98-101).  Requires m + 1 <= 128, else HBO_ERR_UNSUPPORTED. */
+enum hbo_objective_id { HBO_OBJ_NLL = 0, HBO_OBJ_EKL = 1, HBO_OBJ_EUC = 2 };
+int hbo_objective(hbo_ctx* ctx, const hbo_model* model, hbo_dataset* ds, int objective, double* value_sum,
+                  double* value_per_task, double* grad_sum);
 
 /* ---- linalg.py:72-110 solve_gp_linear_system -> GPCache(chol, kinvy) (gp.py:540-560) ----- */
 int hbo_factor(hbo_ctx* ctx, const hbo_model* model, const void* x, int64_t n, const void* y,

@@ -613,3 +613,186 @@ DEFAULT_PRIORS_GRAD = {
     'signal_variance': lambda x: -(np.log(np.asarray(x, dtype=np.float64)) + 1.0) / np.asarray(x, dtype=np.float64),
     'constant': lambda x: -np.asarray(x, dtype=np.float64),
 }
+
+
+# ----------------------------------------------------------------------------
+# divergence objectives -- hyperbo/gp_utils/objectives.py:29-106, hyperbo/gp_utils/utils.py:84-173,
+# hyperbo/basics/linalg.py:113-126 (svd_matrix_sqrt)
+# ----------------------------------------------------------------------------
+def svd_matrix_sqrt(cov):
+  u, s, _ = spla.svd(cov)  # linalg.py:122
+  factor = u * np.sqrt(s[..., None, :])
+  tol = s.max() * np.finfo(s.dtype).eps / 2. * np.sqrt(2 * cov.shape[0] + 1.)
+  rank = np.count_nonzero(s > tol)
+  return factor[:, :rank]
+
+
+def partial_kl_mvn(mu0, cov0, mu1, cov1):
+  """utils.py:84-106: tr(cov1^-1 cov0) + (mu1-mu0)^T cov1^-1 (mu1-mu0) + logdet cov1."""
+  mu_diff = mu1 - mu0
+  chol1 = spla.cholesky(cov1, lower=True)
+  trcov1invcov0 = np.trace(spla.cho_solve((chol1, True), cov0))
+  mahalanobis = float(np.dot(mu_diff, spla.cho_solve((chol1, True), mu_diff)))
+  logdetcov1 = np.sum(2 * np.log(np.diag(chol1)))
+  return trcov1invcov0 + mahalanobis + logdetcov1
+
+
+def kl_multivariate_normal(mu0, cov0, mu1, cov1, weight=1.0, eps=0.0, partial=True):
+  """utils.py:109-148."""
+  cov0 = np.atleast_2d(cov0); cov1 = np.atleast_2d(cov1)
+  if eps > 0.:
+    cov0 = cov0 + np.eye(cov0.shape[0]) * eps
+    cov1 = cov1 + np.eye(cov1.shape[0]) * eps
+  if partial:
+    return weight * partial_kl_mvn(mu0, cov0, mu1, cov1)
+  chol0 = svd_matrix_sqrt(cov0)
+  chol0inv = np.linalg.pinv(chol0)
+  mu1 = np.dot(chol0inv, mu1 - mu0)
+  cov1 = np.dot(np.dot(chol0inv, cov1), chol0inv.T)
+  mu0 = np.zeros_like(mu1)
+  cov0 = np.eye(cov1.shape[0])
+  return weight * 0.5 * (partial_kl_mvn(mu0, cov0, mu1, cov1) - chol0.shape[1])
+
+
+def euclidean_multivariate_normal(mu0, cov0, mu1, cov1, mean_weight=1., cov_weight=1., **unused_kwargs):
+  """utils.py:151-173 (safe_l2norm == l2 norm in value)."""
+  return mean_weight * np.sqrt(np.sum((mu0 - mu1)**2)) + cov_weight * np.sqrt(np.sum((cov0 - cov1)**2))
+
+
+def included_aligned_sub_datasets(dataset):
+  """objectives.py:85-96: aligned sub-datasets with data; malformed y raises."""
+  out = []
+  for k, s in dataset.items():
+    if s.aligned is None:
+      continue
+    if s.x.shape[0] == 0:
+      continue
+    if s.y.shape[1] == 0 or s.y.shape[0] != s.x.shape[0]:
+      raise ValueError(f'dataset[{k}].x has shape {s.x.shape} but dataset[{k}].y has shape {s.y.shape}')
+    out.append((k, s))
+  return out
+
+
+def multivariate_normal_divergence(mean_func, cov_func, params, dataset, warp_func=None,
+                                   distance=kl_multivariate_normal):
+  """objectives.py:29-101: mean over aligned sub-datasets of distance(N(mu_data, cov_data), GP model)."""
+  total, num = 0., 0
+  for _, s in included_aligned_sub_datasets(dataset):
+    y = np.asarray(s.y); x = np.asarray(s.x)
+    mu_data = np.mean(y, axis=1)
+    cov_data = np.atleast_2d(np.cov(y, bias=True))
+    mu_model = mean_func(params, x, warp_func=warp_func).flatten()
+    noise_variance, = retrieve_params(params, ['noise_variance'], warp_func=warp_func)
+    cov_model = cov_func(params, x, warp_func=warp_func) + np.eye(x.shape[0]) * np.squeeze(noise_variance)
+    total += distance(mu0=mu_data, cov0=cov_data, mu1=mu_model, cov1=cov_model)
+    num += 1
+  return 0. if num == 0 else total / num
+
+
+def _divergence_sub_dataset_value_and_grad(kind, mean_func, cov_func, params, vx, vy, warp_func):
+  """Value and d/d(raw params.model) of one aligned sub-dataset's partial KL ('ekl') or Euclidean ('euc')
+  divergence.  Implemented by re-using the NLL machinery's chain rule with
+     ekl:  f = tr(K1^-1 C0) + d^T K1^-1 d + logdet K1,   df/dK1 = K1^-1 - K1^-1 (C0 + d d^T) K1^-1,  df/dmu1 = 2 K1^-1 d
+     euc:  f = |d| + |C0 - K1|_F,                          df/dK1 = (K1 - C0)/|C0-K1|_F,               df/dmu1 = d/|d|
+  (d = mu1 - mu0, K1 = K + noise I, no jitter: objectives.py:63-65)."""
+  model = params.model
+  vx = np.asarray(vx, dtype=np.float64); vy = np.asarray(vy, dtype=np.float64)
+  n, m = vy.shape
+  mu0 = vy.mean(axis=1)
+  yc = vy - mu0[:, None]
+  c0 = yc @ yc.T / m
+  # forward pieces through the NLL helper's internals: recompute K, features, etc.
+  val_dummy, _ = 0.0, None
+  base = cov_func.base_name; use_mlp_k = cov_func.uses_mlp; mean_name = mean_func.__name__
+  wf = warp_func or {}
+
+  def warped(key):
+    raw = np.asarray(model[key], dtype=np.float64)
+    return wf[key](raw) if key in wf else raw
+
+  def chain(key, g):
+    raw = np.asarray(model[key], dtype=np.float64)
+    return np.asarray(g) * (warp_derivative(wf[key], raw) if key in wf else 1.0)
+
+  acts = None
+  if use_mlp_k or mean_name == 'linear_mlp':
+    acts = _mlp_forward_cache(model['mlp_params'], vx)
+  feat = acts[-1] if use_mlp_k else vx
+  if mean_name == 'zero':
+    mu1 = np.zeros(n)
+  elif mean_name == 'constant':
+    mu1 = np.full(n, float(np.squeeze(warped('constant'))))
+  else:
+    lm = model['linear_mean']
+    inp = vx if mean_name == 'linear' else acts[-1]
+    mu1 = (inp @ np.asarray(lm['kernel'], dtype=np.float64) + np.asarray(lm['bias'], dtype=np.float64))[:, 0]
+  noise = float(np.squeeze(warped('noise_variance')))
+  if base == 'dot_product':
+    sigma = float(np.squeeze(warped('dot_prod_sigma'))); bias = float(np.squeeze(warped('dot_prod_bias')))
+    dots = feat @ feat.T
+    kmat = dots / sigma**2 + bias**2
+  else:
+    ls = np.broadcast_to(np.asarray(warped('lengthscale'), dtype=np.float64).reshape(-1), (feat.shape[1],))
+    sv = float(np.squeeze(warped('signal_variance')))
+    diff = feat[:, None, :] - feat[None, :, :]
+    u = np.sum((diff / ls)**2, axis=-1)
+    if base == 'squared_exponential':
+      kmat = sv * np.exp(-u / 2); dk_du = -0.5 * kmat
+    elif base == 'matern32':
+      rr = np.sqrt(3.0 * u); kmat = sv * (1 + rr) * np.exp(-rr); dk_du = np.where(u == 0, 0.0, -sv * 1.5 * np.exp(-rr))
+    else:
+      rr = np.sqrt(5.0 * u); kmat = sv * (1 + rr + rr**2 / 3) * np.exp(-rr)
+      dk_du = np.where(u == 0, 0.0, -sv * 5.0 * np.exp(-rr) * (1 + rr) / 6)
+  k1 = kmat + np.eye(n) * noise
+  d = mu1 - mu0
+  if kind == 'ekl':
+    chol = spla.cholesky(k1, lower=True)
+    kinv = spla.cho_solve((chol, True), np.eye(n))
+    value = float(np.sum(kinv * c0) + d @ kinv @ d + 2 * np.sum(np.log(np.diag(chol))))
+    gmat = kinv - kinv @ (c0 + np.outer(d, d)) @ kinv
+    dmu = 2 * kinv @ d
+  else:
+    nd = np.sqrt(np.sum(d * d)); fn = np.sqrt(np.sum((c0 - k1)**2))
+    value = float(nd + fn)
+    gmat = (k1 - c0) / fn if fn > 0 else np.zeros_like(k1)
+    dmu = d / nd if nd > 0 else np.zeros_like(d)
+  dmu = dmu[:, None]
+  grads = _tree_zeros_like(model)
+  grads['noise_variance'] = chain('noise_variance', np.trace(gmat)).reshape(np.shape(model['noise_variance']))
+  dfeat = np.zeros_like(acts[-1]) if acts is not None else None   # d f / d (MLP output)
+  if base == 'dot_product':
+    grads['dot_prod_sigma'] = chain('dot_prod_sigma', np.sum(gmat * dots) * (-2.0 / sigma**3)).reshape(np.shape(model['dot_prod_sigma']))
+    grads['dot_prod_bias'] = chain('dot_prod_bias', np.sum(gmat) * 2.0 * bias).reshape(np.shape(model['dot_prod_bias']))
+    if use_mlp_k:
+      dfeat += 2.0 * (gmat @ feat) / sigma**2
+  else:
+    grads['signal_variance'] = chain('signal_variance', np.sum(gmat * kmat) / sv).reshape(np.shape(model['signal_variance']))
+    gw = gmat * dk_du
+    per_dim = np.einsum('ij,ijd->d', gw, diff**2) * (-2.0 / ls**3)
+    g_ls = np.sum(per_dim) if np.asarray(model['lengthscale']).size == 1 else per_dim
+    grads['lengthscale'] = chain('lengthscale', np.reshape(g_ls, np.shape(model['lengthscale'])))
+    if use_mlp_k:
+      dfeat += 4.0 * np.einsum('ij,ijd->id', gw, diff) / ls**2
+  if mean_name == 'constant':
+    grads['constant'] = chain('constant', np.sum(dmu)).reshape(np.shape(model['constant']))
+  elif mean_name in ('linear', 'linear_mlp'):
+    inp = vx if mean_name == 'linear' else acts[-1]
+    lm = model['linear_mean']
+    grads['linear_mean'] = {'kernel': (inp.T @ dmu).reshape(np.shape(lm['kernel'])),
+                            'bias': np.sum(dmu, axis=0).reshape(np.shape(lm['bias']))}
+    if mean_name == 'linear_mlp':
+      dfeat = dfeat + dmu @ np.asarray(lm['kernel'], dtype=np.float64).T
+  if acts is not None and (use_mlp_k or mean_name == 'linear_mlp'):
+    grads['mlp_params'] = _mlp_backward(model['mlp_params'], acts, dfeat)
+  return value, grads
+
+
+def divergence_value_and_grad(kind, mean_func, cov_func, params, dataset, warp_func=None):
+  """Mean over aligned sub-datasets (objectives.py:98-101) of the 'ekl' / 'euc' divergence and its gradient."""
+  total = 0.; grads = _tree_zeros_like(params.model); num = 0
+  for _, s in included_aligned_sub_datasets(dataset):
+    v, g = _divergence_sub_dataset_value_and_grad(kind, mean_func, cov_func, params, s.x, s.y, warp_func)
+    total += v; grads = _tree_add(grads, g); num += 1
+  if num:
+    total /= num; grads = _tree_scale(grads, 1.0 / num)
+  return total, grads

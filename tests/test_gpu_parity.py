@@ -443,6 +443,149 @@ def test_cfg5_full_size_closed_form(gpu_ctx):
   assert abs(v - expect) <= 1e-9 * abs(expect)
 
 
+# ---- divergence objectives (objectives.py:29-106): EKL / Euclid on the device vs the oracle ------------------
+def _aligned_datasets(rng, d):
+  dso = {'a': o.SubDataset(*helpers.synthetic_task(rng, 150, d, m=6), aligned=1),
+         'b': o.SubDataset(*helpers.synthetic_task(rng, 20, d, m=10), aligned='x'),
+         'iid': o.SubDataset(*helpers.synthetic_task(rng, 40, d)),
+         'one': o.SubDataset(*helpers.synthetic_task(rng, 130, d, m=1), aligned=2),
+         'empty': o.SubDataset(np.zeros((0, d)), np.zeros((0, 2)), aligned=3)}
+  return dso
+
+
+@pytest.mark.parametrize('kind', ['ekl', 'euc'])
+@pytest.mark.parametrize('kname', helpers.KERNELS)
+@pytest.mark.parametrize('mlp', [False, True])
+@pytest.mark.parametrize('mname', helpers.MEANS)
+def test_divergence_value_and_grad_vs_oracle_fp64(gpu_ctx, kind, kname, mlp, mname):
+  defs, _, _, _, kernel, mean, objectives, utils = _native()
+  rng = np.random.default_rng(13)
+  d = 3
+  model = helpers.make_model(rng, mname, mlp, d)
+  po, pn = _pair(model)
+  dso = _aligned_datasets(rng, d)
+  dsn = {k: defs.SubDataset(v.x, v.y, v.aligned) for k, v in dso.items()}
+  ko = getattr(o, kname + ('_mlp' if mlp else '')); kn = getattr(kernel, kname + ('_mlp' if mlp else ''))
+  vo, go = o.divergence_value_and_grad(kind, getattr(o, mname), ko, po, dso, WFO)
+  fn = objectives.ekl if kind == 'ekl' else objectives.euc
+  vn, gn = fn.value_and_grad(getattr(mean, mname), kn, pn, dsn, utils.DEFAULT_WARP_FUNC)
+  assert set(gn) == set(go)
+  # the partial KL adds tr(K1^-1 C0) + logdet of opposite signs: scale the tolerance by the terms' size
+  assert abs(vn - vo) <= 1e-10 * max(abs(vo), 1.0) * (50 if kind == 'ekl' else 1)
+  fo, fng = helpers.flatten(go), helpers.flatten(gn)
+  assert np.max(np.abs(fo - fng)) <= 1e-8 * np.max(np.abs(fo))
+  v_only = fn(getattr(mean, mname), kn, pn, dsn, utils.DEFAULT_WARP_FUNC)
+  assert abs(v_only - vn) <= 1e-12 * max(abs(vn), 1.0)
+  if kind == 'euc':
+    v_dist = objectives.multivariate_normal_divergence(getattr(mean, mname), kn, pn, dsn, utils.DEFAULT_WARP_FUNC,
+                                                       distance=utils.euclidean_multivariate_normal)
+    assert v_dist == v_only
+
+
+def test_divergence_fp32_and_no_aligned_data(gpu_ctx):
+  defs, _, _, _, kernel, mean, objectives, utils = _native()
+  rng = np.random.default_rng(14)
+  d = 2
+  model = helpers.make_model(rng, 'constant', False, d)
+  po, _ = _pair(model)
+  model32 = {k: np.asarray(v, dtype=np.float32) for k, v in model.items()}
+  pn = defs.GPParams(model=model32, config={'mlp_features': helpers.MLP_FEATURES})
+  dso = {'a': o.SubDataset(*helpers.synthetic_task(rng, 200, d, m=8), aligned=1)}
+  dsn = {k: defs.SubDataset(v.x.astype(np.float32), v.y.astype(np.float32), v.aligned) for k, v in dso.items()}
+  for kind, fn in (('ekl', objectives.ekl), ('euc', objectives.euc)):
+    vo, go = o.divergence_value_and_grad(kind, o.constant, o.matern52, po, dso, WFO)
+    vn, gn = fn.value_and_grad(mean.constant, kernel.matern52, pn, dsn, utils.DEFAULT_WARP_FUNC)
+    assert abs(vn - vo) <= 2e-3 * max(abs(vo), 1.0)
+    fo, fng = helpers.flatten(go), helpers.flatten(gn)
+    assert np.max(np.abs(fo - fng)) <= 2e-2 * np.max(np.abs(fo))
+  only_iid = {'iid': defs.SubDataset(*helpers.synthetic_task(rng, 10, d))}
+  p64 = defs.GPParams(model=model, config={})
+  assert objectives.ekl(mean.constant, kernel.matern52, p64, only_iid, utils.DEFAULT_WARP_FUNC) == 0.
+  v, g = objectives.euc.value_and_grad(mean.constant, kernel.matern52, p64, only_iid, utils.DEFAULT_WARP_FUNC)
+  assert v == 0. and all(np.all(np.asarray(x) == 0) for x in g.values())
+  bad = {'bad': defs.SubDataset(np.zeros((4, d)), np.zeros((3, 2)), aligned=1)}
+  with pytest.raises(ValueError):
+    objectives.ekl(mean.constant, kernel.matern52, p64, bad, utils.DEFAULT_WARP_FUNC)
+
+
+def test_kl_of_model_samples_is_small_and_array_level_distances(gpu_ctx):
+  # objectives_test.py:60-100 flavour: data drawn from the model itself; utils_test.py:26-55 inputs
+  defs, linalg, _, _, kernel, mean, objectives, utils = _native()
+  np.random.seed(1)
+  mu0 = np.random.uniform(-5, 5, (10,)); mu1 = np.random.uniform(-5, 5, (10,))
+  cov0 = np.random.uniform(-5, 5, (10, 100)); cov0 = cov0 @ cov0.T
+  cov1 = np.random.uniform(-5, 5, (10, 100)); cov1 = cov1 @ cov1.T
+  kl_01 = utils.kl_multivariate_normal(mu0, cov0, mu1, cov1, partial=False)
+  assert kl_01 > 0 and abs(kl_01 - o.kl_multivariate_normal(mu0, cov0, mu1, cov1, partial=False)) <= 1e-9 * kl_01
+  assert abs(utils.kl_multivariate_normal(mu0, cov0, mu0, cov0, partial=False)) <= 1e-5
+  pk, pko = utils.partial_kl_mvn(mu0, cov0, mu1, cov1), o.partial_kl_mvn(mu0, cov0, mu1, cov1)
+  assert abs(pk - pko) <= 1e-10 * abs(pko)
+  assert abs(utils.kl_multivariate_normal(mu0, cov0, mu1, cov1, weight=2., eps=1e-3)
+             - o.kl_multivariate_normal(mu0, cov0, mu1, cov1, weight=2., eps=1e-3)) <= 1e-10 * abs(pko)
+  np.random.seed(1)
+  mu0 = np.random.uniform(-5, 5, (100,)); mu1 = np.random.uniform(-5, 5, (100,))
+  feat0 = np.random.uniform(-5, 5, (100, 5)); cov0 = feat0 @ feat0.T
+  cov1 = np.random.uniform(-5, 5, (100, 1000)); cov1 = cov1 @ cov1.T
+  kl = utils.kl_multivariate_normal(mu0, cov0, mu1, cov1, partial=False)
+  assert 0 < kl < np.inf
+  assert abs(utils.euclidean_multivariate_normal(mu0, cov0, mu1, cov1, mean_weight=2., cov_weight=.5)
+             - o.euclidean_multivariate_normal(mu0, cov0, mu1, cov1, mean_weight=2., cov_weight=.5)) <= 1e-9
+  v = np.random.randn(100)
+  np.testing.assert_allclose(cov1 @ linalg.inverse_spdmatrix_vector_product(cov1, v), v, rtol=1e-8, atol=1e-8)
+  # data whose sample mean / covariance ARE the model's: Euclid distance 0, partial KL = n + logdet K1 and the
+  # model is a stationary point of the KL (zero gradient)
+  rng = np.random.default_rng(0)
+  n, d, m = 40, 2, 120
+  x = rng.uniform(size=(n, d))
+  model = helpers.make_model(rng, 'constant', False, d)
+  po, pn = _pair(model)
+  k1 = o.squared_exponential(po, x, warp_func=WFO) + np.eye(n) * o.retrieve_params(po, ['noise_variance'], WFO)[0]
+  mu = o.constant(po, x, warp_func=WFO)
+  basis = np.linalg.qr(np.concatenate([np.ones((m, 1)), rng.normal(size=(m, n))], axis=1))[0][:, 1:]   # m x n, cols _|_ 1
+  y = mu + np.sqrt(m) * np.linalg.cholesky(k1) @ basis.T
+  dsn = {'s': defs.SubDataset(x, y, aligned=1)}
+  args = (mean.constant, kernel.squared_exponential, pn, dsn, utils.DEFAULT_WARP_FUNC)
+  assert objectives.euc(*args) <= 1e-10
+  v, g = objectives.ekl.value_and_grad(*args)
+  assert abs(v - (n + np.linalg.slogdet(k1)[1])) <= 1e-9 * n
+  assert np.max(np.abs(helpers.flatten(g))) <= 1e-8 * n
+
+
+@pytest.mark.parametrize('objective_name,method,cov_name', [
+    ('euc', 'lbfgs', 'squared_exponential'), ('kl', 'adam', 'dot_product_mlp'), ('kl', 'adam', 'squared_exponential_mlp'),
+    ('nll_regkl1', 'adam', 'matern32'), ('nll_regeuc1', 'lbfgs', 'matern52')])
+def test_infer_parameters_on_divergence_objectives(gpu_ctx, objective_name, method, cov_name):
+  # objectives_test.py:60-130: constant mean, n=20, d=2, 10 aligned samples, a couple of training steps
+  defs, _, _, gp, kernel, mean, objectives, utils = _native()
+  rng = np.random.default_rng(2)
+  n, d, m = 20, 2, 10
+  mlp = cov_name.endswith('_mlp')
+  model = helpers.make_model(rng, 'constant', mlp, d)
+  x = rng.uniform(size=(n, d))
+  ds = {'all_data': defs.SubDataset(x, np.sin(3 * x[:, :1]) + 0.3 * rng.normal(size=(n, m)), aligned='all_data'),
+        'iid0': defs.SubDataset(*helpers.synthetic_task(rng, 30, d)), 'iid1': defs.SubDataset(*helpers.synthetic_task(rng, 25, d))}
+  objective = getattr(objectives, objective_name)
+  cfg = {'method': method, 'batch_size': 100, 'max_training_step': 5, 'learning_rate': 1e-3,
+         'mlp_features': helpers.MLP_FEATURES, 'objective': objective}
+  params = defs.GPParams(model=model, config=cfg)
+  cov, mu = getattr(kernel, cov_name), mean.constant
+  init = objective(mean_func=mu, cov_func=cov, params=params, dataset=ds, warp_func=utils.DEFAULT_WARP_FUNC)
+  # the composed value equals the sum of its native parts (oracle for the pieces)
+  dso = {k: o.SubDataset(v.x, v.y, v.aligned) for k, v in ds.items()}
+  po = o.GPParams(model=model, config=cfg)
+  ko = getattr(o, cov_name)
+  parts = {'euc': lambda: o.divergence_value_and_grad('euc', o.constant, ko, po, dso, WFO)[0],
+           'kl': lambda: o.divergence_value_and_grad('ekl', o.constant, ko, po, dso, WFO)[0],
+           'nll': lambda: o.neg_log_marginal_likelihood(o.constant, ko, po, dso, WFO)}
+  expect = {'euc': lambda: parts['euc'](), 'kl': lambda: parts['kl'](),
+            'nll_regkl1': lambda: parts['nll']() + parts['kl'](),
+            'nll_regeuc1': lambda: parts['nll']() + parts['euc']()}[objective_name]()
+  assert abs(init - expect) <= 1e-9 * max(abs(expect), 1.0)
+  out = gp.infer_parameters(mu, cov, params, ds, warp_func=utils.DEFAULT_WARP_FUNC, objective=objective, key=0)
+  final = objective(mean_func=mu, cov_func=cov, params=out, dataset=ds, warp_func=utils.DEFAULT_WARP_FUNC)
+  assert np.isfinite(final) and final < init
+
+
 # ---- training driver on the native objective (gp_test.py:58-148, objectives_test.py:206-324) -------
 @pytest.mark.parametrize('method,steps,lr', [('adam', 10, 1e-2), ('lbfgs', 3, None)])
 @pytest.mark.parametrize('kname,mname', [('squared_exponential', 'constant'), ('matern32', 'zero'),

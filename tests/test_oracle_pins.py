@@ -129,11 +129,11 @@ def test_finite_difference_gradient_multicolumn_quirk():
 
 
 # --- (3) independent torch.autograd re-expression -------------------------------------------
-def _torch_nll(kname, mlp, mname, model_t, xs, ys, torch):
+def _torch_mu_k(kname, mlp, mname, model_t, x, torch):
+  """(mean vector [n,1], kernel matrix without noise, warp) of one sub-dataset, differentiable."""
   def warp(v):
     return torch.nn.functional.softplus(v) + 1e-10
-  total = 0.
-  for x, y in zip(xs, ys):
+  if True:
     feat = x
     if mlp or mname == 'linear_mlp':
       h = x
@@ -163,6 +163,13 @@ def _torch_nll(kname, mlp, mname, model_t, xs, ys, torch):
         # safe sqrt: gradient contribution 0 where u == 0 (hyperbo/basics/linalg.py:173-197)
         r = torch.sqrt(c * torch.where(u > 0, u, torch.ones_like(u))) * (u > 0)
         k = sv * (1 + r) * torch.exp(-r) if kname == 'matern32' else sv * (1 + r + r**2 / 3) * torch.exp(-r)
+  return mu, k, warp
+
+
+def _torch_nll(kname, mlp, mname, model_t, xs, ys, torch):
+  total = 0.
+  for x, y in zip(xs, ys):
+    mu, k, warp = _torch_mu_k(kname, mlp, mname, model_t, x, torch)
     n = x.shape[0]
     cov = k + torch.eye(n, dtype=x.dtype) * (warp(model_t['noise_variance']) + 1e-6)
     chol = torch.linalg.cholesky(cov)
@@ -202,6 +209,102 @@ def test_torch_autograd_matches_oracle_gradient(kname, mlp, mname):
     return np.zeros(t.shape) if t.grad is None else t.grad.numpy()
   gt = grad_tree(model_t)
   np.testing.assert_allclose(helpers.flatten(g), helpers.flatten(gt), rtol=1e-8, atol=1e-10)
+
+
+# --- (3b) divergence objectives (objectives.py:29-106, utils.py:84-173): FD, torch.autograd, identities -------
+def _aligned_dataset(rng, d):
+  return {'a': o.SubDataset(*helpers.synthetic_task(rng, 11, d, m=4), aligned=1),
+          'b': o.SubDataset(*helpers.synthetic_task(rng, 6, d, m=7), aligned='x'),
+          'iid': o.SubDataset(*helpers.synthetic_task(rng, 9, d)),                 # not aligned -> skipped
+          'one': o.SubDataset(*helpers.synthetic_task(rng, 5, d, m=1), aligned=2),  # m = 1 -> cov_data = 0
+          'empty': o.SubDataset(np.zeros((0, d)), np.zeros((0, 2)), aligned=3)}
+
+
+@pytest.mark.parametrize('kind', ['ekl', 'euc'])
+@pytest.mark.parametrize('kname', helpers.KERNELS)
+@pytest.mark.parametrize('mlp,mname', [(False, 'constant'), (True, 'linear_mlp'), (False, 'linear'), (True, 'zero'),
+                                       (False, 'linear_mlp')])
+def test_divergence_gradient_finite_difference_and_value(kind, kname, mlp, mname):
+  rng = np.random.default_rng(77)
+  d = 3
+  model = helpers.make_model(rng, mname, mlp, d)
+  kern = getattr(o, kname + ('_mlp' if mlp else '')); mean = getattr(o, mname)
+  ds = _aligned_dataset(rng, d)
+  dist = o.kl_multivariate_normal if kind == 'ekl' else o.euclidean_multivariate_normal
+  v, g = o.divergence_value_and_grad(kind, mean, kern, _params(model), ds, WF)
+  v_direct = o.multivariate_normal_divergence(mean, kern, _params(model), ds, WF, distance=dist)
+  assert abs(v - v_direct) <= 1e-12 * abs(v_direct)
+  x0 = helpers.flatten(model); gf = helpers.flatten(g)
+  num = np.zeros_like(x0); h = 1e-6
+  for i in range(x0.size):
+    vals = []
+    for sgn in (+1, -1):
+      xp = x0.copy(); xp[i] += sgn * h
+      vals.append(o.multivariate_normal_divergence(mean, kern, _params(helpers.unflatten_like(model, xp)), ds, WF,
+                                                   distance=dist))
+    num[i] = (vals[0] - vals[1]) / (2 * h)
+  np.testing.assert_allclose(gf, num, rtol=2e-4, atol=2e-6)
+
+
+@pytest.mark.parametrize('kind', ['ekl', 'euc'])
+@pytest.mark.parametrize('kname,mlp,mname', [('squared_exponential', False, 'constant'), ('matern32', True, 'linear_mlp'),
+                                             ('dot_product', True, 'linear'), ('matern52', False, 'zero')])
+def test_divergence_torch_autograd(kind, kname, mlp, mname):
+  torch = pytest.importorskip('torch')
+  rng = np.random.default_rng(5)
+  d = 2
+  model = helpers.make_model(rng, mname, mlp, d)
+  ds = {k: v for k, v in _aligned_dataset(rng, d).items() if k in ('a', 'b', 'one')}
+
+  def to_t(t):
+    if isinstance(t, dict):
+      return {k: to_t(v) for k, v in t.items()}
+    return torch.tensor(np.asarray(t, dtype=np.float64), requires_grad=True)
+  model_t = to_t(model)
+  total = 0.
+  for s in ds.values():
+    x = torch.tensor(s.x); y = torch.tensor(s.y)
+    mu, k, warp = _torch_mu_k(kname, mlp, mname, model_t, x, torch)
+    n, m = y.shape
+    mu0 = y.mean(dim=1); yc = y - mu0[:, None]; c0 = yc @ yc.T / m
+    k1 = k + torch.eye(n, dtype=x.dtype) * warp(model_t['noise_variance'])
+    dvec = mu[:, 0] - mu0
+    if kind == 'ekl':
+      total = total + torch.trace(torch.linalg.solve(k1, c0)) + dvec @ torch.linalg.solve(k1, dvec) + torch.logdet(k1)
+    else:
+      total = total + torch.sqrt((dvec**2).sum()) + torch.sqrt(((c0 - k1)**2).sum())
+  loss = total / len(ds)
+  loss.backward()
+  kern = getattr(o, kname + ('_mlp' if mlp else ''))
+  v, g = o.divergence_value_and_grad(kind, getattr(o, mname), kern, _params(model), ds, WF)
+  assert abs(v - loss.item()) <= 1e-10 * abs(v)
+
+  def grad_tree(t):
+    if isinstance(t, dict):
+      return {k: grad_tree(v) for k, v in t.items()}
+    return np.zeros(t.shape) if t.grad is None else t.grad.numpy()
+  np.testing.assert_allclose(helpers.flatten(g), helpers.flatten(grad_tree(model_t)), rtol=1e-8, atol=1e-9)
+
+
+def test_kl_multivariate_normal_reference_test_inputs():
+  # hyperbo/gp_utils/utils_test.py:26-55 (NumPy-seeded inputs, same assertions)
+  np.random.seed(1)
+  mu0 = np.random.uniform(-5, 5, (10,)); mu1 = np.random.uniform(-5, 5, (10,))
+  cov0 = np.random.uniform(-5, 5, (10, 100)); cov0 = cov0 @ cov0.T
+  cov1 = np.random.uniform(-5, 5, (10, 100)); cov1 = cov1 @ cov1.T
+  assert o.kl_multivariate_normal(mu0, cov0, mu1, cov1, partial=False) > 0
+  assert abs(o.kl_multivariate_normal(mu0, cov0, mu0, cov0, partial=False)) <= 1e-5
+  # closed form KL between two Gaussians
+  n = 10
+  kl_exact = 0.5 * (np.trace(np.linalg.solve(cov1, cov0)) + (mu1 - mu0) @ np.linalg.solve(cov1, mu1 - mu0) - n
+                    + np.linalg.slogdet(cov1)[1] - np.linalg.slogdet(cov0)[1])
+  assert abs(o.kl_multivariate_normal(mu0, cov0, mu1, cov1, partial=False) - kl_exact) <= 1e-8 * abs(kl_exact)
+  np.random.seed(1)
+  mu0 = np.random.uniform(-5, 5, (100,)); mu1 = np.random.uniform(-5, 5, (100,))
+  feat0 = np.random.uniform(-5, 5, (100, 5)); cov0 = feat0 @ feat0.T
+  cov1 = np.random.uniform(-5, 5, (100, 1000)); cov1 = cov1 @ cov1.T
+  kl = o.kl_multivariate_normal(mu0, cov0, mu1, cov1, partial=False)
+  assert 0 < kl < np.inf
 
 
 # --- (4) identities the reference's tests assert ---------------------------------------------

@@ -105,3 +105,41 @@ def test_infer_parameters_guards():
     gp.infer_parameters(mean.constant, kernel.squared_exponential, p, ds, objective=nan_obj)
   with pytest.raises(NotImplementedError):
     gp.infer_parameters(mean.constant, kernel.squared_exponential, p, ds, objective=lambda **kw: 0.0)
+
+
+def test_objective_algebra_composes_value_and_grad():
+  # objectives.py:221-247 add / mul and the nll_reg* aliases, with stand-in companions (no device needed)
+  from hyperbo_amd.gp_utils import objectives as obj
+  def f(**kw):
+    return 2.0
+  f.value_and_grad = lambda **kw: (2.0, {'a': np.array([1.0, 2.0]), 'b': {'c': np.array(3.0)}})
+  def g(**kw):
+    return 5.0
+  g.value_and_grad = lambda **kw: (5.0, {'a': np.array([10.0, 20.0]), 'b': {'c': np.array(30.0)}})
+  h = obj.add(f, obj.mul(0.1, g))
+  assert h() == 2.5
+  v, gr = h.value_and_grad()
+  assert v == 2.5
+  np.testing.assert_allclose(gr['a'], [2.0, 4.0]); np.testing.assert_allclose(gr['b']['c'], 6.0)
+  plain = obj.mul(3.0, lambda **kw: 1.0)
+  assert plain() == 3.0 and not hasattr(plain, 'value_and_grad')
+  assert obj.kl is obj.multivariate_normal_divergence and obj.ekl is obj.kl and obj.regkl is obj.kl
+  assert obj.euc is obj.multivariate_normal_euc_distance and obj.regeuc is obj.euc
+  for name in ('nll_regkl1', 'nll_regeuc1', 'nll_regkl01', 'nll_regeuc01', 'nll_regkl10', 'nll_regeuc10'):
+    composed = getattr(obj, name)
+    assert callable(composed) and composed.value_and_grad.accepts_device_batch
+  assert gp._value_and_grad_of(obj.nll) is obj.nll_value_and_grad
+  assert gp._value_and_grad_of(obj.ekl) is obj.ekl_value_and_grad
+  assert gp._value_and_grad_of(obj.euc) is obj.euc_value_and_grad
+  with pytest.raises(NotImplementedError):
+    gp._value_and_grad_of(lambda **kw: 0.0)
+
+
+def test_divergence_selection_rule_and_malformed_y():
+  from hyperbo_amd.gp_utils import objectives as obj
+  ds = {'iid': defs.SubDataset(np.zeros((3, 1)), np.zeros((3, 1))),
+        'al': defs.SubDataset(np.zeros((4, 1)), np.zeros((4, 2)), aligned=1),
+        'empty': defs.SubDataset(np.zeros((0, 1)), np.zeros((0, 2)), aligned=2)}
+  assert [k for k, _ in obj.included_sub_datasets(ds, only_aligned=True)] == ['al']
+  assert [k for k, _ in obj.included_sub_datasets(ds, exclude_aligned=True)] == ['iid']
+  assert [k for k, _ in obj.included_sub_datasets(ds, exclude_aligned=False)] == ['iid', 'al']
