@@ -81,6 +81,8 @@ SIGNATURES = {
     'hbo_cache_export': (C.c_int, [_P, _P, _P, _P, _P]),
     'hbo_cache_free': (C.c_int, [_P, _P]),
     'hbo_cache_append': (C.c_int, [_P, C.POINTER(Model), _P, _P, C.c_int64, _P]),
+    'hbo_acq_grad': (C.c_int, [_P, C.POINTER(Model), _P, _P, C.c_int64, C.c_int, C.c_double, C.c_double, C.c_double,
+                               _P, C.POINTER(C.c_double)]),
     'hbo_predict': (C.c_int, [_P, C.POINTER(Model), _P, _P, C.c_int64, C.c_int, _P, _P]),
     'hbo_acq': (C.c_int, [_P, C.POINTER(Model), _P, _P, C.c_int64, C.c_int, C.c_double, C.c_double,
                           C.c_double, _P]),

@@ -78,6 +78,34 @@ def acfun_wrapper(acfun_sub, acfun_callback_default):
                                 float(add_noise), float(scale), nat.ptr(out)))
     return out
 
+  def value_and_grad(*, model, sub_dataset_key, x_queries, acfun_callback=acfun_callback_default):
+    """(values (M,1), d value_q / d x_queries[q] (M,D) in float64) -- the pair jax.value_and_grad of
+    `lambda x: ac_func(model=..., x_queries=x[None])` yields inside bayesopt() (bayesopt.py:116-125)."""
+    if isinstance(model, gp.HGP):
+      raise NotImplementedError('acquisition gradients are only implemented for a plain GP')
+    x_queries = np.asarray(x_queries)
+    acfun_param = acfun_callback(model, sub_dataset_key)
+    handle = None
+    if sub_dataset_key in model.dataset:
+      model.setup_predictor(sub_dataset_key)
+      handle = model.params.cache[sub_dataset_key].handle
+    dtype = handle.dtype if handle is not None else _model.infer_dtype(x_queries)
+    xq = np.ascontiguousarray(x_queries, dtype=dtype)
+    out = np.empty((xq.shape[0], 1), dtype=dtype)
+    grad = np.zeros((xq.shape[0], model.input_dim), dtype=np.float64)
+    if xq.shape[0] == 0:
+      return out, grad
+    add_noise, scale = model.predict_noise_and_scale(True, True)
+    bm = _model.BuiltModel(model.mean_func, model.cov_func, model.params, model.warp_func, dtype,
+                           model.input_dim)
+    ctx = handle.ctx if handle is not None else nat.default_context()
+    ctx.check(nat.lib().hbo_acq_grad(ctx.handle, bm.ref(), handle.handle if handle is not None else None,
+                                     nat.ptr(xq), xq.shape[0], _NATIVE_ID[acfun_sub], float(acfun_param),
+                                     float(add_noise), float(scale), nat.ptr(out),
+                                     grad.ctypes.data_as(nat.C.POINTER(nat.C.c_double))))
+    return out, grad
+
+  acquisition_function.value_and_grad = value_and_grad
   return acquisition_function
 
 

@@ -1,5 +1,6 @@
-"""Registries -- hyperbo/bo_utils/const.py:22-50: the closed set the native dispatcher covers."""
+"""Registries -- hyperbo/bo_utils/const.py:22-81: the closed set the native dispatcher covers."""
 from hyperbo_amd.bo_utils import acfun
+from hyperbo_amd.bo_utils import data
 from hyperbo_amd.gp_utils import kernel
 from hyperbo_amd.gp_utils import mean
 
@@ -28,3 +29,6 @@ ACFUN_SUB = {
     'ucb': acfun.ucb_sub,
 }
 EPS = 1e-6
+
+HYPERBO_DATASETS = {'pd1': data.pd1, 'random': data.random}   # const.py:54-59
+INPUT_SAMPLERS = {}                                             # const.py:61 (empty in the reference too)

@@ -75,7 +75,8 @@ static inline int64_t padded_ld(int64_t extent, int dtype) { return extent + 128
 
 // grow-only scratch buffer for `slot`; nullptr on allocation failure (ctx->err is set)
 enum WsSlot { WS_XQ = 1, WS_MU0, WS_KD, WS_MU, WS_VAR, WS_ACQ, WS_K, WS_COLSQ, WS_V, WS_KQQ, WS_COV,
-              WS_AP_KX, WS_AP_L, WS_AP_W, WS_AP_MU, WS_AP_KD, WS_FQ0 /* + layer */ };
+              WS_AP_KX, WS_AP_L, WS_AP_W, WS_AP_MU, WS_AP_KD,
+              WS_AG_K, WS_AG_L, WS_AG_B, WS_AG_GF, WS_AG_DMU, WS_AG_GX, WS_AG_T0, WS_AG_T1, WS_AG_DW, WS_FQ0 /* + layer */ };
 static void* ws_get(hbo_ctx* c, int slot, size_t bytes) {
   auto& e = c->ws[slot];
   if (e.second < bytes || !e.first) {
@@ -1153,6 +1154,110 @@ extern "C" int hbo_acq(hbo_ctx* c, const hbo_model* m, hbo_cache* k, const void*
   if (acq_id < 0 || acq_id > HBO_ACQ_UCB) return fail(c, HBO_ERR_ARG, "hbo_acq: bad acq_id");
   if (!out) return fail(c, HBO_ERR_ARG, "hbo_acq: out is null");
   return posterior(c, m, k, xq, M, 0, nullptr, nullptr, out, acq_id, param, add_noise, scale);
+}
+
+// ---- d acquisition / d x_query: what jaxopt's L-BFGS-B differentiates in bayesopt() (bayesopt.py:116-125) ----
+extern "C" int hbo_acq_grad(hbo_ctx* c, const hbo_model* m, hbo_cache* k, const void* xq, int64_t M, int acq_id,
+                            double param, double add_noise, double scale, void* acq_out, double* grad_out) {
+  if (!c || !xq || !acq_out || !grad_out || !m) return fail(c, HBO_ERR_ARG, "hbo_acq_grad: null argument");
+  if (acq_id < 0 || acq_id > HBO_ACQ_UCB) return fail(c, HBO_ERR_ARG, "hbo_acq_grad: bad acq_id");
+  if (M <= 0) return HBO_OK;
+  HIPCHK(c, hipSetDevice(c->device));
+  int rc = validate_model(c, m);
+  if (rc) return rc;
+  rc = upload_model(c, m);
+  if (rc) return rc;
+  const int dtype = m->dtype;
+  if (k && (k->dtype != dtype || k->D != m->input_dim)) return fail(c, HBO_ERR_ARG, "hbo_acq_grad: cache/model mismatch");
+  const size_t es = esize(dtype);
+  hipStream_t st = c->stream;
+  const int D = m->input_dim, fdim = feature_dim(m), fm = mean_feature_dim(m);
+  const bool mlp = needs_mlp(m);
+  const int L = m->n_layers, flast = mlp ? m->features[L - 1] : 0;
+  TaskHost* t = (k && k->t->n > 0) ? k->t : nullptr;
+  const int64_t CH = 1024;   // queries per pass: three [CH][npad] panels of workspace
+  const int64_t mc_max = std::min<int64_t>(M, CH);
+  int maxf = D;
+  for (int l = 0; l < L; ++l) maxf = std::max(maxf, (int)m->features[l]);
+  size_t nparam = 1;
+  { int fin0 = D; for (int l = 0; l < L; ++l) { nparam = std::max(nparam, (size_t)(fin0 + 1) * m->features[l]); fin0 = m->features[l]; } }
+  void* d_xq = ws_get(c, WS_XQ, (size_t)mc_max * D * es);
+  void* d_mu0 = ws_get(c, WS_MU0, (size_t)mc_max * es);
+  void* d_kd = ws_get(c, WS_KD, (size_t)mc_max * es);
+  void* d_acq = ws_get(c, WS_ACQ, (size_t)mc_max * es);
+  double* d_gf = (double*)ws_get(c, WS_AG_GF, (size_t)mc_max * fdim * sizeof(double));
+  double* d_dmu = (double*)ws_get(c, WS_AG_DMU, (size_t)mc_max * sizeof(double));
+  double* d_gx = (double*)ws_get(c, WS_AG_GX, (size_t)mc_max * D * sizeof(double));
+  double* d_t0 = (double*)ws_get(c, WS_AG_T0, (size_t)mc_max * maxf * sizeof(double));
+  double* d_t1 = (double*)ws_get(c, WS_AG_T1, (size_t)mc_max * maxf * sizeof(double));
+  double* d_dw = (double*)ws_get(c, WS_AG_DW, nparam * sizeof(double));   // weight-gradient sink of the shared MLP backward
+  if (!d_xq || !d_mu0 || !d_kd || !d_acq || !d_gf || !d_dmu || !d_gx || !d_t0 || !d_t1 || !d_dw) return HBO_ERR_HIP;
+  void *d_K = nullptr, *d_L = nullptr, *d_B = nullptr;
+  if (t) {
+    d_K = ws_get(c, WS_AG_K, (size_t)mc_max * t->npad * es); d_L = ws_get(c, WS_AG_L, (size_t)mc_max * t->npad * es);
+    d_B = ws_get(c, WS_AG_B, (size_t)mc_max * t->npad * es);
+    if (!d_K || !d_L || !d_B) return HBO_ERR_HIP;
+  }
+  void* fq_acts[HBO_MAX_MLP_LAYERS] = {nullptr};
+  if (mlp) for (int l = 0; l < L; ++l) { fq_acts[l] = ws_get(c, WS_FQ0 + l, (size_t)mc_max * m->features[l] * es); if (!fq_acts[l]) return HBO_ERR_HIP; }
+  const bool bad = k && k->info != INT_MAX;
+#define HIPCHK_D(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) { c->err = std::string(#call " failed: ") + hipGetErrorString(e__); return HBO_ERR_HIP; } } while (0)
+  for (int64_t q0 = 0; q0 < M; q0 += CH) {
+    const int64_t mc = std::min<int64_t>(CH, M - q0);
+    HIPCHK_D(hipMemcpyAsync(d_xq, (const char*)xq + (size_t)q0 * D * es, (size_t)mc * D * es, hipMemcpyHostToDevice, st));
+    const void* fq_last = nullptr;
+    if (mlp) { run_mlp(c, m, d_xq, mc, fq_acts); fq_last = fq_acts[L - 1]; }
+    const void* Fq = m->kernel_uses_mlp ? fq_last : d_xq;
+    const void* Fmq = (m->mean_id == HBO_MEAN_LINEAR) ? d_xq : (m->mean_id == HBO_MEAN_LINEAR_MLP ? fq_last : nullptr);
+    launch_mean(dtype, Fmq, mc, fm, c->d_model, d_mu0, st);
+    launch_kdiag(dtype, Fq, mc, fdim, c->d_model, d_kd, st);
+    if (t) {
+      HIPCHK_D(hipMemsetAsync(d_K, 0, (size_t)mc * t->npad * es, st));
+      GramArgs g = {}; g.x1 = Fq; g.x2 = k->h_desc.F; g.out = d_K; g.n1 = mc; g.n2 = t->n; g.ldo = t->npad; g.fdim = fdim;
+      launch_gram(dtype, g, c->d_model, dim3((unsigned)((t->n + 127) / 128), (unsigned)((mc + 127) / 128), 1), st);
+      launch_tri_matvec(dtype, t->W, t->ld, t->npad, d_K, t->npad, (int)mc, 0, d_L, t->npad, st);
+      launch_tri_matvec(dtype, t->W, t->ld, t->npad, d_L, t->npad, (int)mc, 1, d_B, t->npad, st);
+    }
+    AcqGradArgs a = {};
+    a.Fq = Fq; a.F = t ? k->h_desc.F : nullptr; a.fdim = fdim; a.n = t ? t->n : 0; a.npad = t ? t->npad : 0;
+    a.Kq = d_K; a.L = d_L; a.B = d_B; a.alpha = t ? t->svec : nullptr; a.kdiag = d_kd; a.muq = d_mu0;
+    a.acq_id = acq_id; a.param = param; a.add_noise = add_noise; a.scale = scale;
+    a.acq_out = d_acq; a.gfeat = d_gf; a.dmu = d_dmu; a.M = mc;
+    launch_acq_grad(dtype, a, c->d_model, st);
+    // assemble d/dx: kernel part (direct or through the MLP) + mean part (mean.py:62-79)
+    double* gmlp = nullptr;   // gradient w.r.t. the MLP output
+    if (m->kernel_uses_mlp) {
+      gmlp = d_gf;
+      if (m->mean_id == HBO_MEAN_LINEAR_MLP) launch_acq_grad_mean(d_dmu, c->d_model, mc, flast, gmlp, 1, st);
+      HIPCHK_D(hipMemsetAsync(d_gx, 0, (size_t)mc * D * sizeof(double), st));
+      if (m->mean_id == HBO_MEAN_LINEAR) launch_acq_grad_mean(d_dmu, c->d_model, mc, D, d_gx, 1, st);
+    } else {
+      HIPCHK_D(hipMemcpyAsync(d_gx, d_gf, (size_t)mc * D * sizeof(double), hipMemcpyDeviceToDevice, st));
+      if (m->mean_id == HBO_MEAN_LINEAR) launch_acq_grad_mean(d_dmu, c->d_model, mc, D, d_gx, 1, st);
+      if (m->mean_id == HBO_MEAN_LINEAR_MLP) { gmlp = d_t0; launch_acq_grad_mean(d_dmu, c->d_model, mc, flast, gmlp, 0, st); }
+    }
+    if (gmlp) {
+      double* cur = gmlp; double* other = (gmlp == d_t0) ? d_t1 : d_t0;
+      for (int l = L - 1; l >= 0; --l) {
+        const int fin = l ? m->features[l - 1] : D;
+        const void* in = l ? fq_acts[l - 1] : d_xq;
+        launch_dense_bwd(dtype, in, fq_acts[l], c->d_mlp_w[l], cur, other, d_dw, d_dw + (size_t)fin * m->features[l], mc, fin, m->features[l], st);
+        cur = other; other = (cur == d_t0) ? d_t1 : d_t0;
+      }
+      launch_add_inplace(d_gx, cur, mc * D, st);
+    }
+    HIPCHK_D(hipMemcpyAsync((char*)acq_out + (size_t)q0 * es, d_acq, (size_t)mc * es, hipMemcpyDeviceToHost, st));
+    HIPCHK_D(hipMemcpyAsync(grad_out + (size_t)q0 * D, d_gx, (size_t)mc * D * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIPCHK_D(hipStreamSynchronize(st));
+  }
+  HIPCHK_D(hipGetLastError());
+#undef HIPCHK_D
+  if (bad) {
+    fill_nan(acq_out, (size_t)M, dtype);
+    for (int64_t i = 0; i < M * D; ++i) grad_out[i] = NAN;
+    return HBO_NOT_PD;
+  }
+  return HBO_OK;
 }
 
 // ---- Gram / mean on host arrays --------------------------------------------------------------

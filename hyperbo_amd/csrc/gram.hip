@@ -753,6 +753,103 @@ __global__ __launch_bounds__(256) void grad_finalize_kernel(const TaskDesc* task
 __device__ __forceinline__ double norm_pdf(double x) { return exp(-0.5 * x * x) * 0.3989422804014327; }
 __device__ __forceinline__ double norm_cdf(double x) { return 0.5 * erfc(-x * 0.7071067811865476); }
 
+// ---------------------------------------------------------------------------------------
+// d acquisition / d (kernel features of the query), one workgroup per query (bayesopt.py:116-125 differentiates
+// -ac_func w.r.t. a single x; batches of restarts come as M rows).  With l = W k(X,x), beta = W^T l:
+//   mu = k.alpha + m(x), var = k(x,x) - |l|^2, coef_i = a_mu alpha_i - 2 a_var beta_i,
+//   SE/Matern: g_d = sum_i coef_i dk/du_i * 2 (f_d - F_id)/ls_d^2;  dot: g = sum_i coef_i F_i/sigma^2 + a_var 2 f/sigma^2.
+// ---------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void acq_grad_kernel(AcqGradArgs a, const ModelDev* __restrict__ md) {
+  __shared__ double sred[4];
+  __shared__ double s_w[256];
+  __shared__ double s_fq[HBO_MAX_FEATURE_DIM];
+  __shared__ double s_acc[256];
+  __shared__ double s_amu, s_avar;
+  const int64_t q = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int fdim = a.fdim;
+  const int kid = md->kernel_id;
+  const bool is_dot = (kid == HBO_KERNEL_DOT);
+  const T* Fq = static_cast<const T*>(a.Fq) + q * fdim;
+  const T* F = static_cast<const T*>(a.F);
+  const T* Kq = a.Kq ? static_cast<const T*>(a.Kq) + q * a.npad : nullptr;
+  const T* L = a.L ? static_cast<const T*>(a.L) + q * a.npad : nullptr;
+  const T* B = a.B ? static_cast<const T*>(a.B) + q * a.npad : nullptr;
+  const T* al = static_cast<const T*>(a.alpha);
+  for (int d = tid; d < fdim; d += 256) s_fq[d] = (double)Fq[d];
+  double ka = 0, ll = 0;
+  for (int64_t i = tid; i < a.n; i += 256) { ka += (double)Kq[i] * (double)al[i]; const double l = (double)L[i]; ll += l * l; }
+  ka = block_sum(ka, sred);
+  ll = block_sum(ll, sred);
+  if (tid == 0) {
+    const double mu = ka + (double)static_cast<const T*>(a.muq)[q];
+    const double var = (double)static_cast<const T*>(a.kdiag)[q] - ll;
+    const double v2 = (var + a.add_noise) * a.scale;
+    const double sd = sqrt(v2);
+    double val, amu, asd;
+    if (a.acq_id == HBO_ACQ_UCB) { val = mu + a.param * sd; amu = 1.0; asd = a.param; }
+    else if (a.acq_id == HBO_ACQ_PI) { val = (mu - a.param) / sd; amu = 1.0 / sd; asd = -(mu - a.param) / (sd * sd); }
+    else { const double u = (mu - a.param) / sd; val = sd * (norm_pdf(u) + u * norm_cdf(u)); amu = norm_cdf(u); asd = norm_pdf(u); }
+    s_amu = amu; s_avar = asd / (2.0 * sd) * a.scale;
+    static_cast<T*>(a.acq_out)[q] = (T)val;
+    a.dmu[q] = amu;
+  }
+  __syncthreads();
+  const double amu = s_amu, avar = s_avar;
+  // thread layout for the feature reduction: FD = pow2 >= fdim lanes per group, G groups over i
+  int FD = 1; while (FD < fdim) FD <<= 1;
+  const int G = 256 / FD, grp = tid / FD, dl = tid % FD;
+  const double sv = md->sv;
+  const double inv_sigma2 = 1.0 / (md->dot_sigma * md->dot_sigma);
+  double acc = 0;
+  for (int64_t i0 = 0; i0 < a.n; i0 += 256) {
+    const int64_t i = i0 + tid;
+    double w = 0;
+    if (i < a.n) {
+      const double coef = amu * (double)al[i] - 2.0 * avar * (double)B[i];
+      if (is_dot) w = coef * inv_sigma2;
+      else {
+        double u = 0;
+        for (int d = 0; d < fdim; ++d) { const double df = (s_fq[d] - (double)F[i * fdim + d]) * md->inv_ls[d]; u += df * df; }
+        const double k = kfun<double>(kid, u, sv, inv_sigma2, 0.0);
+        w = coef * dk_du<double>(kid, u, k, sv) * 2.0;
+      }
+    }
+    __syncthreads();
+    s_w[tid] = w;
+    __syncthreads();
+    const int lim = (int)((a.n - i0) < 256 ? (a.n - i0) : 256);
+    if (dl < fdim)
+      for (int ii = grp; ii < lim; ii += G) {
+        const double fi = (double)F[(i0 + ii) * fdim + dl];
+        acc += is_dot ? s_w[ii] * fi : s_w[ii] * (s_fq[dl] - fi);
+      }
+  }
+  __syncthreads();
+  s_acc[tid] = acc;
+  __syncthreads();
+  if (grp == 0 && dl < fdim) {
+    double s = 0;
+    for (int g = 0; g < G; ++g) s += s_acc[g * FD + dl];
+    if (is_dot) s += avar * 2.0 * s_fq[dl] * inv_sigma2;
+    else s *= md->inv_ls[dl] * md->inv_ls[dl];
+    a.gfeat[q * fdim + dl] = s;
+  }
+}
+// out[q][d] (+)= dmu[q] * lin_w[d]   (linear / linear_mlp mean, mean.py:62-79)
+__global__ void acq_grad_mean_kernel(const double* dmu, const ModelDev* __restrict__ md, int64_t M, int fm,
+                                     double* out, int accumulate) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= M * fm) return;
+  const double v = dmu[idx / fm] * md->lin_w[idx % fm];
+  out[idx] = accumulate ? out[idx] + v : v;
+}
+__global__ void add_inplace_kernel(double* dst, const double* src, int64_t count) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < count) dst[idx] += src[idx];
+}
+
 template <typename T>
 __global__ void post_epilogue_kernel(PostArgs a) {
   const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -970,6 +1067,20 @@ void launch_dense_bwd(int dtype, const void* in, const void* out, const void* w,
     hipLaunchKernelGGL((dense_bwd_w_kernel<float>), gw, dim3(thr), 0, st, (const float*)in, dout, n, fin, fout, dW, db, rpb);
     if (din) hipLaunchKernelGGL((dense_bwd_in_kernel<float>), dim3((unsigned)((n * fin + 255) / 256)), dim3(256), 0, st, dout, (const float*)w, n, fin, fout, din);
   }
+}
+void launch_acq_grad(int dtype, const AcqGradArgs& a, const ModelDev* md, hipStream_t st) {
+  if (a.M <= 0) return;
+  if (dtype == HBO_F64) hipLaunchKernelGGL((acq_grad_kernel<double>), dim3((unsigned)a.M), dim3(256), 0, st, a, md);
+  else hipLaunchKernelGGL((acq_grad_kernel<float>), dim3((unsigned)a.M), dim3(256), 0, st, a, md);
+}
+void launch_acq_grad_mean(const double* dmu, const ModelDev* md, int64_t M, int fm, double* out, int accumulate,
+                          hipStream_t st) {
+  if (M * fm <= 0) return;
+  hipLaunchKernelGGL(acq_grad_mean_kernel, dim3((unsigned)((M * fm + 255) / 256)), dim3(256), 0, st, dmu, md, M, fm, out, accumulate);
+}
+void launch_add_inplace(double* dst, const double* src, int64_t count, hipStream_t st) {
+  if (count <= 0) return;
+  hipLaunchKernelGGL(add_inplace_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, dst, src, count);
 }
 void launch_post_epilogue(int dtype, const PostArgs& a, hipStream_t st) {
   if (a.M <= 0) return;

@@ -135,6 +135,21 @@ struct PostArgs {
   int acq_id; double param, add_noise, scale;
 };
 void launch_post_epilogue(int dtype, const PostArgs& a, hipStream_t st);
+
+struct AcqGradArgs {
+  const void* Fq; const void* F; int fdim; int64_t n; int npad;   // kernel features: queries [M][fdim], training [n][fdim]
+  const void* Kq; const void* L; const void* B;   // [M][npad]: k(x_q, X), W k, W^T W k  (null when n == 0)
+  const void* alpha; const void* kdiag; const void* muq;
+  int acq_id; double param, add_noise, scale;
+  void* acq_out;     // [M] model dtype
+  double* gfeat;     // [M][fdim] d acq / d kernel features
+  double* dmu;       // [M] d acq / d mu
+  int64_t M;
+};
+void launch_acq_grad(int dtype, const AcqGradArgs& a, const ModelDev* md, hipStream_t st);
+void launch_acq_grad_mean(const double* dmu, const ModelDev* md, int64_t M, int fm, double* out, int accumulate,
+                          hipStream_t st);
+void launch_add_inplace(double* dst, const double* src, int64_t count, hipStream_t st);
 void launch_fullcov(int dtype, const void* V, int64_t ldq, int npad, const void* Kqq, int64_t M, void* out,
                     hipStream_t st);
 void launch_extract_lower(int dtype, const void* A, int64_t ld, int64_t n, void* out, hipStream_t st);

@@ -51,6 +51,24 @@ def _value_and_grad_of(objective):
   return vg
 
 
+def sample_from_gp(key, mean_func, cov_func, params, x, warp_func=None, num_samples=1, method='cholesky', eps=1e-6):
+  """gp.py:198-240: (n, num_samples) draws of N(mean(x), K(x,x) + (noise + eps) I).  Gram and Cholesky run on
+  the device (hbo_gram, hbo_spd_solve); the O(n^2) product with the normal draws is on the host.
+  `key`: NumPy Generator or seed; `method` other than 'cholesky' is not offered."""
+  if method != 'cholesky':
+    raise NotImplementedError("sample_from_gp: only method='cholesky'")
+  from hyperbo_amd.basics import linalg
+  rng = key if isinstance(key, np.random.Generator) else np.random.default_rng(0 if key is None else key)
+  x = np.asarray(x)
+  n = x.shape[0]
+  mu = np.asarray(mean_func(params, x, warp_func=warp_func), dtype=np.float64).reshape(-1)
+  noise_variance, = params_utils.retrieve_params(params, ['noise_variance'], warp_func=warp_func)
+  cov = np.asarray(cov_func(params, x, warp_func=warp_func), dtype=np.float64)
+  cov = cov + np.eye(n) * (float(np.squeeze(noise_variance)) + eps)
+  chol, _ = linalg.solve_linear_system(cov, np.zeros((n, 1)))
+  return mu[:, None] + chol @ rng.standard_normal((n, num_samples))
+
+
 def infer_parameters(mean_func, cov_func, init_params, dataset, warp_func=None,
                      objective=obj.neg_log_marginal_likelihood, key=None, get_params_path=None, callback=None):
   """Posterior inference for a meta GP -- the training driver of hyperbo/gp_utils/gp.py:53-195.

@@ -163,6 +163,13 @@ int hbo_predict(hbo_ctx* ctx, const hbo_model* model, hbo_cache* cache, const vo
 int hbo_acq(hbo_ctx* ctx, const hbo_model* model, hbo_cache* cache, const void* xq, int64_t M,
             int acq_id, double param, double add_noise, double scale, void* out);
 
+/* ---- d acquisition / d x_query: the gradient jaxopt.ScipyBoundedMinimize(L-BFGS-B) takes of
+ *      f(x) = -ac_func(model, key, x[None]) in bayesopt() (hyperbo/bo_utils/bayesopt.py:116-125).
+ *      Queries are independent rows: out [M,1] (model dtype) as hbo_acq, grad_out [M, input_dim] doubles.
+ *      Matern kernels: a query at zero distance from a training point contributes 0 (linalg.py:183-188). */
+int hbo_acq_grad(hbo_ctx* ctx, const hbo_model* model, hbo_cache* cache, const void* xq, int64_t M,
+                 int acq_id, double param, double add_noise, double scale, void* out, double* grad_out);
+
 /* ---- dense building blocks (linalg.py:29-33 solve_linear_system); host in/out ----------- */
 /* a: [n,n] SPD (only the lower triangle is read).  chol_out: lower factor (zeros above diag);
  * inv_out (nullable): full symmetric a^-1;  b/x_out (nullable): [n,m] solve a x = b. */

@@ -796,3 +796,91 @@ def divergence_value_and_grad(kind, mean_func, cov_func, params, dataset, warp_f
   if num:
     total /= num; grads = _tree_scale(grads, 1.0 / num)
   return total, grads
+
+
+# ----------------------------------------------------------------------------
+# d acquisition / d x_query -- what jaxopt.ScipyBoundedMinimize differentiates in bayesopt()
+# (hyperbo/bo_utils/bayesopt.py:116-125: f(x) = -ac_func(model, key, x[None]))
+# ----------------------------------------------------------------------------
+def acquisition_value_and_grad(acq_name, mean_func, cov_func, params, x_observed, y_observed, x_query, acq_param,
+                               warp_func=None, add_noise=0.0, scale=1.0):
+  """Values (M,1) and d value_q / d x_query[q] (M,D) of EI / PI / UCB on the posterior of gp.py:242-305 with the
+  GP.predict post-processing var' = (var + add_noise) * scale (gp.py:607-619).  Queries are independent.
+
+  mu = k(x,X) alpha + m(x),  var = k(x,x) - k(x,X) K^-1 k(X,x):
+    d mu/dx = sum_i alpha_i dk(x,X_i)/dx + dm/dx,   d var/dx = dk(x,x)/dx - 2 sum_i beta_i dk(x,X_i)/dx,  beta = K^-1 k(X,x)
+  EI = s (phi(u) + u Phi(u)), u = (mu - t)/s: dEI/dmu = Phi(u), dEI/ds = phi(u);  PI(-gamma) = (mu - t)/s;  UCB = mu + beta s.
+  Matern kernels: zero-distance pairs contribute 0 (linalg.py:183-188 safe sqrt)."""
+  xq = np.asarray(x_query, dtype=np.float64)
+  mq, dim = xq.shape
+  model = params.model
+  base = cov_func.base_name; use_mlp_k = cov_func.uses_mlp; mean_name = mean_func.__name__
+  has_data = x_observed is not None and np.shape(x_observed)[0] > 0
+  mlp_needed = use_mlp_k or mean_name == 'linear_mlp'
+  acts_q = _mlp_forward_cache(model['mlp_params'], xq) if mlp_needed else None
+  fq = acts_q[-1] if use_mlp_k else xq
+  mu0 = np.asarray(mean_func(params, xq, warp_func=warp_func), dtype=np.float64)[:, 0]
+  kdiag = np.asarray(cov_func(params, xq, warp_func=warp_func, diag=True), dtype=np.float64)
+  if has_data:
+    xo = np.asarray(x_observed, dtype=np.float64)
+    chol, kinvy, _ = solve_gp_linear_system(mean_func, cov_func, params, xo, np.asarray(y_observed, dtype=np.float64),
+                                            warp_func)
+    fo = mlp_apply(model['mlp_params'], xo) if use_mlp_k else xo
+    kxq = np.asarray(cov_func(params, xo, xq, warp_func=warp_func), dtype=np.float64)     # (n, M)
+    alpha = kinvy[:, 0]
+    beta = spla.cho_solve((chol, True), kxq)                                               # (n, M)
+    mu = kxq.T @ alpha + mu0
+    var = kdiag - np.sum(kxq * beta, axis=0)
+  else:
+    mu, var = mu0, kdiag
+  v2 = (var + add_noise) * scale
+  sd = np.sqrt(v2)
+  if acq_name == 'ei':
+    u = (mu - acq_param) / sd
+    val = sd * (_norm_pdf(u) + u * _norm_cdf(u)); da_dmu = _norm_cdf(u); da_dsd = _norm_pdf(u)
+  elif acq_name == 'pi':
+    val = (mu - acq_param) / sd; da_dmu = 1.0 / sd; da_dsd = -(mu - acq_param) / sd**2
+  else:
+    val = mu + acq_param * sd; da_dmu = np.ones_like(mu); da_dsd = np.full_like(mu, acq_param)
+  da_dvar = da_dsd / (2 * sd) * scale
+  gfeat = np.zeros_like(fq)
+  if base == 'dot_product':
+    sigma, = retrieve_params(params, ['dot_prod_sigma'], warp_func)
+    s2 = float(np.squeeze(sigma))**2
+    gfeat += (da_dvar * 2.0 / s2)[:, None] * fq
+    if has_data:
+      coef = da_dmu[None, :] * alpha[:, None] - 2.0 * da_dvar[None, :] * beta               # (n, M)
+      gfeat += coef.T @ fo / s2
+  elif has_data:
+    ls, sv = retrieve_params(params, ['lengthscale', 'signal_variance'], warp_func)
+    ls = np.broadcast_to(np.asarray(ls, dtype=np.float64).reshape(-1), (fq.shape[1],)); sv = float(np.squeeze(sv))
+    diff = fq[:, None, :] - fo[None, :, :]                                                 # (M, n, F)
+    u2 = np.sum((diff / ls)**2, axis=-1)
+    if base == 'squared_exponential':
+      dk_du = -0.5 * sv * np.exp(-u2 / 2)
+    elif base == 'matern32':
+      rr = np.sqrt(3.0 * u2); dk_du = np.where(u2 == 0, 0.0, -sv * 1.5 * np.exp(-rr))
+    else:
+      rr = np.sqrt(5.0 * u2); dk_du = np.where(u2 == 0, 0.0, -sv * 5.0 * np.exp(-rr) * (1 + rr) / 6)
+    coef = (da_dmu[None, :] * alpha[:, None] - 2.0 * da_dvar[None, :] * beta).T             # (M, n)
+    gfeat += 2.0 * np.einsum('qi,qid->qd', coef * dk_du, diff) / ls**2
+  grad = np.zeros((mq, dim))
+  gmlp = np.zeros_like(acts_q[-1]) if mlp_needed else None
+  if use_mlp_k:
+    gmlp += gfeat
+  else:
+    grad += gfeat
+  if mean_name == 'linear':
+    grad += da_dmu[:, None] * np.asarray(model['linear_mean']['kernel'], dtype=np.float64)[:, 0][None, :]
+  elif mean_name == 'linear_mlp':
+    gmlp += da_dmu[:, None] * np.asarray(model['linear_mean']['kernel'], dtype=np.float64)[:, 0][None, :]
+  if mlp_needed:
+    # backward through tanh(Dense) layers to the inputs
+    n_layers = len(model['mlp_params'])
+    g = gmlp
+    for l in range(n_layers - 1, -1, -1):
+      out = acts_q[l + 1]   # acts[0] is the input
+      dz = g * (1.0 - out * out)
+      g = dz @ np.asarray(model['mlp_params'][f'Dense_{l}']['kernel'], dtype=np.float64).T
+    grad += g
+  return val[:, None], grad

@@ -307,6 +307,43 @@ def test_kl_multivariate_normal_reference_test_inputs():
   assert 0 < kl < np.inf
 
 
+# --- (3c) d acquisition / d x_query (what bayesopt.py:116-125 differentiates) vs central differences ---------
+@pytest.mark.parametrize('acq', ['ei', 'pi', 'ucb'])
+@pytest.mark.parametrize('kname', helpers.KERNELS)
+@pytest.mark.parametrize('mlp,mname', [(False, 'constant'), (True, 'linear_mlp'), (False, 'linear'), (True, 'zero'),
+                                       (False, 'linear_mlp')])
+@pytest.mark.parametrize('n_obs', [0, 17])
+def test_acquisition_gradient_finite_difference(acq, kname, mlp, mname, n_obs):
+  rng = np.random.default_rng(9)
+  d = 3
+  model = helpers.make_model(rng, mname, mlp, d)
+  params = _params(model)
+  kern = getattr(o, kname + ('_mlp' if mlp else '')); mean = getattr(o, mname)
+  xo, yo = helpers.synthetic_task(rng, max(n_obs, 1), d)
+  xo, yo = xo[:n_obs], yo[:n_obs]
+  xq = rng.uniform(size=(5, d))
+  if n_obs:
+    xq[0] = xo[3]            # a query on top of a training point (Matern safe-sqrt branch)
+  param = {'ei': 0.3, 'pi': 0.4, 'ucb': 3.0}[acq]
+  sub = {'ei': o.expected_improvement_sub, 'pi': o.probability_of_improvement_sub, 'ucb': o.ucb_sub}[acq]
+  add_noise = float(np.squeeze(o.retrieve_params(params, ['noise_variance'], WF)[0])); scale = 1.25
+
+  def value(xqq):
+    mu, var = o.predict(mean, kern, params, xo if n_obs else None, yo if n_obs else None, xqq, warp_func=WF)
+    var = (var + add_noise) * scale
+    return sub(mu, np.sqrt(var), param)
+  val, grad = o.acquisition_value_and_grad(acq, mean, kern, params, xo, yo, xq, param, WF, add_noise, scale)
+  np.testing.assert_allclose(val, value(xq), rtol=1e-10, atol=1e-12)
+  h = 1e-6
+  for q in range(xq.shape[0]):
+    if q == 0 and n_obs and kname.startswith('matern'):
+      continue   # kink of the Matern kernel at zero distance: one-sided derivatives differ
+    for j in range(d):
+      xp = xq.copy(); xp[q, j] += h; xm = xq.copy(); xm[q, j] -= h
+      num = (value(xp)[q, 0] - value(xm)[q, 0]) / (2 * h)
+      assert abs(num - grad[q, j]) <= 2e-5 * max(1.0, abs(num)), (q, j, num, grad[q, j])
+
+
 # --- (4) identities the reference's tests assert ---------------------------------------------
 @pytest.mark.parametrize('kname', helpers.KERNELS)
 def test_svd_nll_equals_cholesky_nll(kname):  # objectives_test.py:168,185
