@@ -51,13 +51,27 @@ constexpr int potf2_lds_bytes() { return (36 * TILE_ELEMS + NB) * (int)sizeof(T)
 // pivot by readlane, rsqrt, scale column j (lanes with col == j), and one rank-1 MFMA update
 // acc -= f f^T with f_c = S[j][c]/sqrt(d) for c > j (taken from row j by symmetry, zero elsewhere,
 // so finished columns are never touched).  Returns the first failing column or -1.
+// 1/sqrt(d): v_rsq_f64 (~26 bits) + one third-order correction step -- the refinement the precise library rsqrt
+// performs, without its special-case selects (d is > 0 or already NaN here)
+__device__ __forceinline__ double fast_rsqrt(double d) {
+  const double y = __builtin_amdgcn_rsq(d);
+  const double e = fma(-d * y, y, 1.0);
+  return fma(y * e, fma(e, 0.375, 0.5), y);
+}
+__device__ __forceinline__ float fast_rsqrt(float d) { return rsqrt(d); }
+
+// Cholesky of one symmetric 16x16 tile held in the MFMA C/D layout of one wave (both triangles present).
+// Column j: broadcast S[j][j] (readlane), inv = 1/sqrt, rank-1 update S -= f f^T on MFMA with f = row j * inv taken
+// from the lanes that hold row j (symmetry: row j == column j, so no cross-lane transposition is needed).  The
+// scaling of column j itself (L[:,j] = S[:,j] * inv) touches no later step -- updates only reach rows and columns
+// > j -- and is applied once at the end.  The 16 steps are a serial dependency chain (the critical path of potf2).
 template <typename T>
 __device__ __forceinline__ int leaf_cholesky(typename Mma<T>::acc_t& acc, T* dinv_out, int lane) {
   const int l15 = lane & 15, lq = lane >> 4;
   int bad_col = -1;
+  T myinv = (T)1;
 #pragma unroll
   for (int j = 0; j < 16; ++j) {
-    constexpr int dummy = 0; (void)dummy;
     // element (j,j): f64 layout row = lq + 4 reg ; f32 layout row = 4 lq + reg
     const int pr = Mma<T>::crow(0, 0) == 0 && Mma<T>::crow(16, 0) == 1 ? (j >> 2) : (j & 3);   // reg index
     const int pq = Mma<T>::crow(16, 0) == 1 ? (j & 3) : (j >> 2);                                // lq of the holder
@@ -66,16 +80,15 @@ __device__ __forceinline__ int leaf_cholesky(typename Mma<T>::acc_t& acc, T* din
       if (bad_col < 0) bad_col = j;
       d = (T)NAN;
     }
-    const T inv = rsqrt(d);
-    if (lane == 0) dinv_out[j] = inv;
+    const T inv = fast_rsqrt(d);
+    dinv_out[j] = inv;                       // every lane stores the same value: no exec-mask round trip
+    if (l15 == j) myinv = inv;
     // f_c for c = l15 > j, from row j (lanes with lq == pq hold S[j][l15] in reg pr)
     const T f = (lq == pq && l15 > j) ? acc[pr] * inv : (T)0;
-    if (l15 == j) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) acc[r] *= inv;   // column j of L (rows >= j are the meaningful ones)
-    }
     acc = Mma<T>::mma(-f, f, acc);
   }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) acc[r] *= myinv;   // column l15 of L (rows >= l15 are the meaningful ones)
   return bad_col;
 }
 
@@ -86,6 +99,13 @@ __device__ __forceinline__ int leaf_cholesky(typename Mma<T>::acc_t& acc, T* din
 //   (C)    : rank-16 MFMA update of the trailing tiles; wave 0 takes the next diagonal tile first and
 //            factors it while waves 1-3 finish the rest (the leaf chain is the critical path).
 // Finally the eight leaf inverses are written to W (used by trsm_kernel and the trtri base case).
+#ifdef HBO_POTF2_TIMING
+__device__ unsigned long long hbo_dbg_stamps[64];
+__device__ unsigned long long hbo_dbg_wall[3 * 256];   // per panel: start, end (100 MHz s_memrealtime), HW_ID
+#define STAMP(i) do { if (threadIdx.x == 0) hbo_dbg_stamps[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define STAMP(i) do {} while (0)
+#endif
 template <typename T>
 __global__ __launch_bounds__(256) void potf2_kernel(const TaskDesc* tasks, int p, int* info) {
   typedef typename Mma<T>::acc_t acc_t;
@@ -101,6 +121,14 @@ __global__ __launch_bounds__(256) void potf2_kernel(const TaskDesc* tasks, int p
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, lq = lane >> 4;
   const int ei = tid >> 4, ej = tid & 15;    // element of a tile owned by this thread for I/O
+  STAMP(0);
+#ifdef HBO_POTF2_TIMING
+  if (tid == 0 && blockIdx.x == 0 && p < 256) {
+    hbo_dbg_wall[3 * p] = wall_clock64();
+    hbo_dbg_wall[3 * p + 2] = ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32) |   // XCC_ID
+                              (unsigned)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));                        // HW_ID
+  }
+#endif
 
   // load: one element of every lower tile per thread; diagonal tiles are mirrored to full symmetry
   {
@@ -142,8 +170,10 @@ __global__ __launch_bounds__(256) void potf2_kernel(const TaskDesc* tasks, int p
     for (int r = 0; r < 4; ++r) ct[Mma<T>::crow(lane, r) * TS + l15] = acc[r];
   };
 
+  STAMP(1);
   if (wave == 0) factor_leaf(0);
   __syncthreads();
+  STAMP(2);
   for (int jb = 0; jb < 8; ++jb) {
     // ---- (B) rows below the leaf: x L_leaf^T = a ; thread = row --------------------------
     if (tid < NB && tid >= jb * 16 + 16) {
@@ -162,11 +192,13 @@ __global__ __launch_bounds__(256) void potf2_kernel(const TaskDesc* tasks, int p
       for (int c = 0; c < 16; ++c) xt[c] = x[c];
     }
     __syncthreads();
+    STAMP(3 + 3 * jb);
     if (jb == 7) break;
     // ---- (C) trailing update; wave 0 owns the next diagonal tile and factors it right away ----
     if (wave == 0) {
       update_tile(jb, jb + 1, jb + 1);
       factor_leaf(jb + 1);
+      STAMP(4 + 3 * jb);
     } else {
       const int m = 7 - jb;
       const int ntiles = m * (m + 1) / 2;
@@ -178,7 +210,9 @@ __global__ __launch_bounds__(256) void potf2_kernel(const TaskDesc* tasks, int p
       }
     }
     __syncthreads();
+    STAMP(5 + 3 * jb);
   }
+  STAMP(30);
 
   // write L (lower; zeros above the diagonal inside the diagonal tiles)
   {
@@ -192,6 +226,7 @@ __global__ __launch_bounds__(256) void potf2_kernel(const TaskDesc* tasks, int p
         gst(Ab + (int64_t)(I * 16 + ei) * ld + J * 16 + ej, v);
       }
   }
+  STAMP(31);
   // inverses of the eight 16x16 diagonal leaves: thread = (leaf b, column c), forward substitution
   if (tid < NB) {
     const int b = tid >> 4, c = tid & 15;
@@ -208,6 +243,10 @@ __global__ __launch_bounds__(256) void potf2_kernel(const TaskDesc* tasks, int p
 #pragma unroll
     for (int i = 0; i < 16; ++i) gst(Wb + (int64_t)(b * 16 + i) * ld + b * 16 + c, w[i]);
   }
+  STAMP(32);
+#ifdef HBO_POTF2_TIMING
+  if (tid == 0 && blockIdx.x == 0 && p < 256) hbo_dbg_wall[3 * p + 1] = wall_clock64();
+#endif
 }
 
 template <typename T>
@@ -368,6 +407,10 @@ void trtri_diag_t(const TaskDesc* tasks, int ntasks, int p_lo, int p_hi, hipStre
 
 }  // namespace
 
+#ifdef HBO_POTF2_TIMING
+void dbg_read_stamps(unsigned long long* host) { hipMemcpyFromSymbol(host, HIP_SYMBOL(hbo_dbg_stamps), sizeof(unsigned long long) * 64); }
+extern "C" void hbo_dbg_potf2_wall(unsigned long long* host) { hipMemcpyFromSymbol(host, HIP_SYMBOL(hbo_dbg_wall), sizeof(unsigned long long) * 3 * 256); }
+#endif
 void launch_potf2(int dtype, const TaskDesc* tasks, int ntasks, int p, int* info, hipStream_t st) {
   if (dtype == HBO_F64) potf2_t<double>(tasks, ntasks, p, info, st);
   else potf2_t<float>(tasks, ntasks, p, info, st);
