@@ -102,6 +102,8 @@ __device__ __forceinline__ int leaf_cholesky(typename Mma<T>::acc_t& acc, T* din
 #ifdef HBO_POTF2_TIMING
 __device__ unsigned long long hbo_dbg_stamps[64];
 __device__ unsigned long long hbo_dbg_wall[3 * 256];   // per panel: start, end (100 MHz s_memrealtime), HW_ID
+__device__ unsigned long long hbo_dbg_trsm[3 * 128];   // trsm of panel hbo_dbg_trsm_panel: per workgroup start, end, HW_ID
+__device__ int hbo_dbg_trsm_panel = 36;
 #define STAMP(i) do { if (threadIdx.x == 0) hbo_dbg_stamps[i] = __builtin_readcyclecounter(); } while (0)
 #else
 #define STAMP(i) do {} while (0)
@@ -265,6 +267,14 @@ __global__ __launch_bounds__(256) void trsm_kernel(const TaskDesc* tasks, int p_
   const TaskDesc& t = tasks[blockIdx.z];
   const int p = IDENT ? p_arg + (int)blockIdx.y : p_arg;   // IDENT: p_arg = first diagonal block
   if (p >= t.nblk) return;
+#ifdef HBO_POTF2_TIMING
+  const bool dbg = !IDENT && p == hbo_dbg_trsm_panel && blockIdx.x < 128 && threadIdx.x == 0;
+  if (dbg) {
+    hbo_dbg_trsm[3 * blockIdx.x] = wall_clock64();
+    hbo_dbg_trsm[3 * blockIdx.x + 2] = ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32) |
+                                       (unsigned)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
+  }
+#endif
   const int64_t ld = t.ld;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, lq = lane >> 4;
@@ -369,6 +379,9 @@ __global__ __launch_bounds__(256) void trsm_kernel(const TaskDesc* tasks, int p_
       for (int kk = 0; kk < 4; ++kk) xneg[jb][kk] = -sc[l15 * TS + kk * 4 + lq];
     }
   }
+#ifdef HBO_POTF2_TIMING
+  if (dbg) hbo_dbg_trsm[3 * blockIdx.x + 1] = wall_clock64();
+#endif
 }
 
 template <typename T>
@@ -409,6 +422,10 @@ void trtri_diag_t(const TaskDesc* tasks, int ntasks, int p_lo, int p_hi, hipStre
 
 #ifdef HBO_POTF2_TIMING
 void dbg_read_stamps(unsigned long long* host) { hipMemcpyFromSymbol(host, HIP_SYMBOL(hbo_dbg_stamps), sizeof(unsigned long long) * 64); }
+extern "C" void hbo_dbg_trsm_wall(unsigned long long* host, int panel) {
+  if (host) hipMemcpyFromSymbol(host, HIP_SYMBOL(hbo_dbg_trsm), sizeof(unsigned long long) * 3 * 128);
+  else hipMemcpyToSymbol(HIP_SYMBOL(hbo_dbg_trsm_panel), &panel, sizeof(int));
+}
 extern "C" void hbo_dbg_potf2_wall(unsigned long long* host) { hipMemcpyFromSymbol(host, HIP_SYMBOL(hbo_dbg_wall), sizeof(unsigned long long) * 3 * 256); }
 #endif
 void launch_potf2(int dtype, const TaskDesc* tasks, int ntasks, int p, int* info, hipStream_t st) {
