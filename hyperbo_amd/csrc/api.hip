@@ -22,8 +22,6 @@ struct hbo_ctx {
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;   // panel stream of the look-ahead Cholesky (high priority)
   hipStream_t stream4 = nullptr;   // early part of trtri, overlapped with the tail of potrf
-  hipStream_t stream3 = nullptr;   // bulk trailing updates, CU-masked so the panel chain always finds free CUs
-  int opt_reserve_cus = 0;   // >0: CU-masked bulk stream (measured: no gain)
   int opt_small_nblk = 32;   // matrices up to this many 128-blocks use 64x64 GEMM tiles in trtri / lauum
   int opt_persist_free = 32; // bulk trailing update runs as 2*(CUs - this) persistent workgroups
   int n_cus = 256;
@@ -168,7 +166,6 @@ extern "C" int hbo_ctx_destroy(hbo_ctx* c) {
   for (auto& kv : c->ws) if (kv.second.first) hipFree(kv.second.first);
   for (hipEvent_t ev : c->ev_pool) hipEventDestroy(ev);
   if (c->stream4) hipStreamDestroy(c->stream4);
-  if (c->stream3) hipStreamDestroy(c->stream3);
   if (c->stream2) hipStreamDestroy(c->stream2);
   if (c->stream) hipStreamDestroy(c->stream);
   delete c;
@@ -181,12 +178,6 @@ extern "C" int hbo_set_option(hbo_ctx* c, const char* name, int64_t value) {
   if (!strcmp(name, "lookahead")) { c->opt_lookahead = value ? 1 : 0; return HBO_OK; }
   if (!strcmp(name, "small_nblk")) { c->opt_small_nblk = (int)value; return HBO_OK; }
   if (!strcmp(name, "persist_free")) { if (value < 0 || value > 200) return fail(c, HBO_ERR_ARG, "persist_free in 0..200"); c->opt_persist_free = (int)value; return HBO_OK; }
-  if (!strcmp(name, "reserve_cus")) {
-    if (value < 0 || value > 128) return fail(c, HBO_ERR_ARG, "reserve_cus in 0..128");
-    c->opt_reserve_cus = (int)value;
-    if (c->stream3) { hipStreamDestroy(c->stream3); c->stream3 = nullptr; }
-    return HBO_OK;
-  }
   return fail(c, HBO_ERR_ARG, std::string("unknown option ") + name);
 }
 extern "C" int hbo_profile_enable(hbo_ctx* c, int level) { if (!c) return HBO_ERR_ARG; c->prof_level = level; return HBO_OK; }
@@ -328,27 +319,6 @@ struct FeatBuf {   // device activations of one input matrix
 };
 
 // ---- blocked factorisation drivers -----------------------------------------------------------
-// stream for the bulk trailing updates: all CUs except `opt_reserve_cus` (spread evenly), so that the
-// single-workgroup potf2 (132 KB LDS) and the panel trsm never wait for a GEMM tile to drain
-static hipStream_t bulk_stream(hbo_ctx* c) {
-  if (c->stream3) return c->stream3;
-  if (c->opt_reserve_cus > 0) {
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, c->device) == hipSuccess) {
-      const int ncu = prop.multiProcessorCount;
-      std::vector<uint32_t> mask((ncu + 31) / 32, 0xffffffffu);
-      if (ncu % 32) mask.back() = (1u << (ncu % 32)) - 1;
-      const int step = ncu / c->opt_reserve_cus;
-      for (int i = 0; i < c->opt_reserve_cus; ++i) { const int cu = i * step; mask[cu / 32] &= ~(1u << (cu % 32)); }
-      if (hipExtStreamCreateWithCUMask(&c->stream3, (uint32_t)mask.size(), mask.data()) == hipSuccess) return c->stream3;
-      c->stream3 = nullptr;
-    }
-  }
-  (void)hipGetLastError();
-  hipStreamCreateWithFlags(&c->stream3, hipStreamNonBlocking);
-  return c->stream3;
-}
-
 static void run_trtri_early(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, int max_nblk, int H,
                             hipStream_t st);
 
@@ -373,7 +343,7 @@ static void run_potrf(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks
   hipStream_t sm = c->stream;
   hipStream_t sp = c->opt_lookahead ? c->stream2 : c->stream;
   const bool la = c->opt_lookahead != 0;
-  hipStream_t sb = (la && c->opt_reserve_cus > 0) ? bulk_stream(c) : sm;
+  hipStream_t sb = sm;   // bulk updates share the main stream (CU-masked queues were measured slower)
   size_t evi = 0;
   if (la) { hipEvent_t e = pool_event(c, evi++); hipEventRecord(e, sm); hipStreamWaitEvent(sp, e, 0); }
   hipEvent_t ev_f1 = nullptr;
