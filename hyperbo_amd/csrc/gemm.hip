@@ -179,17 +179,35 @@ __device__ __forceinline__ bool decode_job(const GemmArgs& g, TileJob<T>& j) {
       return true;
     }
     case GEMM_LAUUM: {
-      // x = row tile i (K = npad - i*TM), y = column tile: concurrently running tiles share the column
-      // panel W[:, jt] through L2.  (Measured alternatives that were slower: strict longest-first
-      // order, 1.4x; XCD-aware 4x16 super-tiles streaming K in lockstep, 2x -- hot L2 channels.)
-      // With 64-tiles the tile right of an even diagonal tile is computed too, so that every
-      // 128x128 block on the diagonal is complete (the contraction kernel reads whole 128-blocks).
+      // C[i,j] = sum_{k >= i*TM} W[k, i-tile]^T W[k, j-tile]   (rows of W[:,j] above j*TM are zero), lower tiles.
+      // Column tile jt is the slow index: concurrently running tiles share the column panel W[:, jt] through L2.
+      // (Measured alternatives that were slower: strict longest-first order, 1.4x; XCD-aware 4x16 super-tiles
+      // streaming K in lockstep, 2x -- hot L2 channels.)
       constexpr int U = HBO_TILE / TM;
-      const int i = blockIdx.x, jt = blockIdx.y;
-      if (i >= nblk * U || jt > (U == 1 ? i : (i | 1))) return false;
+      int i, jt;
+      if (U == 1) {
+        // 128-tiles: 1-D grid over the n(n+1)/2 real tiles only (no workgroups that exit at once), enumerated
+        // column by column with i ascending = K = (n - i) blocks descending.  Workgroups go to the 8 XCDs round-robin
+        // by linear id, so plain order would hand XCD 0 the longest tile of every group of 8 and XCD 7 the shortest
+        // (24 % more K for XCD 0; in-kernel stamps showed 370 of 512 slots busy).  Reversing every second group of 8
+        // pairs the longest with the shortest on each XCD.
+        int lin = blockIdx.x;
+        if (lin >= nblk * (nblk + 1) / 2) return false;
+        const int blk = lin >> 4, pos = lin & 15;
+        lin = (blk << 4) + (pos < 8 ? pos : 23 - pos);
+        if (lin >= nblk * (nblk + 1) / 2) lin = (blk << 4) + pos;   // ragged last group: leave it in plain order
+        jt = 0;
+        int rowlen = nblk;
+        while (lin >= rowlen) { lin -= rowlen; --rowlen; ++jt; }
+        i = jt + lin;
+      } else {
+        // 64-tiles (small / batched matrices): 2-D grid; the tile right of an even diagonal tile is computed too, so
+        // that every 128x128 block on the diagonal is complete (the contraction kernel reads whole 128-blocks)
+        i = blockIdx.x; jt = blockIdx.y;
+        if (i >= nblk * U || jt > (i | 1)) return false;
+      }
       const int64_t k0 = (int64_t)i * TM;
       const T* W = static_cast<const T*>(t.W);
-      // C[i,j] = sum_{k >= i*TM} W[k, i-tile]^T W[k, j-tile]   (rows of W[:,j] above j*TM are zero)
       j.A = W + k0 * ld + (int64_t)i * TM;
       j.B = W + k0 * ld + (int64_t)jt * TM;
       j.C = static_cast<T*>(t.S) + (int64_t)i * TM * ld + (int64_t)jt * TM;
@@ -366,10 +384,25 @@ __device__ __forceinline__ bool decode_syrk_linear(const GemmArgs& g, int tix, T
   return true;
 }
 
+#ifdef HBO_GEMM_TIMING
+__device__ unsigned long long hbo_dbg_gemm[4 * 8192];   // per workgroup of the traced launch: start, end, HW_ID, ksteps
+__device__ int hbo_dbg_gemm_mode = -1;                  // GemmMode to trace (the last such launch wins)
+#endif
 template <typename T, bool AKC, bool BKC, int TM>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   TileJob<T> job;
+#ifdef HBO_GEMM_TIMING
+  const int dbg_id = blockIdx.y * gridDim.x + blockIdx.x;
+  const bool dbg = g.mode == hbo_dbg_gemm_mode && !g.persistent && blockIdx.z == 0 && dbg_id < 8192 && threadIdx.x == 0;
+  if (dbg) {
+    hbo_dbg_gemm[4 * dbg_id] = wall_clock64();
+    hbo_dbg_gemm[4 * dbg_id + 1] = 0;
+    hbo_dbg_gemm[4 * dbg_id + 2] = ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32) |
+                                   (unsigned)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
+    hbo_dbg_gemm[4 * dbg_id + 3] = 0;
+  }
+#endif
   if (AKC && BKC && g.persistent) {
     for (int tix = blockIdx.x; decode_syrk_linear<T, TM>(g, tix, job); tix += gridDim.x)
       gemm_tile<T, AKC, BKC, TM>(job, smem);
@@ -377,6 +410,9 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
   }
   if (!decode_job<T, TM>(g, job)) return;
   gemm_tile<T, AKC, BKC, TM>(job, smem);
+#ifdef HBO_GEMM_TIMING
+  if (dbg) { hbo_dbg_gemm[4 * dbg_id + 1] = wall_clock64(); hbo_dbg_gemm[4 * dbg_id + 3] = (unsigned long long)job.ksteps; }
+#endif
 }
 
 template <typename T>
@@ -423,7 +459,9 @@ void launch_gemm_t(const GemmArgs& a, dim3 grid, hipStream_t st) {
         dim3 g2(grid.x * 2, grid.y * 2, grid.z);
         hipLaunchKernelGGL((gemm_kernel<T, false, false, 64>), g2, dim3(256), GEMM_LDS_BYTES_64, st, a);
       } else {
-        hipLaunchKernelGGL((gemm_kernel<T, false, false, 128>), grid, dim3(256), GEMM_LDS_BYTES, st, a);
+        // 1-D grid over the lower tiles (grid.x = block count of the largest task)
+        dim3 g1(grid.x * (grid.x + 1) / 2, 1, grid.z);
+        hipLaunchKernelGGL((gemm_kernel<T, false, false, 128>), g1, dim3(256), GEMM_LDS_BYTES, st, a);
       }
       break;
   }
@@ -431,6 +469,12 @@ void launch_gemm_t(const GemmArgs& a, dim3 grid, hipStream_t st) {
 
 }  // namespace
 
+#ifdef HBO_GEMM_TIMING
+extern "C" void hbo_dbg_gemm_wall(unsigned long long* host, int mode) {
+  if (host) hipMemcpyFromSymbol(host, HIP_SYMBOL(hbo_dbg_gemm), sizeof(unsigned long long) * 4 * 8192);
+  else hipMemcpyToSymbol(HIP_SYMBOL(hbo_dbg_gemm_mode), &mode, sizeof(int));
+}
+#endif
 void launch_gemm(int dtype, const GemmArgs& a, dim3 grid, hipStream_t st) {
   if (dtype == HBO_F64) launch_gemm_t<double>(a, grid, st);
   else launch_gemm_t<float>(a, grid, st);
