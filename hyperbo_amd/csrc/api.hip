@@ -28,6 +28,7 @@ struct hbo_ctx {
   std::vector<hipEvent_t> ev_pool;
   std::map<int, std::pair<void*, size_t>> ws;   // grow-only device scratch buffers by slot (no per-call hipMalloc/hipFree)
   int opt_lookahead = 1;
+  int opt_dynamic_tiles = 1;       // persistent bulk update draws its tiles from a counter
   int opt_overlap_trtri = 1;
   std::string err;
   ModelDev h_model;
@@ -73,7 +74,7 @@ static inline int64_t padded_ld(int64_t extent, int dtype) { return extent + 128
 
 // grow-only scratch buffer for `slot`; nullptr on allocation failure (ctx->err is set)
 enum WsSlot { WS_XQ = 1, WS_MU0, WS_KD, WS_MU, WS_VAR, WS_ACQ, WS_K, WS_COLSQ, WS_V, WS_KQQ, WS_COV,
-              WS_AP_KX, WS_AP_L, WS_AP_W, WS_AP_MU, WS_AP_KD,
+              WS_AP_KX, WS_AP_L, WS_AP_W, WS_AP_MU, WS_AP_KD, WS_COUNTERS,
               WS_AG_K, WS_AG_L, WS_AG_B, WS_AG_GF, WS_AG_DMU, WS_AG_GX, WS_AG_T0, WS_AG_T1, WS_AG_DW, WS_FQ0 /* + layer */ };
 static void* ws_get(hbo_ctx* c, int slot, size_t bytes) {
   auto& e = c->ws[slot];
@@ -175,6 +176,7 @@ extern "C" int hbo_set_option(hbo_ctx* c, const char* name, int64_t value) {
   if (!c || !name) return HBO_ERR_ARG;
   if (!strcmp(name, "potrf_group")) { if (value < 1 || value > 8) return fail(c, HBO_ERR_ARG, "potrf_group in 1..8"); c->opt_group = (int)value; return HBO_OK; }
   if (!strcmp(name, "overlap_trtri")) { c->opt_overlap_trtri = value ? 1 : 0; return HBO_OK; }
+  if (!strcmp(name, "dynamic_tiles")) { c->opt_dynamic_tiles = value ? 1 : 0; return HBO_OK; }
   if (!strcmp(name, "lookahead")) { c->opt_lookahead = value ? 1 : 0; return HBO_OK; }
   if (!strcmp(name, "small_nblk")) { c->opt_small_nblk = (int)value; return HBO_OK; }
   if (!strcmp(name, "persist_free")) { if (value < 0 || value > 200) return fail(c, HBO_ERR_ARG, "persist_free in 0..200"); c->opt_persist_free = (int)value; return HBO_OK; }
@@ -347,6 +349,10 @@ static void run_potrf(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks
   size_t evi = 0;
   if (la) { hipEvent_t e = pool_event(c, evi++); hipEventRecord(e, sm); hipStreamWaitEvent(sp, e, 0); }
   hipEvent_t ev_f1 = nullptr;
+  // one tile counter per bulk launch (dynamic tile assignment of the persistent form), zeroed up front
+  int* counters = c->opt_dynamic_tiles ? (int*)ws_get(c, WS_COUNTERS, sizeof(int) * 256) : nullptr;
+  int n_counter = 0;
+  if (counters) hipMemsetAsync(counters, 0, sizeof(int) * 256, sm);
   for (int g0 = 0; g0 < max_nblk; g0 += q) {
     const int g1 = std::min(g0 + q, max_nblk);
     const int g2 = std::min(g1 + q, max_nblk);
@@ -396,8 +402,9 @@ static void run_potrf(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks
             const int pblocks = 2 * (c->n_cus - c->opt_persist_free);
             // (for large trailing matrices the bulk update dominates and gets the whole machine)
             a.persistent = (ntasks == 1 && c->opt_persist_free > 0 && ntiles > pblocks && m <= 96) ? pblocks : 0;
+            a.work_counter = (a.persistent && counters && n_counter < 256) ? counters + n_counter++ : nullptr;
             launch_gemm(dtype, a, dim3(max_nblk + 1 - a.c_lo, a.c_hi - a.c_lo, ntasks), sb);
-            a.persistent = 0;
+            a.persistent = 0; a.work_counter = nullptr;
           }
           hipEvent_t e2 = pool_event(c, evi++);
           hipEventRecord(e2, sb);

@@ -386,7 +386,7 @@ __device__ __forceinline__ bool decode_syrk_linear(const GemmArgs& g, int tix, T
 
 #ifdef HBO_GEMM_TIMING
 __device__ unsigned long long hbo_dbg_gemm[4 * 8192];   // per workgroup of the traced launch: start, end, HW_ID, ksteps
-__device__ int hbo_dbg_gemm_mode = -1;                  // GemmMode to trace (the last such launch wins)
+int g_dbg_mode = -1, g_dbg_index = 0, g_dbg_seen = 0;   // host: trace the g_dbg_index-th launch of g_dbg_mode (+100: persistent)
 #endif
 template <typename T, bool AKC, bool BKC, int TM>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
@@ -394,7 +394,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
   TileJob<T> job;
 #ifdef HBO_GEMM_TIMING
   const int dbg_id = blockIdx.y * gridDim.x + blockIdx.x;
-  const bool dbg = g.mode == hbo_dbg_gemm_mode && !g.persistent && blockIdx.z == 0 && dbg_id < 8192 && threadIdx.x == 0;
+  const bool dbg = g.dbg && blockIdx.z == 0 && dbg_id < 8192 && threadIdx.x == 0;
   if (dbg) {
     hbo_dbg_gemm[4 * dbg_id] = wall_clock64();
     hbo_dbg_gemm[4 * dbg_id + 1] = 0;
@@ -404,8 +404,29 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
   }
 #endif
   if (AKC && BKC && g.persistent) {
-    for (int tix = blockIdx.x; decode_syrk_linear<T, TM>(g, tix, job); tix += gridDim.x)
+#ifdef HBO_GEMM_TIMING
+    unsigned long long dbg_ks = 0;
+#endif
+    // Tiles are drawn from a shared counter when one is given: workgroup speeds differ by up to 1.8x (co-resident
+    // panel-chain kernels, a lone workgroup on a CU runs faster), and with a static stride the slowest workgroup
+    // with the most tiles set the kernel's duration (608 us against 460 us at the median speed).
+    __shared__ int s_tix;
+    for (int tix = blockIdx.x;; tix += gridDim.x) {
+      if (g.work_counter) {
+        if (threadIdx.x == 0) s_tix = atomicAdd(g.work_counter, 1);
+        __syncthreads();
+        tix = s_tix;
+        __syncthreads();
+      }
+      if (!decode_syrk_linear<T, TM>(g, tix, job)) break;
       gemm_tile<T, AKC, BKC, TM>(job, smem);
+#ifdef HBO_GEMM_TIMING
+      dbg_ks += (unsigned long long)job.ksteps;
+#endif
+    }
+#ifdef HBO_GEMM_TIMING
+    if (dbg) { hbo_dbg_gemm[4 * dbg_id + 1] = wall_clock64(); hbo_dbg_gemm[4 * dbg_id + 3] = dbg_ks; }
+#endif
     return;
   }
   if (!decode_job<T, TM>(g, job)) return;
@@ -470,12 +491,19 @@ void launch_gemm_t(const GemmArgs& a, dim3 grid, hipStream_t st) {
 }  // namespace
 
 #ifdef HBO_GEMM_TIMING
-extern "C" void hbo_dbg_gemm_wall(unsigned long long* host, int mode) {
-  if (host) hipMemcpyFromSymbol(host, HIP_SYMBOL(hbo_dbg_gemm), sizeof(unsigned long long) * 4 * 8192);
-  else hipMemcpyToSymbol(HIP_SYMBOL(hbo_dbg_gemm_mode), &mode, sizeof(int));
+extern "C" void hbo_dbg_gemm_wall(unsigned long long* host, int mode, int index) {
+  if (host) { hipMemcpyFromSymbol(host, HIP_SYMBOL(hbo_dbg_gemm), sizeof(unsigned long long) * 4 * 8192); return; }
+  static unsigned long long zeros[4 * 8192];
+  hipMemcpyToSymbol(HIP_SYMBOL(hbo_dbg_gemm), zeros, sizeof zeros);
+  g_dbg_mode = mode; g_dbg_index = index; g_dbg_seen = 0;
 }
 #endif
-void launch_gemm(int dtype, const GemmArgs& a, dim3 grid, hipStream_t st) {
+void launch_gemm(int dtype, const GemmArgs& a_in, dim3 grid, hipStream_t st) {
+  GemmArgs a = a_in;
+#ifdef HBO_GEMM_TIMING
+  a.dbg = 0;
+  if ((a.persistent ? a.mode + 100 : a.mode) == g_dbg_mode) a.dbg = (g_dbg_seen++ == g_dbg_index);
+#endif
   if (dtype == HBO_F64) launch_gemm_t<double>(a, grid, st);
   else launch_gemm_t<float>(a, grid, st);
 }

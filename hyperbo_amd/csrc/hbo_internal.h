@@ -70,6 +70,9 @@ struct GemmArgs {
   int aug;       // SYRK: 1 -> include the augmented tile-row
   int small_tiles;  // 1 -> 64x64 output tiles (SYRK / TRTRI / LAUUM; grid is given in 128-tile units)
   int persistent;   // SYRK: >0 -> that many persistent workgroups loop over the tiles
+  int* work_counter; // persistent SYRK: zero-initialised tile counter -> workgroups draw tiles dynamically (a faster
+                     // workgroup takes more of them) instead of striding over them; null: static stride
+  int dbg;          // HBO_GEMM_TIMING builds: 1 -> this launch records per-workgroup wall-clock stamps
   int grp_lo;       // TRTRI: first group (of size 2s blocks) handled by this launch
   void* B;       // POST: Kxq (npad x ldb)
   int64_t ldb;

@@ -8,17 +8,18 @@ from hyperbo_amd import _native as nat
 from hyperbo_amd.basics import definitions as defs
 from hyperbo_amd.gp_utils import kernel, mean, objectives, utils
 mode = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+index = int(sys.argv[2]) if len(sys.argv) > 2 else 0   # which launch of that mode within the evaluation (mode + 100: persistent ones)
 x, y, raw = bench.cfg2_inputs(n=8192)
 dev = objectives.DeviceDataset({0: defs.SubDataset(x, y)})
 p = defs.GPParams(model=raw)
 f = lambda: objectives.nll_value_and_grad(mean.constant, kernel.squared_exponential, p, dev, utils.DEFAULT_WARP_FUNC)
 f(); f()
 lib = nat.lib()
-lib.hbo_dbg_gemm_wall.argtypes = [C.c_void_p, C.c_int]
-lib.hbo_dbg_gemm_wall(None, mode)
+lib.hbo_dbg_gemm_wall.argtypes = [C.c_void_p, C.c_int, C.c_int]
+lib.hbo_dbg_gemm_wall(None, mode, index)
 f()
 buf = (C.c_ulonglong * (4 * 8192))()
-lib.hbo_dbg_gemm_wall(buf, 0)
+lib.hbo_dbg_gemm_wall(buf, 0, 0)
 a = np.array(buf[:], dtype=np.uint64).reshape(8192, 4)
 a = a[a[:, 1] > 0]                       # workgroups that ran a tile
 t0 = a[:, 0].min()
