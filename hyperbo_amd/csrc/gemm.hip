@@ -180,31 +180,29 @@ __device__ __forceinline__ bool decode_job(const GemmArgs& g, TileJob<T>& j) {
     }
     case GEMM_LAUUM: {
       // C[i,j] = sum_{k >= i*TM} W[k, i-tile]^T W[k, j-tile]   (rows of W[:,j] above j*TM are zero), lower tiles.
-      // Column tile jt is the slow index: concurrently running tiles share the column panel W[:, jt] through L2.
-      // (Measured alternatives that were slower: strict longest-first order, 1.4x; XCD-aware 4x16 super-tiles
-      // streaming K in lockstep, 2x -- hot L2 channels.)
       constexpr int U = HBO_TILE / TM;
       int i, jt;
       if (U == 1) {
-        // 128-tiles: 1-D grid over the n(n+1)/2 real tiles only (no workgroups that exit at once), enumerated
-        // column by column with i ascending = K = (n - i) blocks descending.  Workgroups go to the 8 XCDs round-robin
-        // by linear id, so plain order would hand XCD 0 the longest tile of every group of 8 and XCD 7 the shortest
-        // (24 % more K for XCD 0; in-kernel stamps showed 370 of 512 slots busy).  Reversing every second group of 8
-        // pairs the longest with the shortest on each XCD.
+        // 128-tiles: 1-D grid over the n(n+1)/2 real tiles only (no workgroups that exit at once), row tile i slow =
+        // K = (n - i) blocks descending (longest first), column tile jt fast.  Consecutive workgroups -- which the
+        // dispatcher deals to the 8 XCDs round-robin -- then have equal K and share the row panel W[:, i].
+        // History (in-kernel stamps, tools/gemm_wall.py): 2-D grid with i fast: 370 of 512 slots busy, 3.56 ms (XCD 0
+        // always received the longest of every 8 tiles); column-major with every second group of 8 reversed: 412
+        // slots, 3.38 ms; this order: 481 slots, 3.08 ms.
         int lin = blockIdx.x;
         if (lin >= nblk * (nblk + 1) / 2) return false;
-        const int blk = lin >> 4, pos = lin & 15;
-        lin = (blk << 4) + (pos < 8 ? pos : 23 - pos);
-        if (lin >= nblk * (nblk + 1) / 2) lin = (blk << 4) + pos;   // ragged last group: leave it in plain order
-        jt = 0;
-        int rowlen = nblk;
-        while (lin >= rowlen) { lin -= rowlen; --rowlen; ++jt; }
-        i = jt + lin;
+        i = 0;
+        while (lin > i) { lin -= i + 1; ++i; }
+        jt = lin;
       } else {
-        // 64-tiles (small / batched matrices): 2-D grid; the tile right of an even diagonal tile is computed too, so
-        // that every 128x128 block on the diagonal is complete (the contraction kernel reads whole 128-blocks)
-        i = blockIdx.x; jt = blockIdx.y;
-        if (i >= nblk * U || jt > (i | 1)) return false;
+        // 64-tiles (small / batched matrices): same row-major order; the tile right of an even diagonal tile is
+        // computed too, so that every 128x128 block on the diagonal is complete (the contraction kernel reads whole
+        // 128-blocks): row i has (i | 1) + 1 tiles, 2 n (n + 1) in total
+        int lin = blockIdx.x;
+        if (lin >= 2 * nblk * (nblk + 1)) return false;
+        i = 0;
+        while (lin > (i | 1)) { lin -= (i | 1) + 1; ++i; }
+        jt = lin;
       }
       const int64_t k0 = (int64_t)i * TM;
       const T* W = static_cast<const T*>(t.W);
@@ -477,7 +475,7 @@ void launch_gemm_t(const GemmArgs& a, dim3 grid, hipStream_t st) {
       break;
     case GEMM_LAUUM:
       if (a.small_tiles) {
-        dim3 g2(grid.x * 2, grid.y * 2, grid.z);
+        dim3 g2(2 * grid.x * (grid.x + 1), 1, grid.z);
         hipLaunchKernelGGL((gemm_kernel<T, false, false, 64>), g2, dim3(256), GEMM_LDS_BYTES_64, st, a);
       } else {
         // 1-D grid over the lower tiles (grid.x = block count of the largest task)
