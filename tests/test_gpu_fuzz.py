@@ -1,0 +1,93 @@
+"""Randomised parity sweep (`-m gpu`): sizes around the 128 / 512 / 1024 blocking boundaries, every kernel x mean x
+MLP combination, ragged multi-task datasets with empty and multi-column members, all three objectives, posterior and
+acquisition (+gradient) -- each case against the CPU oracle on the same seeded inputs.  Complements the structured
+tests of test_gpu_parity.py; sizes keep the whole file within ~1 minute."""
+import numpy as np
+import pytest
+
+import helpers
+from oracle import hyperbo_oracle as o
+
+pytestmark = pytest.mark.gpu
+WFO = o.DEFAULT_WARP_FUNC
+SIZES = [1, 2, 63, 64, 65, 127, 128, 129, 255, 256, 257, 383, 384, 511, 512, 513, 640, 1023, 1024, 1025, 1300]
+
+
+def _native():
+  from hyperbo_amd.basics import definitions as defs
+  from hyperbo_amd.bo_utils import acfun
+  from hyperbo_amd.gp_utils import gp, kernel, mean, objectives, utils
+  return defs, acfun, gp, kernel, mean, objectives, utils
+
+
+def _case(seed):
+  rng = np.random.default_rng(1000 + seed)
+  kname = helpers.KERNELS[rng.integers(4)]
+  mlp = bool(rng.integers(2))
+  mname = helpers.MEANS[rng.integers(4)]
+  d = int(rng.integers(1, 7))
+  return rng, kname, mlp, mname, d
+
+
+@pytest.mark.parametrize('seed', range(24))
+def test_fuzz_objectives(gpu_ctx, seed):
+  defs, _, _, kernel, mean, objectives, utils = _native()
+  rng, kname, mlp, mname, d = _case(seed)
+  model = helpers.make_model(rng, mname, mlp, d)
+  cfg = {'mlp_features': helpers.MLP_FEATURES}
+  po, pn = o.GPParams(model=model, config=dict(cfg)), defs.GPParams(model=model, config=dict(cfg))
+  ntask = int(rng.integers(1, 6))
+  dso = {}
+  for t in range(ntask):
+    n = int(SIZES[rng.integers(len(SIZES))]) if t == 0 else int(rng.integers(1, 400))
+    m = 1 if rng.integers(3) else int(rng.integers(2, 6))
+    x, y = helpers.synthetic_task(rng, n, d, m=m)
+    dso[f't{t}'] = o.SubDataset(x, y, aligned=(t if m > 1 else None))
+  dso['empty'] = o.SubDataset(np.zeros((0, d)), np.zeros((0, 1)))
+  dsn = {k: defs.SubDataset(v.x, v.y, v.aligned) for k, v in dso.items()}
+  ko = getattr(o, kname + ('_mlp' if mlp else '')); kn = getattr(kernel, kname + ('_mlp' if mlp else ''))
+  mo, mn = getattr(o, mname), getattr(mean, mname)
+  exclude = bool(rng.integers(2))
+  vo, go = o.nll_value_and_grad(mo, ko, po, dso, WFO, exclude_aligned=exclude)
+  vn, gn = objectives.nll_value_and_grad(mn, kn, pn, dsn, utils.DEFAULT_WARP_FUNC, exclude_aligned=exclude)
+  assert abs(vn - vo) <= 1e-9 * max(abs(vo), 1.0)
+  fo, fn = helpers.flatten(go), helpers.flatten(gn)
+  assert np.max(np.abs(fo - fn)) <= 1e-7 * max(np.max(np.abs(fo)), 1e-6)
+  for kind, fnc in (('ekl', objectives.ekl), ('euc', objectives.euc)):
+    vo, go = o.divergence_value_and_grad(kind, mo, ko, po, dso, WFO)
+    vn, gn = fnc.value_and_grad(mn, kn, pn, dsn, utils.DEFAULT_WARP_FUNC)
+    assert abs(vn - vo) <= 1e-8 * max(abs(vo), 1.0)
+    fo, fn = helpers.flatten(go), helpers.flatten(gn)
+    assert np.max(np.abs(fo - fn)) <= 1e-6 * max(np.max(np.abs(fo)), 1e-6)
+
+
+@pytest.mark.parametrize('seed', range(16))
+def test_fuzz_posterior_and_acquisition(gpu_ctx, seed):
+  defs, acfun, gp, kernel, mean, _, utils = _native()
+  rng, kname, mlp, mname, d = _case(100 + seed)
+  model = helpers.make_model(rng, mname, mlp, d)
+  cfg = {'mlp_features': helpers.MLP_FEATURES}
+  po, pn = o.GPParams(model=model, config=dict(cfg)), defs.GPParams(model=model, config=dict(cfg))
+  n = int(SIZES[rng.integers(len(SIZES))])
+  x, y = helpers.synthetic_task(rng, n, d)
+  mq = int(rng.integers(1, 300))
+  xq = rng.uniform(size=(mq, d))
+  ko = getattr(o, kname + ('_mlp' if mlp else '')); kn = getattr(kernel, kname + ('_mlp' if mlp else ''))
+  mo, mn = getattr(o, mname), getattr(mean, mname)
+  ds = {'a': defs.SubDataset(x, y), 'b': defs.SubDataset(*helpers.synthetic_task(rng, 5, d))}
+  m = gp.GP(ds, mn, kn, pn, utils.DEFAULT_WARP_FUNC)
+  mu, var = m.predict(xq, 'a', full_cov=False, with_noise=True)
+  mu_o, var_o = o.predict(mo, ko, po, x, y, xq, WFO)
+  mu_o, var_o = o.gp_predict_postprocess(po, {k: o.SubDataset(v.x, v.y) for k, v in ds.items()}, mu_o, var_o, WFO, False, True, True)
+  # conditioning of K + (sigma^2 + 1e-6) I bounds what fp64 can reproduce
+  cond = np.linalg.cond(ko(po, x, warp_func=WFO) + np.eye(n) * (o.retrieve_params(po, ['noise_variance'], WFO)[0] + 1e-6))
+  tol = 1e-13 * max(cond, 1e3)
+  assert helpers.rel_err(mu, mu_o) <= tol and np.max(np.abs(var - var_o)) <= tol * max(np.max(np.abs(var_o)), 1.0)
+  acq = ['ei', 'pi', 'ucb'][seed % 3]
+  fn = {'ei': acfun.expected_improvement, 'pi': acfun.probability_of_improvement, 'ucb': acfun.ucb}[acq]
+  param = {'ei': float(np.max(y)), 'pi': float(np.max(y)) + 0.1, 'ucb': 3.0}[acq]
+  noise = float(np.squeeze(o.retrieve_params(po, ['noise_variance'], WFO)[0]))
+  val, grad = fn.value_and_grad(model=m, sub_dataset_key='a', x_queries=xq)
+  vo, go = o.acquisition_value_and_grad(acq, mo, ko, po, x, y, xq, param, WFO, add_noise=noise, scale=2.0)
+  assert np.max(np.abs(val - vo)) <= 10 * tol * max(np.max(np.abs(vo)), 1.0)
+  assert np.max(np.abs(grad - go)) <= 100 * tol * max(np.max(np.abs(go)), 1.0)
