@@ -45,7 +45,7 @@ __device__ __forceinline__ int tri_index(int I, int J) { return I * (I + 1) / 2 
 
 
 template <typename T>
-constexpr int potf2_lds_bytes() { return (36 * TILE_ELEMS + NB) * (int)sizeof(T); }
+constexpr int potf2_lds_bytes() { return (37 * TILE_ELEMS + NB) * (int)sizeof(T); }   // 36 tiles + current leaf inverse + pivots
 
 // 16x16 Cholesky of a symmetric tile held in the MFMA accumulator layout (one wave).  Column j:
 // pivot by readlane, rsqrt, scale column j (lanes with col == j), and one rank-1 MFMA update
@@ -60,16 +60,22 @@ __device__ __forceinline__ double fast_rsqrt(double d) {
 }
 __device__ __forceinline__ float fast_rsqrt(float d) { return rsqrt(d); }
 
-// Cholesky of one symmetric 16x16 tile held in the MFMA C/D layout of one wave (both triangles present).
-// Column j: broadcast S[j][j] (readlane), inv = 1/sqrt, rank-1 update S -= f f^T on MFMA with f = row j * inv taken
-// from the lanes that hold row j (symmetry: row j == column j, so no cross-lane transposition is needed).  The
-// scaling of column j itself (L[:,j] = S[:,j] * inv) touches no later step -- updates only reach rows and columns
-// > j -- and is applied once at the end.  The 16 steps are a serial dependency chain (the critical path of potf2).
+// Cholesky of one symmetric 16x16 tile held in the MFMA C/D layout of one wave (both triangles present), and the
+// inverse of its factor.  Column j: broadcast S[j][j] (readlane), inv = 1/sqrt, rank-1 update S -= f f^T on MFMA with
+// f = row j * inv taken from the lanes that hold row j (symmetry: row j == column j, so no cross-lane transposition is
+// needed).  The scaling of column j itself (L[:,j] = S[:,j] * inv) touches no later step -- updates only reach rows and
+// columns > j -- and is applied once at the end.  The 16 steps are a serial dependency chain (the critical path of
+// potf2).  The inverse rides in its shadow: V starts as I and takes the same eliminations, V -= f (inv * V[j,:]); row j
+// of V is final after step j-1 and never touched again, and M = L^-1 = diag(1/L_jj) V.  Its MFMA is independent of the
+// S chain and issues while the next pivot is being prepared.
 template <typename T>
-__device__ __forceinline__ int leaf_cholesky(typename Mma<T>::acc_t& acc, T* dinv_out, int lane) {
+__device__ __forceinline__ int leaf_cholesky(typename Mma<T>::acc_t& acc, typename Mma<T>::acc_t& vinv, T* dinv_out,
+                                             int lane) {
   const int l15 = lane & 15, lq = lane >> 4;
   int bad_col = -1;
   T myinv = (T)1;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) vinv[r] = (Mma<T>::crow(lane, r) == l15) ? (T)1 : (T)0;
 #pragma unroll
   for (int j = 0; j < 16; ++j) {
     // element (j,j): f64 layout row = lq + 4 reg ; f32 layout row = 4 lq + reg
@@ -86,19 +92,28 @@ __device__ __forceinline__ int leaf_cholesky(typename Mma<T>::acc_t& acc, T* din
     // f_c for c = l15 > j, from row j (lanes with lq == pq hold S[j][l15] in reg pr)
     const T f = (lq == pq && l15 > j) ? acc[pr] * inv : (T)0;
     acc = Mma<T>::mma(-f, f, acc);
+    // the inverse's operand is read only now: its previous MFMA has long finished, and nothing of it sits between
+    // the pivot broadcast and the S update (keeps the hazard waits of the second accumulator off the chain)
+    __builtin_amdgcn_sched_barrier(0);
+    const T h = (lq == pq) ? vinv[pr] * inv : (T)0;      // inv * V[j][l15]
+    vinv = Mma<T>::mma(-f, h, vinv);
+    __builtin_amdgcn_sched_barrier(0);
   }
 #pragma unroll
-  for (int r = 0; r < 4; ++r) acc[r] *= myinv;   // column l15 of L (rows >= l15 are the meaningful ones)
+  for (int r = 0; r < 4; ++r) {
+    acc[r] *= myinv;                                       // column l15 of L (rows >= l15 are the meaningful ones)
+    vinv[r] *= dinv_out[Mma<T>::crow(lane, r)];            // M = diag(1/L_jj) V  (dinv_out: this wave's own stores)
+  }
   return bad_col;
 }
 
 // LDS-resident factorisation of one 128x128 diagonal block as 36 packed 16x16 lower tiles (78 KB
 // for fp64, so the workgroup fits on a CU next to a running GEMM workgroup):
 //   leaf   : wave 0 factors the symmetric diagonal tile on MFMA (leaf_cholesky),
-//   (B)    : one thread per remaining row solves its 16 unknowns against the leaf,
+//   (B)    : rows below the leaf: X = A M^T on MFMA with M = leaf^-1 (built inside leaf_cholesky),
 //   (C)    : rank-16 MFMA update of the trailing tiles; wave 0 takes the next diagonal tile first and
 //            factors it while waves 1-3 finish the rest (the leaf chain is the critical path).
-// Finally the eight leaf inverses are written to W (used by trsm_kernel and the trtri base case).
+// The leaf inverses also go to W (used by trsm_kernel and the trtri base case).
 #ifdef HBO_POTF2_TIMING
 __device__ unsigned long long hbo_dbg_stamps[64];
 __device__ unsigned long long hbo_dbg_wall[3 * 256];   // per panel: start, end (100 MHz s_memrealtime), HW_ID
@@ -114,7 +129,8 @@ __global__ __launch_bounds__(256) void potf2_kernel(const TaskDesc* tasks, int p
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __builtin_amdgcn_s_setprio(3);            // critical path: outrank co-resident GEMM waves
   T* sT = reinterpret_cast<T*>(smem);       // 36 tiles [16][17]
-  T* sDinv = sT + 36 * TILE_ELEMS;          // [128] 1 / diag(L)
+  T* sM = sT + 36 * TILE_ELEMS;             // inverse of the current leaf [16][17]
+  T* sDinv = sM + TILE_ELEMS;               // [128] 1 / diag(L)
   const TaskDesc& t = tasks[blockIdx.x];
   if (p >= t.nblk) return;
   const int64_t ld = t.ld;
@@ -151,13 +167,26 @@ __global__ __launch_bounds__(256) void potf2_kernel(const TaskDesc* tasks, int p
 
   auto factor_leaf = [&](int jb) {   // wave 0 only
     T* dt = sT + tri_index(jb, jb) * TILE_ELEMS;
-    acc_t acc;
+    acc_t acc, vinv;
 #pragma unroll
     for (int r = 0; r < 4; ++r) acc[r] = dt[Mma<T>::crow(lane, r) * TS + l15];
-    const int bad = leaf_cholesky<T>(acc, sDinv + jb * 16, lane);
+    const int bad = leaf_cholesky<T>(acc, vinv, sDinv + jb * 16, lane);
     if (bad >= 0 && lane == 0) atomicMin(&info[blockIdx.x], p * NB + jb * 16 + bad + 1);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) dt[Mma<T>::crow(lane, r) * TS + l15] = acc[r];
+    for (int r = 0; r < 4; ++r) {
+      const int row = Mma<T>::crow(lane, r);
+      dt[row * TS + l15] = acc[r];
+      sM[row * TS + l15] = vinv[r];
+      gst(Wb + (int64_t)(jb * 16 + row) * ld + jb * 16 + l15, vinv[r]);   // leaf inverse (lower triangular)
+    }
+  };
+  auto solve_tile = [&](int jb, int R) {   // rows of tile (R, jb): X = A M^T, in place
+    T* xt = sT + tri_index(R, jb) * TILE_ELEMS;
+    acc_t acc = {0, 0, 0, 0};
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) acc = Mma<T>::mma(xt[l15 * TS + kk * 4 + lq], sM[l15 * TS + kk * 4 + lq], acc);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) xt[Mma<T>::crow(lane, r) * TS + l15] = acc[r];
   };
   auto update_tile = [&](int jb, int I, int J) {   // C[I][J] -= X_I X_J^T (K = 16)
     T* ct = sT + tri_index(I, J) * TILE_ELEMS;
@@ -177,22 +206,9 @@ __global__ __launch_bounds__(256) void potf2_kernel(const TaskDesc* tasks, int p
   __syncthreads();
   STAMP(2);
   for (int jb = 0; jb < 8; ++jb) {
-    // ---- (B) rows below the leaf: x L_leaf^T = a ; thread = row --------------------------
-    if (tid < NB && tid >= jb * 16 + 16) {
-      const T* lt = sT + tri_index(jb, jb) * TILE_ELEMS;
-      T* xt = sT + tri_index(tid >> 4, jb) * TILE_ELEMS + (tid & 15) * TS;
-      T x[16];
-#pragma unroll
-      for (int c = 0; c < 16; ++c) {
-        T s = xt[c];
-#pragma unroll
-        for (int k = 0; k < 16; ++k)
-          if (k < c) s -= x[k] * lt[c * TS + k];
-        x[c] = s * sDinv[jb * 16 + c];
-      }
-#pragma unroll
-      for (int c = 0; c < 16; ++c) xt[c] = x[c];
-    }
+    // ---- (B) rows below the leaf: X = A M^T, one 16-row tile per wave and pass (wave 0 takes tile jb+1, whose
+    //      result it needs first in (C)) ------------------------------------------------------
+    for (int R = jb + 1 + wave; R < 8; R += 4) solve_tile(jb, R);
     __syncthreads();
     STAMP(3 + 3 * jb);
     if (jb == 7) break;
@@ -229,22 +245,6 @@ __global__ __launch_bounds__(256) void potf2_kernel(const TaskDesc* tasks, int p
       }
   }
   STAMP(31);
-  // inverses of the eight 16x16 diagonal leaves: thread = (leaf b, column c), forward substitution
-  if (tid < NB) {
-    const int b = tid >> 4, c = tid & 15;
-    const T* lt = sT + tri_index(b, b) * TILE_ELEMS;
-    T w[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      T s = (i == c) ? (T)1 : (T)0;
-#pragma unroll
-      for (int k = 0; k < 16; ++k)
-        if (k < i) s -= lt[i * TS + k] * w[k];
-      w[i] = s * sDinv[b * 16 + i];
-    }
-#pragma unroll
-    for (int i = 0; i < 16; ++i) gst(Wb + (int64_t)(b * 16 + i) * ld + b * 16 + c, w[i]);
-  }
   STAMP(32);
 #ifdef HBO_POTF2_TIMING
   if (tid == 0 && blockIdx.x == 0 && p < 256) hbo_dbg_wall[3 * p + 1] = wall_clock64();
