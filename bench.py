@@ -135,7 +135,9 @@ def main():
     p = defs.GPParams(model=perturb(raw, i, rank))
     return objectives.nll_value_and_grad(mean.constant, kernel.squared_exponential, p, dev, wf)
 
-  ctx.profile_enable(1)
+  # timed region: only the launches of the dominant kernel (bulk trailing update) are bracketed with HIP events
+  # (profile level -1); the per-stage table comes from a separate, untimed pass below
+  ctx.profile_enable(-1)
   for i in range(args.warmup):
     step_fn(-1 - i)
   sync()
@@ -148,6 +150,12 @@ def main():
       a = prof.setdefault(k, [0.0, 0]); a[0] += ms; a[1] += cnt
   sync()
   elapsed = max_over_ranks(time.perf_counter() - t0)
+  stage_prof, stage_evals = {}, 3
+  ctx.profile_enable(1)
+  for i in range(stage_evals):
+    step_fn(10_000 + i)
+    for k, (ms, cnt) in ctx.profile_get().items():
+      a = stage_prof.setdefault(k, [0.0, 0]); a[0] += ms; a[1] += cnt
   assert np.isfinite(last[0]), 'NLL is not finite'
   ms_per_step = elapsed / args.steps * 1e3
   value = world * args.steps / elapsed
@@ -177,7 +185,7 @@ def main():
       if pmc:
         roofline['traffic'] = int((2 * pmc['FETCH_SIZE_KB'] + pmc['WRITE_SIZE_KB']) * 1024)
         roofline['traffic_note'] = 'bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024, profiles/r01_pmc_hbm.json'
-  stages = {k: round(v[0] / args.steps, 4) for k, v in prof.items()}
+  stages = {k: round(v[0] / stage_evals, 4) for k, v in stage_prof.items()}   # separate pass with all stage events on
   ctx.profile_enable(0)
 
   # ---------------- secondary: cfg 4 multi-task objective, task-sharded ----------------------
@@ -245,6 +253,8 @@ def main():
                    'potrf_group': group},
         'algorithmic_tflops': round(float(args.n)**3 / (ms_per_step * 1e-3) / 1e12, 3),
         'stages_ms_per_step': stages,
+        'stages_note': 'separate untimed pass of 3 evaluations with every stage bracketed by HIP events; the timed '
+                       'region brackets only the roofline kernel (stage events cost 0.3 ms per evaluation)',
         'roofline': roofline, 'cpu_baseline': cpu, 'multitask': multitask,
     }
     print(json.dumps(out), flush=True)

@@ -15,7 +15,7 @@
 
 static thread_local std::string g_err;
 
-struct ProfEntry { std::string name; hipEvent_t e0, e1; };
+struct ProfEntry { const char* name; hipEvent_t e0, e1; };
 
 struct hbo_ctx {
   int device = 0;
@@ -40,6 +40,7 @@ struct hbo_ctx {
   int opt_group = 4;         // 128-wide panels per trailing update (K = 128*group)
   int prof_level = 0;
   std::vector<ProfEntry> prof_pending;
+  std::vector<hipEvent_t> prof_events; size_t prof_next = 0;   // event pool of the timing scopes
   std::vector<std::string> prof_names;
   std::vector<double> prof_ms;
   std::vector<int> prof_count;
@@ -89,13 +90,25 @@ static void* ws_get(hbo_ctx* c, int slot, size_t bytes) {
 }
 
 // ---- profiling ---------------------------------------------------------------------------
+// Timing scopes: HIP events recorded on the stream the kernels are launched on.  Events come from a pool owned by
+// the context (creating and destroying ~80 events per evaluation cost 0.4 ms of host time).  prof_level < 0 is the
+// "roofline only" mode of bench.py: just the launches of the dominant kernel (scopes named syrk_bulk) are bracketed.
+static hipEvent_t prof_event(hbo_ctx* c) {
+  if (c->prof_next == c->prof_events.size()) {
+    hipEvent_t ev;
+    hipEventCreate(&ev);
+    c->prof_events.push_back(ev);
+  }
+  return c->prof_events[c->prof_next++];
+}
 struct ProfScope {
   hbo_ctx* c; bool on; ProfEntry e; hipStream_t st;
   ProfScope(hbo_ctx* ctx, const char* name, int level, hipStream_t stream = nullptr)
-      : c(ctx), on(ctx->prof_level >= level), st(stream ? stream : ctx->stream) {
+      : c(ctx), on(ctx->prof_level >= level || (ctx->prof_level < 0 && !strcmp(name, "syrk_bulk"))),
+        st(stream ? stream : ctx->stream) {
     if (!on) return;
     e.name = name;
-    hipEventCreate(&e.e0); hipEventCreate(&e.e1);
+    e.e0 = prof_event(c); e.e1 = prof_event(c);
     hipEventRecord(e.e0, st);
   }
   ~ProfScope() {
@@ -106,8 +119,8 @@ struct ProfScope {
 };
 static void prof_begin(hbo_ctx* c) {
   c->prof_names.clear(); c->prof_ms.clear(); c->prof_count.clear();
-  for (auto& p : c->prof_pending) { hipEventDestroy(p.e0); hipEventDestroy(p.e1); }
   c->prof_pending.clear();
+  c->prof_next = 0;
 }
 static void prof_collect(hbo_ctx* c) {  // stream must be synchronised
   for (auto& p : c->prof_pending) {
@@ -117,7 +130,6 @@ static void prof_collect(hbo_ctx* c) {  // stream must be synchronised
     for (; k < c->prof_names.size(); ++k) if (c->prof_names[k] == p.name) break;
     if (k == c->prof_names.size()) { c->prof_names.push_back(p.name); c->prof_ms.push_back(0); c->prof_count.push_back(0); }
     c->prof_ms[k] += ms; c->prof_count[k] += 1;
-    hipEventDestroy(p.e0); hipEventDestroy(p.e1);
   }
   c->prof_pending.clear();
 }
@@ -163,6 +175,7 @@ extern "C" int hbo_ctx_destroy(hbo_ctx* c) {
   hbo_comm_destroy(c);
   prof_begin(c);
   for (int l = 0; l < HBO_MAX_MLP_LAYERS; ++l) { if (c->d_mlp_w[l]) hipFree(c->d_mlp_w[l]); if (c->d_mlp_b[l]) hipFree(c->d_mlp_b[l]); }
+  for (hipEvent_t ev : c->prof_events) hipEventDestroy(ev);
   if (c->d_model) hipFree(c->d_model);
   for (auto& kv : c->ws) if (kv.second.first) hipFree(kv.second.first);
   for (hipEvent_t ev : c->ev_pool) hipEventDestroy(ev);

@@ -179,7 +179,8 @@ int hbo_spd_solve(hbo_ctx* ctx, int dtype, const void* a, int64_t n, const void*
 /* ---- profiling: per-stage device time of the last hbo_nll / hbo_factor / hbo_acq call,
  *      measured with HIP events on the stream the kernels were launched on ---------------- */
 #define HBO_MAX_PROFILE_STAGES 32
-int hbo_profile_enable(hbo_ctx* ctx, int level); /* 0 off, 1 per stage, 2 per launch */
+int hbo_profile_enable(hbo_ctx* ctx, int level); /* 0 off, 1 per stage, 2 per launch; -1: only the launches of the
+                                                    bulk trailing update ("syrk_bulk", the roofline kernel of bench.py) */
 /* names: array of HBO_MAX_PROFILE_STAGES char[32]; ms: total ms; launches: count */
 int hbo_profile_get(hbo_ctx* ctx, char names[][32], double* ms, int32_t* launches, int32_t* n);
 
