@@ -9,8 +9,14 @@ from hyperbo_amd.basics import definitions as defs
 from hyperbo_amd.gp_utils import kernel, mean, objectives, utils
 mode = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 index = int(sys.argv[2]) if len(sys.argv) > 2 else 0   # which launch of that mode within the evaluation (mode + 100: persistent ones)
-x, y, raw = bench.cfg2_inputs(n=8192)
-dev = objectives.DeviceDataset({0: defs.SubDataset(x, y)})
+if len(sys.argv) > 3 and sys.argv[3] == 'cfg4':
+    data, raw = bench.cfg4_inputs(tasks=64)
+    dev = objectives.DeviceDataset({k: defs.SubDataset(x, y) for k, (x, y) in data.items()})
+else:
+    x, y, raw = bench.cfg2_inputs(n=8192)
+    dev = objectives.DeviceDataset({0: defs.SubDataset(x, y)})
+for opt in sys.argv[4:]:
+    k, v = opt.split('='); nat.default_context().set_option(k, int(v))
 p = defs.GPParams(model=raw)
 f = lambda: objectives.nll_value_and_grad(mean.constant, kernel.squared_exponential, p, dev, utils.DEFAULT_WARP_FUNC)
 f(); f()
