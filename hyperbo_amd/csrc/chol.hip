@@ -123,16 +123,13 @@ __device__ int hbo_dbg_trsm_panel = 36;
 #else
 #define STAMP(i) do {} while (0)
 #endif
+// (device function: also called by the persistent panel-chain kernel, chain.hip)
 template <typename T>
-__global__ __launch_bounds__(256) void potf2_kernel(const TaskDesc* tasks, int p, int* info) {
+__device__ __forceinline__ void potf2_body(const TaskDesc& t, int p, int* info_slot, unsigned char* smem) {
   typedef typename Mma<T>::acc_t acc_t;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  __builtin_amdgcn_s_setprio(3);            // critical path: outrank co-resident GEMM waves
   T* sT = reinterpret_cast<T*>(smem);       // 36 tiles [16][17]
   T* sM = sT + 36 * TILE_ELEMS;             // inverse of the current leaf [16][17]
   T* sDinv = sM + TILE_ELEMS;               // [128] 1 / diag(L)
-  const TaskDesc& t = tasks[blockIdx.x];
-  if (p >= t.nblk) return;
   const int64_t ld = t.ld;
   T* Ab = static_cast<T*>(t.A) + (int64_t)p * NB * ld + (int64_t)p * NB;
   T* Wb = static_cast<T*>(t.W) + (int64_t)p * NB * ld + (int64_t)p * NB;
@@ -171,7 +168,7 @@ __global__ __launch_bounds__(256) void potf2_kernel(const TaskDesc* tasks, int p
 #pragma unroll
     for (int r = 0; r < 4; ++r) acc[r] = dt[Mma<T>::crow(lane, r) * TS + l15];
     const int bad = leaf_cholesky<T>(acc, vinv, sDinv + jb * 16, lane);
-    if (bad >= 0 && lane == 0) atomicMin(&info[blockIdx.x], p * NB + jb * 16 + bad + 1);
+    if (bad >= 0 && lane == 0) atomicMin(info_slot, p * NB + jb * 16 + bad + 1);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = Mma<T>::crow(lane, r);
@@ -250,44 +247,32 @@ __global__ __launch_bounds__(256) void potf2_kernel(const TaskDesc* tasks, int p
   if (tid == 0 && blockIdx.x == 0 && p < 256) hbo_dbg_wall[3 * p + 1] = wall_clock64();
 #endif
 }
+template <typename T>
+__global__ __launch_bounds__(256) void potf2_kernel(const TaskDesc* tasks, int p, int* info) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __builtin_amdgcn_s_setprio(3);            // critical path: outrank co-resident GEMM waves
+  const TaskDesc& t = tasks[blockIdx.x];
+  if (p >= t.nblk) return;
+  potf2_body<T>(t, p, info + blockIdx.x, smem);
+}
 
 template <typename T>
 constexpr int trsm_lds_bytes() { return (28 + 8 + 4) * TILE_ELEMS * (int)sizeof(T); }   // 87 KB fp64: fits beside one GEMM workgroup
 __device__ __forceinline__ int strict_index(int I, int J) { return I * (I - 1) / 2 + J; }
 
 // grid.x = 64-row group, grid.y = (IDENT ? diagonal block p : unused), grid.z = task
+// 64 rows [row0, row0 + 64) of the panel (or of the identity for IDENT) against diagonal block p.  `stage`: load
+// L_pp and its leaf inverses into LDS first -- a caller that walks several row groups of the same panel (chain.hip)
+// stages once.
 template <typename T, bool IDENT>
-__global__ __launch_bounds__(256) void trsm_kernel(const TaskDesc* tasks, int p_arg) {
+__device__ __forceinline__ void trsm_body(const TaskDesc& t, int p, int64_t row0, unsigned char* smem, bool stage) {
   typedef typename Mma<T>::acc_t acc_t;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  __builtin_amdgcn_s_setprio(3);                // critical path: outrank co-resident GEMM waves
   T* sLt = reinterpret_cast<T*>(smem);          // 28 packed strictly-lower tiles of L_pp
   T* sWi = sLt + 28 * TILE_ELEMS;               // 8 leaf inverses (stand in for the diagonal tiles)
   T* sSc = sWi + 8 * TILE_ELEMS;                // 4 per-wave scratch tiles
-  const TaskDesc& t = tasks[blockIdx.z];
-  const int p = IDENT ? p_arg + (int)blockIdx.y : p_arg;   // IDENT: p_arg = first diagonal block
-  if (p >= t.nblk) return;
-#ifdef HBO_POTF2_TIMING
-  const bool dbg = !IDENT && p == hbo_dbg_trsm_panel && blockIdx.x < 128 && threadIdx.x == 0;
-  if (dbg) {
-    hbo_dbg_trsm[3 * blockIdx.x] = wall_clock64();
-    hbo_dbg_trsm[3 * blockIdx.x + 2] = ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32) |
-                                       (unsigned)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
-  }
-#endif
   const int64_t ld = t.ld;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, lq = lane >> 4;
-  // first row handled by this workgroup
-  int64_t row0;
-  if (IDENT) {
-    row0 = (int64_t)p * NB + (int64_t)blockIdx.x * 64;            // blockIdx.x in {0,1}
-  } else {
-    const int64_t first = (int64_t)(p + 1) * NB;
-    const int64_t nrows = (int64_t)(t.nblk + 1) * NB - first;     // incl. augmented tile-row
-    if ((int64_t)blockIdx.x * 64 >= nrows) return;
-    row0 = first + (int64_t)blockIdx.x * 64;
-  }
   const T* Lb = static_cast<const T*>(t.A) + (int64_t)p * NB * ld + (int64_t)p * NB;
   const T* Wb = static_cast<const T*>(t.W) + (int64_t)p * NB * ld + (int64_t)p * NB;
 
@@ -307,7 +292,7 @@ __global__ __launch_bounds__(256) void trsm_kernel(const TaskDesc* tasks, int p_
       else areg[jb][r] = gld(Ap + (int64_t)row * ld + jb * 16 + l15);
     }
   // stage L_pp (lower tiles) and the leaf inverses: thread = one element of each 16x16 tile
-  {
+  if (stage) {
     const int i = tid >> 4, j = tid & 15;
     int tile = 0;
 #pragma unroll
@@ -319,7 +304,7 @@ __global__ __launch_bounds__(256) void trsm_kernel(const TaskDesc* tasks, int p_
     for (int b = 0; b < 8; ++b)
       sWi[b * TILE_ELEMS + i * TS + j] = gld(Wb + (int64_t)(b * 16 + i) * ld + b * 16 + j);
   }
-  __syncthreads();
+  if (stage) __syncthreads();
 
   T* sc = sSc + wave * TILE_ELEMS;   // wave-private: LDS ops of one wave execute in order
   T xneg[8][4];                      // -X in A-operand layout, per 16-column block
@@ -379,11 +364,39 @@ __global__ __launch_bounds__(256) void trsm_kernel(const TaskDesc* tasks, int p_
       for (int kk = 0; kk < 4; ++kk) xneg[jb][kk] = -sc[l15 * TS + kk * 4 + lq];
     }
   }
+}
+template <typename T, bool IDENT>
+__global__ __launch_bounds__(256) void trsm_kernel(const TaskDesc* tasks, int p_arg) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __builtin_amdgcn_s_setprio(3);                // critical path: outrank co-resident GEMM waves
+  const TaskDesc& t = tasks[blockIdx.z];
+  const int p = IDENT ? p_arg + (int)blockIdx.y : p_arg;   // IDENT: p_arg = first diagonal block
+  if (p >= t.nblk) return;
+#ifdef HBO_POTF2_TIMING
+  const bool dbg = !IDENT && p == hbo_dbg_trsm_panel && blockIdx.x < 128 && threadIdx.x == 0;
+  if (dbg) {
+    hbo_dbg_trsm[3 * blockIdx.x] = wall_clock64();
+    hbo_dbg_trsm[3 * blockIdx.x + 2] = ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32) |
+                                       (unsigned)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
+  }
+#endif
+  // first row handled by this workgroup
+  int64_t row0;
+  if (IDENT) {
+    row0 = (int64_t)p * NB + (int64_t)blockIdx.x * 64;            // blockIdx.x in {0,1}
+  } else {
+    const int64_t first = (int64_t)(p + 1) * NB;
+    const int64_t nrows = (int64_t)(t.nblk + 1) * NB - first;     // incl. augmented tile-row
+    if ((int64_t)blockIdx.x * 64 >= nrows) return;
+    row0 = first + (int64_t)blockIdx.x * 64;
+  }
+  trsm_body<T, IDENT>(t, p, row0, smem, true);
 #ifdef HBO_POTF2_TIMING
   if (dbg) hbo_dbg_trsm[3 * blockIdx.x + 1] = wall_clock64();
 #endif
 }
 
+#ifndef HBO_DEVICE_ONLY
 template <typename T>
 void set_attrs() {
   static bool done = false;
@@ -418,8 +431,10 @@ void trtri_diag_t(const TaskDesc* tasks, int ntasks, int p_lo, int p_hi, hipStre
                      tasks, p_lo);
 }
 
+#endif  // HBO_DEVICE_ONLY
 }  // namespace
 
+#ifndef HBO_DEVICE_ONLY
 #ifdef HBO_POTF2_TIMING
 void dbg_read_stamps(unsigned long long* host) { hipMemcpyFromSymbol(host, HIP_SYMBOL(hbo_dbg_stamps), sizeof(unsigned long long) * 64); }
 extern "C" void hbo_dbg_trsm_wall(unsigned long long* host, int panel) {
@@ -440,3 +455,4 @@ void launch_trtri_diag(int dtype, const TaskDesc* tasks, int ntasks, int p_lo, i
   if (dtype == HBO_F64) trtri_diag_t<double>(tasks, ntasks, p_lo, p_hi, st);
   else trtri_diag_t<float>(tasks, ntasks, p_lo, p_hi, st);
 }
+#endif  // HBO_DEVICE_ONLY
