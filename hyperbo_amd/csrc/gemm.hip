@@ -434,6 +434,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
 #endif
 }
 
+#ifndef HBO_DEVICE_ONLY
 template <typename T>
 void launch_gemm_t(const GemmArgs& a, dim3 grid, hipStream_t st) {
   static bool attr_set = false;
@@ -486,8 +487,10 @@ void launch_gemm_t(const GemmArgs& a, dim3 grid, hipStream_t st) {
   }
 }
 
+#endif  // HBO_DEVICE_ONLY
 }  // namespace
 
+#ifndef HBO_DEVICE_ONLY
 #ifdef HBO_GEMM_TIMING
 extern "C" void hbo_dbg_gemm_wall(unsigned long long* host, int mode, int index) {
   if (host) { hipMemcpyFromSymbol(host, HIP_SYMBOL(hbo_dbg_gemm), sizeof(unsigned long long) * 4 * 8192); return; }
@@ -505,3 +508,4 @@ void launch_gemm(int dtype, const GemmArgs& a_in, dim3 grid, hipStream_t st) {
   if (dtype == HBO_F64) launch_gemm_t<double>(a, grid, st);
   else launch_gemm_t<float>(a, grid, st);
 }
+#endif  // HBO_DEVICE_ONLY
