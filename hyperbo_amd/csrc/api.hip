@@ -23,6 +23,7 @@ struct hbo_ctx {
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;   // panel stream of the look-ahead Cholesky (high priority)
   hipStream_t stream4 = nullptr;   // early part of trtri, overlapped with the tail of potrf
+  hipStream_t stream5 = nullptr;   // in-group column updates beside the persistent chain kernel
   int opt_small_nblk = 32;   // matrices up to this many 128-blocks use 64x64 GEMM tiles in trtri / lauum
   int opt_persist_free = 32; // bulk trailing update runs as 2*(CUs - this) persistent workgroups
   int n_cus = 256;
@@ -30,7 +31,7 @@ struct hbo_ctx {
   std::map<int, std::pair<void*, size_t>> ws;   // grow-only device scratch buffers by slot (no per-call hipMalloc/hipFree)
   int opt_lookahead = 1;
   int opt_chain = 0;               // persistent panel-chain kernel (chain.hip) instead of per-panel launches
-  int opt_chain_wgs = 48;          // its workgroups (one CU each)
+  int opt_chain_wgs = 32;          // its workgroups (one CU each)
   unsigned long long* sig_panels = nullptr;   // signal memory (hipStreamWaitValue64 / WriteValue64), monotonic counters
   unsigned long long* sig_bulk = nullptr;
   unsigned long long panels_count = 0, bulk_count = 0;
@@ -163,6 +164,7 @@ extern "C" int hbo_ctx_create(int device, hbo_ctx** out) {
   if (e == hipSuccess) e = hipStreamCreate(&c->stream);
   if (e == hipSuccess) e = hipStreamCreate(&c->stream2);
   if (e == hipSuccess) e = hipStreamCreate(&c->stream4);
+  if (e == hipSuccess) e = hipStreamCreate(&c->stream5);
   if (const char* v = getenv("HBO_CHAIN")) c->opt_chain = atoi(v) ? 1 : 0;   // test / benchmark override of the default
   if (const char* v = getenv("HBO_CHAIN_WGS")) { const int k = atoi(v); if (k >= 2 && k <= 128) c->opt_chain_wgs = k; }
   if (e == hipSuccess) e = hipMalloc((void**)&c->d_model, sizeof(ModelDev));
@@ -203,6 +205,7 @@ extern "C" int hbo_ctx_destroy(hbo_ctx* c) {
   for (auto& kv : c->ws) if (kv.second.first) hipFree(kv.second.first);
   for (hipEvent_t ev : c->ev_pool) hipEventDestroy(ev);
   if (c->stream4) hipStreamDestroy(c->stream4);
+  if (c->stream5) hipStreamDestroy(c->stream5);
   if (c->stream2) hipStreamDestroy(c->stream2);
   if (c->stream) hipStreamDestroy(c->stream);
   delete c;
@@ -377,52 +380,73 @@ static hipEvent_t pool_event(hbo_ctx* c, size_t i) {
 // launches: F1 updates only the NEXT group's block columns, F2 the rest; the next group's panel
 // work (potf2 -> trsm, the serial chain) runs on a second stream as soon as F1 is done, so F2
 // -- the bulk of the flops -- overlaps it.
-// Single-task factorisation driven by the persistent panel-chain kernel (chain.hip): the chain is ONE kernel on the
-// panel stream; the main stream holds, per group of q panels, a wait on the chain's signal, the bulk trailing update
-// of that group and a write to the signal the chain waits on before it touches the updated block columns.
+// Single-task factorisation driven by the persistent panel-chain kernel (chain.hip).  The chain (potf2 + trsm of
+// every panel) is ONE kernel on the panel stream.  Per panel the column stream holds: wait for the chain's panel
+// counter, the left-looking update of the next block column, a write to the signal the chain waits on.  Per group of
+// q panels the main stream holds: wait, F1 (next group's block columns), signal write, F2 (bulk update).
 static void run_potrf_chain(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int max_nblk, int* d_info, int early_H) {
   const int q = c->opt_group;
-  hipStream_t sm = c->stream, sp = c->stream2;
+  hipStream_t sm = c->stream, sp = c->stream2, sc = c->stream5;
   size_t evi = 0;
   void* sync = ws_get(c, WS_CHAIN_SYNC, 64);
   int* counters = c->opt_dynamic_tiles ? (int*)ws_get(c, WS_COUNTERS, sizeof(int) * 256) : nullptr;
   int n_counter = 0;
   hipMemsetAsync(sync, 0, 64, sm);
   if (counters) hipMemsetAsync(counters, 0, sizeof(int) * 256, sm);
-  { hipEvent_t e = pool_event(c, evi++); hipEventRecord(e, sm); hipStreamWaitEvent(sp, e, 0); }
+  { hipEvent_t e = pool_event(c, evi++); hipEventRecord(e, sm); hipStreamWaitEvent(sp, e, 0); hipStreamWaitEvent(sc, e, 0); }
   ChainArgs ca = {};
-  ca.tasks = d_tasks; ca.info = d_info; ca.sync = sync; ca.s_panels = c->sig_panels; ca.s_bulk = c->sig_bulk;
-  ca.bulk_base = c->bulk_count; ca.q = q;
-  const unsigned long long panels_base = c->panels_count;
+  ca.tasks = d_tasks; ca.info = d_info; ca.sync = sync; ca.s_panels = c->sig_panels; ca.s_col = c->sig_bulk;
+  ca.col_base = c->bulk_count;
+  const unsigned long long pbase = c->panels_count, cbase = c->bulk_count;
+  const unsigned long long all = 0xFFFFFFFFFFFFFFFFull;
   { ProfScope ps(c, "chain", 1, sp); launch_chain(dtype, ca, c->opt_chain_wgs, sp); }
-  const int ngroups = (max_nblk + q - 1) / q;
+  const int pblocks = 2 * (c->n_cus - c->opt_chain_wgs);      // the chain's workgroups own their CUs
   bool early_started = false;
-  for (int g = 0; g < ngroups; ++g) {
-    const int g0 = g * q, g1 = std::min(g0 + q, max_nblk), g2 = std::min(g1 + q, max_nblk);
-    hipStreamWaitValue64(sm, c->sig_panels, panels_base + g + 1, hipStreamWaitValueGte, 0xFFFFFFFFFFFFFFFFull);
-    if (g2 < max_nblk) {
-      GemmArgs a = {}; a.tasks = d_tasks; a.mode = GEMM_SYRK; a.p0 = g0; a.kt = g1 - g0; a.aug = 1;
-      a.c_lo = g2; a.c_hi = max_nblk;
-      const int64_t m = max_nblk - g2;
-      a.small_tiles = m * (m + 1) / 2 < 600;
-      const int64_t ntiles = (m * (m + 1) / 2 + m) * (a.small_tiles ? 4 : 1);
-      const int pblocks = 2 * (c->n_cus - c->opt_chain_wgs);      // the chain's workgroups own their CUs
-      a.persistent = (ntiles > pblocks && m <= 96) ? pblocks : 0;
-      a.work_counter = (a.persistent && counters && n_counter < 256) ? counters + n_counter++ : nullptr;
-      ProfScope ps(c, a.small_tiles ? "syrk_trailing" : "syrk_bulk", 1, sm);
-      launch_gemm(dtype, a, dim3(max_nblk + 1 - a.c_lo, a.c_hi - a.c_lo, 1), sm);
+  for (int g0 = 0; g0 < max_nblk; g0 += q) {
+    const int g1 = std::min(g0 + q, max_nblk), g2 = std::min(g1 + q, max_nblk);
+    // in-group column updates: column p+1 after panel p
+    for (int p = g0; p + 1 < g1; ++p) {
+      hipStreamWaitValue64(sc, c->sig_panels, pbase + p + 1, hipStreamWaitValueGte, all);
+      {
+        ProfScope ps(c, "syrk_col", 2, sc);
+        GemmArgs a = {}; a.tasks = d_tasks; a.mode = GEMM_SYRK; a.p0 = g0; a.kt = p + 1 - g0; a.c_lo = p + 1; a.c_hi = p + 2; a.aug = 1; a.small_tiles = 1;
+        launch_gemm(dtype, a, dim3(max_nblk + 1 - (p + 1), 1, 1), sc);
+      }
+      hipStreamWriteValue64(sc, c->sig_bulk, cbase + p + 1, 0);
     }
-    hipStreamWriteValue64(sm, c->sig_bulk, c->bulk_count + g + 1, 0);
+    // group finished: F1 (the next group's block columns), release the chain, then the bulk update F2
+    hipStreamWaitValue64(sm, c->sig_panels, pbase + g1, hipStreamWaitValueGte, all);
+    if (g1 < max_nblk) {
+      GemmArgs a = {}; a.tasks = d_tasks; a.mode = GEMM_SYRK; a.p0 = g0; a.kt = g1 - g0; a.aug = 1;
+      {
+        ProfScope ps(c, "syrk_trailing", 1, sm);
+        a.c_lo = g1; a.c_hi = g2;
+        a.small_tiles = (int64_t)(max_nblk + 1 - a.c_lo) * (a.c_hi - a.c_lo) < 600;
+        launch_gemm(dtype, a, dim3(max_nblk + 1 - a.c_lo, a.c_hi - a.c_lo, 1), sm);
+      }
+      hipStreamWriteValue64(sm, c->sig_bulk, cbase + g1, 0);
+      if (g2 < max_nblk) {
+        a.c_lo = g2; a.c_hi = max_nblk;
+        const int64_t m = max_nblk - g2;
+        a.small_tiles = m * (m + 1) / 2 < 600;
+        const int64_t ntiles = (m * (m + 1) / 2 + m) * (a.small_tiles ? 4 : 1);
+        a.persistent = (ntiles > pblocks && m <= 96) ? pblocks : 0;
+        a.work_counter = (a.persistent && counters && n_counter < 256) ? counters + n_counter++ : nullptr;
+        ProfScope ps(c, a.small_tiles ? "syrk_trailing" : "syrk_bulk", 1, sm);
+        launch_gemm(dtype, a, dim3(max_nblk + 1 - a.c_lo, a.c_hi - a.c_lo, 1), sm);
+      }
+    }
     if (early_H > 0 && !early_started && g1 >= early_H) {
       // the first H block columns of L are final: early part of the inverse on its side stream
-      hipStreamWaitValue64(c->stream4, c->sig_panels, panels_base + g + 1, hipStreamWaitValueGte, 0xFFFFFFFFFFFFFFFFull);
+      hipStreamWaitValue64(c->stream4, c->sig_panels, pbase + g1, hipStreamWaitValueGte, all);
       ProfScope ps(c, "trtri_early", 1, c->stream4);
       run_trtri_early(c, dtype, d_tasks, 1, max_nblk, early_H, c->stream4);
       early_started = true;
     }
   }
-  c->panels_count += ngroups; c->bulk_count += ngroups;
+  c->panels_count += max_nblk; c->bulk_count += max_nblk;
   { hipEvent_t e = pool_event(c, evi++); hipEventRecord(e, sp); hipStreamWaitEvent(sm, e, 0); }
+  { hipEvent_t e = pool_event(c, evi++); hipEventRecord(e, sc); hipStreamWaitEvent(sm, e, 0); }
   if (early_H > 0) { hipEvent_t e = pool_event(c, evi++); hipEventRecord(e, c->stream4); hipStreamWaitEvent(sm, e, 0); }
 }
 

@@ -1,25 +1,17 @@
 // Persistent panel-chain kernel of the blocked Cholesky (single task, look-ahead mode).
 //
-// The factorisation's critical path -- per 128-column panel: left-looking update of the block column, potf2 of the
-// diagonal block, trsm of the rows below -- used to be three kernel launches per panel that had to find free workgroup
-// slots between the workgroups of the trailing-update GEMMs (profiles/r01_potrf_chain.md: slot waiting, 3x slower
-// kernels beside the bulk update, a 0.8 ms stall when the early inverse starts).  Here `nwg` workgroups are launched
-// once and stay resident for the whole factorisation; each requests more than half of a CU's LDS, so a workgroup owns
-// its CU (no trailing-update workgroup fits beside it) and the chain never waits for placement.  Steps inside a panel
-// are separated by a grid barrier (atomic counter, agent-scope release/acquire), not by kernel boundaries.
-//
-// The trailing updates stay host-launched GEMMs on the other CUs and are tied to the chain with signal memory:
-//   s_panels : the chain adds 1 when a group of q panels is final      -> hipStreamWaitValue64 releases F2(g)
-//   s_bulk   : hipStreamWriteValue64 after F2(g) completes             -> the chain spins on it before it touches
-//              block columns that F2 wrote (group g + 2 onwards).
-// Block column p is brought up to date left-looking inside the chain: K = [start of the previous group, p), i.e. the
-// previous group's panels (F2 skips the next group's columns) plus the earlier panels of its own group.
+// potf2 of the diagonal block and trsm of the rows below it -- the two latency-bound steps of every 128-column panel
+// -- run inside ONE kernel that stays resident for the whole factorisation: `nwg` workgroups, each requesting more
+// than 3/4 of a CU's LDS so that it owns its CU (no GEMM workgroup of the trailing updates fits beside it; beside
+// such workgroups potf2 ran 3x slower and waited for slots, profiles/r01_potrf_chain.md).  The GEMM work -- the
+// left-looking update of the next block column, the next group's columns (F1), the bulk update (F2) -- stays in
+// host-launched kernels on the other CUs, tied to the chain with signal memory instead of kernel boundaries:
+//   s_panels : the chain adds 1 per finished panel      -> hipStreamWaitValue64 releases the kernels that need it
+//   s_col    : hipStreamWriteValue64(col_base + p) once block column p is up to date -> the chain spins on it
+//              before potf2 of panel p.
 #include "hbo_internal.h"
 #include <limits.h>
 #define HBO_DEVICE_ONLY
-namespace hbo_gemm {
-#include "gemm.hip"
-}
 namespace hbo_chol {
 #include "chol.hip"
 }
@@ -68,54 +60,25 @@ __device__ unsigned long long hbo_dbg_chain[6 * 256];   // per panel (workgroup 
 template <typename T>
 __global__ __launch_bounds__(256) void chain_kernel(ChainArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  constexpr int BKE = 128 / sizeof(T);
   const TaskDesc& t = a.tasks[0];
   const int nblk = t.nblk;
   const int nwg = gridDim.x, wg = blockIdx.x;
-  const int64_t ld = t.ld;
   ChainSync* sy = reinterpret_cast<ChainSync*>(a.sync);
   unsigned gen = 0;
-  T* Am = static_cast<T*>(t.A);
-  const int nrt64 = (nblk + 1) * 2;      // 64-row tiles incl. the augmented tile-row
 
   for (int p = 0; p < nblk; ++p) {
-    const int grp = p / a.q, g0 = grp * a.q;
     CSTAMP(0);
-    // block columns of group >= 2 carry the bulk update of group - 2: wait for it before touching them
-    if (p == g0 && grp >= 2) {
+    // block column p has to be up to date (host-launched column update / F1 of the previous group)
+    if (p > 0) {
       if (threadIdx.x == 0) {
-        const unsigned long long need = a.bulk_base + (unsigned long long)(grp - 1);
-        HBO_SPIN_WHILE(__hip_atomic_load(a.s_bulk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < need &&
+        const unsigned long long need = a.col_base + (unsigned long long)p;
+        HBO_SPIN_WHILE(__hip_atomic_load(a.s_col, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < need &&
                        !__hip_atomic_load(&sy->timed_out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
       }
       __syncthreads();
       __threadfence();
     }
     CSTAMP(1);
-    // ---- left-looking update of block column p: K = [max(0, g0 - q), p) ---------------------------------------
-    const int kbeg = g0 - a.q > 0 ? g0 - a.q : 0;
-    if (p > kbeg) {
-      hbo_gemm::TileJob<T> job;
-      job.lda = job.ldb = job.ldc = ld;
-      job.colsq = nullptr;
-      job.ksteps = (p - kbeg) * HBO_TILE / BKE;
-      job.alpha = (T)-1; job.beta = 1;
-      const int c0 = 2 * p;
-      int tix = 0;
-      for (int r = c0; r < nrt64; ++r)
-        for (int ch = 0; ch < 2; ++ch) {
-          const int c = c0 + ch;
-          if (r < c) continue;
-          if (tix++ % nwg != wg) continue;
-          job.A = Am + (int64_t)r * 64 * ld + (int64_t)kbeg * HBO_TILE;
-          job.B = Am + (int64_t)c * 64 * ld + (int64_t)kbeg * HBO_TILE;
-          job.C = Am + (int64_t)r * 64 * ld + (int64_t)c * 64;
-          hbo_gemm::gemm_tile<T, true, true, 64>(job, smem);
-          __syncthreads();
-        }
-      grid_barrier(sy, nwg, gen);
-    }
-    CSTAMP(2);
     // ---- potf2 of the diagonal block (workgroup 0), the others wait for its flag ------------------------------
     if (wg == 0) {
       hbo_chol::potf2_body<T>(t, p, a.info, smem);
@@ -144,8 +107,8 @@ __global__ __launch_bounds__(256) void chain_kernel(ChainArgs a) {
     CSTAMP(4);
     grid_barrier(sy, nwg, gen);
     CSTAMP(5);
-    // ---- a finished group releases its bulk update ------------------------------------------------------------
-    if ((p == g0 + a.q - 1 || p == nblk - 1) && wg == 0 && threadIdx.x == 0) atomicAdd(a.s_panels, 1ull);
+    // ---- a finished panel releases the kernels that consume it -------------------------------------------------
+    if (wg == 0 && threadIdx.x == 0) atomicAdd(a.s_panels, 1ull);
   }
   // (after a time-out every group has still been signalled: the host streams are never left waiting)
   if (wg == 0 && threadIdx.x == 0 && sy->timed_out) atomicMin(a.info, 0);   // reported as "not positive definite"
@@ -156,7 +119,7 @@ __global__ __launch_bounds__(256) void chain_kernel(ChainArgs a) {
 #ifdef HBO_CHAIN_TIMING
 extern "C" void hbo_dbg_chain_stamps(unsigned long long* host) { hipMemcpyFromSymbol(host, HIP_SYMBOL(hbo_dbg_chain), sizeof(unsigned long long) * 6 * 256); }
 #endif
-int chain_lds_bytes() { return 100 * 1024; }
+int chain_lds_bytes() { return 124 * 1024; }   // nothing with >= 36 KB of LDS fits beside a chain workgroup
 void launch_chain(int dtype, const ChainArgs& a, int nwg, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {

@@ -88,10 +88,9 @@ struct ChainArgs {
   const TaskDesc* tasks;              // single task
   int* info;                          // potf2 status slot of that task
   void* sync;                         // 16 zeroed bytes: grid barrier + potf2 flag
-  unsigned long long* s_panels;       // signal memory: +1 per finished panel group
-  unsigned long long* s_bulk;         // signal memory: bulk_base + number of completed bulk updates
-  unsigned long long bulk_base;
-  int q;                              // panels per group
+  unsigned long long* s_panels;       // signal memory: +1 per finished panel
+  unsigned long long* s_col;          // signal memory: col_base + p once block column p is up to date
+  unsigned long long col_base;
 };
 void launch_chain(int dtype, const ChainArgs& a, int nwg, hipStream_t st);
 void launch_potf2(int dtype, const TaskDesc* tasks, int ntasks, int p, int* info, hipStream_t st);

@@ -19,7 +19,7 @@ buf = (C.c_ulonglong * (6 * 256))()
 nat.lib().hbo_dbg_chain_stamps(buf)
 a = np.array(buf[:6 * 64], dtype=np.uint64).reshape(64, 6).astype(np.float64) / 100.0
 d = np.diff(a, axis=1)
-print('panel: wait_bulk  col_update  potf2  trsm  barrier   | total')
+print("panel: (unused) wait_col  potf2  trsm  barrier   | total")
 for i in list(range(0, 64, 4)) + [1, 2, 3, 61, 62, 63]:
     print('%4d  %8.1f %10.1f %7.1f %6.1f %7.1f   | %7.1f' % (i, d[i, 0], d[i, 1], d[i, 2], d[i, 3], d[i, 4], a[i, 5] - a[i, 0]))
 print('sums (ms): wait %.2f  update %.2f  potf2 %.2f  trsm %.2f  barrier %.2f  total %.2f' % tuple(list(d.sum(axis=0) / 1e3) + [(a[-1, 5] - a[0, 0]) / 1e3]))
