@@ -23,18 +23,12 @@ struct hbo_ctx {
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;   // panel stream of the look-ahead Cholesky (high priority)
   hipStream_t stream4 = nullptr;   // early part of trtri, overlapped with the tail of potrf
-  hipStream_t stream5 = nullptr;   // in-group column updates beside the persistent chain kernel
   int opt_small_nblk = 32;   // matrices up to this many 128-blocks use 64x64 GEMM tiles in trtri / lauum
   int opt_persist_free = 32; // bulk trailing update runs as 2*(CUs - this) persistent workgroups
   int n_cus = 256;
   std::vector<hipEvent_t> ev_pool;
   std::map<int, std::pair<void*, size_t>> ws;   // grow-only device scratch buffers by slot (no per-call hipMalloc/hipFree)
   int opt_lookahead = 1;
-  int opt_chain = 0;               // persistent panel-chain kernel (chain.hip) instead of per-panel launches
-  int opt_chain_wgs = 32;          // its workgroups (one CU each)
-  unsigned long long* sig_panels = nullptr;   // signal memory (hipStreamWaitValue64 / WriteValue64), monotonic counters
-  unsigned long long* sig_bulk = nullptr;
-  unsigned long long panels_count = 0, bulk_count = 0;
   int opt_dynamic_tiles = 1;       // persistent bulk update draws its tiles from a counter
   int opt_overlap_trtri = 1;
   std::string err;
@@ -82,7 +76,7 @@ static inline int64_t padded_ld(int64_t extent, int dtype) { return extent + 128
 
 // grow-only scratch buffer for `slot`; nullptr on allocation failure (ctx->err is set)
 enum WsSlot { WS_XQ = 1, WS_MU0, WS_KD, WS_MU, WS_VAR, WS_ACQ, WS_K, WS_COLSQ, WS_V, WS_KQQ, WS_COV,
-              WS_AP_KX, WS_AP_L, WS_AP_W, WS_AP_MU, WS_AP_KD, WS_COUNTERS, WS_CHAIN_SYNC,
+              WS_AP_KX, WS_AP_L, WS_AP_W, WS_AP_MU, WS_AP_KD, WS_COUNTERS,
               WS_AG_K, WS_AG_L, WS_AG_B, WS_AG_GF, WS_AG_DMU, WS_AG_GX, WS_AG_T0, WS_AG_T1, WS_AG_DW, WS_FQ0 /* + layer */ };
 static void* ws_get(hbo_ctx* c, int slot, size_t bytes) {
   auto& e = c->ws[slot];
@@ -164,23 +158,7 @@ extern "C" int hbo_ctx_create(int device, hbo_ctx** out) {
   if (e == hipSuccess) e = hipStreamCreate(&c->stream);
   if (e == hipSuccess) e = hipStreamCreate(&c->stream2);
   if (e == hipSuccess) e = hipStreamCreate(&c->stream4);
-  if (e == hipSuccess) e = hipStreamCreate(&c->stream5);
-  if (const char* v = getenv("HBO_CHAIN")) c->opt_chain = atoi(v) ? 1 : 0;   // test / benchmark override of the default
-  if (const char* v = getenv("HBO_CHAIN_WGS")) { const int k = atoi(v); if (k >= 2 && k <= 128) c->opt_chain_wgs = k; }
   if (e == hipSuccess) e = hipMalloc((void**)&c->d_model, sizeof(ModelDev));
-  if (e == hipSuccess) {
-    int can = 0;
-    if (hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, device) == hipSuccess && can &&
-        hipExtMallocWithFlags((void**)&c->sig_panels, 8, hipMallocSignalMemory) == hipSuccess &&
-        hipExtMallocWithFlags((void**)&c->sig_bulk, 8, hipMallocSignalMemory) == hipSuccess) {
-      unsigned long long zero = 0;
-      e = hipMemcpy(c->sig_panels, &zero, 8, hipMemcpyHostToDevice);
-      if (e == hipSuccess) e = hipMemcpy(c->sig_bulk, &zero, 8, hipMemcpyHostToDevice);
-    } else {
-      c->sig_panels = c->sig_bulk = nullptr;   // the chain kernel is then not offered
-      (void)hipGetLastError();
-    }
-  }
   if (e != hipSuccess) {
     g_err = std::string("hbo_ctx_create: ") + hipGetErrorString(e);
     delete c;
@@ -199,13 +177,10 @@ extern "C" int hbo_ctx_destroy(hbo_ctx* c) {
   prof_begin(c);
   for (int l = 0; l < HBO_MAX_MLP_LAYERS; ++l) { if (c->d_mlp_w[l]) hipFree(c->d_mlp_w[l]); if (c->d_mlp_b[l]) hipFree(c->d_mlp_b[l]); }
   for (hipEvent_t ev : c->prof_events) hipEventDestroy(ev);
-  if (c->sig_panels) hipFree(c->sig_panels);
-  if (c->sig_bulk) hipFree(c->sig_bulk);
   if (c->d_model) hipFree(c->d_model);
   for (auto& kv : c->ws) if (kv.second.first) hipFree(kv.second.first);
   for (hipEvent_t ev : c->ev_pool) hipEventDestroy(ev);
   if (c->stream4) hipStreamDestroy(c->stream4);
-  if (c->stream5) hipStreamDestroy(c->stream5);
   if (c->stream2) hipStreamDestroy(c->stream2);
   if (c->stream) hipStreamDestroy(c->stream);
   delete c;
@@ -216,8 +191,6 @@ extern "C" int hbo_set_option(hbo_ctx* c, const char* name, int64_t value) {
   if (!strcmp(name, "potrf_group")) { if (value < 1 || value > 8) return fail(c, HBO_ERR_ARG, "potrf_group in 1..8"); c->opt_group = (int)value; return HBO_OK; }
   if (!strcmp(name, "overlap_trtri")) { c->opt_overlap_trtri = value ? 1 : 0; return HBO_OK; }
   if (!strcmp(name, "dynamic_tiles")) { c->opt_dynamic_tiles = value ? 1 : 0; return HBO_OK; }
-  if (!strcmp(name, "chain")) { c->opt_chain = value ? 1 : 0; return HBO_OK; }
-  if (!strcmp(name, "chain_wgs")) { if (value < 2 || value > 128) return fail(c, HBO_ERR_ARG, "chain_wgs in 2..128"); c->opt_chain_wgs = (int)value; return HBO_OK; }
   if (!strcmp(name, "lookahead")) { c->opt_lookahead = value ? 1 : 0; return HBO_OK; }
   if (!strcmp(name, "small_nblk")) { c->opt_small_nblk = (int)value; return HBO_OK; }
   if (!strcmp(name, "persist_free")) { if (value < 0 || value > 200) return fail(c, HBO_ERR_ARG, "persist_free in 0..200"); c->opt_persist_free = (int)value; return HBO_OK; }
@@ -380,82 +353,8 @@ static hipEvent_t pool_event(hbo_ctx* c, size_t i) {
 // launches: F1 updates only the NEXT group's block columns, F2 the rest; the next group's panel
 // work (potf2 -> trsm, the serial chain) runs on a second stream as soon as F1 is done, so F2
 // -- the bulk of the flops -- overlaps it.
-// Single-task factorisation driven by the persistent panel-chain kernel (chain.hip).  The chain (potf2 + trsm of
-// every panel) is ONE kernel on the panel stream.  Per panel the column stream holds: wait for the chain's panel
-// counter, the left-looking update of the next block column, a write to the signal the chain waits on.  Per group of
-// q panels the main stream holds: wait, F1 (next group's block columns), signal write, F2 (bulk update).
-static void run_potrf_chain(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int max_nblk, int* d_info, int early_H) {
-  const int q = c->opt_group;
-  hipStream_t sm = c->stream, sp = c->stream2, sc = c->stream5;
-  size_t evi = 0;
-  void* sync = ws_get(c, WS_CHAIN_SYNC, 64);
-  int* counters = c->opt_dynamic_tiles ? (int*)ws_get(c, WS_COUNTERS, sizeof(int) * 256) : nullptr;
-  int n_counter = 0;
-  hipMemsetAsync(sync, 0, 64, sm);
-  if (counters) hipMemsetAsync(counters, 0, sizeof(int) * 256, sm);
-  { hipEvent_t e = pool_event(c, evi++); hipEventRecord(e, sm); hipStreamWaitEvent(sp, e, 0); hipStreamWaitEvent(sc, e, 0); }
-  ChainArgs ca = {};
-  ca.tasks = d_tasks; ca.info = d_info; ca.sync = sync; ca.s_panels = c->sig_panels; ca.s_col = c->sig_bulk;
-  ca.col_base = c->bulk_count;
-  const unsigned long long pbase = c->panels_count, cbase = c->bulk_count;
-  const unsigned long long all = 0xFFFFFFFFFFFFFFFFull;
-  { ProfScope ps(c, "chain", 1, sp); launch_chain(dtype, ca, c->opt_chain_wgs, sp); }
-  const int pblocks = 2 * (c->n_cus - c->opt_chain_wgs);      // the chain's workgroups own their CUs
-  bool early_started = false;
-  for (int g0 = 0; g0 < max_nblk; g0 += q) {
-    const int g1 = std::min(g0 + q, max_nblk), g2 = std::min(g1 + q, max_nblk);
-    // in-group column updates: column p+1 after panel p
-    for (int p = g0; p + 1 < g1; ++p) {
-      hipStreamWaitValue64(sc, c->sig_panels, pbase + p + 1, hipStreamWaitValueGte, all);
-      {
-        ProfScope ps(c, "syrk_col", 2, sc);
-        GemmArgs a = {}; a.tasks = d_tasks; a.mode = GEMM_SYRK; a.p0 = g0; a.kt = p + 1 - g0; a.c_lo = p + 1; a.c_hi = p + 2; a.aug = 1; a.small_tiles = 1;
-        launch_gemm(dtype, a, dim3(max_nblk + 1 - (p + 1), 1, 1), sc);
-      }
-      hipStreamWriteValue64(sc, c->sig_bulk, cbase + p + 1, 0);
-    }
-    // group finished: F1 (the next group's block columns), release the chain, then the bulk update F2
-    hipStreamWaitValue64(sm, c->sig_panels, pbase + g1, hipStreamWaitValueGte, all);
-    if (g1 < max_nblk) {
-      GemmArgs a = {}; a.tasks = d_tasks; a.mode = GEMM_SYRK; a.p0 = g0; a.kt = g1 - g0; a.aug = 1;
-      {
-        ProfScope ps(c, "syrk_trailing", 1, sm);
-        a.c_lo = g1; a.c_hi = g2;
-        a.small_tiles = (int64_t)(max_nblk + 1 - a.c_lo) * (a.c_hi - a.c_lo) < 600;
-        launch_gemm(dtype, a, dim3(max_nblk + 1 - a.c_lo, a.c_hi - a.c_lo, 1), sm);
-      }
-      hipStreamWriteValue64(sm, c->sig_bulk, cbase + g1, 0);
-      if (g2 < max_nblk) {
-        a.c_lo = g2; a.c_hi = max_nblk;
-        const int64_t m = max_nblk - g2;
-        a.small_tiles = m * (m + 1) / 2 < 600;
-        const int64_t ntiles = (m * (m + 1) / 2 + m) * (a.small_tiles ? 4 : 1);
-        a.persistent = (ntiles > pblocks && m <= 96) ? pblocks : 0;
-        a.work_counter = (a.persistent && counters && n_counter < 256) ? counters + n_counter++ : nullptr;
-        ProfScope ps(c, a.small_tiles ? "syrk_trailing" : "syrk_bulk", 1, sm);
-        launch_gemm(dtype, a, dim3(max_nblk + 1 - a.c_lo, a.c_hi - a.c_lo, 1), sm);
-      }
-    }
-    if (early_H > 0 && !early_started && g1 >= early_H) {
-      // the first H block columns of L are final: early part of the inverse on its side stream
-      hipStreamWaitValue64(c->stream4, c->sig_panels, pbase + g1, hipStreamWaitValueGte, all);
-      ProfScope ps(c, "trtri_early", 1, c->stream4);
-      run_trtri_early(c, dtype, d_tasks, 1, max_nblk, early_H, c->stream4);
-      early_started = true;
-    }
-  }
-  c->panels_count += max_nblk; c->bulk_count += max_nblk;
-  { hipEvent_t e = pool_event(c, evi++); hipEventRecord(e, sp); hipStreamWaitEvent(sm, e, 0); }
-  { hipEvent_t e = pool_event(c, evi++); hipEventRecord(e, sc); hipStreamWaitEvent(sm, e, 0); }
-  if (early_H > 0) { hipEvent_t e = pool_event(c, evi++); hipEventRecord(e, c->stream4); hipStreamWaitEvent(sm, e, 0); }
-}
-
 static void run_potrf(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, int max_nblk, int* d_info,
                       int early_H = 0) {
-  if (c->opt_chain && c->opt_lookahead && ntasks == 1 && c->sig_panels && max_nblk > c->opt_group) {
-    run_potrf_chain(c, dtype, d_tasks, max_nblk, d_info, early_H);
-    return;
-  }
   const int q = c->opt_group;
   hipStream_t sm = c->stream;
   hipStream_t sp = c->opt_lookahead ? c->stream2 : c->stream;

@@ -83,16 +83,6 @@ struct GemmArgs {
 // ---- launchers (defined in the .hip files) ---------------------------------------------
 void launch_gemm(int dtype, const GemmArgs& a, dim3 grid, hipStream_t st);
 
-// persistent panel-chain kernel (chain.hip)
-struct ChainArgs {
-  const TaskDesc* tasks;              // single task
-  int* info;                          // potf2 status slot of that task
-  void* sync;                         // 16 zeroed bytes: grid barrier + potf2 flag
-  unsigned long long* s_panels;       // signal memory: +1 per finished panel
-  unsigned long long* s_col;          // signal memory: col_base + p once block column p is up to date
-  unsigned long long col_base;
-};
-void launch_chain(int dtype, const ChainArgs& a, int nwg, hipStream_t st);
 void launch_potf2(int dtype, const TaskDesc* tasks, int ntasks, int p, int* info, hipStream_t st);
 void launch_trsm(int dtype, const TaskDesc* tasks, int ntasks, int p, int max_nblk, hipStream_t st);
 // inverses of the diagonal blocks p in [p_lo, p_hi)
