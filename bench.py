@@ -202,12 +202,22 @@ def main():
         obj = [b]
         dist.broadcast_object_list(obj, src=0)
         return obj[0]
+      # the [nll, count, grad] all-reduce: RCCL through torch.distributed's own 'nccl' backend (the well-trodden path
+      # on ROCm; HBO_BENCH_COMM=libhbo selects libhbo's direct RCCL binding), gloo if no communicator can be built
+      pref = os.environ.get('HBO_BENCH_COMM', 'torch-nccl')
       try:
-        comm = parallel.RcclComm(ctx, rank, world, bcast)
-        comm_kind = 'rccl (libhbo, xGMI)'
+        if pref == 'libhbo':
+          comm = parallel.RcclComm(ctx, rank, world, bcast)
+          comm_kind = 'rccl (libhbo, xGMI)'
+        else:
+          import datetime
+          grp = dist.new_group(backend='nccl', timeout=datetime.timedelta(seconds=120))
+          comm = parallel.TorchDistComm(device=f'cuda:{local_rank % torch.cuda.device_count()}', group=grp)
+          comm.allreduce_sum(np.zeros(4))          # builds the communicator now; raises if it cannot
+          comm_kind = 'torch.distributed nccl (RCCL over xGMI)'
       except Exception as e:  # pylint: disable=broad-except
         comm = parallel.TorchDistComm()
-        comm_kind = f'torch.distributed gloo (RCCL init failed: {e})'
+        comm_kind = f'torch.distributed gloo (RCCL communicator unavailable: {str(e)[:120]})'
     def step4(i):
       p = defs.GPParams(model=perturb(raw4, i, 0))
       return objectives.nll_value_and_grad(mean.constant, kernel.squared_exponential, p, dev4, wf, comm=comm)

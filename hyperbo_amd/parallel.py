@@ -50,20 +50,23 @@ class LocalComm:
 class TorchDistComm:
   """torch.distributed is plumbing only (rendezvous + all_reduce); no tensors elsewhere."""
 
-  def __init__(self, device=None):
+  def __init__(self, device=None, group=None):
+    """`group`: a torch.distributed process group (e.g. one created with backend='nccl', which is RCCL on ROCm --
+    then pass the rank's `device` so that the buffer travels over xGMI); default: the default group, host tensors."""
     import torch.distributed as dist
     if not dist.is_initialized():
       raise RuntimeError('torch.distributed is not initialised')
     self._dist = dist
     self.rank, self.world_size = dist.get_rank(), dist.get_world_size()
     self.device = device
+    self.group = group
 
   def allreduce_sum(self, buf: np.ndarray) -> np.ndarray:
     import torch
     t = torch.from_numpy(np.ascontiguousarray(buf, dtype=np.float64).copy())
     if self.device is not None:
       t = t.to(self.device)
-    self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM)
+    self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM, group=self.group)
     return t.cpu().numpy()
 
 
