@@ -387,7 +387,7 @@ __device__ unsigned long long hbo_dbg_gemm[4 * 8192];   // per workgroup of the 
 int g_dbg_mode = -1, g_dbg_index = 0, g_dbg_seen = 0;   // host: trace the g_dbg_index-th launch of g_dbg_mode (+100: persistent)
 #endif
 template <typename T, bool AKC, bool BKC, int TM>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(GemmArgs g) {
+__global__ __launch_bounds__(256, TM == 64 ? 4 : 2) void gemm_kernel(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   TileJob<T> job;
 #ifdef HBO_GEMM_TIMING
