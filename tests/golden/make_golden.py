@@ -46,7 +46,17 @@ def build(case):
   _, cov = o.predict(mean, kern, params, x, y, xq, wf, full_cov=True)
   mu_n, var_n = o.gp_predict_postprocess(params, dataset, mu, var, wf, False, True, True)
   target = float(np.max(y))
+  # divergence objectives on an aligned sub-dataset (objectives.py:29-106) and d acquisition / d x (bayesopt.py:116-125)
+  ya = np.sin(3 * x[:, :1]) + 0.3 * rng.normal(size=(n, 6))
+  aligned = {'al': o.SubDataset(x, ya, aligned='al'), 0: o.SubDataset(x, y)}
+  ekl, ekl_g = o.divergence_value_and_grad('ekl', mean, kern, params, aligned, wf)
+  euc, euc_g = o.divergence_value_and_grad('euc', mean, kern, params, aligned, wf)
+  noise = float(np.squeeze(o.retrieve_params(params, ['noise_variance'], wf)[0]))
+  ei_v, ei_g = o.acquisition_value_and_grad('ei', mean, kern, params, x, y, xq, target, wf, add_noise=noise, scale=2.0)
+  ucb_v, ucb_g = o.acquisition_value_and_grad('ucb', mean, kern, params, x, y, xq, 3.0, wf, add_noise=noise, scale=2.0)
   out = dict(
+      y_aligned=ya, ekl=ekl, ekl_grad_flat=helpers.flatten(ekl_g), euc=euc, euc_grad_flat=helpers.flatten(euc_g),
+      ei_value=ei_v, ei_dx=ei_g, ucb_value=ucb_v, ucb_dx=ucb_g,
       model_flat=helpers.flatten(model), x=x, y=y, x2=x2, y2=y2, xq=xq,
       gram=kern(params, x, warp_func=wf), cross=kern(params, x, xq, warp_func=wf),
       mean_x=mean(params, x, warp_func=wf),

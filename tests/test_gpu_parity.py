@@ -321,6 +321,17 @@ def test_against_golden_fixtures(gpu_ctx, case):
   for nm, key in (('expected_improvement', 'ei'), ('probability_of_improvement', 'pi'), ('ucb', 'ucb')):
     a = getattr(acfun, nm)(model=m, sub_dataset_key=0, x_queries=xq)
     assert helpers.rel_err(a, ref[key]) < 1e-7, nm
+  # divergence objectives and acquisition gradients (fixtures of round 1's later rows)
+  al = {'al': defs.SubDataset(x, ref['y_aligned'], aligned='al'), 0: defs.SubDataset(x, y)}
+  for fnc, key in ((objectives.ekl, 'ekl'), (objectives.euc, 'euc')):
+    v, g = fnc.value_and_grad(mn, kn, pn, al, wf)
+    assert abs(v - float(ref[key])) <= 1e-9 * max(abs(float(ref[key])), 1.0), key
+    gr = ref[key + '_grad_flat']
+    assert np.max(np.abs(helpers.flatten(g) - gr)) <= 1e-7 * max(np.max(np.abs(gr)), 1e-6), key
+  for fnc, key in ((acfun.expected_improvement, 'ei'), (acfun.ucb, 'ucb')):
+    v, dx = fnc.value_and_grad(model=m, sub_dataset_key=0, x_queries=xq)
+    assert helpers.rel_err(v, ref[key + '_value']) < 1e-7, key
+    assert np.max(np.abs(dx - ref[key + '_dx'])) <= 1e-6 * max(np.max(np.abs(ref[key + '_dx'])), 1e-6), key
 
 
 # ---- BASELINE sizes: oracle where it still finishes in seconds, size-independent properties above --
