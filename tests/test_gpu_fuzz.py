@@ -91,3 +91,58 @@ def test_fuzz_posterior_and_acquisition(gpu_ctx, seed):
   vo, go = o.acquisition_value_and_grad(acq, mo, ko, po, x, y, xq, param, WFO, add_noise=noise, scale=2.0)
   assert np.max(np.abs(val - vo)) <= 10 * tol * max(np.max(np.abs(vo)), 1.0)
   assert np.max(np.abs(grad - go)) <= 100 * tol * max(np.max(np.abs(go)), 1.0)
+
+
+def test_edge_shapes(gpu_ctx):
+  """Limits of the ABI: m + 1 = 128 aligned columns (the augmented tile-row is full), one more is refused; the
+  maximum feature dimension (256); eight MLP layers; a single point."""
+  from hyperbo_amd import _native as nat
+  defs, acfun, gp, kernel, mean, objectives, utils = _native()
+  rng = np.random.default_rng(77)
+  d = 2
+  model = helpers.make_model(rng, 'constant', False, d)
+  po, pn = o.GPParams(model=model, config={}), defs.GPParams(model=model, config={})
+  x = rng.uniform(size=(40, d))
+  for m, ok in ((127, True), (128, False)):
+    y = rng.normal(size=(40, m))
+    dso = {'a': o.SubDataset(x, y, aligned=1)}
+    dsn = {'a': defs.SubDataset(x, y, aligned=1)}
+    if ok:
+      vo, go = o.divergence_value_and_grad('ekl', o.constant, o.matern52, po, dso, WFO)
+      vn, gn = objectives.ekl.value_and_grad(mean.constant, kernel.matern52, pn, dsn, utils.DEFAULT_WARP_FUNC)
+      assert abs(vn - vo) <= 1e-9 * abs(vo)
+      assert np.max(np.abs(helpers.flatten(gn) - helpers.flatten(go))) <= 1e-7 * np.max(np.abs(helpers.flatten(go)))
+    else:
+      with pytest.raises(nat.HboError):
+        objectives.ekl(mean.constant, kernel.matern52, pn, dsn, utils.DEFAULT_WARP_FUNC)
+  # D = 256 (HBO_MAX_FEATURE_DIM) with a per-dimension lengthscale
+  dmax = 256
+  big = {'lengthscale': helpers.inv_softplus(np.full(dmax, 6.0)), 'signal_variance': helpers.inv_softplus(1.0),
+         'noise_variance': helpers.inv_softplus(0.05), 'constant': np.array(0.1)}
+  xb = rng.uniform(size=(200, dmax)); yb = rng.normal(size=(200, 1))
+  pob, pnb = o.GPParams(model=big, config={}), defs.GPParams(model=big, config={})
+  vo, go = o.nll_value_and_grad(o.constant, o.squared_exponential, pob, {0: o.SubDataset(xb, yb)}, WFO)
+  vn, gn = objectives.nll_value_and_grad(mean.constant, kernel.squared_exponential, pnb, {0: defs.SubDataset(xb, yb)}, utils.DEFAULT_WARP_FUNC)
+  assert abs(vn - vo) <= 1e-10 * abs(vo)
+  assert np.max(np.abs(helpers.flatten(gn) - helpers.flatten(go))) <= 1e-8 * np.max(np.abs(helpers.flatten(go)))
+  # eight MLP layers (HBO_MAX_MLP_LAYERS), kernel and mean on the features
+  feats = (5, 7, 3, 6, 4, 8, 5, 6)
+  deep = {'lengthscale': (rng.normal(size=feats[-1]) * 0.3 + 0.5), 'signal_variance': np.array(0.3), 'noise_variance': np.array(-2.0),
+          'mlp_params': {}, 'linear_mean': {'kernel': rng.normal(size=(feats[-1], 1)), 'bias': rng.normal(size=1)}}
+  fin = d
+  for l, f in enumerate(feats):
+    deep['mlp_params'][f'Dense_{l}'] = {'kernel': rng.normal(size=(fin, f)) * 0.6, 'bias': rng.normal(size=f) * 0.1}
+    fin = f
+  cfg = {'mlp_features': feats}
+  pod, pnd = o.GPParams(model=deep, config=dict(cfg)), defs.GPParams(model=deep, config=dict(cfg))
+  xd, yd = helpers.synthetic_task(rng, 150, d)
+  vo, go = o.nll_value_and_grad(o.linear_mlp, o.matern32_mlp, pod, {0: o.SubDataset(xd, yd)}, WFO)
+  vn, gn = objectives.nll_value_and_grad(mean.linear_mlp, kernel.matern32_mlp, pnd, {0: defs.SubDataset(xd, yd)}, utils.DEFAULT_WARP_FUNC)
+  assert abs(vn - vo) <= 1e-10 * abs(vo)
+  assert np.max(np.abs(helpers.flatten(gn) - helpers.flatten(go))) <= 1e-8 * np.max(np.abs(helpers.flatten(go)))
+  # a single observation: posterior and acquisition
+  m1 = gp.GP({0: defs.SubDataset(xd[:1], yd[:1])}, mean.constant, kernel.matern52, pn, utils.DEFAULT_WARP_FUNC)
+  mu, var = m1.predict(xd[1:6], 0)
+  mu_o, var_o = o.predict(o.constant, o.matern52, po, xd[:1], yd[:1], xd[1:6], WFO)
+  noise = float(np.squeeze(o.retrieve_params(po, ['noise_variance'], WFO)[0]))
+  np.testing.assert_allclose(mu, mu_o, rtol=1e-10); np.testing.assert_allclose(var, var_o + noise, rtol=1e-9)
