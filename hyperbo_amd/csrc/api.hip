@@ -29,6 +29,7 @@ struct hbo_ctx {
   std::vector<hipEvent_t> ev_pool;
   std::map<int, std::pair<void*, size_t>> ws;   // grow-only device scratch buffers by slot (no per-call hipMalloc/hipFree)
   int opt_lookahead = 1;
+  int opt_f1_on_chain = 1;         // F1 on the panel stream (no event hops around it)
   int opt_dynamic_tiles = 1;       // persistent bulk update draws its tiles from a counter
   int opt_overlap_trtri = 1;
   std::string err;
@@ -191,6 +192,7 @@ extern "C" int hbo_set_option(hbo_ctx* c, const char* name, int64_t value) {
   if (!strcmp(name, "potrf_group")) { if (value < 1 || value > 8) return fail(c, HBO_ERR_ARG, "potrf_group in 1..8"); c->opt_group = (int)value; return HBO_OK; }
   if (!strcmp(name, "overlap_trtri")) { c->opt_overlap_trtri = value ? 1 : 0; return HBO_OK; }
   if (!strcmp(name, "dynamic_tiles")) { c->opt_dynamic_tiles = value ? 1 : 0; return HBO_OK; }
+  if (!strcmp(name, "f1_on_chain")) { c->opt_f1_on_chain = value ? 1 : 0; return HBO_OK; }
   if (!strcmp(name, "lookahead")) { c->opt_lookahead = value ? 1 : 0; return HBO_OK; }
   if (!strcmp(name, "small_nblk")) { c->opt_small_nblk = (int)value; return HBO_OK; }
   if (!strcmp(name, "persist_free")) { if (value < 0 || value > 200) return fail(c, HBO_ERR_ARG, "persist_free in 0..200"); c->opt_persist_free = (int)value; return HBO_OK; }
@@ -362,7 +364,7 @@ static void run_potrf(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks
   hipStream_t sb = sm;   // bulk updates share the main stream (CU-masked queues were measured slower)
   size_t evi = 0;
   if (la) { hipEvent_t e = pool_event(c, evi++); hipEventRecord(e, sm); hipStreamWaitEvent(sp, e, 0); }
-  hipEvent_t ev_f1 = nullptr;
+  hipEvent_t ev_f1 = nullptr, ev_f2 = nullptr;
   // one tile counter per bulk launch (dynamic tile assignment of the persistent form), zeroed up front
   int* counters = c->opt_dynamic_tiles ? (int*)ws_get(c, WS_COUNTERS, sizeof(int) * 256) : nullptr;
   int n_counter = 0;
@@ -388,23 +390,29 @@ static void run_potrf(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks
         run_trtri_early(c, dtype, d_tasks, ntasks, max_nblk, early_H, c->stream4);
       }
     }
-    if (la) { hipEvent_t e = pool_event(c, evi++); hipEventRecord(e, sp); hipStreamWaitEvent(sm, e, 0); }
+    // F1 (next group's block columns) is on the critical path: with look-ahead it is launched on the panel stream
+    // itself -- no cross-stream event hop before and after it -- once the previous bulk update, which wrote the same
+    // tiles, is done (ev_f2); the main stream only learns that F1 is finished (ev_f1) to start F2 behind it.
+    hipStream_t s1 = (la && c->opt_f1_on_chain) ? sp : sm;
+    if (la && s1 == sm) { hipEvent_t e = pool_event(c, evi++); hipEventRecord(e, sp); hipStreamWaitEvent(sm, e, 0); }
     if (g1 < max_nblk) {
       GemmArgs a = {}; a.tasks = d_tasks; a.mode = GEMM_SYRK; a.p0 = g0; a.kt = g1 - g0; a.aug = 1;
       {
-        ProfScope ps(c, "syrk_trailing", 1, sm);
+        if (s1 == sp && ev_f2) hipStreamWaitEvent(sp, ev_f2, 0);
+        ProfScope ps(c, "syrk_trailing", 1, s1);
         a.c_lo = g1; a.c_hi = la ? g2 : max_nblk;
         // few tiles (one group's block columns, or a small remainder): 64x64 tiles for latency
         a.small_tiles = (int64_t)(max_nblk + 1 - a.c_lo) * (a.c_hi - a.c_lo) * ntasks < 600;
-        launch_gemm(dtype, a, dim3(max_nblk + 1 - a.c_lo, a.c_hi - a.c_lo, ntasks), sm);
+        launch_gemm(dtype, a, dim3(max_nblk + 1 - a.c_lo, a.c_hi - a.c_lo, ntasks), s1);
       }
       if (la) {
         ev_f1 = pool_event(c, evi++);
-        hipEventRecord(ev_f1, sm);
+        hipEventRecord(ev_f1, s1);
+        if (s1 == sp) { hipStreamWaitEvent(sm, ev_f1, 0); ev_f1 = nullptr; }   // the panel stream continues in order
         if (g2 < max_nblk) {
           // F2 on the CU-masked bulk stream: after F1(g) (same C columns are not shared, but F2(g)
           // must precede F1(g+1)/F2(g+1) which accumulate into the same tiles)
-          hipStreamWaitEvent(sb, ev_f1, 0);
+          if (ev_f1) hipStreamWaitEvent(sb, ev_f1, 0);
           {
             a.c_lo = g2; a.c_hi = max_nblk;
             const int64_t m = max_nblk - g2;
@@ -423,10 +431,12 @@ static void run_potrf(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks
           hipEvent_t e2 = pool_event(c, evi++);
           hipEventRecord(e2, sb);
           hipStreamWaitEvent(sm, e2, 0);   // later F1 / final consumers on the main stream
+          ev_f2 = e2;
         }
       }
     }
   }
+  if (la) { hipEvent_t e = pool_event(c, evi++); hipEventRecord(e, sp); hipStreamWaitEvent(sm, e, 0); }   // join
   if (early_H > 0) {   // the late part of the inverse (main stream) needs the early part
     hipEvent_t e = pool_event(c, evi++);
     hipEventRecord(e, c->stream4);
