@@ -113,6 +113,9 @@ def main():
 
   ctx = nat.default_context()
   wf = utils.DEFAULT_WARP_FUNC
+  potrf_group = int(os.environ.get('HBO_BENCH_POTRF_GROUP', '4'))   # libhbo default: 4 panels (K = 512 trailing updates)
+  if potrf_group != 4:
+    ctx.set_option('potrf_group', potrf_group)
 
   def sync():
     if torch is not None and torch.cuda.is_available():
@@ -160,7 +163,7 @@ def main():
   ms_per_step = elapsed / args.steps * 1e3
   value = world * args.steps / elapsed
 
-  group = 4   # libhbo default potrf_group (K = 512 trailing updates)
+  group = potrf_group
   fl = bulk_update_flops(args.n, group)
   roofline = None
   if 'syrk_bulk' in prof and prof['syrk_bulk'][1] > 0 and fl:
