@@ -61,7 +61,7 @@ def acfun_wrapper(acfun_sub, acfun_callback_default):
     acfun_param = acfun_callback(model, sub_dataset_key)
     # fused device path: posterior (gp.py:562-620 incl. +noise and T/(T-1)) + acquisition epilogue
     handle = None
-    if sub_dataset_key in model.dataset:
+    if model.has_observations(sub_dataset_key):
       model.setup_predictor(sub_dataset_key)
       handle = model.params.cache[sub_dataset_key].handle
     dtype = handle.dtype if handle is not None else _model.infer_dtype(x_queries)
@@ -86,7 +86,7 @@ def acfun_wrapper(acfun_sub, acfun_callback_default):
     x_queries = np.asarray(x_queries)
     acfun_param = acfun_callback(model, sub_dataset_key)
     handle = None
-    if sub_dataset_key in model.dataset:
+    if model.has_observations(sub_dataset_key):
       model.setup_predictor(sub_dataset_key)
       handle = model.params.cache[sub_dataset_key].handle
     dtype = handle.dtype if handle is not None else _model.infer_dtype(x_queries)

@@ -90,3 +90,35 @@ def simulated_bayesopt(model, sub_dataset_key, queried_sub_dataset, ac_func, ite
     eval_datapoint = queried_sub_dataset.x[select_idx], queried_sub_dataset.y[select_idx]
     model.update_sub_dataset(eval_datapoint, sub_dataset_key=sub_dataset_key, is_append=True)
   return model.dataset.get(sub_dataset_key, SubDataset(np.empty(0), np.empty(0)))
+
+
+def run_bayesopt(dataset, sub_dataset_key, queried_sub_dataset, mean_func, cov_func, init_params, ac_func, iters,
+                 warp_func=None, init_random_key=None, method='hyperbo', init_model=False, data_loader_name='',
+                 get_params_path=None, callback=None, save_retrain_model=False):
+  """bayesopt.py:193-302: build the model, optionally initialise + pre-train it, then run the simulated loop on a
+  candidate SubDataset or the continuous loop on a query oracle.  Returns ((x, y) of the test sub-dataset after BO,
+  the best candidate (x, y) or None, the model's params)."""
+  from hyperbo_amd.bo_utils import const
+  from hyperbo_amd.gp_utils import gp
+  if method in const.USE_HGP:
+    raise NotImplementedError('hierarchical GP (slice sampling over hyper-parameters) is outside the native path')
+  model = gp.GP(dataset=dataset, mean_func=mean_func, cov_func=cov_func, params=init_params, warp_func=warp_func)
+  rng = _rng(init_random_key)
+  if init_model:
+    assert init_random_key is not None, 'Cannot initialize with init_random_key == None.'
+    model.initialize_params(rng)
+    model.train(rng, get_params_path, callback=callback)
+  else:
+    model.rng = rng
+  if isinstance(queried_sub_dataset, SubDataset):
+    best_query = get_best_datapoint(queried_sub_dataset)
+    sub = simulated_bayesopt(model=model, sub_dataset_key=sub_dataset_key, queried_sub_dataset=queried_sub_dataset,
+                             ac_func=ac_func, iters=iters, random_key=rng,
+                             get_params_path=get_params_path if save_retrain_model else None,
+                             callback=callback if save_retrain_model else None)
+    return (sub.x, sub.y), best_query, model.params
+  if data_loader_name not in const.INPUT_SAMPLERS:
+    raise NotImplementedError(f'Input sampler for {data_loader_name} not found.')
+  sub = bayesopt(key=rng, model=model, sub_dataset_key=sub_dataset_key, query_oracle=queried_sub_dataset,
+                 ac_func=ac_func, iters=iters, input_sampler=const.INPUT_SAMPLERS[data_loader_name])
+  return (sub.x, sub.y), None, model.params

@@ -172,6 +172,31 @@ def pd1(key, p_observed, verbose=True, sub_dataset_key=None, input_warp=True, ou
                            verbose=verbose, sub_dataset_key=sub_dataset_key, num_remove=num_remove, p_remove=p_remove)
 
 
+def _deduplicate(x, y, dataset_name, verbose=True):
+  """data.py:446-457: one row per distinct x, the one with the highest y; rows come out in np.unique order."""
+  x = np.asarray(x); y = np.asarray(y)
+  order = np.argsort(-y.reshape(y.shape[0], -1)[:, 0], kind='stable')   # best reward first
+  x, y = x[order], y[order]
+  _, first = np.unique(x, axis=0, return_index=True)
+  if verbose:
+    print(f'Removed {x.shape[0] - len(first)} duplicated points from {dataset_name}')
+  return x[first, :], y[first, :]
+
+
+def _normalize_maf_dataset(maf_dataset, num_hparams, neg_error_to_accuracy):
+  """data.py:460-486: affine map of every hyper-parameter to [0, 1] over ALL sub-datasets; optionally y -> 1 + y
+  (negative error rate -> accuracy).  Modifies and returns `maf_dataset` ({name: {'X': ..., 'Y': ...}})."""
+  lo = np.full(num_hparams, np.inf); hi = np.full(num_hparams, -np.inf)
+  for sub in maf_dataset.values():
+    lo = np.minimum(lo, np.min(sub['X'], axis=0))
+    hi = np.maximum(hi, np.max(sub['X'], axis=0))
+  for sub in maf_dataset.values():
+    sub['X'] = (sub['X'] - lo) / (hi - lo)
+    if neg_error_to_accuracy:
+      sub['Y'] = 1 + sub['Y']
+  return maf_dataset
+
+
 def random(key, mean_func, cov_func, params, dim, n_observed, n_queries, n_func_historical=0,
            m_points_historical=0, warp_func=None):
   """data.py:720-775: historical functions + one queried function, all drawn from the GP prior

@@ -292,8 +292,14 @@ class GP:
     self.params.model = model_params
     self._drop_cache()
 
+  def has_observations(self, sub_dataset_key) -> bool:
+    """True when the sub-dataset exists and is non-empty; an empty one predicts from the prior (gp.py:275-282)."""
+    return sub_dataset_key in self.dataset and np.shape(self.dataset[sub_dataset_key].x)[0] > 0
+
   def setup_predictor(self, sub_dataset_key: Union[int, str] = 0):
     """gp.py:540-560."""
+    if not self.has_observations(sub_dataset_key):
+      return   # nothing to factorise: predict() takes the prior branch
     if sub_dataset_key in self.params.cache and not self.params.cache[sub_dataset_key].needs_update:
       return
     old = self.params.cache.get(sub_dataset_key)
@@ -320,7 +326,7 @@ class GP:
   def predict(self, queried_inputs, sub_dataset_key: Union[int, str] = 0, full_cov: bool = False,
               with_noise: bool = True, unbiased: bool = True) -> Tuple[np.ndarray, np.ndarray]:
     """gp.py:562-620."""
-    if sub_dataset_key not in self.dataset:
+    if not self.has_observations(sub_dataset_key):
       mu, cov = predict(self.mean_func, self.cov_func, self.params, None, None, queried_inputs,
                         warp_func=self.warp_func, full_cov=full_cov)
     else:

@@ -78,3 +78,28 @@ def test_pd1_loader_holdout_and_subsampling(tmp_path):
     data.pd1(0, p_observed=0., verbose=False, sub_dataset_key='nope', data_files=files)
   with pytest.raises(ValueError):
     data.sample_dataframe(0, None, p_remove=1.0)
+
+
+@pytest.mark.parametrize('x,y,expected_x,expected_y', [
+    # hyperbo/bo_utils/data_test.py:85-100 (the reference's own known-answer vectors)
+    ([[2., 3.], [2., 1.], [2., 3], [2., 3.]], [[1.], [2.], [4.], [3]], [[2., 1.], [2., 3.]], [[2.], [4.]]),
+    ([[1., 2.], [3., 4.]], [[1.], [2.]], [[1., 2.], [3., 4.]], [[1.], [2.]]),
+])
+def test_deduplicate_reference_vectors(x, y, expected_x, expected_y):
+  ax, ay = data._deduplicate(np.array(x), np.array(y), dataset_name='', verbose=False)
+  np.testing.assert_array_equal(ax, expected_x)
+  np.testing.assert_array_equal(ay, expected_y)
+
+
+@pytest.mark.parametrize('neg_error_to_accuracy', [True, False])
+def test_normalize_maf_dataset_reference_vectors(neg_error_to_accuracy):
+  # hyperbo/bo_utils/data_test.py:111-157
+  maf = {'workload_a': {'X': np.array([[-1, 2, 1], [2, 2, 2]]), 'Y': np.array([[-.1], [0.]])},
+         'workload_b': {'X': np.array([[1, 1, 2], [3, 2, 2]]), 'Y': np.array([[-.9], [-.2]])}}
+  upd = (lambda v: v + 1) if neg_error_to_accuracy else (lambda v: v)
+  expected = {'workload_a': {'X': np.array([[0, 1, 0], [.75, 1, 1]]), 'Y': upd(np.array([[-.1], [0.]]))},
+              'workload_b': {'X': np.array([[.5, 0, 1], [1, 1, 1]]), 'Y': upd(np.array([[-.9], [-.2]]))}}
+  out = data._normalize_maf_dataset(maf, num_hparams=3, neg_error_to_accuracy=neg_error_to_accuracy)
+  for wl in expected:
+    np.testing.assert_array_equal(expected[wl]['X'], out[wl]['X'])
+    np.testing.assert_array_equal(expected[wl]['Y'], out[wl]['Y'])

@@ -757,6 +757,36 @@ def test_continuous_bayesopt_loop(gpu_ctx):
     bayesopt.simulated_bayesopt(m, 'test', pool, acfun.rand, iters=1)
 
 
+@pytest.mark.parametrize('acname', ['expected_improvement', 'probability_of_improvement', 'ucb3', 'random_search', 'ucb2', 'ucb'])
+def test_run_bayesopt_synthetic(gpu_ctx, acname):
+  """hyperbo/bo_utils/bayesopt_test.py:45-103 (test_run_synthetic) and data_test.py:45-83 (test_dataset_shape) on the
+  native path: data.random -> run_bayesopt -> shapes and the best-query invariant."""
+  defs, _, acfun, gp, kernel, mean, _, utils = _native()
+  from hyperbo_amd.bo_utils import bayesopt, const, data
+  params = defs.GPParams(model={'constant': 5., 'lengthscale': 1., 'signal_variance': 1.0, 'noise_variance': 0.01},
+                         config={'method': 'adam', 'learning_rate': 1e-5, 'beta': 0.9, 'max_training_step': 1})
+  mean_func, cov_func = mean.constant, kernel.squared_exponential
+  dataset, key, queried = data.random(key=0, mean_func=mean_func, cov_func=cov_func, params=params, dim=5, n_observed=0,
+                                      n_queries=30, n_func_historical=2, m_points_historical=10)
+  assert len(dataset) == 3
+  for i in range(2):
+    assert dataset[i].x.shape == (10, 5) and dataset[i].y.shape == (10, 1) and dataset[i].aligned is None
+  assert dataset[key].x.shape == (0, 5) and queried.x.shape == (30, 5) and queried.y.shape == (30, 1)
+  observations, queries, out_params = bayesopt.run_bayesopt(
+      dataset=dataset, sub_dataset_key=key, queried_sub_dataset=queried, mean_func=mean_func, cov_func=cov_func,
+      init_params=params, ac_func=const.ACFUN[acname], iters=3, init_random_key=0)
+  assert observations[0].shape == (3, 5) and observations[1].shape == (3, 1)
+  assert queries[0].shape == (5,) and queries[1] == np.max(queried.y)
+  assert set(out_params.model) == set(params.model)
+  # data_test.py:45-83 with observed points
+  ds2, k2, q2 = data.random(key=1, mean_func=mean_func, cov_func=cov_func, params=params, dim=5, n_observed=20, n_queries=10,
+                            n_func_historical=3, m_points_historical=7)
+  assert k2 == 3 and ds2[3].x.shape == (20, 5) and ds2[3].y.shape == (20, 1) and q2.x.shape == (10, 5)
+  assert all(ds2[i].x.shape == (7, 5) and ds2[i].y.shape == (7, 1) for i in range(3))
+  with pytest.raises(NotImplementedError):
+    bayesopt.run_bayesopt(dataset, key, queried, mean_func, cov_func, params, acfun.ucb, 1, method=const.HBO_SS)
+
+
 @pytest.mark.parametrize('kname,mlp,mname', CASES)
 def test_incremental_cache_append_matches_refactorisation(gpu_ctx, kname, mlp, mname):
   """O(N^2) row append (hbo_cache_append) vs the reference behaviour (re-factorise from scratch)."""
