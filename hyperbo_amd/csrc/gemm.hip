@@ -150,7 +150,7 @@ __device__ __forceinline__ bool decode_job(const GemmArgs& g, TileJob<T>& j) {
       const int inner = (int)blockIdx.x % su;
       int jt, it;
       if (g.mode == GEMM_TRTRI_A) { jt = blockIdx.y; it = inner; }            // K = s*128 - jt*TM
-      else { it = su - 1 - (int)blockIdx.y; jt = inner; }                     // K = (it+1)*TM
+      else { it = (g.kt > 0 ? g.kt * U : su) - 1 - (int)blockIdx.y; jt = inner; }   // K = (it+1)*TM; kt = valid rows (single group)
       const int64_t o = (int64_t)grp * 2 * s * HBO_TILE;                      // element offsets from here on
       const int64_t R = o + (int64_t)s * HBO_TILE + (int64_t)it * TM;
       if (R >= (int64_t)nblk * HBO_TILE) return false;
