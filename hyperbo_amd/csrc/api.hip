@@ -460,7 +460,8 @@ static void trtri_level(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntas
   const int vlast = std::min(s, max_nblk - ((grp_hi - 1) * 2 * s + s));
   if (vlast <= 0 && ngroups == 1) return;
   const int xa = (ngroups - 1) * s + std::max(vlast, 0);
-  if (do_a) { a.mode = GEMM_TRTRI_A; launch_gemm(dtype, a, dim3(xa, s, ntasks), st); }
+  a.c_hi = grp_hi - 1; a.c_lo = std::max(vlast, 0);   // TRTRI_A: last group and its launched tile rows
+  if (do_a && xa > 0) { a.mode = GEMM_TRTRI_A; launch_gemm(dtype, a, dim3(xa, s, ntasks), st); }
   if (do_b) {
     a.mode = GEMM_TRTRI_B;
     const int vy = ngroups == 1 ? vlast : s;

@@ -120,7 +120,10 @@ __device__ __forceinline__ bool decode_job(const GemmArgs& g, TileJob<T>& j) {
       constexpr int U = HBO_TILE / TM;
       // plain (r fastest) order.  Measured slower: XCD-aware 8x8 super-tiles that concentrate the 16
       // panels of 64 tiles on one XCD's L2 (61 -> 41 TFLOP/s at N=16384, K=1024).
-      const int bx = blockIdx.x, by = blockIdx.y;
+      // (batches: rows rotated per (column, task) -- in a ragged batch the rows that exist are the low ones of every
+      // task and workgroup i runs on XCD i mod 8)
+      const int by = blockIdx.y;
+      const int bx = gridDim.z > 1 ? (int)((blockIdx.x + 5 * blockIdx.y + 3 * blockIdx.z) % gridDim.x) : (int)blockIdx.x;
       const int c = g.c_lo * U + by;
       const int r = g.c_lo * U + bx;
       const int nrt = (nblk + ((g.aug & 1) ? 1 : 0)) * U;
@@ -149,7 +152,13 @@ __device__ __forceinline__ bool decode_job(const GemmArgs& g, TileJob<T>& j) {
       const int grp = g.grp_lo + (int)blockIdx.x / su;
       const int inner = (int)blockIdx.x % su;
       int jt, it;
-      if (g.mode == GEMM_TRTRI_A) { jt = blockIdx.y; it = inner; }            // K = s*128 - jt*TM
+      if (g.mode == GEMM_TRTRI_A) {
+        // K = s*128 - jt*TM.  Ragged batches: the row tiles that exist are the low ones in every task and workgroup i
+        // runs on XCD i mod 8, so the row order is rotated per (column, task)
+        jt = blockIdx.y;
+        const int vu = (grp == g.c_hi ? g.c_lo : s) * U;   // tile rows launched for this group (the last may be cut)
+        it = (inner + 5 * (int)blockIdx.y + 3 * (int)blockIdx.z) % vu;
+      }
       else { it = (g.kt > 0 ? g.kt * U : su) - 1 - (int)blockIdx.y; jt = inner; }   // K = (it+1)*TM; kt = valid rows (single group)
       const int64_t o = (int64_t)grp * 2 * s * HBO_TILE;                      // element offsets from here on
       const int64_t R = o + (int64_t)s * HBO_TILE + (int64_t)it * TM;

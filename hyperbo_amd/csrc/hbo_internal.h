@@ -64,9 +64,9 @@ struct GemmArgs {
   const TaskDesc* tasks;
   int mode;
   int p0;        // SYRK: first panel tile-column of the K range;   TRTRI: half size s (tiles)
-  int kt;        // SYRK: number of 128-wide K tiles
-  int c_lo;      // SYRK: first updated tile column
-  int c_hi;      // SYRK: end (exclusive) of updated tile columns
+  int kt;        // SYRK: number of 128-wide K tiles;   TRTRI_B with a single group: tile rows launched
+  int c_lo;      // SYRK: first updated tile column;   TRTRI_A: tile rows launched for the last group
+  int c_hi;      // SYRK: end (exclusive) of updated tile columns;   TRTRI_A: index of the last group
   int aug;       // SYRK: 1 -> include the augmented tile-row
   int small_tiles;  // 1 -> 64x64 output tiles (SYRK / TRTRI / LAUUM; grid is given in 128-tile units)
   int persistent;   // SYRK: >0 -> that many persistent workgroups loop over the tiles
