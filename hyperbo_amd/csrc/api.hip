@@ -23,6 +23,7 @@ struct hbo_ctx {
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;   // panel stream of the look-ahead Cholesky (high priority)
   hipStream_t stream4 = nullptr;   // early part of trtri, overlapped with the tail of potrf
+  int opt_trtri_gran = 0;    // panels between two launches of the inverse's computable pieces during the factorisation (0: auto)
   int opt_small_nblk = 32;   // matrices up to this many 128-blocks use 64x64 GEMM tiles in trtri / lauum
   int opt_persist_free = 32; // bulk trailing update runs as 2*(CUs - this) persistent workgroups
   int n_cus = 256;
@@ -194,6 +195,7 @@ extern "C" int hbo_set_option(hbo_ctx* c, const char* name, int64_t value) {
   if (!strcmp(name, "dynamic_tiles")) { c->opt_dynamic_tiles = value ? 1 : 0; return HBO_OK; }
   if (!strcmp(name, "f1_on_chain")) { c->opt_f1_on_chain = value ? 1 : 0; return HBO_OK; }
   if (!strcmp(name, "lookahead")) { c->opt_lookahead = value ? 1 : 0; return HBO_OK; }
+  if (!strcmp(name, "trtri_gran")) { if (value < 0) return fail(c, HBO_ERR_ARG, "trtri_gran >= 0"); c->opt_trtri_gran = (int)value; return HBO_OK; }
   if (!strcmp(name, "small_nblk")) { c->opt_small_nblk = (int)value; return HBO_OK; }
   if (!strcmp(name, "persist_free")) { if (value < 0 || value > 200) return fail(c, HBO_ERR_ARG, "persist_free in 0..200"); c->opt_persist_free = (int)value; return HBO_OK; }
   return fail(c, HBO_ERR_ARG, std::string("unknown option ") + name);
@@ -337,8 +339,10 @@ struct FeatBuf {   // device activations of one input matrix
 };
 
 // ---- blocked factorisation drivers -----------------------------------------------------------
-static void run_trtri_early(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, int max_nblk, int H,
-                            hipStream_t st);
+// progress of the block-recursive inverse (see trtri_advance)
+struct TrtriProgress { int diag = 0; int a[12] = {0}; int b[12] = {0}; };
+static void trtri_advance(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, int max_nblk, int cfin,
+                          hipStream_t st, TrtriProgress& pg);
 
 static hipEvent_t pool_event(hbo_ctx* c, size_t i) {
   while (c->ev_pool.size() <= i) {
@@ -356,7 +360,7 @@ static hipEvent_t pool_event(hbo_ctx* c, size_t i) {
 // work (potf2 -> trsm, the serial chain) runs on a second stream as soon as F1 is done, so F2
 // -- the bulk of the flops -- overlaps it.
 static void run_potrf(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, int max_nblk, int* d_info,
-                      int early_H = 0) {
+                      TrtriProgress* early = nullptr) {
   const int q = c->opt_group;
   hipStream_t sm = c->stream;
   hipStream_t sp = c->opt_lookahead ? c->stream2 : c->stream;
@@ -365,6 +369,11 @@ static void run_potrf(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks
   size_t evi = 0;
   if (la) { hipEvent_t e = pool_event(c, evi++); hipEventRecord(e, sm); hipStreamWaitEvent(sp, e, 0); }
   hipEvent_t ev_f1 = nullptr, ev_f2 = nullptr;
+  // early inverse: a batch takes every piece as soon as four more panels are final (16.9 against 17.35 ms for 64 tasks
+  // of ~2000 points, 3.77 against 3.92 for 8); one large matrix only at half time -- more launches on the side stream
+  // take slots from the panel chain (N = 8192: 13.63 ms at 32 panels, 13.8 at 4, 14.0 at 2)
+  int tgran = c->opt_trtri_gran;
+  if (tgran <= 0) { tgran = 4; if (ntasks == 1) while (tgran * 2 < max_nblk) tgran *= 2; }
   // one tile counter per bulk launch (dynamic tile assignment of the persistent form), zeroed up front
   int* counters = c->opt_dynamic_tiles ? (int*)ws_get(c, WS_COUNTERS, sizeof(int) * 256) : nullptr;
   int n_counter = 0;
@@ -381,13 +390,14 @@ static void run_potrf(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks
       }
       { ProfScope ps(c, "potf2", 2, sp); launch_potf2(dtype, d_tasks, ntasks, p, d_info, sp); }
       { ProfScope ps(c, "trsm", 2, sp); launch_trsm(dtype, d_tasks, ntasks, p, max_nblk, sp); }
-      if (early_H > 0 && p == early_H - 1) {
-        // the first H block columns of L are final: start the early part of the inverse on a side stream
+      if (early && (p + 1) % tgran == 0 && p + 1 < max_nblk) {
+        // block columns 0..p of L are final: everything of the inverse that only needs them goes to a side stream
+        // (the panel chain leaves most of the machine idle in the second half of the factorisation)
         hipEvent_t e = pool_event(c, evi++);
         hipEventRecord(e, sp);
         hipStreamWaitEvent(c->stream4, e, 0);
         ProfScope ps(c, "trtri_early", 1, c->stream4);
-        run_trtri_early(c, dtype, d_tasks, ntasks, max_nblk, early_H, c->stream4);
+        trtri_advance(c, dtype, d_tasks, ntasks, max_nblk, p + 1, c->stream4, *early);
       }
     }
     // F1 (next group's block columns) is on the critical path: with look-ahead it is launched on the panel stream
@@ -437,7 +447,7 @@ static void run_potrf(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks
     }
   }
   if (la) { hipEvent_t e = pool_event(c, evi++); hipEventRecord(e, sp); hipStreamWaitEvent(sm, e, 0); }   // join
-  if (early_H > 0) {   // the late part of the inverse (main stream) needs the early part
+  if (early) {   // the rest of the inverse (main stream) needs the early part
     hipEvent_t e = pool_event(c, evi++);
     hipEventRecord(e, c->stream4);
     hipStreamWaitEvent(sm, e, 0);
@@ -470,36 +480,38 @@ static void trtri_level(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntas
   }
 }
 
-// W = L^-1 by recursive doubling.  The tree is cut at H = the largest power of two below the block
-// count: everything that only needs the first H block columns of L -- the inverse of the leading H
-// blocks and the top-level product S21 = L21 W11 -- is "early" work that run_potrf can enqueue on a
-// side stream as soon as panel H-1 is final (the second half of the factorisation is bound by the
-// serial panel chain and leaves most CUs idle); the rest is "late".
-static int trtri_split(int max_nblk) {
-  int h = 1;
-  while (h * 2 < max_nblk) h *= 2;
-  return max_nblk >= 4 ? h : 0;
-}
-static void run_trtri_early(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, int max_nblk, int H,
-                            hipStream_t st) {
-  { ProfScope ps(c, "trtri_diag", 2, st); launch_trtri_diag(dtype, d_tasks, ntasks, 0, H, st); }
-  for (int s = 1; s < H; s *= 2) trtri_level(c, dtype, d_tasks, ntasks, max_nblk, s, 0, H / (2 * s), true, true, st);
-  trtri_level(c, dtype, d_tasks, ntasks, max_nblk, H, 0, 1, true, false, st);
-}
-static void run_trtri_late(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, int max_nblk, int H,
-                           hipStream_t st) {
-  { ProfScope ps(c, "trtri_diag", 2, st); launch_trtri_diag(dtype, d_tasks, ntasks, H, max_nblk, st); }
-  for (int s = 1; s < H; s *= 2) {
-    const int glo = H / (2 * s), ghi = (max_nblk + 2 * s - 1) / (2 * s);
-    trtri_level(c, dtype, d_tasks, ntasks, max_nblk, s, glo, ghi, true, true, st);
+// W = L^-1 by recursive doubling over the block tree: level s merges pairs of inverted s-block diagonal pieces,
+//   S21 = L21 W11 (A),  W21 = -W22 S21 (B)   for every group g = blocks [2sg, 2sg + 2s).
+// A of a group only needs the block columns below 2sg + s of L, B those below the group's end, so the tree can be
+// walked while the factorisation is still running: trtri_advance(cfin) launches -- level by level, which is also the
+// dependency order on one stream -- every piece that has become computable now that block columns [0, cfin) are
+// final and was not launched before.  run_potrf calls it on a side stream after every fourth panel (the second half
+// of the factorisation is bound by the serial panel chain and leaves most CUs idle); the last call, with
+// cfin = max_nblk on the main stream, launches what is left (for a 64-block matrix: the B products on the right
+// spine of the tree, 1.25 of the inverse's 3.7 ms).
+static void trtri_advance(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, int max_nblk, int cfin,
+                          hipStream_t st, TrtriProgress& pg) {
+  if (cfin > pg.diag) {
+    ProfScope ps(c, "trtri_diag", 2, st);
+    launch_trtri_diag(dtype, d_tasks, ntasks, pg.diag, cfin, st);
+    pg.diag = cfin;
   }
-  trtri_level(c, dtype, d_tasks, ntasks, max_nblk, H, 0, 1, false, true, st);
+  int li = 0;
+  for (int s = 1; s < max_nblk && li < 12; s *= 2, ++li) {
+    // groups with a lower half: g*2s + s < max_nblk
+    const int ngrp = (max_nblk - s + 2 * s - 1) / (2 * s);
+    // A: left half final (cfin >= g*2s + s);  B: whole group final (cfin >= min(g*2s + 2s, max_nblk))
+    int na = cfin >= s ? (cfin - s) / (2 * s) + 1 : 0;
+    int nb = cfin >= max_nblk ? ngrp : cfin / (2 * s);
+    na = std::min(na, ngrp); nb = std::min(nb, ngrp);
+    if (na > pg.a[li]) { trtri_level(c, dtype, d_tasks, ntasks, max_nblk, s, pg.a[li], na, true, false, st); pg.a[li] = na; }
+    if (nb > pg.b[li]) { trtri_level(c, dtype, d_tasks, ntasks, max_nblk, s, pg.b[li], nb, false, true, st); pg.b[li] = nb; }
+  }
 }
-static void run_trtri(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, int max_nblk) {
-  hipStream_t st = c->stream;
-  { ProfScope ps(c, "trtri_diag", 2); launch_trtri_diag(dtype, d_tasks, ntasks, 0, max_nblk, st); }
-  for (int s = 1; s < max_nblk; s *= 2)
-    trtri_level(c, dtype, d_tasks, ntasks, max_nblk, s, 0, (max_nblk + 2 * s - 1) / (2 * s), true, true, st);
+static void run_trtri(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, int max_nblk,
+                      TrtriProgress* pg = nullptr) {
+  TrtriProgress fresh;
+  trtri_advance(c, dtype, d_tasks, ntasks, max_nblk, max_nblk, c->stream, pg ? *pg : fresh);
 }
 static void run_lauum(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, int max_nblk) {
   ProfScope ps(c, "lauum", 2);
@@ -719,14 +731,15 @@ extern "C" int hbo_objective(hbo_ctx* c, const hbo_model* m_in, hbo_dataset* ds,
   }
   int max_naug = 1;
   for (int k = 0; k < T; ++k) max_naug = std::max(max_naug, ds->h_desc[k].naug);
-  const int early_H = (want_grad && c->opt_lookahead && c->opt_overlap_trtri) ? trtri_split(max_nblk) : 0;
+  TrtriProgress trtri_pg;
+  const bool early_trtri = want_grad && c->opt_lookahead && c->opt_overlap_trtri && max_nblk >= 4;
   if (!euc) {
     {
       ProfScope ps(c, "gram", 1);
       GramArgs g = {}; g.tasks = ds->d_desc; g.fdim = feature_dim(m); g.symmetric = 1; g.padded = 1;
       launch_gram(dtype, g, c->d_model, dim3(max_nblk, max_nblk, T), st);
     }
-    { ProfScope ps(c, "potrf", 1); run_potrf(c, dtype, ds->d_desc, T, max_nblk, ds->d_info, early_H); }
+    { ProfScope ps(c, "potrf", 1); run_potrf(c, dtype, ds->d_desc, T, max_nblk, ds->d_info, early_trtri ? &trtri_pg : nullptr); }
     { ProfScope ps(c, "nll_reduce", 1); launch_nll_reduce(dtype, ds->d_desc, T, ds->d_info, ds->d_nll, st); }
   }
 
@@ -740,8 +753,7 @@ extern "C" int hbo_objective(hbo_ctx* c, const hbo_model* m_in, hbo_dataset* ds,
     if (ds->gradout_bytes < gb) { if (ds->d_gradout) hipFree(ds->d_gradout); HIPCHK(c, hipMalloc((void**)&ds->d_gradout, gb)); ds->gradout_bytes = gb; }
     if (!euc) {
       { ProfScope ps(c, "trtri", 1);
-        if (early_H) run_trtri_late(c, dtype, ds->d_desc, T, max_nblk, early_H, st);
-        else run_trtri(c, dtype, ds->d_desc, T, max_nblk); }
+        run_trtri(c, dtype, ds->d_desc, T, max_nblk, &trtri_pg); }
       { ProfScope ps(c, "wt_z", 1);
         for (int b = 0; b < max_naug; ++b) launch_wt_z(dtype, ds->d_desc, T, max_nblk, b, b, max_npad, st); }
       { ProfScope ps(c, "lauum", 1); run_lauum(c, dtype, ds->d_desc, T, max_nblk); }
