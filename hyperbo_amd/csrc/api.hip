@@ -34,7 +34,9 @@ struct hbo_ctx {
   int opt_dynamic_tiles = 1;       // persistent bulk update draws its tiles from a counter
   int opt_overlap_trtri = 1;
   std::string err;
-  ModelDev h_model;
+  ModelDev* h_model = nullptr;      // pinned: uploaded without a staging copy or a synchronisation
+  void* hp_stage = nullptr; size_t hp_stage_bytes = 0;   // pinned staging (descriptors up, results down)
+  hipEvent_t ev_upload = nullptr;   // last host->device copy out of the pinned buffers
   ModelDev* d_model = nullptr;
   void* d_mlp_w[HBO_MAX_MLP_LAYERS] = {nullptr};
   void* d_mlp_b[HBO_MAX_MLP_LAYERS] = {nullptr};
@@ -161,6 +163,8 @@ extern "C" int hbo_ctx_create(int device, hbo_ctx** out) {
   if (e == hipSuccess) e = hipStreamCreate(&c->stream2);
   if (e == hipSuccess) e = hipStreamCreate(&c->stream4);
   if (e == hipSuccess) e = hipMalloc((void**)&c->d_model, sizeof(ModelDev));
+  if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_model, sizeof(ModelDev), hipHostMallocDefault);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_upload, hipEventDisableTiming);
   if (e != hipSuccess) {
     g_err = std::string("hbo_ctx_create: ") + hipGetErrorString(e);
     delete c;
@@ -180,6 +184,9 @@ extern "C" int hbo_ctx_destroy(hbo_ctx* c) {
   for (int l = 0; l < HBO_MAX_MLP_LAYERS; ++l) { if (c->d_mlp_w[l]) hipFree(c->d_mlp_w[l]); if (c->d_mlp_b[l]) hipFree(c->d_mlp_b[l]); }
   for (hipEvent_t ev : c->prof_events) hipEventDestroy(ev);
   if (c->d_model) hipFree(c->d_model);
+  if (c->h_model) hipHostFree(c->h_model);
+  if (c->hp_stage) hipHostFree(c->hp_stage);
+  if (c->ev_upload) hipEventDestroy(c->ev_upload);
   for (auto& kv : c->ws) if (kv.second.first) hipFree(kv.second.first);
   for (hipEvent_t ev : c->ev_pool) hipEventDestroy(ev);
   if (c->stream4) hipStreamDestroy(c->stream4);
@@ -255,7 +262,9 @@ static double host_elem(const void* p, int dtype, int64_t i) {
 static int upload_model(hbo_ctx* c, const hbo_model* m) {
   int rc = validate_model(c, m);
   if (rc) return rc;
-  ModelDev& h = c->h_model;
+  // the pinned copy may still be read by the previous upload (calls that return without waiting for the stream)
+  HIPCHK(c, hipEventSynchronize(c->ev_upload));
+  ModelDev& h = *c->h_model;
   memset(&h, 0, sizeof h);
   h.kernel_id = m->kernel_id; h.mean_id = m->mean_id; h.fdim = feature_dim(m);
   h.n_ls = (m->kernel_id == HBO_KERNEL_DOT) ? 0 : m->n_lengthscale;
@@ -271,6 +280,7 @@ static int upload_model(hbo_ctx* c, const hbo_model* m) {
   const int fm = mean_feature_dim(m);
   for (int d = 0; d < fm; ++d) h.lin_w[d] = host_elem(m->linear_kernel, m->dtype, d);
   HIPCHK(c, hipMemcpyAsync(c->d_model, &h, sizeof h, hipMemcpyHostToDevice, c->stream));
+  HIPCHK(c, hipEventRecord(c->ev_upload, c->stream));
   if (needs_mlp(m)) {
     int fin = m->input_dim;
     for (int l = 0; l < m->n_layers; ++l) {
@@ -282,8 +292,8 @@ static int upload_model(hbo_ctx* c, const hbo_model* m) {
       fin = m->features[l];
     }
   }
-  // pageable host memory: make sure the copies have consumed h before it can change
-  HIPCHK(c, hipStreamSynchronize(c->stream));
+  // the MLP weights come from the caller's pageable memory: make sure the copies have consumed them
+  if (needs_mlp(m)) HIPCHK(c, hipStreamSynchronize(c->stream));
   return HBO_OK;
 }
 
@@ -351,6 +361,16 @@ static hipEvent_t pool_event(hbo_ctx* c, size_t i) {
     c->ev_pool.push_back(ev);
   }
   return c->ev_pool[i];
+}
+
+static void* pinned_stage(hbo_ctx* c, size_t bytes) {
+  if (c->hp_stage_bytes < bytes) {
+    if (c->hp_stage) { hipDeviceSynchronize(); hipHostFree(c->hp_stage); c->hp_stage = nullptr; c->hp_stage_bytes = 0; }
+    const size_t want = std::max<size_t>(bytes * 2, 1 << 16);
+    if (hipHostMalloc(&c->hp_stage, want, hipHostMallocDefault) != hipSuccess) { c->hp_stage = nullptr; return nullptr; }
+    c->hp_stage_bytes = want;
+  }
+  return c->hp_stage;
 }
 
 // Right-looking blocked Cholesky with look-ahead.  Panels are 128 wide; `group` consecutive panels
@@ -535,10 +555,13 @@ struct hbo_dataset {
   std::vector<TaskHost*> tasks;
   std::vector<TaskDesc> h_desc;
   TaskDesc* d_desc = nullptr;
+  // results of one evaluation, one device block = one copy back: [value T][gradient T x out_stride][info T (int)]
+  double* d_pack = nullptr; size_t pack_bytes = 0;
   int* d_info = nullptr;
   double* d_nll = nullptr;
+  std::vector<TaskDesc> h_desc_dev;   // what d_desc holds
   double* d_partials = nullptr; size_t partials_bytes = 0;
-  double* d_gradout = nullptr; size_t gradout_bytes = 0;
+  double* d_gradout = nullptr;
   double* d_mlpgrad = nullptr; size_t mlpgrad_elems = 0;
   bool has_S = false;
 };
@@ -553,7 +576,7 @@ extern "C" int hbo_dataset_free(hbo_ctx* c, hbo_dataset* ds) {
   if (!ds) return HBO_OK;
   if (c) hipSetDevice(c->device);
   for (TaskHost* t : ds->tasks) free_task(t);
-  for (void* p : {(void*)ds->d_desc, (void*)ds->d_info, (void*)ds->d_nll, (void*)ds->d_partials, (void*)ds->d_gradout, (void*)ds->d_mlpgrad}) if (p) hipFree(p);
+  for (void* p : {(void*)ds->d_desc, (void*)ds->d_pack, (void*)ds->d_partials, (void*)ds->d_mlpgrad}) if (p) hipFree(p);
   delete ds;
   return HBO_OK;
 }
@@ -716,12 +739,25 @@ extern "C" int hbo_objective(hbo_ctx* c, const hbo_model* m_in, hbo_dataset* ds,
     fill_desc(ds->h_desc[k], t, m, dtype, obj);
   }
   if (!ds->d_desc) HIPCHK(c, hipMalloc((void**)&ds->d_desc, sizeof(TaskDesc) * T));
-  if (!ds->d_info) HIPCHK(c, hipMalloc((void**)&ds->d_info, sizeof(int) * T));
-  if (!ds->d_nll) HIPCHK(c, hipMalloc((void**)&ds->d_nll, sizeof(double) * T));
-  HIPCHK(c, hipMemcpyAsync(ds->d_desc, ds->h_desc.data(), sizeof(TaskDesc) * T, hipMemcpyHostToDevice, st));
-  std::vector<int> h_info(T, INT_MAX);
-  HIPCHK(c, hipMemcpyAsync(ds->d_info, h_info.data(), sizeof(int) * T, hipMemcpyHostToDevice, st));
-  HIPCHK(c, hipStreamSynchronize(st));
+  const int out_stride = (m->kernel_id == HBO_KERNEL_DOT ? 0 : m->n_lengthscale) + 6 + mean_feature_dim(m);
+  const size_t pack_bytes = sizeof(double) * T * (1 + (size_t)out_stride) + sizeof(int) * T;
+  if (ds->pack_bytes < pack_bytes) {
+    if (ds->d_pack) hipFree(ds->d_pack);
+    ds->d_pack = nullptr; ds->pack_bytes = 0;
+    HIPCHK(c, hipMalloc((void**)&ds->d_pack, pack_bytes));
+    ds->pack_bytes = pack_bytes;
+  }
+  ds->d_nll = ds->d_pack; ds->d_gradout = ds->d_pack + T; ds->d_info = reinterpret_cast<int*>(ds->d_pack + T + (size_t)T * out_stride);
+  // small transfers go through one pinned buffer: descriptors up (only when they changed), results down in one copy
+  unsigned char* stage = static_cast<unsigned char*>(pinned_stage(c, std::max(sizeof(TaskDesc) * T, pack_bytes)));
+  if (!stage) return fail(c, HBO_ERR_HIP, "hbo_objective: pinned staging buffer");
+  if (ds->h_desc_dev.size() != (size_t)T || memcmp(ds->h_desc_dev.data(), ds->h_desc.data(), sizeof(TaskDesc) * T) != 0) {
+    HIPCHK(c, hipEventSynchronize(c->ev_upload));
+    memcpy(stage, ds->h_desc.data(), sizeof(TaskDesc) * T);
+    HIPCHK(c, hipMemcpyAsync(ds->d_desc, stage, sizeof(TaskDesc) * T, hipMemcpyHostToDevice, st));
+    ds->h_desc_dev = ds->h_desc;
+  }
+  HIPCHK(c, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ds->d_info), INT_MAX, T, st));
 
   const int max_nblk = ds->max_nblk, max_npad = max_nblk * HBO_TILE;
   {
@@ -745,12 +781,10 @@ extern "C" int hbo_objective(hbo_ctx* c, const hbo_model* m_in, hbo_dataset* ds,
 
   const int fdim = feature_dim(m);
   const int nacc = grad_nacc(m->kernel_id, fdim);
-  const int out_stride = (m->kernel_id == HBO_KERNEL_DOT ? 0 : m->n_lengthscale) + 6 + mean_feature_dim(m);
   const int64_t stride_task = (int64_t)(max_nblk * (max_nblk + 1) / 2) * nacc;
   if (want_grad || euc) {   // EUC: the Frobenius norm of the value comes out of the contraction pass
-    const size_t pb = sizeof(double) * stride_task * T, gb = sizeof(double) * out_stride * T;
+    const size_t pb = sizeof(double) * stride_task * T;
     if (ds->partials_bytes < pb) { if (ds->d_partials) hipFree(ds->d_partials); HIPCHK(c, hipMalloc((void**)&ds->d_partials, pb)); ds->partials_bytes = pb; }
-    if (ds->gradout_bytes < gb) { if (ds->d_gradout) hipFree(ds->d_gradout); HIPCHK(c, hipMalloc((void**)&ds->d_gradout, gb)); ds->gradout_bytes = gb; }
     if (!euc) {
       { ProfScope ps(c, "trtri", 1);
         run_trtri(c, dtype, ds->d_desc, T, max_nblk, &trtri_pg); }
@@ -792,10 +826,10 @@ extern "C" int hbo_objective(hbo_ctx* c, const hbo_model* m_in, hbo_dataset* ds,
       }
     }
   }
-  std::vector<double> h_nll(T), h_grad(want_grad ? (size_t)out_stride * T : 0);
-  HIPCHK(c, hipMemcpyAsync(h_nll.data(), ds->d_nll, sizeof(double) * T, hipMemcpyDeviceToHost, st));
-  HIPCHK(c, hipMemcpyAsync(h_info.data(), ds->d_info, sizeof(int) * T, hipMemcpyDeviceToHost, st));
-  if (want_grad) HIPCHK(c, hipMemcpyAsync(h_grad.data(), ds->d_gradout, sizeof(double) * out_stride * T, hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipMemcpyAsync(stage, ds->d_pack, pack_bytes, hipMemcpyDeviceToHost, st));
+  const double* h_nll = reinterpret_cast<const double*>(stage);
+  const double* h_grad = h_nll + T;
+  const int* h_info = reinterpret_cast<const int*>(h_grad + (size_t)T * out_stride);
   std::vector<double> h_mlp;
   if (want_grad && needs_mlp(m)) {
     h_mlp.resize(ds->mlpgrad_elems);
@@ -813,7 +847,7 @@ extern "C" int hbo_objective(hbo_ctx* c, const hbo_model* m_in, hbo_dataset* ds,
     const int n_ls = m->kernel_id == HBO_KERNEL_DOT ? 0 : m->n_lengthscale;
     const int fm = mean_feature_dim(m);
     for (int k = 0; k < T; ++k) {
-      const double* o = h_grad.data() + (size_t)k * out_stride;
+      const double* o = h_grad + (size_t)k * out_stride;
       const bool bad = h_info[k] != INT_MAX;
       auto add = [&](int off, double v) { if (off >= 0) grad_sum[off] += bad ? NAN : v; };
       for (int d = 0; d < n_ls; ++d) add(lay.lengthscale < 0 ? -1 : lay.lengthscale + d, o[d]);
