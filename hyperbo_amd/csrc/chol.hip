@@ -199,23 +199,37 @@ __device__ __forceinline__ void potf2_body(const TaskDesc& t, int p, int* info_s
   };
 
   STAMP(1);
-  if (wave == 0) factor_leaf(0);
+  // leaves that hold data: the identity padding of the last block factors to itself (a matrix of 64 points has four
+  // of its eight leaves empty); their leaf inverse is the identity, written here once
+  int nleaf = 8;
+  {
+    const int64_t rows = (int64_t)t.n - (int64_t)p * NB;
+    if (rows < NB) nleaf = rows <= 0 ? 0 : (int)((rows + 15) / 16);
+    for (int jb = nleaf + wave; jb < 8; jb += 4)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = Mma<T>::crow(lane, r);
+        gst(Wb + (int64_t)(jb * 16 + row) * ld + jb * 16 + l15, row == l15 ? (T)1 : (T)0);
+      }
+    if (tid < NB && tid >= nleaf * 16) sDinv[tid] = (T)1;
+  }
+  if (wave == 0 && nleaf > 0) factor_leaf(0);
   __syncthreads();
   STAMP(2);
-  for (int jb = 0; jb < 8; ++jb) {
+  for (int jb = 0; jb < nleaf; ++jb) {
     // ---- (B) rows below the leaf: X = A M^T, one 16-row tile per wave and pass (wave 0 takes tile jb+1, whose
     //      result it needs first in (C)) ------------------------------------------------------
-    for (int R = jb + 1 + wave; R < 8; R += 4) solve_tile(jb, R);
+    for (int R = jb + 1 + wave; R < nleaf; R += 4) solve_tile(jb, R);   // (tiles of padding rows are zero)
     __syncthreads();
     STAMP(3 + 3 * jb);
-    if (jb == 7) break;
+    if (jb == nleaf - 1) break;   // (the rows below the last data leaf are zero: (B) left them zero)
     // ---- (C) trailing update; wave 0 owns the next diagonal tile and factors it right away ----
     if (wave == 0) {
       update_tile(jb, jb + 1, jb + 1);
       factor_leaf(jb + 1);
       STAMP(4 + 3 * jb);
     } else {
-      const int m = 7 - jb;
+      const int m = nleaf - 1 - jb;
       const int ntiles = m * (m + 1) / 2;
       for (int tix = wave; tix < ntiles; tix += 3) {   // tix 0 is the (jb+1,jb+1) tile: skipped
         int ii = 0;

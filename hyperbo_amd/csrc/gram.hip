@@ -280,7 +280,17 @@ __global__ __launch_bounds__(256) void wtz_partial_kernel(const TaskDesc* tasks,
     if (r_end > t.npad) r_end = t.npad;
     const int64_t diag0 = (int64_t)cb * HBO_TILE;
     if (r_begin < diag0) r_begin = diag0;
-    for (int64_t r = r_begin; r < r_end; ++r) acc += W[r * t.ld + diag0 + col] * z[r];
+    // four independent accumulators: the loads of a row group are in flight together (a single dependent chain ran
+    // at a quarter of the HBM rate, and took 31 us on one 128-row block)
+    T a0 = (T)0, a1 = (T)0, a2 = (T)0, a3 = (T)0;
+    const T* wp = W + diag0 + col;
+    int64_t r = r_begin;
+    for (; r + 4 <= r_end; r += 4) {
+      const T w0 = wp[r * t.ld], w1 = wp[(r + 1) * t.ld], w2 = wp[(r + 2) * t.ld], w3 = wp[(r + 3) * t.ld];
+      a0 += w0 * z[r]; a1 += w1 * z[r + 1]; a2 += w2 * z[r + 2]; a3 += w3 * z[r + 3];
+    }
+    for (; r < r_end; ++r) a0 += wp[r * t.ld] * z[r];
+    acc = (a0 + a1) + (a2 + a3);
   }
   sred[threadIdx.x] = acc;
   __syncthreads();
