@@ -383,8 +383,9 @@ static void run_potrf(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks
                       TrtriProgress* early = nullptr) {
   const int q = c->opt_group;
   hipStream_t sm = c->stream;
-  hipStream_t sp = c->opt_lookahead ? c->stream2 : c->stream;
-  const bool la = c->opt_lookahead != 0;
+  // (a single block column has no trailing matrix to look ahead over: it stays on the caller's stream)
+  const bool la = c->opt_lookahead != 0 && max_nblk > 1;
+  hipStream_t sp = la ? c->stream2 : c->stream;
   hipStream_t sb = sm;   // bulk updates share the main stream (CU-masked queues were measured slower)
   size_t evi = 0;
   if (la) { hipEvent_t e = pool_event(c, evi++); hipEventRecord(e, sm); hipStreamWaitEvent(sp, e, 0); }
