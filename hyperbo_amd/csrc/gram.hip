@@ -336,7 +336,7 @@ __global__ __launch_bounds__(256) void grad_contract_kernel(const TaskDesc* task
   const int obj = MULTI ? obj_arg : (int)OBJ_NLL;
   __shared__ T sA[DC * SXS];
   __shared__ T sB[DC * SXS];
-  __shared__ double sred[4];
+  __shared__ double swred[4][DC + 4];   // per-wave partial sums: 4 scalars + one per staged feature
   const TaskDesc& t = tasks[blockIdx.z];
   const int ti = blockIdx.x, tj = blockIdx.y;
   if (ti >= t.nblk || tj > ti) return;
@@ -442,11 +442,20 @@ __global__ __launch_bounds__(256) void grad_contract_kernel(const TaskDesc* task
       acc[a][q] = gw;
     }
   }
-  a_gk = block_sum(a_gk, sred);
-  a_tr = block_sum(a_tr, sred);
-  if (is_dot) a_g = block_sum(a_g, sred);
-  if (MULTI) a_fro = block_sum(a_fro, sred);
-  if (tid == 0) { out[0] = a_gk; out[1] = a_tr; if (is_dot) out[2] = a_g; out[nacc - 1] = a_fro; }
+  // block sums: per-wave sums meet in LDS, one barrier for all accumulators (the tile's 40 us are the 64 fp64
+  // exponentials per thread, not the reductions -- measured equal with a barrier pair per accumulator)
+  const int lane = tid & 63, wave = tid >> 6;
+  a_gk = wave_sum(a_gk); a_tr = wave_sum(a_tr);
+  if (is_dot) a_g = wave_sum(a_g);
+  if (MULTI) a_fro = wave_sum(a_fro);
+  if (lane == 0) { swred[wave][0] = a_gk; swred[wave][1] = a_tr; swred[wave][2] = a_g; swred[wave][3] = a_fro; }
+  __syncthreads();
+  if (tid == 0) {
+    out[0] = (swred[0][0] + swred[1][0]) + (swred[2][0] + swred[3][0]);
+    out[1] = (swred[0][1] + swred[1][1]) + (swred[2][1] + swred[3][1]);
+    if (is_dot) out[2] = (swred[0][2] + swred[1][2]) + (swred[2][2] + swred[3][2]);
+    out[nacc - 1] = (swred[0][3] + swred[1][3]) + (swred[2][3] + swred[3][3]);
+  }
   if (is_dot) return;
   // second pass over the features: sum gw * ds_d^2
   for (int d0 = 0; d0 < fdim; d0 += DC) {
@@ -466,9 +475,11 @@ __global__ __launch_bounds__(256) void grad_contract_kernel(const TaskDesc* task
       for (int a = 0; a < 8; ++a)
 #pragma unroll
         for (int q = 0; q < 8; ++q) { const T df = av[a] - bv[q]; s += acc[a][q] * df * df; }
-      const double tot = block_sum((double)s, sred);
-      if (tid == 0) out[2 + d0 + dd] = tot;
+      const double ws = wave_sum((double)s);
+      if (lane == 0) swred[wave][4 + dd] = ws;
     }
+    __syncthreads();
+    if (tid < dlim) out[2 + d0 + tid] = (swred[0][4 + tid] + swred[1][4 + tid]) + (swred[2][4 + tid] + swred[3][4 + tid]);
   }
 }
 
