@@ -113,9 +113,10 @@ def main():
 
   ctx = nat.default_context()
   wf = utils.DEFAULT_WARP_FUNC
-  potrf_group = int(os.environ.get('HBO_BENCH_POTRF_GROUP', '4'))   # libhbo default: 4 panels (K = 512 trailing updates)
-  if potrf_group != 4:
-    ctx.set_option('potrf_group', potrf_group)
+  # panels per trailing update: set explicitly (libhbo's own choice for <= 96 blocks is also 3, K = 384) because the
+  # roofline's algorithmic flops per launch below are computed from it
+  potrf_group = int(os.environ.get('HBO_BENCH_POTRF_GROUP', '3'))
+  ctx.set_option('potrf_group', potrf_group)
 
   def sync():
     if torch is not None and torch.cuda.is_available():
@@ -171,7 +172,7 @@ def main():
     assert launches == len(fl) * args.steps, (launches, len(fl), args.steps)
     flops_total = sum(fl) * args.steps
     achieved = flops_total / (tot_ms * 1e-3) / 1e12
-    roofline = {'bound': 'mfma', 'kernel': 'gemm_kernel<double,true,true,128> (bulk Cholesky trailing update, syrk K=512)',
+    roofline = {'bound': 'mfma', 'kernel': f'gemm_kernel<double,true,true,128> (bulk Cholesky trailing update, syrk K={128 * group})',
                 'achieved': round(achieved, 3), 'peak': FP64_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': round(achieved / FP64_MFMA_PEAK_TFLOPS, 4), 'traffic': None,
                 'launches': launches, 'avg_launch_ms': round(tot_ms / launches, 4),

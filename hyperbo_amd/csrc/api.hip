@@ -25,7 +25,7 @@ struct hbo_ctx {
   hipStream_t stream4 = nullptr;   // early part of trtri, overlapped with the tail of potrf
   int opt_trtri_gran = 0;    // panels between two launches of the inverse's computable pieces during the factorisation (0: auto)
   int opt_small_nblk = 32;   // matrices up to this many 128-blocks use 64x64 GEMM tiles in trtri / lauum
-  int opt_persist_free = 32; // bulk trailing update runs as 2*(CUs - this) persistent workgroups
+  int opt_persist_free = -1; // bulk trailing update runs as 2*(CUs - this) persistent workgroups (-1: auto, see run_potrf)
   int n_cus = 256;
   std::vector<hipEvent_t> ev_pool;
   std::map<int, std::pair<void*, size_t>> ws;   // grow-only device scratch buffers by slot (no per-call hipMalloc/hipFree)
@@ -42,7 +42,7 @@ struct hbo_ctx {
   void* d_mlp_b[HBO_MAX_MLP_LAYERS] = {nullptr};
   size_t mlp_w_bytes[HBO_MAX_MLP_LAYERS] = {0};
   size_t mlp_b_bytes[HBO_MAX_MLP_LAYERS] = {0};
-  int opt_group = 4;         // 128-wide panels per trailing update (K = 128*group)
+  int opt_group = 0;         // 128-wide panels per trailing update (K = 128*group); 0: auto, see run_potrf
   int prof_level = 0;
   std::vector<ProfEntry> prof_pending;
   std::vector<hipEvent_t> prof_events; size_t prof_next = 0;   // event pool of the timing scopes
@@ -197,14 +197,14 @@ extern "C" int hbo_ctx_destroy(hbo_ctx* c) {
 }
 extern "C" int hbo_set_option(hbo_ctx* c, const char* name, int64_t value) {
   if (!c || !name) return HBO_ERR_ARG;
-  if (!strcmp(name, "potrf_group")) { if (value < 1 || value > 8) return fail(c, HBO_ERR_ARG, "potrf_group in 1..8"); c->opt_group = (int)value; return HBO_OK; }
+  if (!strcmp(name, "potrf_group")) { if (value < 0 || value > 8) return fail(c, HBO_ERR_ARG, "potrf_group in 0..8 (0: auto)"); c->opt_group = (int)value; return HBO_OK; }
   if (!strcmp(name, "overlap_trtri")) { c->opt_overlap_trtri = value ? 1 : 0; return HBO_OK; }
   if (!strcmp(name, "dynamic_tiles")) { c->opt_dynamic_tiles = value ? 1 : 0; return HBO_OK; }
   if (!strcmp(name, "f1_on_chain")) { c->opt_f1_on_chain = value ? 1 : 0; return HBO_OK; }
   if (!strcmp(name, "lookahead")) { c->opt_lookahead = value ? 1 : 0; return HBO_OK; }
   if (!strcmp(name, "trtri_gran")) { if (value < 0) return fail(c, HBO_ERR_ARG, "trtri_gran >= 0"); c->opt_trtri_gran = (int)value; return HBO_OK; }
   if (!strcmp(name, "small_nblk")) { c->opt_small_nblk = (int)value; return HBO_OK; }
-  if (!strcmp(name, "persist_free")) { if (value < 0 || value > 200) return fail(c, HBO_ERR_ARG, "persist_free in 0..200"); c->opt_persist_free = (int)value; return HBO_OK; }
+  if (!strcmp(name, "persist_free")) { if (value < -1 || value > 200) return fail(c, HBO_ERR_ARG, "persist_free in -1..200 (-1: auto)"); c->opt_persist_free = (int)value; return HBO_OK; }
   return fail(c, HBO_ERR_ARG, std::string("unknown option ") + name);
 }
 extern "C" int hbo_profile_enable(hbo_ctx* c, int level) { if (!c) return HBO_ERR_ARG; c->prof_level = level; return HBO_OK; }
@@ -381,7 +381,12 @@ static void* pinned_stage(hbo_ctx* c, size_t bytes) {
 // -- the bulk of the flops -- overlaps it.
 static void run_potrf(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, int max_nblk, int* d_info,
                       TrtriProgress* early = nullptr) {
-  const int q = c->opt_group;
+  // panels per trailing update and CUs the persistent bulk update leaves to the panel chain.  Measured (NLL+grad, ms):
+  //   N = 4096: (4, 32) 3.61, (3, 32) 3.54, (3, 64) 3.51;   N = 8192: (4, 32) 13.49, (3, 32) 13.34, (3, 64) 13.25,
+  //   (3, 96) 13.43, (2, 64) 13.57, (5, 32) 13.61;   N = 16384: (4, 32) 78.4, (3, 32) 79.1, (3, 64) 79.5
+  const bool small_mat = max_nblk <= 96;
+  const int q = c->opt_group > 0 ? c->opt_group : (small_mat ? 3 : 4);
+  const int persist_free = c->opt_persist_free >= 0 ? c->opt_persist_free : (small_mat ? 64 : 32);
   hipStream_t sm = c->stream;
   // (a single block column has no trailing matrix to look ahead over: it stays on the caller's stream)
   const bool la = c->opt_lookahead != 0 && max_nblk > 1;
@@ -452,9 +457,9 @@ static void run_potrf(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks
             ProfScope ps(c, a.small_tiles ? "syrk_trailing" : "syrk_bulk", 1, sb);
             // persistent form (single task, enough tiles to fill the machine): leave CUs for the panel chain
             const int64_t ntiles = (m * (m + 1) / 2 + m) * (a.small_tiles ? 4 : 1);
-            const int pblocks = 2 * (c->n_cus - c->opt_persist_free);
+            const int pblocks = 2 * (c->n_cus - persist_free);
             // (for large trailing matrices the bulk update dominates and gets the whole machine)
-            a.persistent = (ntasks == 1 && c->opt_persist_free > 0 && ntiles > pblocks && m <= 96) ? pblocks : 0;
+            a.persistent = (ntasks == 1 && persist_free > 0 && ntiles > pblocks && m <= 96) ? pblocks : 0;
             a.work_counter = (a.persistent && counters && n_counter < 256) ? counters + n_counter++ : nullptr;
             launch_gemm(dtype, a, dim3(max_nblk + 1 - a.c_lo, a.c_hi - a.c_lo, ntasks), sb);
             a.persistent = 0; a.work_counter = nullptr;
