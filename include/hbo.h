@@ -184,7 +184,16 @@ int hbo_profile_enable(hbo_ctx* ctx, int level); /* 0 off, 1 per stage, 2 per la
 /* names: array of HBO_MAX_PROFILE_STAGES char[32]; ms: total ms; launches: count */
 int hbo_profile_get(hbo_ctx* ctx, char names[][32], double* ms, int32_t* launches, int32_t* n);
 
-/* tuning knobs (integers by name), e.g. "potrf_group", "lookahead", "streams". */
+/* Scheduling knobs (integers by name); the defaults are the measured best, the knobs exist for A/B runs
+ * (tools/ab_opt.py).  Unknown names are an error.
+ *   potrf_group    0..8  128-wide panels per trailing update, K = 128*group (0 = auto: 3 up to 96 blocks, else 4)
+ *   persist_free  -1..200 CUs the persistent bulk trailing update leaves to the panel chain (-1 = auto: 64 / 32)
+ *   lookahead      0/1   panel chain on its own stream, one group ahead of the bulk update
+ *   f1_on_chain    0/1   next group's column update launched on the panel stream
+ *   dynamic_tiles  0/1   persistent bulk update draws tiles from a counter
+ *   overlap_trtri  0/1   inverse walks the block tree while the factorisation runs
+ *   trtri_gran     >=0   panels between two launches of the inverse's computable pieces (0 = auto)
+ *   small_nblk     int   matrices up to this many blocks use 64x64 tiles in trtri / lauum */
 int hbo_set_option(hbo_ctx* ctx, const char* name, int64_t value);
 
 /* ---- multi-GPU: one process per GPU; sum-all-reduce of [nll, grads] over RCCL (xGMI) ------ */
