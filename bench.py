@@ -90,6 +90,7 @@ def main():
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--no-multitask', action='store_true')
   ap.add_argument('--cpu-evals', type=int, default=8)
+  ap.add_argument('--secondary-timeout', type=float, default=420.0, help='seconds for the multitask + CPU legs')
   args = ap.parse_args()
 
   rank = int(os.environ.get('RANK', '0'))
@@ -192,6 +193,34 @@ def main():
   stages = {k: round(v[0] / stage_evals, 4) for k, v in stage_prof.items()}   # separate pass with all stage events on
   ctx.profile_enable(0)
 
+  def result_line(cpu, multitask):
+    return {
+        'metric': 'GP NLL+grad evals/sec at N=8192 D=16 fp64', 'value': round(value, 4), 'unit': 'evals/s',
+        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 4),
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
+        'config': {'workload': f'cfg2: single-task SE-ARD GP + constant mean, N={args.n}, D={args.d}, fp64, NLL+grad '
+                               '(Gram -> blocked Cholesky -> trtri -> lauum -> gradient contraction)',
+                   'parallelism': 'single GPU' if world == 1 else f'{world} independent replicas (one per GPU)',
+                   'potrf_group': group},
+        'algorithmic_tflops': round(float(args.n)**3 / (ms_per_step * 1e-3) / 1e12, 3),
+        'stages_ms_per_step': stages,
+        'stages_note': 'separate untimed pass of 3 evaluations with every stage bracketed by HIP events; the timed '
+                       'region brackets only the roofline kernel (stage events cost 0.3 ms per evaluation)',
+        'roofline': roofline, 'cpu_baseline': cpu, 'multitask': multitask,
+    }
+
+  # The headline is measured; the secondary legs below must not be able to lose it: if they do not finish in time
+  # (a communicator that never forms, a rank that died) every rank's watchdog ends the process and rank 0 prints the
+  # line without them.
+  import threading
+  def bail():
+    if rank == 0:
+      print(json.dumps(result_line(None, {'error': f'secondary legs did not finish within {args.secondary_timeout} s'})), flush=True)
+    os._exit(0)
+  watchdog = threading.Timer(args.secondary_timeout, bail)
+  watchdog.daemon = True
+  watchdog.start()
+
   # ---------------- secondary: cfg 4 multi-task objective, task-sharded ----------------------
   multitask = None
   if not args.no_multitask:
@@ -220,8 +249,15 @@ def main():
           comm.allreduce_sum(np.zeros(4))          # builds the communicator now; raises if it cannot
           comm_kind = 'torch.distributed nccl (RCCL over xGMI)'
       except Exception as e:  # pylint: disable=broad-except
-        comm = parallel.TorchDistComm()
+        comm = None
         comm_kind = f'torch.distributed gloo (RCCL communicator unavailable: {str(e)[:120]})'
+      # every rank must use the same transport: agree (over gloo) on whether all of them built the RCCL one
+      ok = torch.tensor([1.0 if comm is not None else 0.0], dtype=torch.float64)
+      dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+      if float(ok.item()) < 0.5:
+        if comm is not None:
+          comm_kind = 'torch.distributed gloo (RCCL communicator unavailable on another rank)'
+        comm = parallel.TorchDistComm()
     def step4(i):
       p = defs.GPParams(model=perturb(raw4, i, 0))
       return objectives.nll_value_and_grad(mean.constant, kernel.squared_exponential, p, dev4, wf, comm=comm)
@@ -256,22 +292,9 @@ def main():
                      f'cores, LAPACK potrf/potrs/potri via SciPy/OpenBLAS)',
            'seconds': round(el, 2), 'nll_matches_gpu': bool(abs(vals[-1] - float(step_fn(args.cpu_evals - 1)[0])) <= 1e-8 * abs(vals[-1]))}
 
+  watchdog.cancel()
   if rank == 0:
-    out = {
-        'metric': 'GP NLL+grad evals/sec at N=8192 D=16 fp64', 'value': round(value, 4), 'unit': 'evals/s',
-        'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 4),
-        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f64', 'data': 'synthetic',
-        'config': {'workload': f'cfg2: single-task SE-ARD GP + constant mean, N={args.n}, D={args.d}, fp64, NLL+grad '
-                               '(Gram -> blocked Cholesky -> trtri -> lauum -> gradient contraction)',
-                   'parallelism': 'single GPU' if world == 1 else f'{world} independent replicas (one per GPU)',
-                   'potrf_group': group},
-        'algorithmic_tflops': round(float(args.n)**3 / (ms_per_step * 1e-3) / 1e12, 3),
-        'stages_ms_per_step': stages,
-        'stages_note': 'separate untimed pass of 3 evaluations with every stage bracketed by HIP events; the timed '
-                       'region brackets only the roofline kernel (stage events cost 0.3 ms per evaluation)',
-        'roofline': roofline, 'cpu_baseline': cpu, 'multitask': multitask,
-    }
-    print(json.dumps(out), flush=True)
+    print(json.dumps(result_line(cpu, multitask)), flush=True)
   dev.close()
   if dist is not None:
     dist.barrier()
