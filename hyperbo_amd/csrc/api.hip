@@ -778,7 +778,7 @@ extern "C" int hbo_objective(hbo_ctx* c, const hbo_model* m_in, hbo_dataset* ds,
   if (!euc) {
     {
       ProfScope ps(c, "gram", 1);
-      GramArgs g = {}; g.tasks = ds->d_desc; g.fdim = feature_dim(m); g.symmetric = 1; g.padded = 1;
+      GramArgs g = {}; g.kernel_id = c->h_model->kernel_id; g.tasks = ds->d_desc; g.fdim = feature_dim(m); g.symmetric = 1; g.padded = 1;
       launch_gram(dtype, g, c->d_model, dim3(max_nblk, max_nblk, T), st);
     }
     { ProfScope ps(c, "potrf", 1); run_potrf(c, dtype, ds->d_desc, T, max_nblk, ds->d_info, early_trtri ? &trtri_pg : nullptr); }
@@ -940,7 +940,7 @@ extern "C" int hbo_factor(hbo_ctx* c, const hbo_model* m, const void* x, int64_t
     launch_aug_rows(dtype, k->d_desc, 1, t->npad, c->d_model, st); }
   HIPCHK_K(hipMemcpy2DAsync(k->resid, (size_t)t->npad * es, (char*)t->A + (size_t)t->npad * t->ld * es, (size_t)t->ld * es, (size_t)t->npad * es, mcols, hipMemcpyDeviceToDevice, st));
   { ProfScope ps(c, "gram", 1);
-    GramArgs g = {}; g.tasks = k->d_desc; g.fdim = feature_dim(m); g.symmetric = 1; g.padded = 1;
+    GramArgs g = {}; g.kernel_id = c->h_model->kernel_id; g.tasks = k->d_desc; g.fdim = feature_dim(m); g.symmetric = 1; g.padded = 1;
     launch_gram(dtype, g, c->d_model, dim3(t->nblk, t->nblk, 1), st); }
   { ProfScope ps(c, "potrf", 1); run_potrf(c, dtype, k->d_desc, 1, t->nblk, k->d_info); }
   HIPCHK_K(hipMemcpy2DAsync(k->zvec, (size_t)t->npad * es, (char*)t->A + (size_t)t->npad * t->ld * es, (size_t)t->ld * es, (size_t)t->npad * es, mcols, hipMemcpyDeviceToDevice, st));
@@ -1015,7 +1015,7 @@ extern "C" int hbo_cache_append(hbo_ctx* c, const hbo_model* m, hbo_cache* k, co
     launch_kdiag(dtype, Fq, 1, fdim, c->d_model, d_kd, st);
     // k(X, x*)  (n x 1), zero-padded to npad
     HIPCHK_A(hipMemsetAsync(d_kx, 0, (size_t)t->npad * es, st));
-    { GramArgs g = {}; g.x1 = k->h_desc.F; g.x2 = Fq; g.out = d_kx; g.n1 = n; g.n2 = 1; g.ldo = 1; g.fdim = fdim;
+    { GramArgs g = {}; g.kernel_id = c->h_model->kernel_id; g.x1 = k->h_desc.F; g.x2 = Fq; g.out = d_kx; g.n1 = n; g.n2 = 1; g.ldo = 1; g.fdim = fdim;
       launch_gram(dtype, g, c->d_model, dim3(1, (unsigned)((n + 127) / 128), 1), st); }
     // l = W kx ; wl = W^T l
     launch_tri_matvec(dtype, t->W, t->ld, t->npad, d_kx, t->npad, 1, 0, d_l, t->npad, st);
@@ -1158,7 +1158,7 @@ static int posterior(hbo_ctx* c, const hbo_model* m, hbo_cache* k, const void* x
     if (!k) {  // prior branch (gp.py:275-282)
       if (mu_out) HIPCHK_P(hipMemcpyAsync((char*)mu_out + (size_t)q0 * es, d_mu0, (size_t)mc * es, hipMemcpyDeviceToHost, st));
       if (full_cov) {
-        GramArgs g = {}; g.x1 = Fq; g.x2 = Fq; g.out = d_cov; g.n1 = mc; g.n2 = mc; g.ldo = mc; g.fdim = fdim;
+        GramArgs g = {}; g.kernel_id = c->h_model->kernel_id; g.x1 = Fq; g.x2 = Fq; g.out = d_cov; g.n1 = mc; g.n2 = mc; g.ldo = mc; g.fdim = fdim;
         launch_gram(dtype, g, c->d_model, dim3((unsigned)((mc + 127) / 128), (unsigned)((mc + 127) / 128), 1), st);
         if (var_out) HIPCHK_P(hipMemcpyAsync(var_out, d_cov, (size_t)M * M * es, hipMemcpyDeviceToHost, st));
       } else if (var_out) {
@@ -1174,7 +1174,7 @@ static int posterior(hbo_ctx* c, const hbo_model* m, hbo_cache* k, const void* x
       continue;
     }
     { ProfScope ps(c, "cross_gram", 1);
-      GramArgs g = {}; g.x1 = k->h_desc.F; g.x2 = Fq; g.out = d_K; g.n1 = t->n; g.n2 = mc; g.ldo = ldq;
+      GramArgs g = {}; g.kernel_id = c->h_model->kernel_id; g.x1 = k->h_desc.F; g.x2 = Fq; g.out = d_K; g.n1 = t->n; g.n2 = mc; g.ldo = ldq;
       g.n1pad = t->npad; g.n2pad = mpad; g.fdim = fdim; g.symmetric = 0; g.padded = 1;
       launch_gram(dtype, g, c->d_model, dim3(mpad / HBO_TILE, t->nblk, 1), st); }
     { ProfScope ps(c, "post_gemm", 1);
@@ -1187,7 +1187,7 @@ static int posterior(hbo_ctx* c, const hbo_model* m, hbo_cache* k, const void* x
       launch_post_epilogue(dtype, pa, st); }
     if (mu_out) HIPCHK_P(hipMemcpyAsync((char*)mu_out + (size_t)q0 * es, d_mu, (size_t)mc * es, hipMemcpyDeviceToHost, st));
     if (full_cov) {
-      GramArgs g = {}; g.x1 = Fq; g.x2 = Fq; g.out = d_Kqq; g.n1 = mc; g.n2 = mc; g.ldo = mc; g.fdim = fdim;
+      GramArgs g = {}; g.kernel_id = c->h_model->kernel_id; g.x1 = Fq; g.x2 = Fq; g.out = d_Kqq; g.n1 = mc; g.n2 = mc; g.ldo = mc; g.fdim = fdim;
       launch_gram(dtype, g, c->d_model, dim3((unsigned)((mc + 127) / 128), (unsigned)((mc + 127) / 128), 1), st);
       launch_fullcov(dtype, d_V, ldq, t->npad, d_Kqq, mc, d_cov, st);
       if (var_out) HIPCHK_P(hipMemcpyAsync(var_out, d_cov, (size_t)M * M * es, hipMemcpyDeviceToHost, st));
@@ -1278,7 +1278,7 @@ extern "C" int hbo_acq_grad(hbo_ctx* c, const hbo_model* m, hbo_cache* k, const 
     launch_kdiag(dtype, Fq, mc, fdim, c->d_model, d_kd, st);
     if (t) {
       HIPCHK_D(hipMemsetAsync(d_K, 0, (size_t)mc * t->npad * es, st));
-      GramArgs g = {}; g.x1 = Fq; g.x2 = k->h_desc.F; g.out = d_K; g.n1 = mc; g.n2 = t->n; g.ldo = t->npad; g.fdim = fdim;
+      GramArgs g = {}; g.kernel_id = c->h_model->kernel_id; g.x1 = Fq; g.x2 = k->h_desc.F; g.out = d_K; g.n1 = mc; g.n2 = t->n; g.ldo = t->npad; g.fdim = fdim;
       launch_gram(dtype, g, c->d_model, dim3((unsigned)((t->n + 127) / 128), (unsigned)((mc + 127) / 128), 1), st);
       launch_tri_matvec(dtype, t->W, t->ld, t->npad, d_K, t->npad, (int)mc, 0, d_L, t->npad, st);
       launch_tri_matvec(dtype, t->W, t->ld, t->npad, d_L, t->npad, (int)mc, 1, d_B, t->npad, st);
@@ -1359,7 +1359,7 @@ extern "C" int hbo_gram(hbo_ctx* c, const hbo_model* m, const void* x1, int64_t 
     HIPCHK_G(hipMemcpyAsync(out, dout, (size_t)n1 * es, hipMemcpyDeviceToHost, st));
   } else {
     HIPCHK_G(hipMalloc(&dout, (size_t)n1 * n2 * es));
-    GramArgs g = {}; g.x1 = F1; g.x2 = F2; g.out = dout; g.n1 = n1; g.n2 = n2; g.ldo = n2; g.fdim = fdim;
+    GramArgs g = {}; g.kernel_id = c->h_model->kernel_id; g.x1 = F1; g.x2 = F2; g.out = dout; g.n1 = n1; g.n2 = n2; g.ldo = n2; g.fdim = fdim;
     launch_gram(dtype, g, c->d_model, dim3((unsigned)((n2 + 127) / 128), (unsigned)((n1 + 127) / 128), 1), st);
     HIPCHK_G(hipMemcpyAsync(out, dout, (size_t)n1 * n2 * es, hipMemcpyDeviceToHost, st));
   }

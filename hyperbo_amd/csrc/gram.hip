@@ -75,7 +75,9 @@ __device__ __forceinline__ void stage_x(T* s, const T* __restrict__ x, int64_t n
 constexpr int GRA = 4;            // rows per thread
 constexpr int GTR = 16 * GRA;     // tile rows
 
-template <typename T, bool PADDED>
+// KID: covariance id as a compile-time constant -- with a run-time id every one of a thread's 32 elements carried the
+// switch over all four covariances (188 VGPRs, 2 waves per SIMD, constants re-materialised per exponential)
+template <typename T, bool PADDED, int KID>
 __global__ __launch_bounds__(256) void gram_kernel(GramArgs g, const ModelDev* __restrict__ md) {
   typedef typename V16<T>::type vec_t;
   constexpr int VEC = 16 / sizeof(T);
@@ -96,8 +98,8 @@ __global__ __launch_bounds__(256) void gram_kernel(GramArgs g, const ModelDev* _
   const int64_t r0 = (int64_t)ti * GTR, c0 = (int64_t)tj * HBO_TILE;
   if (g.symmetric && c0 > r0 + GTR - 1) return;   // entirely above the diagonal
   const int fdim = g.fdim;
-  const int kid = md->kernel_id;
-  const bool is_dot = (kid == HBO_KERNEL_DOT);
+  constexpr int kid = KID;
+  constexpr bool is_dot = (kid == HBO_KERNEL_DOT);
   const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
 
   T acc[GRA][8];
@@ -149,7 +151,11 @@ __global__ __launch_bounds__(256) void gram_kernel(GramArgs g, const ModelDev* _
         const int64_t col = col0 + e;
         T v;
         if (row < n1 && col < n2) {
+#ifdef HBO_GRAM_NOEXP
+          v = acc[a][qb * VEC + e] * sv;
+#else
           v = kfun<T>(kid, acc[a][qb * VEC + e], sv, inv_sigma2, bias2);
+#endif
           if (g.symmetric && row == col) v += diag_add;
         } else {
           v = (g.symmetric && row == col) ? (T)1 : (T)0;   // identity / zero padding
@@ -160,7 +166,11 @@ __global__ __launch_bounds__(256) void gram_kernel(GramArgs g, const ModelDev* _
         vec_t vv;
 #pragma unroll
         for (int e = 0; e < VEC; ++e) vv[e] = vals[e];
+#ifdef HBO_GRAM_NOSTORE
+        if (vv[0] == (T)123.456) gst(reinterpret_cast<vec_t*>(out + row * ldo + col0), vv);
+#else
         gst(reinterpret_cast<vec_t*>(out + row * ldo + col0), vv);
+#endif
       } else {
 #pragma unroll
         for (int e = 0; e < VEC; ++e)
@@ -329,7 +339,7 @@ __device__ __forceinline__ const T* outer_vecs(const TaskDesc& t, int obj, int64
   return static_cast<const T*>(t.svec);
 }
 // MULTI = false: the NLL fast path (one outer-product vector, no Frobenius accumulator)
-template <typename T, bool MULTI>
+template <typename T, bool MULTI, int KID>
 __global__ __launch_bounds__(256) void grad_contract_kernel(const TaskDesc* tasks, const ModelDev* __restrict__ md,
                                                             int fdim, int nacc, int obj_arg, double* partials,
                                                             int64_t stride_task) {
@@ -341,8 +351,8 @@ __global__ __launch_bounds__(256) void grad_contract_kernel(const TaskDesc* task
   const int ti = blockIdx.x, tj = blockIdx.y;
   if (ti >= t.nblk || tj > ti) return;
   constexpr int VEC = 16 / sizeof(T);
-  const int kid = md->kernel_id;
-  const bool is_dot = (kid == HBO_KERNEL_DOT);
+  constexpr int kid = KID;   // compile-time covariance id, as in gram_kernel
+  constexpr bool is_dot = (kid == HBO_KERNEL_DOT);
   const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
   const int64_t r0 = (int64_t)ti * HBO_TILE, c0 = (int64_t)tj * HBO_TILE;
   const T* F = static_cast<const T*>(t.F);
@@ -975,11 +985,20 @@ __global__ __launch_bounds__(256) void tri_matvec_kernel(const T* __restrict__ W
   }
 }
 
+template <typename T, int KID>
+void launch_gram_k(const GramArgs& a, const ModelDev* md, dim3 grid, hipStream_t st) {
+  if (a.padded || a.tasks) hipLaunchKernelGGL((gram_kernel<T, true, KID>), grid, dim3(256), 0, st, a, md);
+  else hipLaunchKernelGGL((gram_kernel<T, false, KID>), grid, dim3(256), 0, st, a, md);
+}
 template <typename T>
 void launch_gram_t(const GramArgs& a, const ModelDev* md, dim3 grid, hipStream_t st) {
   grid.y *= HBO_TILE / GTR;   // callers size the grid in 128x128 tiles; the kernel tiles rows by GTR
-  if (a.padded || a.tasks) hipLaunchKernelGGL((gram_kernel<T, true>), grid, dim3(256), 0, st, a, md);
-  else hipLaunchKernelGGL((gram_kernel<T, false>), grid, dim3(256), 0, st, a, md);
+  switch (a.kernel_id) {
+    case HBO_KERNEL_SE: launch_gram_k<T, HBO_KERNEL_SE>(a, md, grid, st); break;
+    case HBO_KERNEL_MATERN32: launch_gram_k<T, HBO_KERNEL_MATERN32>(a, md, grid, st); break;
+    case HBO_KERNEL_MATERN52: launch_gram_k<T, HBO_KERNEL_MATERN52>(a, md, grid, st); break;
+    default: launch_gram_k<T, HBO_KERNEL_DOT>(a, md, grid, st); break;
+  }
 }
 
 }  // namespace
@@ -1032,16 +1051,28 @@ void launch_wt_z(int dtype, const TaskDesc* tasks, int ntasks, int max_nblk, int
   }
 }
 int grad_nacc(int kernel_id, int fdim) { return (kernel_id == HBO_KERNEL_DOT ? 3 : 2 + fdim) + 1; }
+namespace {
+template <typename T, bool MULTI>
+void launch_grad_contract_t(dim3 grid, hipStream_t st, int kernel_id, const TaskDesc* tasks, const ModelDev* md, int fdim,
+                            int nacc, int obj, double* partials, int64_t stride_task) {
+  switch (kernel_id) {
+    case HBO_KERNEL_SE: hipLaunchKernelGGL((grad_contract_kernel<T, MULTI, HBO_KERNEL_SE>), grid, dim3(256), 0, st, tasks, md, fdim, nacc, obj, partials, stride_task); break;
+    case HBO_KERNEL_MATERN32: hipLaunchKernelGGL((grad_contract_kernel<T, MULTI, HBO_KERNEL_MATERN32>), grid, dim3(256), 0, st, tasks, md, fdim, nacc, obj, partials, stride_task); break;
+    case HBO_KERNEL_MATERN52: hipLaunchKernelGGL((grad_contract_kernel<T, MULTI, HBO_KERNEL_MATERN52>), grid, dim3(256), 0, st, tasks, md, fdim, nacc, obj, partials, stride_task); break;
+    default: hipLaunchKernelGGL((grad_contract_kernel<T, MULTI, HBO_KERNEL_DOT>), grid, dim3(256), 0, st, tasks, md, fdim, nacc, obj, partials, stride_task); break;
+  }
+}
+}  // namespace
 void launch_grad_contract(int dtype, const TaskDesc* tasks, int ntasks, int max_nblk, const ModelDev* md,
                           int kernel_id, int fdim, int obj, double* partials, int64_t stride_task, hipStream_t st) {
   dim3 grid(max_nblk, max_nblk, ntasks);
   const int nacc = grad_nacc(kernel_id, fdim);
   if (obj == OBJ_NLL) {
-    if (dtype == HBO_F64) hipLaunchKernelGGL((grad_contract_kernel<double, false>), grid, dim3(256), 0, st, tasks, md, fdim, nacc, obj, partials, stride_task);
-    else hipLaunchKernelGGL((grad_contract_kernel<float, false>), grid, dim3(256), 0, st, tasks, md, fdim, nacc, obj, partials, stride_task);
+    if (dtype == HBO_F64) launch_grad_contract_t<double, false>(grid, st, kernel_id, tasks, md, fdim, nacc, obj, partials, stride_task);
+    else launch_grad_contract_t<float, false>(grid, st, kernel_id, tasks, md, fdim, nacc, obj, partials, stride_task);
   } else {
-    if (dtype == HBO_F64) hipLaunchKernelGGL((grad_contract_kernel<double, true>), grid, dim3(256), 0, st, tasks, md, fdim, nacc, obj, partials, stride_task);
-    else hipLaunchKernelGGL((grad_contract_kernel<float, true>), grid, dim3(256), 0, st, tasks, md, fdim, nacc, obj, partials, stride_task);
+    if (dtype == HBO_F64) launch_grad_contract_t<double, true>(grid, st, kernel_id, tasks, md, fdim, nacc, obj, partials, stride_task);
+    else launch_grad_contract_t<float, true>(grid, st, kernel_id, tasks, md, fdim, nacc, obj, partials, stride_task);
   }
 }
 void launch_dmu(int dtype, const TaskDesc* tasks, int ntasks, int obj, hipStream_t st) {

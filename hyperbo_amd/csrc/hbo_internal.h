@@ -96,6 +96,7 @@ struct GramArgs {
   int fdim;
   int symmetric;           // lower tiles only + (noise+eps) on the diagonal + identity padding
   int padded;              // out has a padded ld/extent (16-byte vector stores, zero fill)
+  int kernel_id;           // covariance of the model behind the ModelDev pointer (selects the kernel instantiation)
 };
 void launch_gram(int dtype, const GramArgs& a, const ModelDev* model, dim3 grid, hipStream_t st);
 void launch_kdiag(int dtype, const void* f, int64_t n, int fdim, const ModelDev* model, void* out,
