@@ -815,7 +815,7 @@ extern "C" int hbo_objective(hbo_ctx* c, const hbo_model* m_in, hbo_dataset* ds,
       HIPCHK(c, hipMemsetAsync(ds->d_mlpgrad, 0, tot * sizeof(double), st));
       for (int k = 0; k < T; ++k) HIPCHK(c, hipMemsetAsync(ds->tasks[k]->dF, 0, (size_t)ds->tasks[k]->n * flast * sizeof(double), st));
       if (m->kernel_uses_mlp) {
-        launch_grad_feat(dtype, ds->d_desc, T, max_nblk, c->d_model, flast, obj, st);
+        launch_grad_feat(dtype, ds->d_desc, T, max_nblk, c->d_model, m->kernel_id, flast, obj, st);
         if (euc) launch_scale_dF(ds->d_desc, T, (int64_t)max_npad, flast, st);
       }
       if (m->mean_id == HBO_MEAN_LINEAR_MLP) launch_grad_feat_mean(dtype, ds->d_desc, T, (int64_t)max_npad, c->d_model, flast, st);

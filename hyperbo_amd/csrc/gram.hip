@@ -500,7 +500,7 @@ __global__ __launch_bounds__(256) void grad_contract_kernel(const TaskDesc* task
 // with g = G * dk/du, c_d = 4/ls_d (SE / Matern);  dot product: dF[a] += 2/sigma^2 sum_j G_aj f_j.
 // Accumulated with fp64 atomics into tasks[t].dF (n x fdim doubles, zeroed by the caller).
 // ---------------------------------------------------------------------------------------
-template <typename T>
+template <typename T, int KID>
 __global__ __launch_bounds__(256) void grad_feat_kernel(const TaskDesc* tasks, const ModelDev* __restrict__ md,
                                                         int fdim, int obj) {
   __shared__ T sA[DC * SXS];
@@ -509,8 +509,8 @@ __global__ __launch_bounds__(256) void grad_feat_kernel(const TaskDesc* tasks, c
   const int ti = blockIdx.x, tj = blockIdx.y;
   if (ti >= t.nblk || tj > ti) return;
   constexpr int VEC = 16 / sizeof(T);
-  const int kid = md->kernel_id;
-  const bool is_dot = (kid == HBO_KERNEL_DOT);
+  constexpr int kid = KID;
+  constexpr bool is_dot = (kid == HBO_KERNEL_DOT);
   const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
   const int64_t r0 = (int64_t)ti * HBO_TILE, c0 = (int64_t)tj * HBO_TILE;
   const T* F = static_cast<const T*>(t.F);
@@ -1090,11 +1090,22 @@ void launch_scale_dF(const TaskDesc* tasks, int ntasks, int64_t max_n, int fdim,
   dim3 grid((unsigned)((max_n * fdim + 255) / 256), 1, ntasks);
   hipLaunchKernelGGL(scale_dF_kernel, grid, dim3(256), 0, st, tasks, fdim);
 }
-void launch_grad_feat(int dtype, const TaskDesc* tasks, int ntasks, int max_nblk, const ModelDev* md, int fdim,
-                      int obj, hipStream_t st) {
+namespace {
+template <typename T>
+void launch_grad_feat_t(dim3 grid, hipStream_t st, int kernel_id, const TaskDesc* tasks, const ModelDev* md, int fdim, int obj) {
+  switch (kernel_id) {
+    case HBO_KERNEL_SE: hipLaunchKernelGGL((grad_feat_kernel<T, HBO_KERNEL_SE>), grid, dim3(256), 0, st, tasks, md, fdim, obj); break;
+    case HBO_KERNEL_MATERN32: hipLaunchKernelGGL((grad_feat_kernel<T, HBO_KERNEL_MATERN32>), grid, dim3(256), 0, st, tasks, md, fdim, obj); break;
+    case HBO_KERNEL_MATERN52: hipLaunchKernelGGL((grad_feat_kernel<T, HBO_KERNEL_MATERN52>), grid, dim3(256), 0, st, tasks, md, fdim, obj); break;
+    default: hipLaunchKernelGGL((grad_feat_kernel<T, HBO_KERNEL_DOT>), grid, dim3(256), 0, st, tasks, md, fdim, obj); break;
+  }
+}
+}  // namespace
+void launch_grad_feat(int dtype, const TaskDesc* tasks, int ntasks, int max_nblk, const ModelDev* md, int kernel_id,
+                      int fdim, int obj, hipStream_t st) {
   dim3 grid(max_nblk, max_nblk, ntasks);
-  if (dtype == HBO_F64) hipLaunchKernelGGL((grad_feat_kernel<double>), grid, dim3(256), 0, st, tasks, md, fdim, obj);
-  else hipLaunchKernelGGL((grad_feat_kernel<float>), grid, dim3(256), 0, st, tasks, md, fdim, obj);
+  if (dtype == HBO_F64) launch_grad_feat_t<double>(grid, st, kernel_id, tasks, md, fdim, obj);
+  else launch_grad_feat_t<float>(grid, st, kernel_id, tasks, md, fdim, obj);
 }
 void launch_grad_feat_mean(int dtype, const TaskDesc* tasks, int ntasks, int64_t max_n, const ModelDev* md,
                            int fdim, hipStream_t st) {

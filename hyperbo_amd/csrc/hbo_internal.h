@@ -122,8 +122,8 @@ void launch_grad_finalize(int dtype, const TaskDesc* tasks, int ntasks, const Mo
                           int fdim, int obj, const double* partials, int64_t stride_task, double* out,
                           int out_stride, double* value_out, hipStream_t st);
 void launch_scale_dF(const TaskDesc* tasks, int ntasks, int64_t max_n, int fdim, hipStream_t st);
-void launch_grad_feat(int dtype, const TaskDesc* tasks, int ntasks, int max_nblk, const ModelDev* md, int fdim,
-                      int obj, hipStream_t st);
+void launch_grad_feat(int dtype, const TaskDesc* tasks, int ntasks, int max_nblk, const ModelDev* md, int kernel_id,
+                      int fdim, int obj, hipStream_t st);
 void launch_grad_feat_mean(int dtype, const TaskDesc* tasks, int ntasks, int64_t max_n, const ModelDev* md,
                            int fdim, hipStream_t st);
 void launch_dense_bwd(int dtype, const void* in, const void* out, const void* w, double* dout, double* din,
