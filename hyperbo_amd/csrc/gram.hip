@@ -83,7 +83,11 @@ __global__ __launch_bounds__(256) void gram_kernel(GramArgs g, const ModelDev* _
   constexpr int VEC = 16 / sizeof(T);
   __shared__ T sA[DC * SXS];
   __shared__ T sB[DC * SXS];
-  const int ti = blockIdx.y, tj = blockIdx.x;   // ti in units of GTR rows, tj in units of 128 columns
+  // ti in units of GTR rows, tj in units of 128 columns.  Symmetric mode computes the tiles with tj <= ti/2 only, and
+  // workgroup i runs on XCD i mod 8: with tj = blockIdx.x the low XCDs would get one more tile than the high ones in
+  // every row (grid.x is a multiple of 8 for the sizes that matter), so the column index is rotated by the row
+  const int ti = blockIdx.y;
+  const int tj = g.symmetric ? (int)((blockIdx.x + blockIdx.y) % gridDim.x) : (int)blockIdx.x;
   const T* x1; const T* x2; T* out; int64_t n1, n2, ldo; int64_t e1, e2;  // e*: padded extents
   if (g.tasks) {
     const TaskDesc& t = g.tasks[blockIdx.z];
