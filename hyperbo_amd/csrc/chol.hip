@@ -34,6 +34,16 @@ __device__ __forceinline__ double readlane_t(double v, int lane) {
   hi = __builtin_amdgcn_readlane(hi, lane);
   return __hiloint2double(hi, lo);
 }
+// value of the lane 16 away inside each 32-lane half (ds_swizzle bit mode: and 0x1f, or 0, xor 0x10)
+__device__ __forceinline__ double swap16(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_ds_swizzle(lo, 0x401F);
+  hi = __builtin_amdgcn_ds_swizzle(hi, 0x401F);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ float swap16(float v) {
+  return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x401F));
+}
 __device__ __forceinline__ float readlane_t(float v, int lane) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
@@ -76,6 +86,44 @@ __device__ __forceinline__ int leaf_cholesky(typename Mma<T>::acc_t& acc, typena
   T myinv = (T)1;
 #pragma unroll
   for (int r = 0; r < 4; ++r) vinv[r] = (Mma<T>::crow(lane, r) == l15) ? (T)1 : (T)0;
+  if constexpr (sizeof(T) == 8) {
+    // fp64: two columns per step.  Rows j and j+1 (j even) sit in the same accumulator register of two neighbouring
+    // 16-lane groups, so both pivots and l10 = S[j+1][j] / sqrt(d00) come from three readlanes, the second pivot is
+    // d11 - l10^2 without waiting for an update, and f1 = (S[j+1][:] - l10 f0) / sqrt(d11') follows from the
+    // un-updated row j+1 (row j reaches its lanes by a 16-lane swap).  The two rank-1 updates become ONE MFMA with
+    // two of its four K slices in use -- algebraically the same elimination, half the MFMA round trips on the chain.
+#pragma unroll
+    for (int j = 0; j < 16; j += 2) {
+      const int pr = j >> 2, pq0 = j & 3, pq1 = pq0 + 1;   // row = lq + 4 reg
+      T d00 = readlane_t(acc[pr], j + 16 * pq0);
+      const T d10 = readlane_t(acc[pr], j + 16 * pq1);
+      const T d11 = readlane_t(acc[pr], j + 1 + 16 * pq1);
+      const T own = acc[pr];                                 // S[j][l15] (lq == pq0) / S[j+1][l15] (lq == pq1)
+      const T vown = vinv[pr];                               // V[j][l15] / V[j+1][l15]
+      const T own_x = swap16(own), vown_x = swap16(vown);
+      const T sj = (lq == pq1) ? own_x : own;                // S[j][l15] in both lane groups
+      const T vj = (lq == pq1) ? vown_x : vown;
+      if (!(d00 > (T)0)) { if (bad_col < 0) bad_col = j; d00 = (T)NAN; }
+      const T inv0 = fast_rsqrt(d00);
+      const T l10 = d10 * inv0;
+      T d11p = fma(-l10, l10, d11);
+      if (!(d11p > (T)0)) { if (bad_col < 0) bad_col = j + 1; d11p = (T)NAN; }
+      const T inv1 = fast_rsqrt(d11p);
+      dinv_out[j] = inv0; dinv_out[j + 1] = inv1;
+      if (l15 == j) myinv = inv0;
+      if (l15 == j + 1) myinv = inv1;
+      const T f0 = (l15 > j) ? sj * inv0 : (T)0;
+      const T f1 = (l15 > j + 1) ? (own - f0 * l10) * inv1 : (T)0;
+      const T a = (lq == pq0) ? f0 : (lq == pq1 ? f1 : (T)0);
+      acc = Mma<T>::mma(-a, a, acc);
+      __builtin_amdgcn_sched_barrier(0);
+      const T h0 = vj * inv0;                                // inv0 * V[j][l15]
+      const T h1 = (vown - l10 * h0) * inv1;                 // inv1 * (V[j+1][l15] - l10 h0): row j+1 after step j
+      const T b = (lq == pq0) ? h0 : (lq == pq1 ? h1 : (T)0);
+      vinv = Mma<T>::mma(-a, b, vinv);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  } else {
 #pragma unroll
   for (int j = 0; j < 16; ++j) {
     // element (j,j): f64 layout row = lq + 4 reg ; f32 layout row = 4 lq + reg
@@ -98,6 +146,7 @@ __device__ __forceinline__ int leaf_cholesky(typename Mma<T>::acc_t& acc, typena
     const T h = (lq == pq) ? vinv[pr] * inv : (T)0;      // inv * V[j][l15]
     vinv = Mma<T>::mma(-f, h, vinv);
     __builtin_amdgcn_sched_barrier(0);
+  }
   }
 #pragma unroll
   for (int r = 0; r < 4; ++r) {
