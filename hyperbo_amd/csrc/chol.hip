@@ -450,7 +450,7 @@ __global__ __launch_bounds__(256) void trsm_kernel(const TaskDesc* tasks, int p_
   } else {
     const int64_t first = (int64_t)(p + 1) * NB;
     const int64_t nrows = (int64_t)(t.nblk + 1) * NB - first;     // incl. augmented tile-row
-    // workgroup i runs on XCD i mod 8 whatever the load: in a ragged batch the rows that exist are the low ones in
+    // workgroup i runs on XCD (i + const) mod 8 whatever the load: in a ragged batch the rows that exist are the low ones in
     // every task, so the row index is rotated by the task index to spread them over the XCDs
     const int64_t bx = ((int64_t)blockIdx.x + 3 * (int64_t)blockIdx.z) % gridDim.x;
     if (bx * 64 >= nrows) return;

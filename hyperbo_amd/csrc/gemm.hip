@@ -121,7 +121,7 @@ __device__ __forceinline__ bool decode_job(const GemmArgs& g, TileJob<T>& j) {
       // plain (r fastest) order.  Measured slower: XCD-aware 8x8 super-tiles that concentrate the 16
       // panels of 64 tiles on one XCD's L2 (61 -> 41 TFLOP/s at N=16384, K=1024).
       // (batches: rows rotated per (column, task) -- in a ragged batch the rows that exist are the low ones of every
-      // task and workgroup i runs on XCD i mod 8)
+      // task and workgroup i runs on XCD (i + const) mod 8)
       const int by = blockIdx.y;
       const int bx = gridDim.z > 1 ? (int)((blockIdx.x + 5 * blockIdx.y + 3 * blockIdx.z) % gridDim.x) : (int)blockIdx.x;
       const int c = g.c_lo * U + by;
@@ -154,7 +154,7 @@ __device__ __forceinline__ bool decode_job(const GemmArgs& g, TileJob<T>& j) {
       int jt, it;
       if (g.mode == GEMM_TRTRI_A) {
         // K = s*128 - jt*TM.  Ragged batches: the row tiles that exist are the low ones in every task and workgroup i
-        // runs on XCD i mod 8, so the row order is rotated per (column, task)
+        // runs on XCD (i + const) mod 8, so the row order is rotated per (column, task)
         jt = blockIdx.y;
         const int vu = (grp == g.c_hi ? g.c_lo : s) * U;   // tile rows launched for this group (the last may be cut)
         it = (inner + 5 * (int)blockIdx.y + 3 * (int)blockIdx.z) % vu;

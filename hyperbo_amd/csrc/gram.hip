@@ -84,7 +84,7 @@ __global__ __launch_bounds__(256) void gram_kernel(GramArgs g, const ModelDev* _
   __shared__ T sA[DC * SXS];
   __shared__ T sB[DC * SXS];
   // ti in units of GTR rows, tj in units of 128 columns.  Symmetric mode computes the tiles with tj <= ti/2 only, and
-  // workgroup i runs on XCD i mod 8: with tj = blockIdx.x the low XCDs would get one more tile than the high ones in
+  // workgroup i runs on XCD (i + const) mod 8: with tj = blockIdx.x the low XCDs would get one more tile than the high ones in
   // every row (grid.x is a multiple of 8 for the sizes that matter), so the column index is rotated by the row
   const int ti = blockIdx.y;
   const int tj = g.symmetric ? (int)((blockIdx.x + blockIdx.y) % gridDim.x) : (int)blockIdx.x;
