@@ -123,6 +123,42 @@ __device__ __forceinline__ int leaf_cholesky(typename Mma<T>::acc_t& acc, typena
       vinv = Mma<T>::mma(-a, b, vinv);
       __builtin_amdgcn_sched_barrier(0);
     }
+  } else if constexpr (true) {
+    // fp32 (row = 4 lq + reg): rows j and j+1 sit in two registers of the SAME 16-lane group, so the second vector has
+    // to come from other lanes to occupy a K slice of its own: the neighbouring group gets copies of both rows (two
+    // 16-lane swaps issued before the pivot chain starts) and computes f1 / h1 itself.
+#pragma unroll
+    for (int j = 0; j < 16; j += 2) {
+      const int r0 = j & 3, pq = j >> 2, pp = pq ^ 1;       // holder group pq, partner group pp
+      T d00 = readlane_t(acc[r0], j + 16 * pq);
+      const T d10 = readlane_t(acc[r0 + 1], j + 16 * pq);
+      const T d11 = readlane_t(acc[r0 + 1], j + 1 + 16 * pq);
+      const T s0x = swap16(acc[r0]), s1x = swap16(acc[r0 + 1]);
+      const T v0x = swap16(vinv[r0]), v1x = swap16(vinv[r0 + 1]);
+      const T s0 = (lq == pp) ? s0x : acc[r0];               // S[j][l15]   in both groups
+      const T s1 = (lq == pp) ? s1x : acc[r0 + 1];           // S[j+1][l15]
+      const T v0 = (lq == pp) ? v0x : vinv[r0];
+      const T v1 = (lq == pp) ? v1x : vinv[r0 + 1];
+      if (!(d00 > (T)0)) { if (bad_col < 0) bad_col = j; d00 = (T)NAN; }
+      const T inv0 = fast_rsqrt(d00);
+      const T l10 = d10 * inv0;
+      T d11p = fmaf(-l10, l10, d11);
+      if (!(d11p > (T)0)) { if (bad_col < 0) bad_col = j + 1; d11p = (T)NAN; }
+      const T inv1 = fast_rsqrt(d11p);
+      dinv_out[j] = inv0; dinv_out[j + 1] = inv1;
+      if (l15 == j) myinv = inv0;
+      if (l15 == j + 1) myinv = inv1;
+      const T f0 = (l15 > j) ? s0 * inv0 : (T)0;
+      const T f1 = (l15 > j + 1) ? (s1 - f0 * l10) * inv1 : (T)0;
+      const T a = (lq == pq) ? f0 : (lq == pp ? f1 : (T)0);
+      acc = Mma<T>::mma(-a, a, acc);
+      __builtin_amdgcn_sched_barrier(0);
+      const T h0 = v0 * inv0;
+      const T h1 = (v1 - l10 * h0) * inv1;
+      const T b = (lq == pq) ? h0 : (lq == pp ? h1 : (T)0);
+      vinv = Mma<T>::mma(-a, b, vinv);
+      __builtin_amdgcn_sched_barrier(0);
+    }
   } else {
 #pragma unroll
   for (int j = 0; j < 16; ++j) {
