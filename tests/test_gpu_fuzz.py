@@ -146,3 +146,33 @@ def test_edge_shapes(gpu_ctx):
   mu_o, var_o = o.predict(o.constant, o.matern52, po, xd[:1], yd[:1], xd[1:6], WFO)
   noise = float(np.squeeze(o.retrieve_params(po, ['noise_variance'], WFO)[0]))
   np.testing.assert_allclose(mu, mu_o, rtol=1e-10); np.testing.assert_allclose(var, var_o + noise, rtol=1e-9)
+
+
+@pytest.mark.parametrize('dtype', ['float64', 'float32'])
+def test_every_size_across_the_leaf_and_block_boundaries(gpu_ctx, dtype):
+  """NLL + gradient for every n in 1..40 (16x16 leaf boundaries, the two-columns-per-step leaf with odd sizes, skipped
+  identity leaves), 120..136 and 250..262 (128-block boundaries, single- vs multi-block path, 3-panel groups) and a few
+  sizes around 4 and 5 blocks (progressive inverse with a partial last group), as ONE ragged batch against the oracle."""
+  defs, _, _, kernel, mean, objectives, utils = _native()
+  rng = np.random.default_rng(77)
+  d = 3
+  sizes = list(range(1, 41)) + list(range(120, 137)) + list(range(250, 263)) + [500, 511, 513, 600, 641]
+  model = helpers.make_model(rng, 'constant', False, d)
+  f32 = dtype == 'float32'
+  cast = (lambda t: {k: cast(v) for k, v in t.items()} if isinstance(t, dict) else np.asarray(t, dtype=np.float32)) if f32 else (lambda t: t)
+  dso, dsn = {}, {}
+  for n in sizes:
+    x, y = helpers.synthetic_task(rng, n, d)
+    if f32: x, y = x.astype(np.float32), y.astype(np.float32)
+    dso[n] = o.SubDataset(x.astype(np.float64), y.astype(np.float64)); dsn[n] = defs.SubDataset(x, y)
+  po, pn = o.GPParams(model=model), defs.GPParams(model=cast(model))
+  vo, k2o = o.neg_log_marginal_likelihood(o.constant, o.squared_exponential, po, dso, WFO, return_key2nll=True)
+  vn, k2n = objectives.neg_log_marginal_likelihood(mean.constant, kernel.squared_exponential, pn, dsn, utils.DEFAULT_WARP_FUNC,
+                                                   return_key2nll=True)
+  tol = 2e-4 if f32 else 1e-9
+  for n in sizes:
+    assert abs(k2n[n] - k2o[n]) <= tol * max(abs(k2o[n]), 1.0), (n, k2n[n], k2o[n])
+  _, go = o.nll_value_and_grad(o.constant, o.squared_exponential, po, dso, WFO)
+  _, gn = objectives.nll_value_and_grad(mean.constant, kernel.squared_exponential, pn, dsn, utils.DEFAULT_WARP_FUNC)
+  fo, fn = helpers.flatten(go), helpers.flatten(gn)
+  assert np.max(np.abs(fo - fn)) <= (5e-3 if f32 else 1e-7) * max(np.max(np.abs(fo)), 1e-6)
