@@ -176,3 +176,51 @@ def test_every_size_across_the_leaf_and_block_boundaries(gpu_ctx, dtype):
   _, gn = objectives.nll_value_and_grad(mean.constant, kernel.squared_exponential, pn, dsn, utils.DEFAULT_WARP_FUNC)
   fo, fn = helpers.flatten(go), helpers.flatten(gn)
   assert np.max(np.abs(fo - fn)) <= (5e-3 if f32 else 1e-7) * max(np.max(np.abs(fo)), 1e-6)
+
+
+OPTION_SETS = [
+    {'lookahead': 0},
+    {'overlap_trtri': 0},
+    {'potrf_group': 1}, {'potrf_group': 2}, {'potrf_group': 4}, {'potrf_group': 8},
+    {'persist_free': 0}, {'persist_free': 128}, {'dynamic_tiles': 0}, {'f1_on_chain': 0},
+    {'trtri_gran': 1}, {'trtri_gran': 2}, {'trtri_gran': 5}, {'trtri_gran': 64},
+    {'small_nblk': 0}, {'small_nblk': 4},
+    {'lookahead': 0, 'potrf_group': 3, 'small_nblk': 0},
+]
+DEFAULTS = {'lookahead': 1, 'overlap_trtri': 1, 'potrf_group': 0, 'persist_free': -1, 'dynamic_tiles': 1, 'f1_on_chain': 1,
+            'trtri_gran': 0, 'small_nblk': 32}
+
+
+@pytest.mark.parametrize('opts', OPTION_SETS, ids=lambda o_: ','.join(f'{k}={v}' for k, v in o_.items()))
+def test_every_scheduling_option_gives_the_same_answer(gpu_ctx, opts):
+  """The knobs of hbo_set_option only move work between streams, launches and tile sizes: NLL, gradient and posterior of
+  a single 2900-point matrix (23 blocks: persistent bulk update, partial groups at every level of the inverse) and of a
+  ragged batch must not depend on them."""
+  defs, acfun, gp, kernel, mean, objectives, utils = _native()
+  rng = np.random.default_rng(5)
+  d = 4
+  model = helpers.make_model(rng, 'constant', False, d)
+  po, pn = o.GPParams(model=model), defs.GPParams(model=model)
+  single = {0: helpers.synthetic_task(rng, 2900, d)}
+  batch = {k: helpers.synthetic_task(rng, n, d) for k, n in enumerate((700, 130, 1, 515, 300, 1290))}
+  try:
+    for k, v in opts.items():
+      gpu_ctx.set_option(k, v)
+    for data in (single, batch):
+      dso = {k: o.SubDataset(x, y) for k, (x, y) in data.items()}
+      dsn = {k: defs.SubDataset(x, y) for k, (x, y) in data.items()}
+      vo, go = o.nll_value_and_grad(o.constant, o.squared_exponential, po, dso, WFO)
+      vn, gn = objectives.nll_value_and_grad(mean.constant, kernel.squared_exponential, pn, dsn, utils.DEFAULT_WARP_FUNC)
+      assert abs(vn - vo) <= 1e-9 * max(abs(vo), 1.0)
+      fo, fn = helpers.flatten(go), helpers.flatten(gn)
+      assert np.max(np.abs(fo - fn)) <= 1e-7 * max(np.max(np.abs(fo)), 1e-6)
+    x, y = single[0]
+    xq = rng.uniform(size=(50, d))
+    mo, so = o.predict(o.constant, o.squared_exponential, po, x[:1500], y[:1500], xq, WFO)
+    m = gp.GP({0: defs.SubDataset(x[:1500], y[:1500])}, mean.constant, kernel.squared_exponential, pn, utils.DEFAULT_WARP_FUNC)
+    mn, sn = m.predict(xq, 0, with_noise=False, unbiased=False)
+    assert np.max(np.abs(np.asarray(mn) - mo)) <= 1e-8 * max(np.max(np.abs(mo)), 1.0)
+    assert np.max(np.abs(np.asarray(sn) - so)) <= 1e-8 * max(np.max(np.abs(so)), 1e-3)
+  finally:
+    for k, v in DEFAULTS.items():
+      gpu_ctx.set_option(k, v)
