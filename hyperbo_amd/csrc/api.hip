@@ -23,6 +23,9 @@ struct hbo_ctx {
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;   // panel stream of the look-ahead Cholesky (high priority)
   hipStream_t stream4 = nullptr;   // early part of trtri, overlapped with the tail of potrf
+  int opt_cu_yield = 1;      // GEMM workgroups pause while potf2 runs on their CU (single matrix, look-ahead)
+  int* d_yield = nullptr;    // the flag: cu_token() of the CU potf2 is on, or 0
+  int* gemm_yield = nullptr; // run_potrf -> trtri_level: GemmArgs::yield_flag of the launches that co-run with the panel chain
   int opt_trtri_gran = 0;    // panels between two launches of the inverse's computable pieces during the factorisation (0: auto)
   int opt_small_nblk = 32;   // matrices up to this many 128-blocks use 64x64 GEMM tiles in trtri / lauum
   int opt_persist_free = -1; // bulk trailing update runs as 2*(CUs - this) persistent workgroups (-1: auto, see run_potrf)
@@ -163,6 +166,8 @@ extern "C" int hbo_ctx_create(int device, hbo_ctx** out) {
   if (e == hipSuccess) e = hipStreamCreate(&c->stream2);
   if (e == hipSuccess) e = hipStreamCreate(&c->stream4);
   if (e == hipSuccess) e = hipMalloc((void**)&c->d_model, sizeof(ModelDev));
+  if (e == hipSuccess) e = hipMalloc((void**)&c->d_yield, 64);
+  if (e == hipSuccess) e = hipMemset(c->d_yield, 0, 64);
   if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_model, sizeof(ModelDev), hipHostMallocDefault);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_upload, hipEventDisableTiming);
   if (e != hipSuccess) {
@@ -184,6 +189,7 @@ extern "C" int hbo_ctx_destroy(hbo_ctx* c) {
   for (int l = 0; l < HBO_MAX_MLP_LAYERS; ++l) { if (c->d_mlp_w[l]) hipFree(c->d_mlp_w[l]); if (c->d_mlp_b[l]) hipFree(c->d_mlp_b[l]); }
   for (hipEvent_t ev : c->prof_events) hipEventDestroy(ev);
   if (c->d_model) hipFree(c->d_model);
+  if (c->d_yield) hipFree(c->d_yield);
   if (c->h_model) hipHostFree(c->h_model);
   if (c->hp_stage) hipHostFree(c->hp_stage);
   if (c->ev_upload) hipEventDestroy(c->ev_upload);
@@ -202,6 +208,7 @@ extern "C" int hbo_set_option(hbo_ctx* c, const char* name, int64_t value) {
   if (!strcmp(name, "dynamic_tiles")) { c->opt_dynamic_tiles = value ? 1 : 0; return HBO_OK; }
   if (!strcmp(name, "f1_on_chain")) { c->opt_f1_on_chain = value ? 1 : 0; return HBO_OK; }
   if (!strcmp(name, "lookahead")) { c->opt_lookahead = value ? 1 : 0; return HBO_OK; }
+  if (!strcmp(name, "cu_yield")) { c->opt_cu_yield = value ? 1 : 0; return HBO_OK; }
   if (!strcmp(name, "trtri_gran")) { if (value < 0) return fail(c, HBO_ERR_ARG, "trtri_gran >= 0"); c->opt_trtri_gran = (int)value; return HBO_OK; }
   if (!strcmp(name, "small_nblk")) { c->opt_small_nblk = (int)value; return HBO_OK; }
   if (!strcmp(name, "persist_free")) { if (value < -1 || value > 200) return fail(c, HBO_ERR_ARG, "persist_free in -1..200 (-1: auto)"); c->opt_persist_free = (int)value; return HBO_OK; }
@@ -386,7 +393,8 @@ static void run_potrf(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks
   //   (3, 96) 13.43, (2, 64) 13.57, (5, 32) 13.61;   N = 16384: (4, 32) 78.4, (3, 32) 79.1, (3, 64) 79.5
   const bool small_mat = max_nblk <= 96;
   const int q = c->opt_group > 0 ? c->opt_group : (small_mat ? 3 : 4);
-  const int persist_free = c->opt_persist_free >= 0 ? c->opt_persist_free : (small_mat ? 64 : 32);
+  //   with the CU yield (below): N = 8192 (3, 64) 12.58, (3, 48) 12.52, (3, 32) 12.61, (3, 16) 13.24, (4, 48) 12.66
+  const int persist_free = c->opt_persist_free >= 0 ? c->opt_persist_free : (small_mat ? 48 : 32);
   hipStream_t sm = c->stream;
   // (a single block column has no trailing matrix to look ahead over: it stays on the caller's stream)
   const bool la = c->opt_lookahead != 0 && max_nblk > 1;
@@ -400,6 +408,10 @@ static void run_potrf(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks
   // take slots from the panel chain (N = 8192: 13.63 ms at 32 panels, 13.8 at 4, 14.0 at 2)
   int tgran = c->opt_trtri_gran;
   if (tgran <= 0) { tgran = 4; if (ntasks == 1) while (tgran * 2 < max_nblk) tgran *= 2; }
+  // (up to 96 blocks: N = 4096 3.37 -> 3.29 ms, N = 8192 12.61 -> 12.52; N = 16384 loses 0.9 % to the polling)
+  int* const yield_flag = (la && ntasks == 1 && c->opt_cu_yield && small_mat) ? c->d_yield : nullptr;
+  if (yield_flag) hipMemsetAsync(yield_flag, 0, sizeof(int), sm);
+  c->gemm_yield = yield_flag;
   // one tile counter per bulk launch (dynamic tile assignment of the persistent form), zeroed up front
   int* counters = c->opt_dynamic_tiles ? (int*)ws_get(c, WS_COUNTERS, sizeof(int) * 256) : nullptr;
   int n_counter = 0;
@@ -414,7 +426,7 @@ static void run_potrf(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks
         GemmArgs a = {}; a.tasks = d_tasks; a.mode = GEMM_SYRK; a.p0 = g0; a.kt = p - g0; a.c_lo = p; a.c_hi = p + 1; a.aug = 1; a.small_tiles = 1;
         launch_gemm(dtype, a, dim3(max_nblk + 1 - p, 1, ntasks), sp);
       }
-      { ProfScope ps(c, "potf2", 2, sp); launch_potf2(dtype, d_tasks, ntasks, p, d_info, sp); }
+      { ProfScope ps(c, "potf2", 2, sp); launch_potf2(dtype, d_tasks, ntasks, p, d_info, sp, yield_flag); }
       { ProfScope ps(c, "trsm", 2, sp); launch_trsm(dtype, d_tasks, ntasks, p, max_nblk, sp); }
       if (early && (p + 1) % tgran == 0 && p + 1 < max_nblk) {
         // block columns 0..p of L are final: everything of the inverse that only needs them goes to a side stream
@@ -433,6 +445,7 @@ static void run_potrf(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks
     if (la && s1 == sm) { hipEvent_t e = pool_event(c, evi++); hipEventRecord(e, sp); hipStreamWaitEvent(sm, e, 0); }
     if (g1 < max_nblk) {
       GemmArgs a = {}; a.tasks = d_tasks; a.mode = GEMM_SYRK; a.p0 = g0; a.kt = g1 - g0; a.aug = 1;
+      a.yield_flag = yield_flag;   // (F1 itself never meets potf2 -- same stream -- but the bulk update does)
       {
         if (s1 == sp && ev_f2) hipStreamWaitEvent(sp, ev_f2, 0);
         ProfScope ps(c, "syrk_trailing", 1, s1);
@@ -472,6 +485,7 @@ static void run_potrf(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks
       }
     }
   }
+  c->gemm_yield = nullptr;
   if (la) { hipEvent_t e = pool_event(c, evi++); hipEventRecord(e, sp); hipStreamWaitEvent(sm, e, 0); }   // join
   if (early) {   // the rest of the inverse (main stream) needs the early part
     hipEvent_t e = pool_event(c, evi++);
@@ -489,6 +503,7 @@ static void trtri_level(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntas
   // few or short tiles (small levels, small / batched matrices): 64x64 tiles -- a lone 128-tile runs
   // its K loop latency-bound, four 64-tiles expose 4x the parallelism for the same flops
   a.small_tiles = (max_nblk <= c->opt_small_nblk) || ((int64_t)ngroups * s * s * ntasks < 600);
+  a.yield_flag = (st == c->stream4) ? c->gemm_yield : nullptr;
   ProfScope ps(c, "trtri_gemm", 2, st);
   // Rows of the last group's lower half that exist in the largest task: workgroups beyond them would be dispatched
   // only to exit, which is not free (56 ns each: at the top level of a batch of 64 matrices of <= 19 blocks, 13 of

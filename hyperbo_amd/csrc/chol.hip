@@ -347,12 +347,19 @@ __device__ __forceinline__ void potf2_body(const TaskDesc& t, int p, int* info_s
 #endif
 }
 template <typename T>
-__global__ __launch_bounds__(256) void potf2_kernel(const TaskDesc* tasks, int p, int* info) {
+__global__ __launch_bounds__(256) void potf2_kernel(const TaskDesc* tasks, int p, int* info, int* yield_flag) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __builtin_amdgcn_s_setprio(3);            // critical path: outrank co-resident GEMM waves
   const TaskDesc& t = tasks[blockIdx.x];
   if (p >= t.nblk) return;
+  // single matrix: name this CU in the yield flag -- GEMM workgroups that share it pause at their next K step (potf2's
+  // small MFMAs queue behind their 64-cycle ones and its LDS traffic behind theirs: 50 us beside them, 22 us alone)
+  if (yield_flag && threadIdx.x == 0) __hip_atomic_store(yield_flag, cu_token(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   potf2_body<T>(t, p, info + blockIdx.x, smem);
+  if (yield_flag) {
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(yield_flag, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 }
 
 template <typename T>
@@ -513,9 +520,10 @@ void set_attrs() {
 }
 
 template <typename T>
-void potf2_t(const TaskDesc* tasks, int ntasks, int p, int* info, hipStream_t st) {
+void potf2_t(const TaskDesc* tasks, int ntasks, int p, int* info, hipStream_t st, int* yield_flag) {
   set_attrs<T>();
-  hipLaunchKernelGGL((potf2_kernel<T>), dim3(ntasks), dim3(256), potf2_lds_bytes<T>(), st, tasks, p, info);
+  hipLaunchKernelGGL((potf2_kernel<T>), dim3(ntasks), dim3(256), potf2_lds_bytes<T>(), st, tasks, p, info,
+                     ntasks == 1 ? yield_flag : nullptr);
 }
 template <typename T>
 void trsm_t(const TaskDesc* tasks, int ntasks, int p, int max_nblk, hipStream_t st) {
@@ -545,9 +553,9 @@ extern "C" void hbo_dbg_trsm_wall(unsigned long long* host, int panel) {
 }
 extern "C" void hbo_dbg_potf2_wall(unsigned long long* host) { hipMemcpyFromSymbol(host, HIP_SYMBOL(hbo_dbg_wall), sizeof(unsigned long long) * 3 * 256); }
 #endif
-void launch_potf2(int dtype, const TaskDesc* tasks, int ntasks, int p, int* info, hipStream_t st) {
-  if (dtype == HBO_F64) potf2_t<double>(tasks, ntasks, p, info, st);
-  else potf2_t<float>(tasks, ntasks, p, info, st);
+void launch_potf2(int dtype, const TaskDesc* tasks, int ntasks, int p, int* info, hipStream_t st, int* yield_flag) {
+  if (dtype == HBO_F64) potf2_t<double>(tasks, ntasks, p, info, st, yield_flag);
+  else potf2_t<float>(tasks, ntasks, p, info, st, yield_flag);
 }
 void launch_trsm(int dtype, const TaskDesc* tasks, int ntasks, int p, int max_nblk, hipStream_t st) {
   if (dtype == HBO_F64) trsm_t<double>(tasks, ntasks, p, max_nblk, st);

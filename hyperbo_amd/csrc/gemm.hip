@@ -105,6 +105,7 @@ struct TileJob {
   int ksteps;
   T alpha;
   int beta;                  // 0: C = alpha*acc ; 1: C += alpha*acc
+  int* yield_flag;           // see GemmArgs::yield_flag
 };
 
 template <typename T, int TM>
@@ -291,7 +292,13 @@ __device__ __forceinline__ void gemm_tile(const TileJob<T>& job, unsigned char* 
   stage_store<T, BKC, TM>(sB0, rb, tid);
   __syncthreads();
 
+  const int my_cu = job.yield_flag ? cu_token() : 0;
   for (int kt = 0; kt < nk; ++kt) {
+    if (job.yield_flag) {
+      // the panel kernel potf2 is running on this CU: stay off its MFMA / LDS paths until it is done (bounded wait)
+      for (int spin = 0; spin < 256 && __hip_atomic_load(job.yield_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == my_cu; ++spin)
+        __builtin_amdgcn_s_sleep(16);
+    }
     const T* cA = (kt & 1) ? sA1 : sA0;
     const T* cB = (kt & 1) ? sB1 : sB0;
     const bool more = (kt + 1 < nk);
@@ -399,6 +406,7 @@ template <typename T, bool AKC, bool BKC, int TM>
 __global__ __launch_bounds__(256, TM == 64 ? 4 : 2) void gemm_kernel(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   TileJob<T> job;
+  job.yield_flag = g.yield_flag;
 #ifdef HBO_GEMM_TIMING
   const int dbg_id = blockIdx.y * gridDim.x + blockIdx.x;
   const bool dbg = g.dbg && blockIdx.z == 0 && dbg_id < 8192 && threadIdx.x == 0;

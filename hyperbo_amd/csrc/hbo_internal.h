@@ -73,6 +73,8 @@ struct GemmArgs {
   int* work_counter; // persistent SYRK: zero-initialised tile counter -> workgroups draw tiles dynamically (a faster
                      // workgroup takes more of them) instead of striding over them; null: static stride
   int dbg;          // HBO_GEMM_TIMING builds: 1 -> this launch records per-workgroup wall-clock stamps
+  int* yield_flag;  // non-null: a workgroup sleeps at a K step while *yield_flag names the CU it runs on (cu_token(): the
+                    // single-workgroup panel kernel potf2 is running there and would otherwise share MFMA / LDS with it)
   int grp_lo;       // TRTRI: first group (of size 2s blocks) handled by this launch
   void* B;       // POST: Kxq (npad x ldb)
   int64_t ldb;
@@ -80,10 +82,19 @@ struct GemmArgs {
   void* colsq;   // POST: partial column sums of squares [nblk][ldb], may be null
 };
 
+#ifdef __HIPCC__
+// identity of the CU a wave runs on: XCC_ID[3:0] and HW_ID[15:8] (cu, sh, se), never 0
+__device__ __forceinline__ int cu_token() {
+  const unsigned xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11));
+  const unsigned hw = __builtin_amdgcn_s_getreg((4 << 0) | (8 << 6) | (7 << 11));   // HW_ID bits [15:8]
+  return (int)(((xcc & 15u) << 8) | (hw & 255u)) + 1;
+}
+#endif
+
 // ---- launchers (defined in the .hip files) ---------------------------------------------
 void launch_gemm(int dtype, const GemmArgs& a, dim3 grid, hipStream_t st);
 
-void launch_potf2(int dtype, const TaskDesc* tasks, int ntasks, int p, int* info, hipStream_t st);
+void launch_potf2(int dtype, const TaskDesc* tasks, int ntasks, int p, int* info, hipStream_t st, int* yield_flag = nullptr);
 void launch_trsm(int dtype, const TaskDesc* tasks, int ntasks, int p, int max_nblk, hipStream_t st);
 // inverses of the diagonal blocks p in [p_lo, p_hi)
 void launch_trtri_diag(int dtype, const TaskDesc* tasks, int ntasks, int p_lo, int p_hi, hipStream_t st);

@@ -187,7 +187,8 @@ int hbo_profile_get(hbo_ctx* ctx, char names[][32], double* ms, int32_t* launche
 /* Scheduling knobs (integers by name); the defaults are the measured best, the knobs exist for A/B runs
  * (tools/ab_opt.py).  Unknown names are an error.
  *   potrf_group    0..8  128-wide panels per trailing update, K = 128*group (0 = auto: 3 up to 96 blocks, else 4)
- *   persist_free  -1..200 CUs the persistent bulk trailing update leaves to the panel chain (-1 = auto: 64 / 32)
+ *   persist_free  -1..200 CUs the persistent bulk trailing update leaves to the panel chain (-1 = auto: 48 / 32)
+ *   cu_yield       0/1   GEMM workgroups pause at a K step while the one-workgroup panel kernel runs on their CU
  *   lookahead      0/1   panel chain on its own stream, one group ahead of the bulk update
  *   f1_on_chain    0/1   next group's column update launched on the panel stream
  *   dynamic_tiles  0/1   persistent bulk update draws tiles from a counter

@@ -184,11 +184,11 @@ OPTION_SETS = [
     {'potrf_group': 1}, {'potrf_group': 2}, {'potrf_group': 4}, {'potrf_group': 8},
     {'persist_free': 0}, {'persist_free': 128}, {'dynamic_tiles': 0}, {'f1_on_chain': 0},
     {'trtri_gran': 1}, {'trtri_gran': 2}, {'trtri_gran': 5}, {'trtri_gran': 64},
-    {'small_nblk': 0}, {'small_nblk': 4},
+    {'small_nblk': 0}, {'small_nblk': 4}, {'cu_yield': 0},
     {'lookahead': 0, 'potrf_group': 3, 'small_nblk': 0},
 ]
 DEFAULTS = {'lookahead': 1, 'overlap_trtri': 1, 'potrf_group': 0, 'persist_free': -1, 'dynamic_tiles': 1, 'f1_on_chain': 1,
-            'trtri_gran': 0, 'small_nblk': 32}
+            'trtri_gran': 0, 'small_nblk': 32, 'cu_yield': 1}
 
 
 @pytest.mark.parametrize('opts', OPTION_SETS, ids=lambda o_: ','.join(f'{k}={v}' for k, v in o_.items()))

@@ -24,9 +24,9 @@ int main(int argc, char** argv) {
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   const int reps = 20;
   // potf2 on (fresh copies of) the same diagonal block: p cycles over blocks so data stays SPD-ish
-  launch_potf2(HBO_F64, d, 1, 0, info, 0); CK(hipDeviceSynchronize());
+  launch_potf2(HBO_F64, d, 1, 0, info, 0, nullptr); CK(hipDeviceSynchronize());
   CK(hipEventRecord(e0));
-  for (int i = 0; i < reps; ++i) launch_potf2(HBO_F64, d, 1, 1 + i, info, 0);
+  for (int i = 0; i < reps; ++i) launch_potf2(HBO_F64, d, 1, 1 + i, info, 0, nullptr);
   CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
   float ms; CK(hipEventElapsedTime(&ms, e0, e1));
   printf("potf2            %8.2f us per launch\n", ms / reps * 1e3);
