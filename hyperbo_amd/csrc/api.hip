@@ -407,7 +407,13 @@ static void run_potrf(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks
   // of ~2000 points, 3.77 against 3.92 for 8); one large matrix only at half time -- more launches on the side stream
   // take slots from the panel chain (N = 8192: 13.63 ms at 32 panels, 13.8 at 4, 14.0 at 2)
   int tgran = c->opt_trtri_gran;
-  if (tgran <= 0) { tgran = 4; if (ntasks == 1) while (tgran * 2 < max_nblk) tgran *= 2; }
+  // (one large matrix, measured later with the CU yield below: a single call after 13/16 of the panels instead of half --
+  //  N = 8192, call after panel 32 / 40 / 44 / 48 / 52 / 56 / 60: 12.42 / 12.37 / 12.34 / 12.25 / 12.21 / 12.30 / 12.50 ms)
+  int early_at = -1;   // single-task form: the one panel count after which the side stream gets its work
+  if (tgran <= 0) {
+    tgran = 4;
+    if (ntasks == 1) { early_at = (max_nblk * 13 / 16) & ~3; if (early_at < 4) early_at = -1; tgran = 1 << 30; }
+  }
   // (up to 96 blocks: N = 4096 3.37 -> 3.29 ms, N = 8192 12.61 -> 12.52; N = 16384 loses 0.9 % to the polling)
   int* const yield_flag = (la && ntasks == 1 && c->opt_cu_yield && small_mat) ? c->d_yield : nullptr;
   if (yield_flag) hipMemsetAsync(yield_flag, 0, sizeof(int), sm);
@@ -428,7 +434,7 @@ static void run_potrf(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks
       }
       { ProfScope ps(c, "potf2", 2, sp); launch_potf2(dtype, d_tasks, ntasks, p, d_info, sp, yield_flag); }
       { ProfScope ps(c, "trsm", 2, sp); launch_trsm(dtype, d_tasks, ntasks, p, max_nblk, sp); }
-      if (early && (p + 1) % tgran == 0 && p + 1 < max_nblk) {
+      if (early && ((p + 1) % tgran == 0 || p + 1 == early_at) && p + 1 < max_nblk) {
         // block columns 0..p of L are final: everything of the inverse that only needs them goes to a side stream
         // (the panel chain leaves most of the machine idle in the second half of the factorisation)
         hipEvent_t e = pool_event(c, evi++);
