@@ -259,12 +259,19 @@ __global__ __launch_bounds__(256) void nll_reduce_kernel(const TaskDesc* tasks, 
   const TaskDesc& t = tasks[blockIdx.x];
   const T* A = static_cast<const T*>(t.A);
   double ld_sum = 0, q = 0;
-  for (int64_t i = threadIdx.x; i < t.n; i += 256) {
-    ld_sum += log((double)A[i * t.ld + i]);
+  // four elements per thread and pass: the strided diagonal loads of a pass are in flight together (this kernel, the
+  // dmu and the finalize kernel sit serially at the end of an evaluation: 36 + 25 + 55 us before)
+  for (int64_t i0 = threadIdx.x; i0 < t.n; i0 += 1024) {
+    T dg[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { const int64_t i = i0 + 256 * u; dg[u] = i < t.n ? A[i * t.ld + i] : (T)1; }
     for (int b = 0; b < t.naug; ++b) {
-      const double z = (double)A[((int64_t)t.npad + b) * t.ld + i];
-      q += z * z;
+      const T* zr = A + ((int64_t)t.npad + b) * t.ld;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { const int64_t i = i0 + 256 * u; const double z = i < t.n ? (double)zr[i] : 0.0; q += z * z; }
     }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) ld_sum += log((double)dg[u]);
   }
   ld_sum = block_sum(ld_sum, sred);
   q = block_sum(q, sred);
@@ -730,23 +737,39 @@ __global__ __launch_bounds__(256) void grad_finalize_kernel(const TaskDesc* task
   const bool is_dot = (md->kernel_id == HBO_KERNEL_DOT);
   int pos = 0;
   double ls_total = 0;
-  {
-    // Frobenius slot first: EUC scales every kernel-parameter gradient by 1 / |C0 - K1|_F
-    double s = 0;
-    for (int tl = threadIdx.x; tl < ntile; tl += 256) s += part[(int64_t)tl * nacc + nacc - 1];
-    s = block_sum(s, sred);
-    if (threadIdx.x == 0) {
-      const double f = sqrt(s);
-      s_scale = (obj == OBJ_EUC) ? (f > 0 ? 1.0 / f : 0.0) : 1.0;
-      if (obj == OBJ_EUC) { t.fnorm[0] = f; if (value_out) value_out[blockIdx.x] = f + t.fnorm[1]; }
+  // column sums of the per-tile partials [ntile][nacc], QW columns at a time (was: one strided pass and two barriers per
+  // column, 55 us at cfg 2)
+  __shared__ double s_col[4][32];
+  __shared__ double s_tot[HBO_MAX_FEATURE_DIM + 4];   // nacc <= 2 + HBO_MAX_FEATURE_DIM + 1
+  constexpr int QW = 32;
+  for (int q0 = 0; q0 < nacc; q0 += QW) {
+    // a thread sums QW columns of every 256th tile (independent loads), then the columns are reduced over the block
+    double sacc[QW];
+#pragma unroll
+    for (int u = 0; u < QW; ++u) sacc[u] = 0;
+    for (int tl = threadIdx.x; tl < ntile; tl += 256) {
+      const double* pt = part + (int64_t)tl * nacc + q0;
+#pragma unroll
+      for (int u = 0; u < QW; ++u) if (q0 + u < nacc) sacc[u] += pt[u];
+    }
+#pragma unroll
+    for (int u = 0; u < QW; ++u) sacc[u] = wave_sum(sacc[u]);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+      for (int u = 0; u < QW; ++u) s_col[threadIdx.x >> 6][u] = sacc[u];
     }
     __syncthreads();
+    if (threadIdx.x < QW && q0 + (int)threadIdx.x < nacc)
+      s_tot[q0 + threadIdx.x] = (s_col[0][threadIdx.x] + s_col[1][threadIdx.x]) + (s_col[2][threadIdx.x] + s_col[3][threadIdx.x]);
   }
-  for (int q = 0; q < nacc - 1; ++q) {
-    double s = 0;
-    for (int tl = threadIdx.x; tl < ntile; tl += 256) s += part[(int64_t)tl * nacc + q];
-    s = block_sum(s, sred) * s_scale;
-    if (threadIdx.x == 0) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double f = sqrt(s_tot[nacc - 1]);   // Frobenius slot: EUC scales every kernel-parameter gradient by 1 / |C0 - K1|_F
+    s_scale = (obj == OBJ_EUC) ? (f > 0 ? 1.0 / f : 0.0) : 1.0;
+    if (obj == OBJ_EUC) { t.fnorm[0] = f; if (value_out) value_out[blockIdx.x] = f + t.fnorm[1]; }
+    for (int q = 0; q < nacc - 1; ++q) {
+      const double s = s_tot[q] * s_scale;
       if (!is_dot) {
         if (q == 0) o[n_ls] = s / md->sv;                 // signal_variance
         else if (q == 1) o[n_ls + 1] = s;                 // noise_variance
