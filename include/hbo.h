@@ -193,7 +193,8 @@ int hbo_profile_get(hbo_ctx* ctx, char names[][32], double* ms, int32_t* launche
  *   f1_on_chain    0/1   next group's column update launched on the panel stream
  *   dynamic_tiles  0/1   persistent bulk update draws tiles from a counter
  *   overlap_trtri  0/1   inverse walks the block tree while the factorisation runs
- *   trtri_gran     >=0   panels between two launches of the inverse's computable pieces (0 = auto)
+ *   trtri_gran     >=0   panels between two launches of the inverse's computable pieces (0 = auto: every 4 panels
+ *                        for a batch, once after 13/16 of the panels for a single matrix)
  *   small_nblk     int   matrices up to this many blocks use 64x64 tiles in trtri / lauum */
 int hbo_set_option(hbo_ctx* ctx, const char* name, int64_t value);
 
