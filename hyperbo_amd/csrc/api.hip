@@ -808,7 +808,7 @@ extern "C" int hbo_objective(hbo_ctx* c, const hbo_model* m_in, hbo_dataset* ds,
 
   const int fdim = feature_dim(m);
   const int nacc = grad_nacc(m->kernel_id, fdim);
-  const int64_t stride_task = (int64_t)(max_nblk * (max_nblk + 1) / 2) * nacc;
+  const int64_t stride_task = (int64_t)(max_nblk * (max_nblk + 1)) * nacc;   // two half-tile slots per lower tile
   if (want_grad || euc) {   // EUC: the Frobenius norm of the value comes out of the contraction pass
     const size_t pb = sizeof(double) * stride_task * T;
     if (ds->partials_bytes < pb) { if (ds->d_partials) hipFree(ds->d_partials); HIPCHK(c, hipMalloc((void**)&ds->d_partials, pb)); ds->partials_bytes = pb; }

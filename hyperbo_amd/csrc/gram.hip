@@ -363,14 +363,16 @@ __global__ __launch_bounds__(256) void grad_contract_kernel(const TaskDesc* task
   __shared__ T sA[DC * SXS];
   __shared__ T sB[DC * SXS];
   __shared__ double swred[4][DC + 4];   // per-wave partial sums: 4 scalars + one per staged feature
+  // 64 x 128 half tiles (blockIdx.x counts 64-row units): a 4 x 8 register micro-tile per thread instead of 8 x 8 keeps
+  // the kernel at ~130 VGPRs (3 waves per SIMD instead of 2: it is bound by the latency of its fp64 exponentials)
   const TaskDesc& t = tasks[blockIdx.z];
-  const int ti = blockIdx.x, tj = blockIdx.y;
+  const int th = blockIdx.x, ti = th >> 1, tj = blockIdx.y;
   if (ti >= t.nblk || tj > ti) return;
   constexpr int VEC = 16 / sizeof(T);
   constexpr int kid = KID;   // compile-time covariance id, as in gram_kernel
   constexpr bool is_dot = (kid == HBO_KERNEL_DOT);
   const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
-  const int64_t r0 = (int64_t)ti * HBO_TILE, c0 = (int64_t)tj * HBO_TILE;
+  const int64_t r0 = (int64_t)th * GTR, c0 = (int64_t)tj * HBO_TILE;
   const T* F = static_cast<const T*>(t.F);
   const T* S = static_cast<const T*>(t.S);
   int64_t vstride; int nvec_rt;
@@ -378,27 +380,27 @@ __global__ __launch_bounds__(256) void grad_contract_kernel(const TaskDesc* task
   const int nvec = MULTI ? nvec_rt : 1;
   const bool euc = MULTI && (obj == OBJ_EUC);
   const int64_t n = t.n;
-  double* out = partials + (int64_t)blockIdx.z * stride_task + ((int64_t)ti * (ti + 1) / 2 + tj) * nacc;
+  double* out = partials + (int64_t)blockIdx.z * stride_task + (((int64_t)ti * (ti + 1) / 2 + tj) * 2 + (th & 1)) * nacc;
 
-  T acc[8][8];
+  T acc[GRA][8];
 #pragma unroll
-  for (int a = 0; a < 8; ++a)
+  for (int a = 0; a < GRA; ++a)
 #pragma unroll
     for (int b = 0; b < 8; ++b) acc[a][b] = (T)0;
   for (int d0 = 0; d0 < fdim; d0 += DC) {
     __syncthreads();
-    stage_x<T>(sA, F, n, fdim, r0, d0, md->inv_ls, !is_dot, tid);
+    stage_x<T, GRA>(sA, F, n, fdim, r0, d0, md->inv_ls, !is_dot, tid);
     stage_x<T>(sB, F, n, fdim, c0, d0, md->inv_ls, !is_dot, tid);
     __syncthreads();
     const int dlim = (fdim - d0) < DC ? (fdim - d0) : DC;
     for (int dd = 0; dd < dlim; ++dd) {
-      T av[8], bv[8];
+      T av[GRA], bv[8];
 #pragma unroll
-      for (int a = 0; a < 8; ++a) av[a] = sA[dd * SXS + ty + 16 * a];
+      for (int a = 0; a < GRA; ++a) av[a] = sA[dd * SXS + ty + 16 * a];
 #pragma unroll
       for (int q = 0; q < 8; ++q) bv[q] = sB[dd * SXS + 16 * VEC * (q / VEC) + VEC * tx + (q % VEC)];
 #pragma unroll
-      for (int a = 0; a < 8; ++a)
+      for (int a = 0; a < GRA; ++a)
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
           if (is_dot) acc[a][q] += av[a] * bv[q];
@@ -427,7 +429,7 @@ __global__ __launch_bounds__(256) void grad_contract_kernel(const TaskDesc* task
     }
   }
 #pragma unroll
-  for (int a = 0; a < 8; ++a) {
+  for (int a = 0; a < GRA; ++a) {
     const int64_t row = r0 + ty + 16 * a;
     const T si = nvec > 0 ? gld(sv_ + row) : (T)0;
     T kinv_row[8], outer[8];
@@ -486,19 +488,19 @@ __global__ __launch_bounds__(256) void grad_contract_kernel(const TaskDesc* task
   // second pass over the features: sum gw * ds_d^2
   for (int d0 = 0; d0 < fdim; d0 += DC) {
     __syncthreads();
-    stage_x<T>(sA, F, n, fdim, r0, d0, md->inv_ls, true, tid);
+    stage_x<T, GRA>(sA, F, n, fdim, r0, d0, md->inv_ls, true, tid);
     stage_x<T>(sB, F, n, fdim, c0, d0, md->inv_ls, true, tid);
     __syncthreads();
     const int dlim = (fdim - d0) < DC ? (fdim - d0) : DC;
     for (int dd = 0; dd < dlim; ++dd) {
-      T av[8], bv[8];
+      T av[GRA], bv[8];
 #pragma unroll
-      for (int a = 0; a < 8; ++a) av[a] = sA[dd * SXS + ty + 16 * a];
+      for (int a = 0; a < GRA; ++a) av[a] = sA[dd * SXS + ty + 16 * a];
 #pragma unroll
       for (int q = 0; q < 8; ++q) bv[q] = sB[dd * SXS + 16 * VEC * (q / VEC) + VEC * tx + (q % VEC)];
       T s = (T)0;
 #pragma unroll
-      for (int a = 0; a < 8; ++a)
+      for (int a = 0; a < GRA; ++a)
 #pragma unroll
         for (int q = 0; q < 8; ++q) { const T df = av[a] - bv[q]; s += acc[a][q] * df * df; }
       const double ws = wave_sum((double)s);
@@ -732,7 +734,7 @@ __global__ __launch_bounds__(256) void grad_finalize_kernel(const TaskDesc* task
   const TaskDesc& t = tasks[blockIdx.x];
   const double* part = partials + (int64_t)blockIdx.x * stride_task;
   double* o = out + (int64_t)blockIdx.x * out_stride;
-  const int ntile = t.nblk * (t.nblk + 1) / 2;
+  const int ntile = t.nblk * (t.nblk + 1);   // two 64-row half-tile slots per lower 128x128 tile
   const int n_ls = md->n_ls;
   const bool is_dot = (md->kernel_id == HBO_KERNEL_DOT);
   int pos = 0;
@@ -1097,7 +1099,7 @@ void launch_grad_contract_t(dim3 grid, hipStream_t st, int kernel_id, const Task
 }  // namespace
 void launch_grad_contract(int dtype, const TaskDesc* tasks, int ntasks, int max_nblk, const ModelDev* md,
                           int kernel_id, int fdim, int obj, double* partials, int64_t stride_task, hipStream_t st) {
-  dim3 grid(max_nblk, max_nblk, ntasks);
+  dim3 grid(2 * max_nblk, max_nblk, ntasks);   // 64-row half tiles: two partial slots per 128x128 tile
   const int nacc = grad_nacc(kernel_id, fdim);
   if (obj == OBJ_NLL) {
     if (dtype == HBO_F64) launch_grad_contract_t<double, false>(grid, st, kernel_id, tasks, md, fdim, nacc, obj, partials, stride_task);
