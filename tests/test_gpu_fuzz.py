@@ -224,3 +224,40 @@ def test_every_scheduling_option_gives_the_same_answer(gpu_ctx, opts):
   finally:
     for k, v in DEFAULTS.items():
       gpu_ctx.set_option(k, v)
+
+
+def test_one_device_dataset_many_models_and_objectives(gpu_ctx):
+  """The same HBM-resident dataset evaluated in turn with different covariances (scalar and ARD length-scales: the
+  packed result block changes size), means, objectives and with / without gradient: descriptors are re-uploaded only when
+  they change and results come back through one pinned block -- every answer must still be the oracle's."""
+  defs, _, _, kernel, mean, objectives, utils = _native()
+  rng = np.random.default_rng(11)
+  d = 3
+  data = {k: helpers.synthetic_task(rng, n, d, m=3) for k, n in enumerate((150, 70, 260))}
+  dso = {k: o.SubDataset(x, y, aligned=k) for k, (x, y) in data.items()}
+  dsn = {k: defs.SubDataset(x, y, aligned=k) for k, (x, y) in data.items()}
+  batch = objectives.DeviceBatch(dsn)
+  plan = [('squared_exponential', 'constant', 'nll', True), ('matern32', 'linear', 'ekl', True),
+          ('squared_exponential', 'constant', 'euc', True), ('dot_product', 'zero', 'nll', False),
+          ('matern52', 'constant', 'nll', True), ('squared_exponential', 'linear', 'nll', False),
+          ('squared_exponential', 'constant', 'ekl', True), ('squared_exponential', 'constant', 'nll', True)]
+  for rep, (kname, mname, obj, grad) in enumerate(plan):
+    model = helpers.make_model(rng, mname, False, d)
+    if rep % 2: model['lengthscale'] = np.asarray(model['lengthscale']).reshape(-1)[:1] * np.ones(())   # scalar length-scale
+    po, pn = o.GPParams(model=model), defs.GPParams(model=model)
+    ko, kn = getattr(o, kname), getattr(kernel, kname)
+    mo, mn = getattr(o, mname), getattr(mean, mname)
+    fo = {'nll': lambda: o.nll_value_and_grad(mo, ko, po, dso, WFO, exclude_aligned=False),
+          'ekl': lambda: o.divergence_value_and_grad('ekl', mo, ko, po, dso, WFO),
+          'euc': lambda: o.divergence_value_and_grad('euc', mo, ko, po, dso, WFO)}[obj]
+    if obj == 'nll':
+      fn = (lambda: objectives.nll_value_and_grad(mn, kn, pn, batch, utils.DEFAULT_WARP_FUNC, exclude_aligned=False)) if grad else \
+           (lambda: (objectives.neg_log_marginal_likelihood(mn, kn, pn, batch, utils.DEFAULT_WARP_FUNC, exclude_aligned=False), None))
+    else:
+      fn = lambda: getattr(objectives, obj + '_value_and_grad')(mn, kn, pn, batch, utils.DEFAULT_WARP_FUNC)
+    vo, go = fo()
+    vn, gn = fn()
+    assert abs(vn - vo) <= 1e-9 * max(abs(vo), 1.0), (rep, kname, mname, obj, vn, vo)
+    if grad and gn is not None:
+      a, b = helpers.flatten(go), helpers.flatten(gn)
+      assert np.max(np.abs(a - b)) <= 1e-7 * max(np.max(np.abs(a)), 1e-6), (rep, kname, mname, obj)
