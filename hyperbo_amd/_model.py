@@ -166,8 +166,32 @@ class BuiltModel:
 
 
 def infer_dtype(*arrays):
-  """float64 only if every given array is float64 (JAX_ENABLE_X64 analogue); else float32."""
+  """Computation dtype for the given inputs, following JAX's promotion under JAX_ENABLE_X64: float32 only when every
+  FLOATING input is float32; any float64 input -- and integer / bool / list inputs, which x64 JAX widens -- gives
+  float64 (mixed float32 / float64 inputs are promoted, never silently narrowed)."""
+  saw32 = False
   for a in arrays:
-    if a is not None and np.asarray(a).dtype != np.float64:
-      return np.dtype(np.float32)
-  return np.dtype(np.float64)
+    if a is None:
+      continue
+    dt = np.asarray(a).dtype
+    if dt == np.float32 or dt == np.float16:
+      saw32 = True
+    elif np.issubdtype(dt, np.integer) or dt == np.bool_:
+      continue   # JAX: int + float32 -> float32, int alone -> float64 under x64
+    else:
+      return np.dtype(np.float64)
+  return np.dtype(np.float32) if saw32 else np.dtype(np.float64)
+
+
+def infer_input_dim(mean_func, cov_func, params):
+  """Input dimension D implied by the parameters alone (first MLP layer, linear mean, ARD lengthscale), or None.
+  Used where no data is at hand: a rank whose task shard is empty must still build the same model as its peers."""
+  model = params.model
+  uses_mlp = bool(getattr(cov_func, 'uses_mlp', False)) or getattr(mean_func, 'mean_id', None) == nat.MEAN_LINEAR_MLP
+  if uses_mlp and isinstance(model.get('mlp_params'), dict) and 'Dense_0' in model['mlp_params']:
+    return int(np.shape(model['mlp_params']['Dense_0']['kernel'])[0])
+  if getattr(mean_func, 'mean_id', None) == nat.MEAN_LINEAR and isinstance(model.get('linear_mean'), dict):
+    return int(np.size(model['linear_mean']['kernel']))
+  if getattr(cov_func, 'kernel_id', None) != nat.KERNEL_DOT and 'lengthscale' in model and np.size(model['lengthscale']) > 1:
+    return int(np.size(model['lengthscale']))
+  return None

@@ -40,9 +40,15 @@ def spd_inverse(coeff):
 
 
 def inverse_spdmatrix_vector_product(spd_matrix, x, cached_cholesky=None):
-  """linalg.py:140-145: spd_matrix^-1 x.  `cached_cholesky` is accepted for signature parity; the device
-  re-factorises (the factor is not kept resident for this array-level entry point)."""
-  del cached_cholesky
+  """linalg.py:129-145: spd_matrix^-1 x.  With `cached_cholesky` (a lower factor as an array, what the reference's
+  GPCache.chol holds) no factorisation is repeated: two O(n^2) triangular solves on the host (the array-level entry
+  point hands host arrays in and out; the device-resident equivalent is the hbo_cache handle)."""
+  if cached_cholesky is not None:
+    import scipy.linalg as spla
+    x = np.asarray(x)
+    chol = np.asarray(cached_cholesky, dtype=np.float64)
+    out = spla.cho_solve((chol, True), np.asarray(x, dtype=np.float64).reshape(chol.shape[0], -1))
+    return out.reshape(x.shape).astype(_model.infer_dtype(spd_matrix, x))
   return solve_linear_system(spd_matrix, x)[1]
 
 
@@ -106,7 +112,10 @@ class CacheHandle:
     bm = _model.BuiltModel(mean_func, cov_func, params, warp_func, self.dtype, d, eps=eps)
     rc = nat.lib().hbo_cache_append(self.ctx.handle, bm.ref(), self._h, nat.ptr(x_new), x_new.shape[0],
                                     nat.ptr(y_new))
-    if rc == nat.HBO_ERR_UNSUPPORTED:
+    if rc == nat.HBO_ERR_UNSUPPORTED or rc == nat.HBO_NOT_PD:
+      # capacity exhausted, or the appended rows made the matrix numerically indefinite part-way (the device stopped at
+      # the failing row): either way the caller re-factorises, which reproduces the reference's NaN cache in the
+      # second case (gp.py:552-560) -- self.n is NOT advanced past what the device accepted
       return False
     self.status = self.ctx.check(rc)
     self.n += x_new.shape[0]

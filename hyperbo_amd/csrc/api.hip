@@ -29,6 +29,8 @@ struct hbo_ctx {
   int opt_trtri_gran = 0;    // panels between two launches of the inverse's computable pieces during the factorisation (0: auto)
   int opt_small_nblk = 32;   // matrices up to this many 128-blocks use 64x64 GEMM tiles in trtri / lauum
   int opt_persist_free = -1; // bulk trailing update runs as 2*(CUs - this) persistent workgroups (-1: auto, see run_potrf)
+  int opt_trtri_free = 48;   // CUs the inverse products that co-run with the panel chain leave free (0: one tile per workgroup)
+  int* trtri_counters = nullptr; int trtri_counter_next = 0;   // run_potrf -> trtri_level: tile counters of those launches
   int n_cus = 256;
   std::vector<hipEvent_t> ev_pool;
   std::map<int, std::pair<void*, size_t>> ws;   // grow-only device scratch buffers by slot (no per-call hipMalloc/hipFree)
@@ -211,6 +213,7 @@ extern "C" int hbo_set_option(hbo_ctx* c, const char* name, int64_t value) {
   if (!strcmp(name, "cu_yield")) { c->opt_cu_yield = value ? 1 : 0; return HBO_OK; }
   if (!strcmp(name, "trtri_gran")) { if (value < 0) return fail(c, HBO_ERR_ARG, "trtri_gran >= 0"); c->opt_trtri_gran = (int)value; return HBO_OK; }
   if (!strcmp(name, "small_nblk")) { c->opt_small_nblk = (int)value; return HBO_OK; }
+  if (!strcmp(name, "trtri_free")) { if (value < 0 || value > 200) return fail(c, HBO_ERR_ARG, "trtri_free in 0..200"); c->opt_trtri_free = (int)value; return HBO_OK; }
   if (!strcmp(name, "persist_free")) { if (value < -1 || value > 200) return fail(c, HBO_ERR_ARG, "persist_free in -1..200 (-1: auto)"); c->opt_persist_free = (int)value; return HBO_OK; }
   return fail(c, HBO_ERR_ARG, std::string("unknown option ") + name);
 }
@@ -422,6 +425,8 @@ static void run_potrf(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks
   int* counters = c->opt_dynamic_tiles ? (int*)ws_get(c, WS_COUNTERS, sizeof(int) * 256) : nullptr;
   int n_counter = 0;
   if (counters) hipMemsetAsync(counters, 0, sizeof(int) * 256, sm);
+  c->trtri_counters = counters ? counters + 128 : nullptr;   // second half: the persistent inverse products (trtri_level)
+  c->trtri_counter_next = 0;
   for (int g0 = 0; g0 < max_nblk; g0 += q) {
     const int g1 = std::min(g0 + q, max_nblk);
     const int g2 = std::min(g1 + q, max_nblk);
@@ -479,7 +484,7 @@ static void run_potrf(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks
             const int pblocks = 2 * (c->n_cus - persist_free);
             // (for large trailing matrices the bulk update dominates and gets the whole machine)
             a.persistent = (ntasks == 1 && persist_free > 0 && ntiles > pblocks && m <= 96) ? pblocks : 0;
-            a.work_counter = (a.persistent && counters && n_counter < 256) ? counters + n_counter++ : nullptr;
+            a.work_counter = (a.persistent && counters && n_counter < 128) ? counters + n_counter++ : nullptr;
             launch_gemm(dtype, a, dim3(max_nblk + 1 - a.c_lo, a.c_hi - a.c_lo, ntasks), sb);
             a.persistent = 0; a.work_counter = nullptr;
           }
@@ -492,6 +497,7 @@ static void run_potrf(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks
     }
   }
   c->gemm_yield = nullptr;
+  c->trtri_counters = nullptr;
   if (la) { hipEvent_t e = pool_event(c, evi++); hipEventRecord(e, sp); hipStreamWaitEvent(sm, e, 0); }   // join
   if (early) {   // the rest of the inverse (main stream) needs the early part
     hipEvent_t e = pool_event(c, evi++);
@@ -510,6 +516,10 @@ static void trtri_level(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntas
   // its K loop latency-bound, four 64-tiles expose 4x the parallelism for the same flops
   a.small_tiles = (max_nblk <= c->opt_small_nblk) || ((int64_t)ngroups * s * s * ntasks < 600);
   a.yield_flag = (st == c->stream4) ? c->gemm_yield : nullptr;
+  // products that co-run with the panel chain (single matrix, side stream): persistent, 2 workgroups on all but
+  // `trtri_free` CUs, tiles from a counter -- see gemm_kernel
+  const bool corun = st == c->stream4 && ntasks == 1 && !a.small_tiles && c->opt_trtri_free > 0 && c->trtri_counters;
+  const int pblocks = 2 * (c->n_cus - c->opt_trtri_free);
   ProfScope ps(c, "trtri_gemm", 2, st);
   // Rows of the last group's lower half that exist in the largest task: workgroups beyond them would be dispatched
   // only to exit, which is not free (56 ns each: at the top level of a batch of 64 matrices of <= 19 blocks, 13 of
@@ -518,11 +528,16 @@ static void trtri_level(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntas
   if (vlast <= 0 && ngroups == 1) return;
   const int xa = (ngroups - 1) * s + std::max(vlast, 0);
   a.c_hi = grp_hi - 1; a.c_lo = std::max(vlast, 0);   // TRTRI_A: last group and its launched tile rows
-  if (do_a && xa > 0) { a.mode = GEMM_TRTRI_A; launch_gemm(dtype, a, dim3(xa, s, ntasks), st); }
+  auto persist = [&](int64_t tiles) {
+    a.persistent = 0; a.work_counter = nullptr;
+    if (corun && tiles > pblocks && c->trtri_counter_next < 128) { a.persistent = pblocks; a.work_counter = c->trtri_counters + c->trtri_counter_next++; }
+  };
+  if (do_a && xa > 0) { a.mode = GEMM_TRTRI_A; persist((int64_t)xa * s); launch_gemm(dtype, a, dim3(xa, s, ntasks), st); }
   if (do_b) {
     a.mode = GEMM_TRTRI_B;
     const int vy = ngroups == 1 ? vlast : s;
     a.kt = vy;   // valid tile rows when there is a single group (blockIdx.y counts down from them)
+    persist((int64_t)ngroups * s * vy);
     launch_gemm(dtype, a, dim3(ngroups * s, vy, ntasks), st);
   }
 }

@@ -108,8 +108,10 @@ struct TileJob {
   int* yield_flag;           // see GemmArgs::yield_flag
 };
 
+// (bx, by) = tile coordinates inside a gdx-wide grid: blockIdx of a one-tile-per-workgroup launch, or the tile a
+// persistent workgroup drew from the counter
 template <typename T, int TM>
-__device__ __forceinline__ bool decode_job(const GemmArgs& g, TileJob<T>& j) {
+__device__ __forceinline__ bool decode_job(const GemmArgs& g, TileJob<T>& j, const int bxi, const int byi, const int gdx) {
   constexpr int BKE = 128 / sizeof(T);
   const TaskDesc& t = g.tasks[blockIdx.z];
   const int64_t ld = t.ld;
@@ -123,8 +125,8 @@ __device__ __forceinline__ bool decode_job(const GemmArgs& g, TileJob<T>& j) {
       // panels of 64 tiles on one XCD's L2 (61 -> 41 TFLOP/s at N=16384, K=1024).
       // (batches: rows rotated per (column, task) -- in a ragged batch the rows that exist are the low ones of every
       // task and workgroup i runs on XCD (i + const) mod 8)
-      const int by = blockIdx.y;
-      const int bx = gridDim.z > 1 ? (int)((blockIdx.x + 5 * blockIdx.y + 3 * blockIdx.z) % gridDim.x) : (int)blockIdx.x;
+      const int by = byi;
+      const int bx = gridDim.z > 1 ? (int)((bxi + 5 * byi + 3 * blockIdx.z) % gdx) : bxi;
       const int c = g.c_lo * U + by;
       const int r = g.c_lo * U + bx;
       const int nrt = (nblk + ((g.aug & 1) ? 1 : 0)) * U;
@@ -150,17 +152,17 @@ __device__ __forceinline__ bool decode_job(const GemmArgs& g, TileJob<T>& j) {
       // dispatcher hands out tiles in longest-processing-time order (x runs over groups x tiles).
       constexpr int U = HBO_TILE / TM;
       const int s = g.p0, su = s * U;
-      const int grp = g.grp_lo + (int)blockIdx.x / su;
-      const int inner = (int)blockIdx.x % su;
+      const int grp = g.grp_lo + bxi / su;
+      const int inner = bxi % su;
       int jt, it;
       if (g.mode == GEMM_TRTRI_A) {
         // K = s*128 - jt*TM.  Ragged batches: the row tiles that exist are the low ones in every task and workgroup i
         // runs on XCD (i + const) mod 8, so the row order is rotated per (column, task)
-        jt = blockIdx.y;
+        jt = byi;
         const int vu = (grp == g.c_hi ? g.c_lo : s) * U;   // tile rows launched for this group (the last may be cut)
-        it = (inner + 5 * (int)blockIdx.y + 3 * (int)blockIdx.z) % vu;
+        it = (inner + 5 * byi + 3 * (int)blockIdx.z) % vu;
       }
-      else { it = (g.kt > 0 ? g.kt * U : su) - 1 - (int)blockIdx.y; jt = inner; }   // K = (it+1)*TM; kt = valid rows (single group)
+      else { it = (g.kt > 0 ? g.kt * U : su) - 1 - byi; jt = inner; }   // K = (it+1)*TM; kt = valid rows (single group)
       const int64_t o = (int64_t)grp * 2 * s * HBO_TILE;                      // element offsets from here on
       const int64_t R = o + (int64_t)s * HBO_TILE + (int64_t)it * TM;
       if (R >= (int64_t)nblk * HBO_TILE) return false;
@@ -199,7 +201,7 @@ __device__ __forceinline__ bool decode_job(const GemmArgs& g, TileJob<T>& j) {
         // History (in-kernel stamps, tools/gemm_wall.py): 2-D grid with i fast: 370 of 512 slots busy, 3.56 ms (XCD 0
         // always received the longest of every 8 tiles); column-major with every second group of 8 reversed: 412
         // slots, 3.38 ms; this order: 481 slots, 3.08 ms.
-        int lin = blockIdx.x;
+        int lin = bxi;
         if (lin >= nblk * (nblk + 1) / 2) return false;
         i = 0;
         while (lin > i) { lin -= i + 1; ++i; }
@@ -208,7 +210,7 @@ __device__ __forceinline__ bool decode_job(const GemmArgs& g, TileJob<T>& j) {
         // 64-tiles (small / batched matrices): same row-major order; the tile right of an even diagonal tile is
         // computed too, so that every 128x128 block on the diagonal is complete (the contraction kernel reads whole
         // 128-blocks): row i has (i | 1) + 1 tiles, 2 n (n + 1) in total
-        int lin = blockIdx.x;
+        int lin = bxi;
         if (lin >= 2 * nblk * (nblk + 1)) return false;
         i = 0;
         while (lin > (i | 1)) { lin -= (i | 1) + 1; ++i; }
@@ -225,9 +227,9 @@ __device__ __forceinline__ bool decode_job(const GemmArgs& g, TileJob<T>& j) {
       return true;
     }
     case GEMM_POST: {
-      const int i = nblk - 1 - (int)blockIdx.y;  // heavy (long K) row tiles first
+      const int i = nblk - 1 - byi;  // heavy (long K) row tiles first
       if (i < 0) return false;
-      const int jq = blockIdx.x;
+      const int jq = bxi;
       const T* W = static_cast<const T*>(t.W);
       j.A = W + (int64_t)i * HBO_TILE * ld;
       j.lda = ld;
@@ -444,7 +446,25 @@ __global__ __launch_bounds__(256, TM == 64 ? 4 : 2) void gemm_kernel(GemmArgs g)
 #endif
     return;
   }
-  if (!decode_job<T, TM>(g, job)) return;
+  if (!(AKC && BKC) && g.persistent) {
+    // Persistent form of the other modes (single matrix): g.pgx x g.pgy tiles in the order a one-tile-per-workgroup
+    // launch would dispatch them (x fast, y -- which fixes the K length, longest first -- slow), drawn from a counter
+    // by a grid that is smaller than the machine.  Used for the inverse products that co-run with the panel chain:
+    // the whole grid is resident at once and leaves CUs free, so the chain's kernels never wait for a tile of up to
+    // 256 K steps to finish before they get a slot (potf2 took 600 us once per evaluation, tools/trace_potrf.py).
+    __shared__ int s_tix2;
+    const int total = g.pgx * g.pgy;
+    for (;;) {
+      if (threadIdx.x == 0) s_tix2 = atomicAdd(g.work_counter, 1);
+      __syncthreads();
+      const int tix = s_tix2;
+      __syncthreads();
+      if (tix >= total) break;
+      if (decode_job<T, TM>(g, job, tix % g.pgx, tix / g.pgx, g.pgx)) gemm_tile<T, AKC, BKC, TM>(job, smem);
+    }
+    return;
+  }
+  if (!decode_job<T, TM>(g, job, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x)) return;
   gemm_tile<T, AKC, BKC, TM>(job, smem);
 #ifdef HBO_GEMM_TIMING
   if (dbg) { hbo_dbg_gemm[4 * dbg_id + 1] = wall_clock64(); hbo_dbg_gemm[4 * dbg_id + 3] = (unsigned long long)job.ksteps; }
@@ -453,7 +473,11 @@ __global__ __launch_bounds__(256, TM == 64 ? 4 : 2) void gemm_kernel(GemmArgs g)
 
 #ifndef HBO_DEVICE_ONLY
 template <typename T>
-void launch_gemm_t(const GemmArgs& a, dim3 grid, hipStream_t st) {
+void launch_gemm_t(const GemmArgs& a_in, dim3 grid, hipStream_t st) {
+  GemmArgs a = a_in;
+  // the persistent forms: SYRK (any tile size), TRTRI on 128-tiles of a single matrix with a tile counter
+  if (a.mode != GEMM_SYRK && !((a.mode == GEMM_TRTRI_A || a.mode == GEMM_TRTRI_B) && !a.small_tiles && a.work_counter && grid.z == 1))
+    a.persistent = 0;
   static bool attr_set = false;
   if (!attr_set) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T, true, true, 128>),
@@ -484,8 +508,12 @@ void launch_gemm_t(const GemmArgs& a, dim3 grid, hipStream_t st) {
       if (a.small_tiles) {
         dim3 g2(grid.x * 2, grid.y * 2, grid.z);
         hipLaunchKernelGGL((gemm_kernel<T, true, false, 64>), g2, dim3(256), GEMM_LDS_BYTES_64, st, a);
+      } else if (a.persistent > 0 && a.work_counter && grid.z == 1) {
+        GemmArgs b = a; b.pgx = (int)grid.x; b.pgy = (int)grid.y;
+        hipLaunchKernelGGL((gemm_kernel<T, true, false, 128>), dim3(a.persistent, 1, 1), dim3(256), GEMM_LDS_BYTES, st, b);
       } else {
-        hipLaunchKernelGGL((gemm_kernel<T, true, false, 128>), grid, dim3(256), GEMM_LDS_BYTES, st, a);
+        GemmArgs b = a; b.persistent = 0;
+        hipLaunchKernelGGL((gemm_kernel<T, true, false, 128>), grid, dim3(256), GEMM_LDS_BYTES, st, b);
       }
       break;
     case GEMM_POST:

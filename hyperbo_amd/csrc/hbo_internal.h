@@ -69,7 +69,8 @@ struct GemmArgs {
   int c_hi;      // SYRK: end (exclusive) of updated tile columns;   TRTRI_A: index of the last group
   int aug;       // SYRK: 1 -> include the augmented tile-row
   int small_tiles;  // 1 -> 64x64 output tiles (SYRK / TRTRI / LAUUM; grid is given in 128-tile units)
-  int persistent;   // SYRK: >0 -> that many persistent workgroups loop over the tiles
+  int persistent;   // >0 -> that many persistent workgroups loop over the tiles (SYRK; TRTRI on 128-tiles with a work_counter)
+  int pgx, pgy;     // persistent TRTRI: the tile grid the workgroups walk (set by launch_gemm)
   int* work_counter; // persistent SYRK: zero-initialised tile counter -> workgroups draw tiles dynamically (a faster
                      // workgroup takes more of them) instead of striding over them; null: static stride
   int dbg;          // HBO_GEMM_TIMING builds: 1 -> this launch records per-workgroup wall-clock stamps

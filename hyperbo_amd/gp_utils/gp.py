@@ -280,12 +280,29 @@ class GP:
     return self.params
 
   def neg_log_marginal_likelihood(self):
-    """Total nll and key->nll dict (gp.py:487-497).  NB the reference uses the SVD variant here;
-    the Cholesky variant agrees with it to ~2 decimals in the reference's own tests
-    (objectives_test.py:168) and is what runs natively."""
+    """Total nll and key->nll dict with the SVD variant, as the reference (gp.py:487-497): device Gram + mean,
+    host LAPACK SVD -- finite where the Cholesky variant would report NaN for a numerically low-rank covariance."""
     return obj.neg_log_marginal_likelihood(
         mean_func=self.mean_func, cov_func=self.cov_func, params=self.params, dataset=self.dataset,
-        warp_func=self.warp_func, return_key2nll=True, use_cholesky=True)
+        warp_func=self.warp_func, return_key2nll=True, use_cholesky=False)
+
+  def empirical_divergence(self, distance=None) -> float:
+    """Empirical divergence between sample mean / covariance and the model (gp.py:499-510)."""
+    return obj.multivariate_normal_divergence(
+        mean_func=self.mean_func, cov_func=self.cov_func, params=self.params, dataset=self.dataset,
+        warp_func=self.warp_func, distance=distance)
+
+  def stats(self, verbose=True):
+    """(nll, ekl, ekl_partial, euc, key2nll) of the current model (gp.py:512-533)."""
+    import functools
+    from hyperbo_amd.gp_utils import utils as _utils
+    nll, key2nll = self.neg_log_marginal_likelihood()
+    ekl = self.empirical_divergence(functools.partial(_utils.kl_multivariate_normal, eps=1e-6, partial=False))
+    ekl_partial = self.empirical_divergence(functools.partial(_utils.kl_multivariate_normal, eps=1e-6, partial=True))
+    euc = self.empirical_divergence(_utils.euclidean_multivariate_normal)
+    if verbose:
+      print(f'nll = {nll}, ekl = {ekl}, ekl_partial = {ekl_partial}, euc = {euc}')
+    return nll, ekl, ekl_partial, euc, key2nll
 
   def update_model_params(self, model_params: Dict[str, Any]):
     """gp.py:535-538."""
@@ -364,6 +381,23 @@ class HGP(GP):
 
   def get_model_params_samples(self):
     return self.params.samples if self.params.samples else [self.params.model]
+
+  def stats(self, verbose=True):
+    """Mean over the parameter samples of GP.stats (gp.py:633-664)."""
+    samples = self.get_model_params_samples()
+    rows, acc, key2nll = [], {}, {}
+    for model_params in samples:
+      self.update_model_params(model_params)
+      nll, ekl, ekl_partial, euc, key2nll = super().stats(verbose=False)
+      rows.append((nll, ekl, ekl_partial, euc))
+      for k, v in key2nll.items():
+        acc[k] = acc.get(k, 0.) + v
+    for k in key2nll:
+      acc[k] /= len(samples)
+    nll, ekl, ekl_partial, euc = np.mean(np.asarray(rows, dtype=np.float64), axis=0)
+    if verbose:
+      print(f'HGP nll = {nll}, ekl = {ekl}, ekl_partial = {ekl_partial}, euc = {euc}')
+    return nll, ekl, ekl_partial, euc, acc
 
   def predict(self, queried_inputs, sub_dataset_key=0, full_cov=False, with_noise=True):
     results = []

@@ -90,7 +90,13 @@ class DeviceDataset:
   def evaluate(self, mean_func, cov_func, params, warp_func=None, want_grad=False, per_task=False,
                objective=OBJ_NLL):
     """Returns (value_sum, per_task dict or None, flat grad_sum (warped) or None, BuiltModel)."""
-    bm = _model.BuiltModel(mean_func, cov_func, params, warp_func, self.dtype, self.input_dim)
+    input_dim = self.input_dim
+    if self.num_tasks == 0:
+      # an empty selection (e.g. a task shard of a rank beyond the task count) carries no inputs: take D from the
+      # parameters so that this rank builds the same model -- and the same gradient layout -- as its peers and
+      # reaches the all-reduce with zeros instead of raising on a shape mismatch
+      input_dim = _model.infer_input_dim(mean_func, cov_func, params) or self.input_dim
+    bm = _model.BuiltModel(mean_func, cov_func, params, warp_func, self.dtype, input_dim)
     nll = C.c_double(0.0)
     pt = (C.c_double * max(self.num_tasks, 1))() if per_task else None
     g = (C.c_double * max(bm.layout.total, 1))() if want_grad else None
@@ -149,12 +155,33 @@ def _apply_priors(total_nll, params, warp_func):
   return total_nll
 
 
+def _nll_sub_dataset_svd(mean_func, cov_func, params, vx, vy, warp_func):
+  """objectives.py:157-176: 0.5 * sum(y^T K^-1 y + sum(log s) + n log 2 pi) with K^-1 = V^T diag(1/s) U^T from the SVD
+  of the jittered Gram matrix.  Mean and Gram come from the device (hbo_mean / hbo_gram through mean_func / cov_func);
+  the SVD itself is host LAPACK -- the reference's reporting path for covariances that are numerically low rank, where
+  the Cholesky variant returns NaN.  For y of shape (n, m > 1) the (m, m) + scalar broadcast of the reference is kept."""
+  from hyperbo_amd.basics import linalg
+  vy, cov = linalg.compute_delta_y_and_cov(mean_func, cov_func, params, vx, vy, warp_func=warp_func)
+  u, s, vt = np.linalg.svd(np.asarray(cov, dtype=np.float64))
+  if s[-1] <= 0:
+    logging.warning('Covariance matrix is low rank. s = %s', s)
+  with np.errstate(divide='ignore', invalid='ignore'):
+    kinvy = vt.T @ ((u.T @ np.asarray(vy, dtype=np.float64)) / s[:, None])
+    return float(0.5 * np.sum(vy.T @ kinvy + np.sum(np.log(s)) + len(vx) * np.log(2 * np.pi)))
+
+
 def neg_log_marginal_likelihood(mean_func, cov_func, params, dataset, warp_func=None, exclude_aligned=True,
                                 return_key2nll=False, use_cholesky=True):
-  """Negative log marginal likelihood of a (multi-task) GP: mean over included sub-datasets."""
+  """Negative log marginal likelihood of a (multi-task) GP: mean over included sub-datasets
+  (objectives.py:109-210).  use_cholesky=False is the SVD variant (objectives.py:157-176)."""
   if not use_cholesky:
-    raise NotImplementedError('the SVD variant (objectives.py:157-176) is a CPU reporting path; '
-                              'it is restated in oracle/ only')
+    if isinstance(dataset, (DeviceDataset, DeviceBatch)):
+      raise TypeError('use_cholesky=False takes the host dataset dict (the SVD runs on host LAPACK)')
+    key2nll = {k: _nll_sub_dataset_svd(mean_func, cov_func, params, s.x, s.y, warp_func)
+               for k, s in included_sub_datasets(dataset, exclude_aligned)}
+    total = sum(key2nll.values()) / len(key2nll) if key2nll else 0.
+    total = _apply_priors(total, params, warp_func)
+    return (total, key2nll) if return_key2nll else total
   dev, owned = _as_device(dataset, exclude_aligned)
   try:
     nll_sum, key2nll, _, _ = dev.evaluate(mean_func, cov_func, params, warp_func, per_task=return_key2nll)
@@ -231,21 +258,47 @@ def _divergence(objective_id, mean_func, cov_func, params, dataset, warp_func, w
   return 0., bm.unflatten_grad(grad * 0.)
 
 
+def _divergence_host(mean_func, cov_func, params, dataset, warp_func, distance):
+  """objectives.py:53-101 for an arbitrary `distance` callable (e.g. functools.partial(utils.kl_multivariate_normal,
+  eps=1e-6, partial=False) in GP.stats, gp.py:512-533): sample statistics on the host, model mean / covariance from
+  the device (hbo_mean / hbo_gram), then distance(mu0=, cov0=, mu1=, cov1=) -- the utils distances factorise on the
+  device themselves."""
+  total, count = 0., 0
+  for key, sd in dataset.items():
+    if sd.aligned is None or sd.x.shape[0] == 0:
+      continue
+    if sd.y.shape[1] == 0 or sd.y.shape[0] != sd.x.shape[0]:
+      raise ValueError(f'dataset[{key}].x has shape {sd.x.shape} but dataset[{key}].y has shape {sd.y.shape}')
+    y = np.asarray(sd.y, dtype=np.float64)
+    mu_data = np.mean(y, axis=1)
+    yc = y - mu_data[:, None]
+    cov_data = yc @ yc.T / y.shape[1]                     # jnp.cov(y, bias=True)
+    mu_model = np.asarray(mean_func(params, sd.x, warp_func=warp_func), dtype=np.float64).flatten()
+    noise_variance, = retrieve_params(params, ['noise_variance'], warp_func=warp_func)
+    cov_model = np.asarray(cov_func(params, sd.x, warp_func=warp_func), dtype=np.float64) \
+        + np.eye(sd.x.shape[0]) * float(np.squeeze(noise_variance))
+    total += float(distance(mu0=mu_data, cov0=cov_data, mu1=mu_model, cov1=cov_model))
+    count += 1
+  return total / count if count else 0.
+
+
 def multivariate_normal_divergence(mean_func, cov_func, params, dataset, warp_func=None, distance=None):
   """objectives.py:29-101: mean over the aligned sub-datasets of distance(N(mean_a y, cov_a y), GP prior).
 
   `distance`: None / utils.kl_multivariate_normal (partial KL, utils.py:109-148 defaults) or
-  utils.euclidean_multivariate_normal; both run natively (hbo_objective).  Other callables, or functools
-  partials that change weight / eps / partial, are not on the device path and raise.
+  utils.euclidean_multivariate_normal run fused on the device (hbo_objective).  Any other callable -- e.g. the
+  functools.partial(kl_multivariate_normal, eps=..., partial=...) of GP.stats -- is evaluated per sub-dataset from
+  the device Gram matrix and mean (`_divergence_host`); such a distance has no gradient companion.
   """
   from hyperbo_amd.gp_utils import utils as _utils
   if distance is None or distance is _utils.kl_multivariate_normal:
     oid = OBJ_EKL
   elif distance is _utils.euclidean_multivariate_normal:
     oid = OBJ_EUC
+  elif callable(distance) and not isinstance(dataset, (DeviceDataset, DeviceBatch)):
+    return _divergence_host(mean_func, cov_func, params, dataset, warp_func, distance)
   else:
-    raise NotImplementedError('multivariate_normal_divergence: only utils.kl_multivariate_normal (partial, '
-                              'eps=0) and utils.euclidean_multivariate_normal run on the device')
+    raise NotImplementedError('multivariate_normal_divergence: a custom distance needs the host dataset dict')
   return _divergence(oid, mean_func, cov_func, params, dataset, warp_func, False)[0]
 
 

@@ -195,6 +195,8 @@ int hbo_profile_get(hbo_ctx* ctx, char names[][32], double* ms, int32_t* launche
  *   overlap_trtri  0/1   inverse walks the block tree while the factorisation runs
  *   trtri_gran     >=0   panels between two launches of the inverse's computable pieces (0 = auto: every 4 panels
  *                        for a batch, once after 13/16 of the panels for a single matrix)
+ *   trtri_free     0..200 CUs left free by the inverse products that co-run with the panel chain (persistent form,
+ *                        tiles from a counter; 0 = one tile per workgroup)
  *   small_nblk     int   matrices up to this many blocks use 64x64 tiles in trtri / lauum */
 int hbo_set_option(hbo_ctx* ctx, const char* name, int64_t value);
 

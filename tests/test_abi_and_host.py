@@ -132,3 +132,29 @@ def test_selection_rule_and_lpt_partition():
   mine = parallel.shard_dataset(ds, 0, 2, exclude_aligned=False)
   other = parallel.shard_dataset(ds, 1, 2, exclude_aligned=False)
   assert set(mine) | set(other) == {'a', 'c'} and not (set(mine) & set(other))
+
+
+def test_infer_dtype_follows_x64_promotion():
+  from hyperbo_amd import _model
+  f32, f64 = np.zeros(2, np.float32), np.zeros(2, np.float64)
+  assert _model.infer_dtype(f64, f64) == np.float64
+  assert _model.infer_dtype(f32, f32) == np.float32
+  assert _model.infer_dtype(f32, f64) == np.float64          # promoted, never narrowed (was float32)
+  assert _model.infer_dtype(f64, np.arange(3)) == np.float64  # integer y does not drop the computation to float32
+  assert _model.infer_dtype(np.arange(3), [1.0, 2.0]) == np.float64
+  assert _model.infer_dtype(f32, np.arange(3)) == np.float32  # JAX: int + float32 -> float32
+  assert _model.infer_dtype(f32, None) == np.float32 and _model.infer_dtype() == np.float64
+
+
+def test_infer_input_dim_from_parameters_alone():
+  from hyperbo_amd import _model
+  P = lambda m: defs.GPParams(model=m)
+  assert _model.infer_input_dim(mean.constant, kernel.squared_exponential, P({'lengthscale': np.ones(7)})) == 7
+  assert _model.infer_input_dim(mean.constant, kernel.squared_exponential, P({'lengthscale': np.array(1.0)})) is None
+  lin = {'linear_mean': {'kernel': np.ones((5, 1)), 'bias': np.zeros(1)}, 'lengthscale': np.array(1.0)}
+  assert _model.infer_input_dim(mean.linear, kernel.matern32, P(lin)) == 5
+  mlp = {'mlp_params': {'Dense_0': {'kernel': np.ones((6, 9)), 'bias': np.zeros(9)}}, 'lengthscale': np.ones(9),
+         'linear_mean': {'kernel': np.ones((9, 1)), 'bias': np.zeros(1)}}
+  assert _model.infer_input_dim(mean.linear_mlp, kernel.matern52_mlp, P(mlp)) == 6
+  assert _model.infer_input_dim(mean.zero, kernel.squared_exponential_mlp, P(mlp)) == 6
+  assert _model.infer_input_dim(mean.zero, kernel.dot_product, P({'dot_prod_sigma': np.array(1.)})) is None

@@ -354,18 +354,29 @@ def test_cfg2_shape_n2048_vs_oracle(gpu_ctx):
   assert np.max(np.abs(fo - fn)) <= 1e-8 * np.max(np.abs(fo))
 
 
-def test_cfg2_full_size_properties(gpu_ctx):
-  """N=8192, D=16 fp64: (a) NLL agrees with LAPACK's Cholesky of the same Gram (value-only oracle,
-  seconds); (b) the analytic gradient matches a directional central difference of the GPU NLL."""
+def test_cfg2_full_size_value_and_full_gradient(gpu_ctx):
+  """BASELINE.json configs[1] at full size, N=8192, D=16 fp64 (seed 2 of SURVEY.md 8(d) = bench.cfg2_inputs()):
+  (a) the NLL agrees with LAPACK's Cholesky of the same Gram matrix (oracle value path);
+  (b) ALL 19 gradient leaves agree with oracle/cpu_baseline.nll_and_grad_se_ard_constant_omp -- the C/OpenMP +
+      LAPACK potrf/potri port that test_oracle_pins.py pins to oracle/hyperbo_oracle.py -- to 1e-8 of max|g|;
+  (c) a directional central difference of the GPU NLL itself as an oracle-free cross-check."""
+  import bench
+  from oracle import cpu_baseline
   defs, _, _, _, kernel, mean, objectives, utils = _native()
-  rng = np.random.default_rng(2)
-  x, y, model = _cfg2_like(rng, 8192)
+  x, y, model = bench.cfg2_inputs()
+  assert x.shape == (8192, 16)
   pn = defs.GPParams(model=model)
   dev = objectives.DeviceDataset({0: defs.SubDataset(x, y)})
   v, g = objectives.nll_value_and_grad(mean.constant, kernel.squared_exponential, pn, dev, utils.DEFAULT_WARP_FUNC)
   vo = o.neg_log_marginal_likelihood(o.constant, o.squared_exponential, o.GPParams(model=model), {0: o.SubDataset(x, y)}, WFO)
   assert abs(v - vo) <= 1e-10 * abs(vo)
-  x0 = helpers.flatten(model); gf = helpers.flatten(g)
+  vc, gc = cpu_baseline.nll_and_grad_se_ard_constant_omp(x, y, model)
+  assert abs(v - vc) <= 1e-10 * abs(vc)
+  assert set(g) == set(gc) and sum(np.size(a) for a in g.values()) == 19
+  fo, fn = helpers.flatten(gc), helpers.flatten(g)
+  assert np.max(np.abs(fo - fn)) <= 1e-8 * np.max(np.abs(fo)), (fo, fn)
+  rng = np.random.default_rng(2)
+  x0 = helpers.flatten(model)
   direction = rng.normal(size=x0.size); direction /= np.linalg.norm(direction)
   h = 1e-5
   vals = []
@@ -373,8 +384,60 @@ def test_cfg2_full_size_properties(gpu_ctx):
     pm = defs.GPParams(model=helpers.unflatten_like(model, x0 + sgn * h * direction))
     vals.append(objectives.neg_log_marginal_likelihood(mean.constant, kernel.squared_exponential, pm, dev, utils.DEFAULT_WARP_FUNC))
   num = (vals[0] - vals[1]) / (2 * h)
-  assert abs(num - gf @ direction) <= 1e-5 * abs(num) + 1e-6
+  assert abs(num - fn @ direction) <= 1e-5 * abs(num) + 1e-6
   dev.close()
+
+
+def test_cfg1_golden_fixture(gpu_ctx):
+  """BASELINE.json configs[0] (SURVEY.md 8(d) cfg 1: seed 1, N=256, D=4, SE, fp64 NLL): the committed fixture
+  (oracle, cross-checked against LAPACK by its generator) vs the device NLL, gradient, factor diagonal and K^-1 y."""
+  defs, linalg, _, _, kernel, mean, objectives, utils = _native()
+  fx = np.load(os.path.join(GOLDEN, 'cfg1_se_n256_d4.npz'))
+  x, y = fx['x'], fx['y']
+  assert x.shape == (256, 4)
+  model = helpers.unflatten_like({'lengthscale': np.zeros(4), 'signal_variance': np.array(0.), 'noise_variance': np.array(0.),
+                                  'constant': np.array(0.)}, fx['model_flat'])
+  pn = defs.GPParams(model=model)
+  wf = utils.DEFAULT_WARP_FUNC
+  v, g = objectives.nll_value_and_grad(mean.constant, kernel.squared_exponential, pn, {0: defs.SubDataset(x, y)}, wf)
+  assert abs(v - float(fx['nll'])) <= 1e-10 * abs(float(fx['nll']))
+  assert abs(v - float(fx['nll_lapack'])) <= 1e-10 * abs(float(fx['nll_lapack']))
+  assert np.max(np.abs(helpers.flatten(g) - fx['grad_flat'])) <= 1e-8 * np.max(np.abs(fx['grad_flat']))
+  chol, kinvy, _ = linalg.solve_gp_linear_system(mean.constant, kernel.squared_exponential, pn, x, y, wf)
+  assert helpers.rel_err(np.diag(chol), fx['chol_diag']) < 1e-11 and helpers.rel_err(kinvy, fx['kinvy']) < 1e-8
+  vs = objectives.neg_log_marginal_likelihood(mean.constant, kernel.squared_exponential, pn, {0: defs.SubDataset(x, y)}, wf,
+                                              use_cholesky=False)
+  assert abs(vs - float(fx['nll_svd'])) <= 1e-9 * abs(float(fx['nll_svd']))
+
+
+def test_cfg4_all_64_tasks_vs_oracle_fixture(gpu_ctx):
+  """BASELINE.json configs[3]: the 64 ragged sub-datasets of bench.cfg4_inputs() in ONE batched evaluation (T=64, the
+  z-rotated tile rows of the batched kernels) -- per-task NLL, mean NLL and mean gradient against the oracle's
+  committed outputs (tests/golden/make_golden_configs.py), plus the oracle live on four of the tasks."""
+  import bench
+  defs, _, _, _, kernel, mean, objectives, utils = _native()
+  fx = np.load(os.path.join(GOLDEN, 'cfg4_t64_oracle.npz'))
+  data, raw = bench.cfg4_inputs()
+  assert len(data) == 64 and np.array_equal(fx['sizes'], [len(data[k][0]) for k in sorted(data)])
+  assert np.array_equal(fx['model_flat'], helpers.flatten(raw))
+  ds = {k: defs.SubDataset(xx, yy) for k, (xx, yy) in data.items()}
+  pn = defs.GPParams(model=raw)
+  wf = utils.DEFAULT_WARP_FUNC
+  dev = objectives.DeviceDataset(ds)
+  total, key2nll = objectives.neg_log_marginal_likelihood(mean.constant, kernel.squared_exponential, pn, dev, wf, return_key2nll=True)
+  per = np.array([key2nll[k] for k in sorted(data)])
+  assert np.max(np.abs(per - fx['nll_per_task']) / np.abs(fx['nll_per_task'])) <= 1e-10
+  assert abs(total - float(fx['nll_mean'])) <= 1e-10 * abs(float(fx['nll_mean']))
+  v, g = objectives.nll_value_and_grad(mean.constant, kernel.squared_exponential, pn, dev, wf)
+  assert abs(v - float(fx['nll_mean'])) <= 1e-10 * abs(float(fx['nll_mean']))
+  gf = helpers.flatten(g)
+  assert np.max(np.abs(gf - fx['grad_mean_flat'])) <= 1e-8 * np.max(np.abs(fx['grad_mean_flat']))
+  dev.close()
+  po = o.GPParams(model=raw)
+  for k in (0, 21, 42, 63):   # the fixture is not stale: live oracle on a sample
+    vo, _ = o.nll_sub_dataset_value_and_grad(o.constant, o.squared_exponential, po, data[k][0], data[k][1], WFO)
+    assert abs(vo - fx['nll_per_task'][k]) <= 1e-11 * abs(vo)
+    assert abs(per[k] - vo) <= 1e-10 * abs(vo)
 
 
 def test_cfg4_like_ragged_multitask_vs_oracle(gpu_ctx):
@@ -452,6 +515,177 @@ def test_cfg5_full_size_closed_form(gpu_ctx):
   quad = (float(y.T @ y) - float(uty.T @ np.linalg.solve(cap, uty)) / c) / c
   expect = 0.5 * quad + 0.5 * logdet + 0.5 * n * np.log(2 * np.pi)
   assert abs(v - expect) <= 1e-9 * abs(expect)
+
+
+def test_cfg5_se_ard_full_size_residual_and_schedules(gpu_ctx):
+  """BASELINE.json configs[4] with its STATED workload: SE-ARD, D=16, N=65536 fp64 (seed 5, ls = 0.3 sqrt(D), sv = 1,
+  noise 1e-1; a full-rank 32 GiB Gram matrix).  The oracle cannot run at this size, so size-independent properties:
+  (a) alpha = K^-1 (y - mu) from the blocked factorisation solves the system: on eight sampled 1024-row chunks,
+      |K[rows,:] alpha - (y - mu)[rows]| <= 1e-10 * (|K[rows,:]| |alpha|)  with K rows rebuilt through hbo_gram;
+  (b) the NLL out of hbo_nll is identical (1e-11) under a different blocking and schedule (three panels per update,
+      no look-ahead): every tile is accumulated in another order, the result may not move;
+  (c) the same pipeline against LAPACK on the leading N=16384 sub-problem (value incl. log-determinant)."""
+  defs, linalg, _, _, kernel, mean, objectives, utils = _native()
+  from hyperbo_amd import _native as nat
+  rng = np.random.Generator(np.random.PCG64(5))
+  n, d = 65536, 16
+  x = rng.uniform(size=(n, d)); w = rng.normal(size=d)
+  y = np.sin(2 * np.pi * x @ w)[:, None] + 0.1 * rng.normal(size=(n, 1))
+  model = {'lengthscale': helpers.inv_softplus(np.full(d, np.sqrt(d) * 0.3)), 'signal_variance': helpers.inv_softplus(1.0),
+           'noise_variance': helpers.inv_softplus(1e-1), 'constant': np.array(0.0)}
+  pn = defs.GPParams(model=model)
+  wf = utils.DEFAULT_WARP_FUNC
+  ctx = nat.default_context()
+  dev = objectives.DeviceDataset({0: defs.SubDataset(x, y)})
+  v = objectives.neg_log_marginal_likelihood(mean.constant, kernel.squared_exponential, pn, dev, wf)
+  assert np.isfinite(v)
+  ctx.set_option('potrf_group', 3); ctx.set_option('lookahead', 0)
+  try:
+    v2 = objectives.neg_log_marginal_likelihood(mean.constant, kernel.squared_exponential, pn, dev, wf)
+  finally:
+    ctx.set_option('potrf_group', 0); ctx.set_option('lookahead', 1)
+  assert abs(v - v2) <= 1e-11 * abs(v)
+  dev.close()
+  h = linalg.factor(mean.constant, kernel.squared_exponential, pn, x, y, wf)
+  try:
+    assert h.status == 0
+    kinvy = np.empty((n, 1)); ymu = np.empty((n, 1))
+    ctx.check(nat.lib().hbo_cache_export(ctx.handle, h.handle, None, nat.ptr(kinvy), nat.ptr(ymu)))
+  finally:
+    h.close()
+  noise = 1e-1 + 1e-10 + 1e-6
+  for c in rng.choice(n // 1024, size=8, replace=False):
+    rows = slice(int(c) * 1024, int(c) * 1024 + 1024)
+    kr = kernel.squared_exponential(pn, x[rows], x, warp_func=wf)
+    resid = kr @ kinvy + noise * kinvy[rows] - ymu[rows]
+    bound = np.abs(kr) @ np.abs(kinvy) + noise * np.abs(kinvy[rows])
+    assert np.max(np.abs(resid) / bound) <= 1e-10, float(np.max(np.abs(resid) / bound))
+  quad = float(ymu[:, 0] @ kinvy[:, 0])
+  assert quad > 0
+  # (c) leading sub-problem against LAPACK
+  ns = 16384
+  vs = objectives.neg_log_marginal_likelihood(mean.constant, kernel.squared_exponential, pn, {0: defs.SubDataset(x[:ns], y[:ns])}, wf)
+  ks = kernel.squared_exponential(pn, x[:ns], warp_func=wf)
+  ks[np.diag_indices(ns)] += noise
+  c, info = spla.lapack.dpotrf(ks, lower=1, overwrite_a=1)
+  assert info == 0
+  al = spla.cho_solve((c, True), y[:ns])
+  ref = float(0.5 * (y[:ns].T @ al)[0, 0] + np.sum(np.log(np.diag(c))) + 0.5 * ns * np.log(2 * np.pi))
+  assert abs(vs - ref) <= 1e-10 * abs(ref)
+
+
+# ---- SVD NLL (objectives.py:157-176), GP.stats (gp.py:487-533), HGP (gp.py:623-682, acfun.py:72-82) ------------
+def test_svd_nll_and_gp_stats_vs_oracle(gpu_ctx):
+  defs, _, _, gp, kernel, mean, objectives, utils = _native()
+  import functools
+  rng = np.random.default_rng(21)
+  d = 3
+  model = helpers.make_model(rng, 'linear', False, d)
+  po, pn = _pair(model)
+  dso = {'a': o.SubDataset(*helpers.synthetic_task(rng, 70, d)), 'b': o.SubDataset(*helpers.synthetic_task(rng, 33, d, m=3)),
+         'al': o.SubDataset(*helpers.synthetic_task(rng, 40, d, m=6), aligned=1), 'e': o.SubDataset(np.zeros((0, d)), np.zeros((0, 1)))}
+  dsn = {k: defs.SubDataset(v.x, v.y, v.aligned) for k, v in dso.items()}
+  wf = utils.DEFAULT_WARP_FUNC
+  for exclude in (True, False):
+    vo, ko = o.neg_log_marginal_likelihood(o.linear, o.matern32, po, dso, WFO, exclude_aligned=exclude, return_key2nll=True, use_cholesky=False)
+    vn, kn = objectives.neg_log_marginal_likelihood(mean.linear, kernel.matern32, pn, dsn, wf, exclude_aligned=exclude,
+                                                    return_key2nll=True, use_cholesky=False)
+    assert set(kn) == set(ko) and abs(vn - vo) <= 1e-9 * abs(vo)
+    for k in ko:
+      assert abs(kn[k] - ko[k]) <= 1e-9 * abs(ko[k])
+    vc = objectives.neg_log_marginal_likelihood(mean.linear, kernel.matern32, pn, dsn, wf, exclude_aligned=exclude)
+    assert abs(vn / vc - 1) < 1e-6                      # objectives_test.py:168: SVD and Cholesky variants agree
+  m = gp.GP(dsn, mean.linear, kernel.matern32, pn, wf)
+  nll, key2nll = m.neg_log_marginal_likelihood()       # the reference's SVD variant (gp.py:487-497)
+  vo, _ = o.neg_log_marginal_likelihood(o.linear, o.matern32, po, dso, WFO, return_key2nll=True, use_cholesky=False)
+  assert abs(nll - vo) <= 1e-9 * abs(vo) and set(key2nll) == {'a', 'b'}
+  nll_s, ekl, ekl_partial, euc, k2 = m.stats(verbose=False)
+  assert nll_s == nll and k2 == key2nll
+  kl_full = functools.partial(o.kl_multivariate_normal, eps=1e-6, partial=False)
+  kl_part = functools.partial(o.kl_multivariate_normal, eps=1e-6, partial=True)
+  assert abs(ekl - o.multivariate_normal_divergence(o.linear, o.matern32, po, dso, WFO, distance=kl_full)) <= 1e-7 * abs(ekl)
+  assert abs(ekl_partial - o.multivariate_normal_divergence(o.linear, o.matern32, po, dso, WFO, distance=kl_part)) <= 1e-8 * abs(ekl_partial)
+  assert abs(euc - o.multivariate_normal_divergence(o.linear, o.matern32, po, dso, WFO, distance=o.euclidean_multivariate_normal)) <= 1e-9 * abs(euc)
+  # a numerically singular covariance: Cholesky reports NaN, the SVD variant stays finite (why the reference has it)
+  xr = np.repeat(rng.uniform(size=(5, d)), 30, axis=0)
+  sing = {0: defs.SubDataset(xr, np.sin(xr[:, :1]))}
+  pz = defs.GPParams(model={'dot_prod_sigma': np.array(1.0), 'dot_prod_bias': np.array(0.0), 'noise_variance': np.array(-1e-6)})
+  assert np.isnan(objectives.neg_log_marginal_likelihood(mean.zero, kernel.dot_product, pz, sing))
+  vs = objectives.neg_log_marginal_likelihood(mean.zero, kernel.dot_product, pz, sing, use_cholesky=False)
+  vso = o.neg_log_marginal_likelihood(o.zero, o.dot_product, o.GPParams(model=pz.model), {0: o.SubDataset(xr, np.sin(xr[:, :1]))}, use_cholesky=False)
+  assert (np.isfinite(vs) and abs(vs - vso) <= 1e-6 * abs(vso)) or (np.isnan(vs) and np.isnan(vso)) or (np.isinf(vs) and np.isinf(vso))
+
+
+def test_hgp_acquisition_is_mean_over_parameter_samples(gpu_ctx):
+  defs, _, acfun, gp, kernel, mean, _, utils = _native()
+  rng = np.random.default_rng(22)
+  d = 3
+  samples = [helpers.make_model(np.random.default_rng(100 + i), 'constant', False, d) for i in range(3)]
+  x, y = helpers.synthetic_task(rng, 90, d)
+  x2, y2 = helpers.synthetic_task(rng, 50, d)
+  xq = rng.uniform(size=(37, d))
+  wf = utils.DEFAULT_WARP_FUNC
+  dsn = {0: defs.SubDataset(x, y), 1: defs.SubDataset(x2, y2)}
+  dso = {0: o.SubDataset(x, y), 1: o.SubDataset(x2, y2)}
+  hgp = gp.HGP(dsn, mean.constant, kernel.matern52, defs.GPParams(model=samples[0], samples=samples), wf)
+  assert hgp.get_model_params_samples() is samples
+  preds = hgp.predict(xq, sub_dataset_key=0)
+  assert len(preds) == 3
+  refs = []
+  for smp, (mu_n, var_n) in zip(samples, preds):
+    po = o.GPParams(model=smp)
+    mu, var = o.predict(o.constant, o.matern52, po, x, y, xq, WFO)
+    mu, var = o.gp_predict_postprocess(po, dso, mu, var, WFO, False, True, True)
+    assert helpers.rel_err(mu_n, mu) < 1e-9 and helpers.rel_err(var_n, var) < 1e-8
+    refs.append((mu, var))
+  target = float(np.max(y))
+  for fn, sub, prm in ((acfun.expected_improvement, o.expected_improvement_sub, target),
+                       (acfun.probability_of_improvement, o.probability_of_improvement_sub, target + 0.1),
+                       (acfun.ucb, o.ucb_sub, 3.0)):
+    got = fn(model=hgp, sub_dataset_key=0, x_queries=xq)
+    want = np.mean([sub(mu, np.sqrt(var), prm) for mu, var in refs], axis=0)      # acfun.py:72-82
+    assert got.shape == (37, 1) and helpers.rel_err(got, want) < 1e-7
+  # no samples: HGP degenerates to the single model (gp.py:627-631)
+  single = gp.HGP(dsn, mean.constant, kernel.matern52, defs.GPParams(model=samples[1]), wf)
+  plain = gp.GP(dsn, mean.constant, kernel.matern52, defs.GPParams(model=samples[1]), wf)
+  np.testing.assert_allclose(acfun.ucb(model=single, sub_dataset_key=0, x_queries=xq), acfun.ucb(model=plain, sub_dataset_key=0, x_queries=xq), rtol=1e-12)
+  st = hgp.stats(verbose=False)
+  assert np.isfinite(st[0]) and set(st[4]) == {0, 1}
+
+
+def test_empty_task_shard_builds_the_same_model_and_contributes_zeros(gpu_ctx):
+  """A rank beyond the task count holds an empty shard (parallel.shard_dataset): it must build the peers' model (ARD
+  lengthscale / linear mean / MLP with D > 1) and reach the all-reduce with zeros of the right layout."""
+  from hyperbo_amd import parallel
+  defs, _, _, _, kernel, mean, objectives, utils = _native()
+  rng = np.random.default_rng(23)
+  d = 4
+  full = {0: defs.SubDataset(*helpers.synthetic_task(rng, 50, d))}
+  assert parallel.shard_dataset(full, 1, 2) == {}
+
+  class Recorder(parallel.LocalComm):
+    def allreduce_sum(self, buf):
+      self.buf = np.array(buf)
+      return buf
+  for mname, kname, mlp in (('constant', 'squared_exponential', False), ('linear', 'matern32', False), ('linear_mlp', 'matern52', True)):
+    model = helpers.make_model(rng, mname, mlp, d)
+    pn = defs.GPParams(model=model, config={'mlp_features': helpers.MLP_FEATURES})
+    kn = getattr(kernel, kname + ('_mlp' if mlp else ''))
+    comm = Recorder()
+    v, g = objectives.nll_value_and_grad(getattr(mean, mname), kn, pn, {}, utils.DEFAULT_WARP_FUNC, comm=comm)
+    _, gfull = objectives.nll_value_and_grad(getattr(mean, mname), kn, pn, full, utils.DEFAULT_WARP_FUNC, comm=Recorder())
+    assert v == 0.0 and np.all(comm.buf == 0) and helpers.flatten(g).size == helpers.flatten(gfull).size
+
+
+def test_cached_cholesky_path_of_inverse_spdmatrix_vector_product(gpu_ctx):
+  _, linalg, *_ = _native()
+  rng = np.random.default_rng(24)
+  a = rng.normal(size=(60, 60)); a = a @ a.T + 60 * np.eye(60)
+  v = rng.normal(size=(60, 1))
+  chol, x0 = linalg.solve_linear_system(a, v)
+  x1 = linalg.inverse_spdmatrix_vector_product(a, v, cached_cholesky=chol)
+  np.testing.assert_allclose(x1, x0, rtol=1e-10)
+  np.testing.assert_allclose(a @ x1, v, rtol=1e-9, atol=1e-10)
 
 
 # ---- divergence objectives (objectives.py:29-106): EKL / Euclid on the device vs the oracle ------------------
