@@ -23,12 +23,15 @@ struct hbo_ctx {
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;   // panel stream of the look-ahead Cholesky (high priority)
   hipStream_t stream4 = nullptr;   // early part of trtri, overlapped with the tail of potrf
-  int opt_cu_yield = 1;      // GEMM workgroups pause while potf2 runs on their CU (single matrix, look-ahead)
-  int* d_yield = nullptr;    // the flag: cu_token() of the CU potf2 is on, or 0
+  int opt_cu_yield = 2;      // background GEMM workgroups pause while a panel-chain workgroup runs on their CU (single matrix,
+                             // look-ahead): 1 = potf2 only, 2 = trsm and the chain's column updates too
+  int* d_yield = nullptr;    // per-CU table (cu_token() -> panel-chain workgroups running there)
   int* gemm_yield = nullptr; // run_potrf -> trtri_level: GemmArgs::yield_flag of the launches that co-run with the panel chain
   int opt_trtri_gran = 0;    // panels between two launches of the inverse's computable pieces during the factorisation (0: auto)
   int opt_small_nblk = 32;   // matrices up to this many 128-blocks use 64x64 GEMM tiles in trtri / lauum
   int opt_persist_free = -1; // bulk trailing update runs as 2*(CUs - this) persistent workgroups (-1: auto, see run_potrf)
+  int opt_trtri_at = 0;        // single matrix: panel count (in 64ths of the block count) after which the inverse starts beside the chain (0: 13/16)
+  int opt_trtri_small_wgs = 2; // ... and workgroups per CU of their 64-tile form
   int opt_trtri_free = 48;   // CUs the inverse products that co-run with the panel chain leave free (0: one tile per workgroup)
   int* trtri_counters = nullptr; int trtri_counter_next = 0;   // run_potrf -> trtri_level: tile counters of those launches
   int n_cus = 256;
@@ -168,8 +171,8 @@ extern "C" int hbo_ctx_create(int device, hbo_ctx** out) {
   if (e == hipSuccess) e = hipStreamCreate(&c->stream2);
   if (e == hipSuccess) e = hipStreamCreate(&c->stream4);
   if (e == hipSuccess) e = hipMalloc((void**)&c->d_model, sizeof(ModelDev));
-  if (e == hipSuccess) e = hipMalloc((void**)&c->d_yield, 64);
-  if (e == hipSuccess) e = hipMemset(c->d_yield, 0, 64);
+  if (e == hipSuccess) e = hipMalloc((void**)&c->d_yield, sizeof(int) * HBO_YIELD_TAB_ENTRIES);
+  if (e == hipSuccess) e = hipMemset(c->d_yield, 0, sizeof(int) * HBO_YIELD_TAB_ENTRIES);
   if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_model, sizeof(ModelDev), hipHostMallocDefault);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_upload, hipEventDisableTiming);
   if (e != hipSuccess) {
@@ -210,9 +213,11 @@ extern "C" int hbo_set_option(hbo_ctx* c, const char* name, int64_t value) {
   if (!strcmp(name, "dynamic_tiles")) { c->opt_dynamic_tiles = value ? 1 : 0; return HBO_OK; }
   if (!strcmp(name, "f1_on_chain")) { c->opt_f1_on_chain = value ? 1 : 0; return HBO_OK; }
   if (!strcmp(name, "lookahead")) { c->opt_lookahead = value ? 1 : 0; return HBO_OK; }
-  if (!strcmp(name, "cu_yield")) { c->opt_cu_yield = value ? 1 : 0; return HBO_OK; }
+  if (!strcmp(name, "cu_yield")) { if (value < 0 || value > 2) return fail(c, HBO_ERR_ARG, "cu_yield in 0..2"); c->opt_cu_yield = (int)value; return HBO_OK; }
   if (!strcmp(name, "trtri_gran")) { if (value < 0) return fail(c, HBO_ERR_ARG, "trtri_gran >= 0"); c->opt_trtri_gran = (int)value; return HBO_OK; }
   if (!strcmp(name, "small_nblk")) { c->opt_small_nblk = (int)value; return HBO_OK; }
+  if (!strcmp(name, "trtri_at")) { if (value < 0 || value > 63) return fail(c, HBO_ERR_ARG, "trtri_at in 0..63"); c->opt_trtri_at = (int)value; return HBO_OK; }
+  if (!strcmp(name, "trtri_small_wgs")) { if (value < 1 || value > 4) return fail(c, HBO_ERR_ARG, "trtri_small_wgs in 1..4"); c->opt_trtri_small_wgs = (int)value; return HBO_OK; }
   if (!strcmp(name, "trtri_free")) { if (value < 0 || value > 200) return fail(c, HBO_ERR_ARG, "trtri_free in 0..200"); c->opt_trtri_free = (int)value; return HBO_OK; }
   if (!strcmp(name, "persist_free")) { if (value < -1 || value > 200) return fail(c, HBO_ERR_ARG, "persist_free in -1..200 (-1: auto)"); c->opt_persist_free = (int)value; return HBO_OK; }
   return fail(c, HBO_ERR_ARG, std::string("unknown option ") + name);
@@ -397,7 +402,8 @@ static void run_potrf(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks
   const bool small_mat = max_nblk <= 96;
   const int q = c->opt_group > 0 ? c->opt_group : (small_mat ? 3 : 4);
   //   with the CU yield (below): N = 8192 (3, 64) 12.58, (3, 48) 12.52, (3, 32) 12.61, (3, 16) 13.24, (4, 48) 12.66
-  const int persist_free = c->opt_persist_free >= 0 ? c->opt_persist_free : (small_mat ? 48 : 32);
+  //   round 2 (chain kernels mark their CUs, background workgroups there pause): 32 beats 48 at N = 8192 (11.73 / 11.81)
+  const int persist_free = c->opt_persist_free >= 0 ? c->opt_persist_free : 32;
   hipStream_t sm = c->stream;
   // (a single block column has no trailing matrix to look ahead over: it stays on the caller's stream)
   const bool la = c->opt_lookahead != 0 && max_nblk > 1;
@@ -415,11 +421,19 @@ static void run_potrf(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks
   int early_at = -1;   // single-task form: the one panel count after which the side stream gets its work
   if (tgran <= 0) {
     tgran = 4;
-    if (ntasks == 1) { early_at = (max_nblk * 13 / 16) & ~3; if (early_at < 4) early_at = -1; tgran = 1 << 30; }
+    if (ntasks == 1) {
+      // (round 2, with the persistent / yielding forms of the co-running products -- they no longer stall the chain --
+      //  N = 8192, (start after panel, CUs left free by the inverse, by the bulk update): (40, 48, 32) 11.73 ms,
+      //  (36, 64, 32) 11.74, (40, 32, 32) 11.80, (44, 48, 32) 11.92, (52, 16, 48) 12.27, (48, 96, 32) 12.37)
+      early_at = c->opt_trtri_at > 0 ? std::min(c->opt_trtri_at * max_nblk / 64, max_nblk - 1) : (max_nblk * 5 / 8) & ~3;
+      if (early_at < 4) early_at = -1;
+      tgran = 1 << 30;
+    }
   }
   // (up to 96 blocks: N = 4096 3.37 -> 3.29 ms, N = 8192 12.61 -> 12.52; N = 16384 loses 0.9 % to the polling)
   int* const yield_flag = (la && ntasks == 1 && c->opt_cu_yield && small_mat) ? c->d_yield : nullptr;
-  if (yield_flag) hipMemsetAsync(yield_flag, 0, sizeof(int), sm);
+  if (yield_flag) hipMemsetAsync(yield_flag, 0, sizeof(int) * HBO_YIELD_TAB_ENTRIES, sm);
+  int* const chain_mark = (yield_flag && c->opt_cu_yield >= 2) ? yield_flag : nullptr;   // the chain's wide kernels mark their CUs too
   c->gemm_yield = yield_flag;
   // one tile counter per bulk launch (dynamic tile assignment of the persistent form), zeroed up front
   int* counters = c->opt_dynamic_tiles ? (int*)ws_get(c, WS_COUNTERS, sizeof(int) * 256) : nullptr;
@@ -435,10 +449,11 @@ static void run_potrf(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks
       if (p > g0) {  // left-looking update of block column p with the group's earlier panels
         ProfScope ps(c, "syrk_col", 2, sp);
         GemmArgs a = {}; a.tasks = d_tasks; a.mode = GEMM_SYRK; a.p0 = g0; a.kt = p - g0; a.c_lo = p; a.c_hi = p + 1; a.aug = 1; a.small_tiles = 1;
+        a.yield_mark = chain_mark;
         launch_gemm(dtype, a, dim3(max_nblk + 1 - p, 1, ntasks), sp);
       }
       { ProfScope ps(c, "potf2", 2, sp); launch_potf2(dtype, d_tasks, ntasks, p, d_info, sp, yield_flag); }
-      { ProfScope ps(c, "trsm", 2, sp); launch_trsm(dtype, d_tasks, ntasks, p, max_nblk, sp); }
+      { ProfScope ps(c, "trsm", 2, sp); launch_trsm(dtype, d_tasks, ntasks, p, max_nblk, sp, chain_mark); }
       if (early && ((p + 1) % tgran == 0 || p + 1 == early_at) && p + 1 < max_nblk) {
         // block columns 0..p of L are final: everything of the inverse that only needs them goes to a side stream
         // (the panel chain leaves most of the machine idle in the second half of the factorisation)
@@ -456,8 +471,10 @@ static void run_potrf(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks
     if (la && s1 == sm) { hipEvent_t e = pool_event(c, evi++); hipEventRecord(e, sp); hipStreamWaitEvent(sm, e, 0); }
     if (g1 < max_nblk) {
       GemmArgs a = {}; a.tasks = d_tasks; a.mode = GEMM_SYRK; a.p0 = g0; a.kt = g1 - g0; a.aug = 1;
-      a.yield_flag = yield_flag;   // (F1 itself never meets potf2 -- same stream -- but the bulk update does)
       {
+        // F1 is a chain kernel when it runs on the panel stream: it marks its CUs instead of polling
+        a.yield_flag = (la && c->opt_f1_on_chain && chain_mark) ? nullptr : yield_flag;
+        a.yield_mark = (la && c->opt_f1_on_chain) ? chain_mark : nullptr;
         if (s1 == sp && ev_f2) hipStreamWaitEvent(sp, ev_f2, 0);
         ProfScope ps(c, "syrk_trailing", 1, s1);
         a.c_lo = g1; a.c_hi = la ? g2 : max_nblk;
@@ -474,6 +491,7 @@ static void run_potrf(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks
           // must precede F1(g+1)/F2(g+1) which accumulate into the same tiles)
           if (ev_f1) hipStreamWaitEvent(sb, ev_f1, 0);
           {
+            a.yield_flag = yield_flag; a.yield_mark = nullptr;   // the bulk update is background work
             a.c_lo = g2; a.c_hi = max_nblk;
             const int64_t m = max_nblk - g2;
             a.small_tiles = m * (m + 1) / 2 * ntasks < 600;
@@ -518,8 +536,13 @@ static void trtri_level(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntas
   a.yield_flag = (st == c->stream4) ? c->gemm_yield : nullptr;
   // products that co-run with the panel chain (single matrix, side stream): persistent, 2 workgroups on all but
   // `trtri_free` CUs, tiles from a counter -- see gemm_kernel
-  const bool corun = st == c->stream4 && ntasks == 1 && !a.small_tiles && c->opt_trtri_free > 0 && c->trtri_counters;
-  const int pblocks = 2 * (c->n_cus - c->opt_trtri_free);
+  const bool corun = st == c->stream4 && ntasks == 1 && c->opt_trtri_free > 0 && c->trtri_counters;
+  // The dispatcher spreads a grid over the CUs breadth-first, so "free CUs" really means free room on every CU: a panel
+  // kernel (potf2 78 KB, trsm 87 KB of LDS, 128 VGPRs) fits beside ONE 128-tile workgroup (72 KB) or TWO 64-tile
+  // workgroups (2 x 40 KB), not beside more -- with 4 x (CUs - free) 64-tile workgroups every CU held three or four of
+  // them and potf2 waited 330 us for the whole launch to end (rocprofv3 kernel trace, profiles/r02_potrf_chain.md)
+  const int pblocks = (a.small_tiles ? c->opt_trtri_small_wgs : 2) * (c->n_cus - c->opt_trtri_free);
+  const int tmul = a.small_tiles ? 4 : 1;
   ProfScope ps(c, "trtri_gemm", 2, st);
   // Rows of the last group's lower half that exist in the largest task: workgroups beyond them would be dispatched
   // only to exit, which is not free (56 ns each: at the top level of a batch of 64 matrices of <= 19 blocks, 13 of
@@ -532,12 +555,12 @@ static void trtri_level(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntas
     a.persistent = 0; a.work_counter = nullptr;
     if (corun && tiles > pblocks && c->trtri_counter_next < 128) { a.persistent = pblocks; a.work_counter = c->trtri_counters + c->trtri_counter_next++; }
   };
-  if (do_a && xa > 0) { a.mode = GEMM_TRTRI_A; persist((int64_t)xa * s); launch_gemm(dtype, a, dim3(xa, s, ntasks), st); }
+  if (do_a && xa > 0) { a.mode = GEMM_TRTRI_A; persist((int64_t)xa * s * tmul); launch_gemm(dtype, a, dim3(xa, s, ntasks), st); }
   if (do_b) {
     a.mode = GEMM_TRTRI_B;
     const int vy = ngroups == 1 ? vlast : s;
     a.kt = vy;   // valid tile rows when there is a single group (blockIdx.y counts down from them)
-    persist((int64_t)ngroups * s * vy);
+    persist((int64_t)ngroups * s * vy * tmul);
     launch_gemm(dtype, a, dim3(ngroups * s, vy, ntasks), st);
   }
 }

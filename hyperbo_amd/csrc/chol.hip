@@ -352,13 +352,15 @@ __global__ __launch_bounds__(256) void potf2_kernel(const TaskDesc* tasks, int p
   __builtin_amdgcn_s_setprio(3);            // critical path: outrank co-resident GEMM waves
   const TaskDesc& t = tasks[blockIdx.x];
   if (p >= t.nblk) return;
-  // single matrix: name this CU in the yield flag -- GEMM workgroups that share it pause at their next K step (potf2's
-  // small MFMAs queue behind their 64-cycle ones and its LDS traffic behind theirs: 50 us beside them, 22 us alone)
-  if (yield_flag && threadIdx.x == 0) __hip_atomic_store(yield_flag, cu_token(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // single matrix: count this workgroup into the yield table entry of its CU -- background GEMM workgroups that share the
+  // CU pause at their next K step (potf2's small MFMAs queue behind their 64-cycle ones and its LDS traffic behind theirs:
+  // 50 us beside them, 22 us alone)
+  int tok = 0;
+  if (yield_flag && threadIdx.x == 0) tok = yield_enter(yield_flag);
   potf2_body<T>(t, p, info + blockIdx.x, smem);
   if (yield_flag) {
     __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_store(yield_flag, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) yield_leave(yield_flag, tok);
   }
 }
 
@@ -472,7 +474,7 @@ __device__ __forceinline__ void trsm_body(const TaskDesc& t, int p, int64_t row0
   }
 }
 template <typename T, bool IDENT>
-__global__ __launch_bounds__(256) void trsm_kernel(const TaskDesc* tasks, int p_arg) {
+__global__ __launch_bounds__(256) void trsm_kernel(const TaskDesc* tasks, int p_arg, int* yield_tab) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __builtin_amdgcn_s_setprio(3);                // critical path: outrank co-resident GEMM waves
   const TaskDesc& t = tasks[blockIdx.z];
@@ -499,7 +501,13 @@ __global__ __launch_bounds__(256) void trsm_kernel(const TaskDesc* tasks, int p_
     if (bx * 64 >= nrows) return;
     row0 = first + bx * 64;
   }
+  int tok = 0;
+  if (yield_tab && threadIdx.x == 0) tok = yield_enter(yield_tab);
   trsm_body<T, IDENT>(t, p, row0, smem, true);
+  if (yield_tab) {
+    __syncthreads();
+    if (threadIdx.x == 0) yield_leave(yield_tab, tok);
+  }
 #ifdef HBO_POTF2_TIMING
   if (dbg) hbo_dbg_trsm[3 * blockIdx.x + 1] = wall_clock64();
 #endif
@@ -526,19 +534,19 @@ void potf2_t(const TaskDesc* tasks, int ntasks, int p, int* info, hipStream_t st
                      ntasks == 1 ? yield_flag : nullptr);
 }
 template <typename T>
-void trsm_t(const TaskDesc* tasks, int ntasks, int p, int max_nblk, hipStream_t st) {
+void trsm_t(const TaskDesc* tasks, int ntasks, int p, int max_nblk, hipStream_t st, int* yield_tab) {
   set_attrs<T>();
   const int nrows = (max_nblk + 1 - (p + 1)) * NB;
   if (nrows <= 0) return;
   hipLaunchKernelGGL((trsm_kernel<T, false>), dim3(nrows / 64, 1, ntasks), dim3(256), trsm_lds_bytes<T>(), st,
-                     tasks, p);
+                     tasks, p, ntasks == 1 ? yield_tab : nullptr);
 }
 template <typename T>
 void trtri_diag_t(const TaskDesc* tasks, int ntasks, int p_lo, int p_hi, hipStream_t st) {
   set_attrs<T>();
   if (p_hi <= p_lo) return;
   hipLaunchKernelGGL((trsm_kernel<T, true>), dim3(2, p_hi - p_lo, ntasks), dim3(256), trsm_lds_bytes<T>(), st,
-                     tasks, p_lo);
+                     tasks, p_lo, (int*)nullptr);
 }
 
 #endif  // HBO_DEVICE_ONLY
@@ -557,9 +565,9 @@ void launch_potf2(int dtype, const TaskDesc* tasks, int ntasks, int p, int* info
   if (dtype == HBO_F64) potf2_t<double>(tasks, ntasks, p, info, st, yield_flag);
   else potf2_t<float>(tasks, ntasks, p, info, st, yield_flag);
 }
-void launch_trsm(int dtype, const TaskDesc* tasks, int ntasks, int p, int max_nblk, hipStream_t st) {
-  if (dtype == HBO_F64) trsm_t<double>(tasks, ntasks, p, max_nblk, st);
-  else trsm_t<float>(tasks, ntasks, p, max_nblk, st);
+void launch_trsm(int dtype, const TaskDesc* tasks, int ntasks, int p, int max_nblk, hipStream_t st, int* yield_tab) {
+  if (dtype == HBO_F64) trsm_t<double>(tasks, ntasks, p, max_nblk, st, yield_tab);
+  else trsm_t<float>(tasks, ntasks, p, max_nblk, st, yield_tab);
 }
 void launch_trtri_diag(int dtype, const TaskDesc* tasks, int ntasks, int p_lo, int p_hi, hipStream_t st) {
   if (dtype == HBO_F64) trtri_diag_t<double>(tasks, ntasks, p_lo, p_hi, st);

@@ -297,8 +297,8 @@ __device__ __forceinline__ void gemm_tile(const TileJob<T>& job, unsigned char* 
   const int my_cu = job.yield_flag ? cu_token() : 0;
   for (int kt = 0; kt < nk; ++kt) {
     if (job.yield_flag) {
-      // the panel kernel potf2 is running on this CU: stay off its MFMA / LDS paths until it is done (bounded wait)
-      for (int spin = 0; spin < 256 && __hip_atomic_load(job.yield_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == my_cu; ++spin)
+      // a panel-chain workgroup is running on this CU: stay off its MFMA / LDS paths until it is done (bounded wait)
+      for (int spin = 0; spin < 256 && __hip_atomic_load(job.yield_flag + my_cu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0; ++spin)
         __builtin_amdgcn_s_sleep(16);
     }
     const T* cA = (kt & 1) ? sA1 : sA0;
@@ -465,7 +465,13 @@ __global__ __launch_bounds__(256, TM == 64 ? 4 : 2) void gemm_kernel(GemmArgs g)
     return;
   }
   if (!decode_job<T, TM>(g, job, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x)) return;
+  int ytok = 0;
+  if (g.yield_mark && threadIdx.x == 0) ytok = yield_enter(g.yield_mark);
   gemm_tile<T, AKC, BKC, TM>(job, smem);
+  if (g.yield_mark) {
+    __syncthreads();
+    if (threadIdx.x == 0) yield_leave(g.yield_mark, ytok);
+  }
 #ifdef HBO_GEMM_TIMING
   if (dbg) { hbo_dbg_gemm[4 * dbg_id + 1] = wall_clock64(); hbo_dbg_gemm[4 * dbg_id + 3] = (unsigned long long)job.ksteps; }
 #endif
@@ -476,7 +482,7 @@ template <typename T>
 void launch_gemm_t(const GemmArgs& a_in, dim3 grid, hipStream_t st) {
   GemmArgs a = a_in;
   // the persistent forms: SYRK (any tile size), TRTRI on 128-tiles of a single matrix with a tile counter
-  if (a.mode != GEMM_SYRK && !((a.mode == GEMM_TRTRI_A || a.mode == GEMM_TRTRI_B) && !a.small_tiles && a.work_counter && grid.z == 1))
+  if (a.mode != GEMM_SYRK && !((a.mode == GEMM_TRTRI_A || a.mode == GEMM_TRTRI_B) && a.work_counter && grid.z == 1))
     a.persistent = 0;
   static bool attr_set = false;
   if (!attr_set) {
@@ -505,15 +511,17 @@ void launch_gemm_t(const GemmArgs& a_in, dim3 grid, hipStream_t st) {
       break;
     case GEMM_TRTRI_A:
     case GEMM_TRTRI_B:
-      if (a.small_tiles) {
+      if (a.small_tiles && a.persistent > 0) {
+        GemmArgs b = a; b.pgx = (int)grid.x * 2; b.pgy = (int)grid.y * 2;
+        hipLaunchKernelGGL((gemm_kernel<T, true, false, 64>), dim3(a.persistent, 1, 1), dim3(256), GEMM_LDS_BYTES_64, st, b);
+      } else if (a.small_tiles) {
         dim3 g2(grid.x * 2, grid.y * 2, grid.z);
         hipLaunchKernelGGL((gemm_kernel<T, true, false, 64>), g2, dim3(256), GEMM_LDS_BYTES_64, st, a);
-      } else if (a.persistent > 0 && a.work_counter && grid.z == 1) {
+      } else if (a.persistent > 0) {
         GemmArgs b = a; b.pgx = (int)grid.x; b.pgy = (int)grid.y;
         hipLaunchKernelGGL((gemm_kernel<T, true, false, 128>), dim3(a.persistent, 1, 1), dim3(256), GEMM_LDS_BYTES, st, b);
       } else {
-        GemmArgs b = a; b.persistent = 0;
-        hipLaunchKernelGGL((gemm_kernel<T, true, false, 128>), grid, dim3(256), GEMM_LDS_BYTES, st, b);
+        hipLaunchKernelGGL((gemm_kernel<T, true, false, 128>), grid, dim3(256), GEMM_LDS_BYTES, st, a);
       }
       break;
     case GEMM_POST:

@@ -74,8 +74,10 @@ struct GemmArgs {
   int* work_counter; // persistent SYRK: zero-initialised tile counter -> workgroups draw tiles dynamically (a faster
                      // workgroup takes more of them) instead of striding over them; null: static stride
   int dbg;          // HBO_GEMM_TIMING builds: 1 -> this launch records per-workgroup wall-clock stamps
-  int* yield_flag;  // non-null: a workgroup sleeps at a K step while *yield_flag names the CU it runs on (cu_token(): the
-                    // single-workgroup panel kernel potf2 is running there and would otherwise share MFMA / LDS with it)
+  int* yield_flag;  // non-null (background launches: bulk update, overlapped inverse): per-CU table indexed by cu_token(); a
+                    // workgroup sleeps at a K step while the entry of the CU it runs on is non-zero -- a panel-chain kernel
+                    // (potf2, trsm, the chain's column updates) is running there and would otherwise share MFMA / LDS with it
+  int* yield_mark;  // non-null (launches ON the panel chain): the same table; every workgroup counts itself in and out
   int grp_lo;       // TRTRI: first group (of size 2s blocks) handled by this launch
   void* B;       // POST: Kxq (npad x ldb)
   int64_t ldb;
@@ -84,11 +86,21 @@ struct GemmArgs {
 };
 
 #ifdef __HIPCC__
+#define HBO_YIELD_TAB_ENTRIES 4224   // cu_token() < 4097
 // identity of the CU a wave runs on: XCC_ID[3:0] and HW_ID[15:8] (cu, sh, se), never 0
 __device__ __forceinline__ int cu_token() {
   const unsigned xcc = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11));
   const unsigned hw = __builtin_amdgcn_s_getreg((4 << 0) | (8 << 6) | (7 << 11));   // HW_ID bits [15:8]
   return (int)(((xcc & 15u) << 8) | (hw & 255u)) + 1;
+}
+// a panel-chain workgroup announces itself on its CU (background GEMM workgroups there pause, see GemmArgs::yield_flag)
+__device__ __forceinline__ int yield_enter(int* tab) {
+  const int tok = cu_token();
+  __hip_atomic_fetch_add(tab + tok, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  return tok;
+}
+__device__ __forceinline__ void yield_leave(int* tab, int tok) {
+  __hip_atomic_fetch_add(tab + tok, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 #endif
 
@@ -96,7 +108,7 @@ __device__ __forceinline__ int cu_token() {
 void launch_gemm(int dtype, const GemmArgs& a, dim3 grid, hipStream_t st);
 
 void launch_potf2(int dtype, const TaskDesc* tasks, int ntasks, int p, int* info, hipStream_t st, int* yield_flag = nullptr);
-void launch_trsm(int dtype, const TaskDesc* tasks, int ntasks, int p, int max_nblk, hipStream_t st);
+void launch_trsm(int dtype, const TaskDesc* tasks, int ntasks, int p, int max_nblk, hipStream_t st, int* yield_tab = nullptr);
 // inverses of the diagonal blocks p in [p_lo, p_hi)
 void launch_trtri_diag(int dtype, const TaskDesc* tasks, int ntasks, int p_lo, int p_hi, hipStream_t st);
 

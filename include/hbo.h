@@ -188,7 +188,10 @@ int hbo_profile_get(hbo_ctx* ctx, char names[][32], double* ms, int32_t* launche
  * (tools/ab_opt.py).  Unknown names are an error.
  *   potrf_group    0..8  128-wide panels per trailing update, K = 128*group (0 = auto: 3 up to 96 blocks, else 4)
  *   persist_free  -1..200 CUs the persistent bulk trailing update leaves to the panel chain (-1 = auto: 48 / 32)
- *   cu_yield       0/1   GEMM workgroups pause at a K step while the one-workgroup panel kernel runs on their CU
+ *   cu_yield       0..2  background GEMM workgroups (bulk update, overlapped inverse) pause at a K step while a panel-chain
+ *                        workgroup runs on their CU: 1 = potf2 only, 2 = trsm and the chain's column updates too
+ *   trtri_at       0..63 single matrix: the inverse starts beside the chain after this many 64ths of the panels (0 = auto)
+ *   trtri_small_wgs 1..4 workgroups per CU of the 64-tile form of the co-running inverse products
  *   lookahead      0/1   panel chain on its own stream, one group ahead of the bulk update
  *   f1_on_chain    0/1   next group's column update launched on the panel stream
  *   dynamic_tiles  0/1   persistent bulk update draws tiles from a counter
