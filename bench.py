@@ -1,6 +1,13 @@
 """bench.py -- headline benchmark of the MI355X-native HyperBO GP hot path.
 
-  python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W
+
+N > 1: one rank per GPU.  Launched by torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the env) the
+ranks find each other through hyperbo_amd.parallel.SocketGroup on a port derived from MASTER_PORT; launched plainly
+(`python bench.py --gpus 8`, no WORLD_SIZE) this process SPAWNS the N ranks itself (HBO_DEVICE = rank) and relays rank
+0's JSON line.  Either way the data path is torch-free: rendezvous / barrier / max-over-ranks over localhost sockets,
+the [nll, count, grad] all-reduce through libhbo's own RCCL binding (hbo_comm_*, xGMI).  HBO_BENCH_COMM=torch selects
+torch.distributed's nccl backend for the all-reduce instead (explicit fallback; torch is not imported otherwise).
 
 metric (BASELINE.json): GP NLL+grad evaluations/sec at N=8192, D=16, fp64  (configs[1]).
 A "step" is one NLL+gradient evaluation of a single-task SE-ARD GP (X, y resident in HBM; only the
@@ -9,12 +16,14 @@ At N>1 GPUs a single factorisation does not shard ("replicas only"): 
 its own evaluation stream (different theta -- line-search points / restarts) and `value` is the
 aggregate.  The task-sharded multi-task objective (configs[3]: 64 PD1-shaped sub-datasets, one
 RCCL all-reduce of [nll, grad] per evaluation) is timed in the same run and reported under
-"multitask".
+"multitask"; configs[2] (factor + EI over 65 536 candidates, fp32) and configs[4] (N=65 536 Gram + Cholesky) are
+timed on rank 0 at N=1 under "cfg3" / "cfg5".
 
 Extra objects on the JSON line:
-  roofline     -- the Cholesky trailing-update kernel (fp64 MFMA syrk): algorithmic flops per launch
-                  / HIP-event duration of those launches inside the timed region.
-  cpu_baseline -- oracle/cpu_baseline.py (NumPy/SciPy-LAPACK port, kind "port") on the host cores.
+  roofline       -- the Cholesky trailing-update kernel (fp64 MFMA syrk): algorithmic flops per launch
+                    / HIP-event duration of those launches inside the timed region.
+  roofline_potrf -- the WHOLE factorisation: N^3/3 flops / its HIP-event time (with the overlapped inverse beside it).
+  cpu_baseline   -- oracle/cpu_baseline.py (NumPy/SciPy-LAPACK port, kind "port") on the host cores.
 """
 import argparse
 import json
@@ -28,6 +37,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X datasheet; confirmed 77.1 by tools/mfma_probe.hip (64 cyc/instr)
+FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md
 
 
 def inv_softplus(v):
@@ -80,6 +90,99 @@ def bulk_update_flops(n, group):
   return out
 
 
+def spawn_ranks(n):
+  """`python bench.py --gpus N` without a launcher: start the N ranks (one per GPU, HBO_DEVICE = rank), pass our own
+  arguments through, relay rank 0's JSON line.  The ranks meet on a localhost port chosen here."""
+  import socket
+  import subprocess
+  import uuid
+  s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+  token = uuid.uuid4().hex
+  procs = []
+  for r in range(n):
+    env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), HBO_DEVICE=str(r),
+               HBO_BENCH_PORT=str(port), HBO_BENCH_TOKEN=token)
+    procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                  stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=(r == 0)))
+  out, _ = procs[0].communicate()
+  rcs = [p.wait() for p in procs]
+  sys.stdout.write(out)
+  sys.stdout.flush()
+  return max(abs(rc) for rc in rcs)
+
+
+def bench_cfg3(ctx):
+  """BASELINE.json configs[2]: Matern-5/2 on tanh-MLP(32->64) features + linear_mlp mean, N=16384, fp32: factor once,
+  EI over 65 536 candidates; stage times from HIP events (hbo_profile), wall times around the two calls."""
+  from hyperbo_amd.basics import definitions as defs
+  from hyperbo_amd.bo_utils import acfun
+  from hyperbo_amd.gp_utils import gp, kernel, mean, utils
+  rng = np.random.Generator(np.random.PCG64(3))
+  d, f, n, m = 32, 64, 16384, 65536
+  model = {'lengthscale': inv_softplus(np.ones(f)), 'signal_variance': inv_softplus(1.0), 'noise_variance': inv_softplus(1e-2),
+           'mlp_params': {'Dense_0': {'kernel': rng.normal(size=(d, f)) / np.sqrt(d), 'bias': np.zeros(f)}},
+           'linear_mean': {'kernel': rng.normal(size=(f, 1)) / np.sqrt(f), 'bias': np.zeros(1)}}
+  to32 = lambda t: {k: to32(v) for k, v in t.items()} if isinstance(t, dict) else np.asarray(t, dtype=np.float32)
+  x = rng.uniform(size=(n, d)).astype(np.float32)
+  y = (np.sin(x[:, :4].sum(axis=1, keepdims=True) * 2.0) + 0.1 * rng.normal(size=(n, 1))).astype(np.float32)
+  xq = rng.uniform(size=(m, d)).astype(np.float32)
+  g = gp.GP({0: defs.SubDataset(x, y)}, mean.linear_mlp, kernel.matern52_mlp,
+            defs.GPParams(model=to32(model), config={'mlp_features': (f,)}), utils.DEFAULT_WARP_FUNC)
+  ctx.profile_enable(1)
+  best = None
+  for _ in range(3):
+    g.update_model_params(g.params.model)        # drops the cache -> re-factorise
+    t0 = time.perf_counter(); g.setup_predictor(0); t1 = time.perf_counter()
+    pf = ctx.profile_get()
+    ei = acfun.expected_improvement(model=g, sub_dataset_key=0, x_queries=xq); t2 = time.perf_counter()
+    pe = ctx.profile_get()
+    cur = (t1 - t0, t2 - t1, pf, pe)
+    if best is None or cur[0] + cur[1] < best[0] + best[1]:
+      best = cur
+  ctx.profile_enable(0)
+  assert np.isfinite(ei).all() and (ei >= 0).all()
+  tf, te, pf, pe = best
+  post_ms = pe['post_gemm'][0]
+  post_tf = float(n) * n * m / (post_ms * 1e-3) / 1e12
+  return {'workload': 'cfg3: Matern-5/2 o tanh-MLP(32->64) + linear_mlp mean, N=16384, fp32, factor + EI over 65536 candidates',
+          'factor_ms': round(tf * 1e3, 2), 'potrf_ms': round(pf['potrf'][0], 2), 'trtri_ms': round(pf['trtri'][0], 2),
+          'ei_ms': round(te * 1e3, 2), 'post_gemm_ms': round(post_ms, 2), 'post_gemm_tflops': round(post_tf, 1),
+          'frac_fp32': round(post_tf / FP32_MFMA_PEAK_TFLOPS, 4), 'ei_flops': float(n) * n * m,
+          'note': 'wall times include the host<->device copies of x_query / EI; post_gemm = V = L^-1 Kxq on fp32 MFMA'}
+
+
+def bench_cfg5(ctx):
+  """BASELINE.json configs[4]: SE-ARD, N=65536, D=16, fp64: Gram (32 GiB) + blocked Cholesky (NLL value only)."""
+  from hyperbo_amd.basics import definitions as defs
+  from hyperbo_amd.gp_utils import kernel, mean, objectives, utils
+  n = 65536
+  x, y, raw = cfg2_inputs(seed=5, n=n)
+  raw['noise_variance'] = inv_softplus(1e-1)
+  dev = objectives.DeviceDataset({0: defs.SubDataset(x, y)})
+  ctx.set_option('potrf_group', 0)
+  ctx.profile_enable(1)
+  p = defs.GPParams(model=raw)
+  best = None
+  for _ in range(2):
+    t0 = time.perf_counter()
+    v = objectives.neg_log_marginal_likelihood(mean.constant, kernel.squared_exponential, p, dev, utils.DEFAULT_WARP_FUNC)
+    el = time.perf_counter() - t0
+    prof = ctx.profile_get()
+    if best is None or el < best[0]:
+      best = (el, prof, v)
+  ctx.profile_enable(0)
+  dev.close()
+  el, prof, v = best
+  assert np.isfinite(v)
+  potrf_s = prof['potrf'][0] * 1e-3
+  gram_ms = prof['gram'][0]
+  tf = float(n)**3 / 3 / potrf_s / 1e12
+  return {'workload': 'cfg5: SE-ARD N=65536 D=16 fp64, Gram (lower tiles, 17 GB written) + blocked Cholesky, NLL value',
+          'nll': float(v), 'total_s': round(el, 3), 'gram_ms': round(gram_ms, 2),
+          'gram_tbps': round(8.0 * n * (n + 1) / 2 / (gram_ms * 1e-3) / 1e12, 3), 'potrf_s': round(potrf_s, 4),
+          'potrf_tflops': round(tf, 2), 'frac': round(tf / FP64_MFMA_PEAK_TFLOPS, 4)}
+
+
 def main():
   ap = argparse.ArgumentParser()
   ap.add_argument('--gpus', type=int, default=1)
@@ -89,23 +192,36 @@ def main():
   ap.add_argument('--d', type=int, default=16)
   ap.add_argument('--no-cpu-baseline', action='store_true')
   ap.add_argument('--no-multitask', action='store_true')
+  ap.add_argument('--no-extra', action='store_true', help='skip the cfg3 / cfg5 legs')
   ap.add_argument('--cpu-evals', type=int, default=8)
   ap.add_argument('--secondary-timeout', type=float, default=420.0, help='seconds for the multitask + CPU legs')
   args = ap.parse_args()
 
+  if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+    return spawn_ranks(args.gpus)
+
+  # stdout carries ONE JSON line: librccl prints its version banner to fd 1 when the communicator is built, so fd 1 is
+  # pointed at stderr for the duration of the run and the line goes out through the saved descriptor
+  sys.stdout.flush()
+  json_fd = os.dup(1)
+  os.dup2(2, 1)
+
+  def emit(line):
+    os.write(json_fd, (json.dumps(line) + '\n').encode())
+
   rank = int(os.environ.get('RANK', '0'))
   world = int(os.environ.get('WORLD_SIZE', '1'))
-  local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+  local_rank = int(os.environ.get('LOCAL_RANK', str(rank)))
   os.environ.setdefault('HBO_DEVICE', str(local_rank))
-  dist = None
-  torch = None
+  pgroup = None
   if world > 1:
-    import torch
-    import torch.distributed as dist
-    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-    dist.init_process_group('gloo', rank=rank, world_size=world)   # rendezvous/barriers only
-    if torch.cuda.is_available():
-      torch.cuda.set_device(local_rank % torch.cuda.device_count())
+    from hyperbo_amd import parallel as _par
+    if 'HBO_BENCH_PORT' in os.environ:     # spawned by this script: the port is ours
+      pgroup = _par.SocketGroup(rank, world, int(os.environ['HBO_BENCH_PORT']), token=os.environ.get('HBO_BENCH_TOKEN', ''))
+    else:                                  # torch.distributed.run: MASTER_PORT belongs to the launcher, take one next to it
+      base = int(os.environ.get('MASTER_PORT', '29500')) + 1
+      pgroup = _par.SocketGroup(rank, world, base, addr=os.environ.get('MASTER_ADDR', '127.0.0.1'), scan=32,
+                               token=os.environ.get('TORCHELASTIC_RUN_ID', '') + ':' + os.environ.get('MASTER_PORT', ''))
 
   from hyperbo_amd import _native as nat
   from hyperbo_amd import parallel
@@ -120,17 +236,13 @@ def main():
   ctx.set_option('potrf_group', potrf_group)
 
   def sync():
-    if torch is not None and torch.cuda.is_available():
-      torch.cuda.synchronize()
-    if dist is not None:
-      dist.barrier()
+    # every libhbo entry point returns with its streams drained (hbo.h: calls are synchronous), so the device is
+    # idle here; the barrier lines the ranks up
+    if pgroup is not None:
+      pgroup.barrier()
 
   def max_over_ranks(t):
-    if dist is None:
-      return t
-    tt = torch.tensor([t], dtype=torch.float64)
-    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-    return float(tt.item())
+    return t if pgroup is None else pgroup.allreduce_max(t)
 
   # ---------------- headline: cfg 2 NLL+grad ------------------------------------------------
   x, y, raw = cfg2_inputs(n=args.n, d=args.d)
@@ -192,6 +304,16 @@ def main():
         roofline['traffic_note'] = 'bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024, profiles/r01_pmc_hbm.json'
   stages = {k: round(v[0] / stage_evals, 4) for k, v in stage_prof.items()}   # separate pass with all stage events on
   ctx.profile_enable(0)
+  roofline_potrf = None
+  if 'potrf' in stages and stages['potrf'] > 0:
+    fl_potrf = float(args.n)**3 / 3.0
+    tf = fl_potrf / (stages['potrf'] * 1e-3) / 1e12
+    roofline_potrf = {'bound': 'mfma', 'what': 'whole blocked Cholesky (panel chain + trailing updates), stage events, '
+                                                'with the overlapped part of the inverse running beside it',
+                      'flops': fl_potrf, 'ms': stages['potrf'], 'achieved': round(tf, 3), 'peak': FP64_MFMA_PEAK_TFLOPS,
+                      'unit': 'TFLOP/s', 'frac': round(tf / FP64_MFMA_PEAK_TFLOPS, 4)}
+
+  extra = {}
 
   def result_line(cpu, multitask):
     return {
@@ -206,7 +328,9 @@ def main():
         'stages_ms_per_step': stages,
         'stages_note': 'separate untimed pass of 3 evaluations with every stage bracketed by HIP events; the timed '
                        'region brackets only the roofline kernel (stage events cost 0.3 ms per evaluation)',
-        'roofline': roofline, 'cpu_baseline': cpu, 'multitask': multitask,
+        'torch_imported': 'torch' in sys.modules,
+        'roofline': roofline, 'roofline_potrf': roofline_potrf, 'cpu_baseline': cpu, 'multitask': multitask,
+        'cfg3': extra.get('cfg3'), 'cfg5': extra.get('cfg5'),
     }
 
   # The headline is measured; the secondary legs below must not be able to lose it: if they do not finish in time
@@ -215,7 +339,7 @@ def main():
   import threading
   def bail():
     if rank == 0:
-      print(json.dumps(result_line(None, {'error': f'secondary legs did not finish within {args.secondary_timeout} s'})), flush=True)
+      emit(result_line(None, {'error': f'secondary legs did not finish within {args.secondary_timeout} s'}))
     os._exit(0)
   watchdog = threading.Timer(args.secondary_timeout, bail)
   watchdog.daemon = True
@@ -223,6 +347,7 @@ def main():
 
   # ---------------- secondary: cfg 4 multi-task objective, task-sharded ----------------------
   multitask = None
+  comm = None
   if not args.no_multitask:
     data, raw4 = cfg4_inputs()
     full = {k: defs.SubDataset(xx, yy) for k, (xx, yy) in data.items()}
@@ -231,33 +356,32 @@ def main():
     comm = None
     comm_kind = 'none'
     if world > 1:
-      def bcast(b):
-        obj = [b]
-        dist.broadcast_object_list(obj, src=0)
-        return obj[0]
-      # the [nll, count, grad] all-reduce: RCCL through torch.distributed's own 'nccl' backend (the well-trodden path
-      # on ROCm; HBO_BENCH_COMM=libhbo selects libhbo's direct RCCL binding), gloo if no communicator can be built
-      pref = os.environ.get('HBO_BENCH_COMM', 'torch-nccl')
+      # the [nll, count, grad] all-reduce: libhbo's own RCCL binding (ncclAllReduce on the context's stream, xGMI),
+      # unique id broadcast over the socket group.  HBO_BENCH_COMM=torch: torch.distributed's nccl backend instead.
+      pref = os.environ.get('HBO_BENCH_COMM', 'rccl')
       try:
-        if pref == 'libhbo':
-          comm = parallel.RcclComm(ctx, rank, world, bcast)
-          comm_kind = 'rccl (libhbo, xGMI)'
-        else:
+        if pref == 'torch':
           import datetime
-          grp = dist.new_group(backend='nccl', timeout=datetime.timedelta(seconds=120))
-          comm = parallel.TorchDistComm(device=f'cuda:{local_rank % torch.cuda.device_count()}', group=grp)
-          comm.allreduce_sum(np.zeros(4))          # builds the communicator now; raises if it cannot
+          import torch
+          import torch.distributed as dist
+          os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+          os.environ.setdefault('MASTER_PORT', str(int(os.environ.get('HBO_BENCH_PORT', '29500')) + 40))
+          dist.init_process_group('nccl', rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
+          comm = parallel.TorchDistComm(device=f'cuda:{local_rank % torch.cuda.device_count()}')
+          comm.allreduce_sum(np.zeros(4))
           comm_kind = 'torch.distributed nccl (RCCL over xGMI)'
+        else:
+          comm = parallel.RcclComm(ctx, rank, world, pgroup.bcast_bytes)
+          comm.allreduce_sum(np.zeros(4))          # first collective builds the rings now; raises if it cannot
+          comm_kind = 'rccl (libhbo, xGMI)'
       except Exception as e:  # pylint: disable=broad-except
         comm = None
-        comm_kind = f'torch.distributed gloo (RCCL communicator unavailable: {str(e)[:120]})'
-      # every rank must use the same transport: agree (over gloo) on whether all of them built the RCCL one
-      ok = torch.tensor([1.0 if comm is not None else 0.0], dtype=torch.float64)
-      dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-      if float(ok.item()) < 0.5:
+        comm_kind = f'host sockets (RCCL communicator unavailable: {str(e)[:120]})'
+      # every rank must use the same transport: agree on whether all of them built the RCCL one
+      if not all(pgroup.allgather(comm is not None)):
         if comm is not None:
-          comm_kind = 'torch.distributed gloo (RCCL communicator unavailable on another rank)'
-        comm = parallel.TorchDistComm()
+          comm_kind = 'host sockets (RCCL communicator unavailable on another rank)'
+        comm = parallel.SocketComm(pgroup)
     def step4(i):
       p = defs.GPParams(model=perturb(raw4, i, 0))
       return objectives.nll_value_and_grad(mean.constant, kernel.squared_exponential, p, dev4, wf, comm=comm)
@@ -270,11 +394,49 @@ def main():
       v4 = step4(i)
     sync()
     el4 = max_over_ranks(time.perf_counter() - t0)
+    # parity inside the bench: the mean NLL of ALL 64 tasks at the unperturbed theta against the oracle's committed
+    # value (tests/golden/cfg4_t64_oracle.npz) -- with task shards this goes through the all-reduce
+    p0 = defs.GPParams(model=raw4)
+    v_ref = objectives.nll_value_and_grad(mean.constant, kernel.squared_exponential, p0, dev4, wf, comm=comm)[0]
+    fx = os.path.join(ROOT, 'tests', 'golden', 'cfg4_t64_oracle.npz')
+    expected = float(np.load(fx)['nll_mean']) if os.path.exists(fx) else None
+    if expected is not None:
+      assert abs(v_ref - expected) <= 1e-9 * abs(expected), ('cfg4 mean NLL differs from the oracle fixture', v_ref, expected)
+    comm_us = None
+    if comm is not None:
+      buf = np.zeros(2 + 7)
+      for _ in range(5):
+        comm.allreduce_sum(buf)
+      t0 = time.perf_counter()
+      for _ in range(50):
+        comm.allreduce_sum(buf)
+      comm_us = round(max_over_ranks(time.perf_counter() - t0) / 50 * 1e6, 1)
     multitask = {'workload': 'cfg4: 64 PD1-shaped sub-datasets, N_k in [1600,2400], D=4, fp64, mean-NLL+grad, '
                              'LPT task shards + one all-reduce of [nll,count,grad]',
                  'evals_per_s': round(k4 / el4, 3), 'ms_per_eval': round(el4 / k4 * 1e3, 3), 'steps': k4,
-                 'scaling': 'strong', 'comm': comm_kind, 'nll': float(v4[0]), 'local_tasks': len(mine)}
+                 'scaling': 'strong', 'comm': comm_kind, 'comm_us': comm_us, 'nll': float(v4[0]),
+                 'nll_unperturbed': float(v_ref), 'nll_oracle_fixture': expected, 'local_tasks': len(mine)}
+    if world == 1:
+      # what one rank of an 8-GPU job would hold: the heaviest LPT shard of 8 (eight tasks), timed alone
+      shard8 = parallel.shard_dataset(full, 0, 8)
+      dev8 = objectives.DeviceDataset(shard8)
+      f8 = lambda i: objectives.nll_value_and_grad(mean.constant, kernel.squared_exponential,
+                                                   defs.GPParams(model=perturb(raw4, i, 0)), dev8, wf)
+      f8(-1); f8(-2)
+      t0 = time.perf_counter()
+      for i in range(10):
+        f8(i)
+      multitask['shard_of_8'] = {'tasks': len(shard8), 'ms_per_eval': round((time.perf_counter() - t0) / 10 * 1e3, 3)}
+      dev8.close()
     dev4.close()
+
+  # ---------------- cfg 3 and cfg 5 (rank 0, N=1 only; driver-timed instead of builder-tool numbers) ----------
+  if rank == 0 and world == 1 and not args.no_extra:
+    try:
+      extra['cfg3'] = bench_cfg3(ctx)
+      extra['cfg5'] = bench_cfg5(ctx)
+    except Exception as e:  # pylint: disable=broad-except
+      extra['error'] = str(e)[:200]
 
   # ---------------- CPU baseline (rank 0, N=1 only) -------------------------------------------
   cpu = None
@@ -294,12 +456,14 @@ def main():
 
   watchdog.cancel()
   if rank == 0:
-    print(json.dumps(result_line(cpu, multitask)), flush=True)
+    emit(result_line(cpu, multitask))
   dev.close()
-  if dist is not None:
-    dist.barrier()
-    dist.destroy_process_group()
+  if pgroup is not None:
+    pgroup.barrier()
+    if comm is not None and hasattr(comm, 'close'):
+      comm.close()
+    pgroup.close()
 
 
 if __name__ == '__main__':
-  main()
+  sys.exit(main() or 0)

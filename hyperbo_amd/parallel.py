@@ -5,13 +5,21 @@ sub-datasets, so tasks are partitioned statically (longest-processing-time first
 only exchange is ONE sum-all-reduce of [nll_sum, n_tasks, grad_sum] (<= ~10 KB) per evaluation.
 Communicators:
   RcclComm      -- libhbo's RCCL binding (hbo_comm_*), device buffers over xGMI; the unique id is
-                   distributed by any bootstrap callable (e.g. torch.distributed broadcast_object).
-  TorchDistComm -- torch.distributed all_reduce (gloo on CPU for tests, nccl==RCCL on GPU).
+                   distributed by any bootstrap callable (SocketGroup.bcast_bytes below -- no torch).
+  SocketComm    -- host-side sum through the SocketGroup hub (tests, and the fallback when no RCCL
+                   communicator can be built, e.g. two ranks sharing one GPU).
+  TorchDistComm -- torch.distributed all_reduce (gloo on CPU for tests, nccl==RCCL on GPU); opt-in only.
   LocalComm     -- single process.
+SocketGroup is the torch-free process group of one node (rendezvous, barrier, max, byte broadcast over
+127.0.0.1): the product path needs neither torch nor an MPI launcher.
 """
 from __future__ import annotations
 
 import ctypes as C
+import pickle
+import socket
+import struct
+import time
 from typing import Callable, Dict, Hashable, List, Sequence
 
 import numpy as np
@@ -38,6 +46,147 @@ def shard_dataset(dataset, rank: int, world_size: int, exclude_aligned: bool = T
   sizes = {k: s.x.shape[0] for k, s in items}
   mine = set(lpt_partition(sizes, world_size)[rank])
   return {k: s for k, s in items if k in mine}
+
+
+_MAGIC = b'HBOGRP1\n'
+
+
+def _send_msg(sock, obj):
+  data = pickle.dumps(obj, protocol=4)
+  sock.sendall(struct.pack('<Q', len(data)) + data)
+
+
+def _recv_exact(sock, n):
+  buf = bytearray()
+  while len(buf) < n:
+    chunk = sock.recv(n - len(buf))
+    if not chunk:
+      raise ConnectionError('SocketGroup: peer closed the connection')
+    buf += chunk
+  return bytes(buf)
+
+
+def _recv_msg(sock):
+  n, = struct.unpack('<Q', _recv_exact(sock, 8))
+  return pickle.loads(_recv_exact(sock, n))
+
+
+class SocketGroup:
+  """Process group of the ranks of ONE node over localhost TCP: rank 0 is the hub.
+
+  `port` is where rank 0 listens; with `scan` > 0 rank 0 takes the first free port in [port, port + scan) and the
+  other ranks probe that range for the hub's greeting (magic + world size + `token`) -- so the group can be derived
+  from a launcher's MASTER_PORT (taken by the launcher itself) without a second agreed port.  Collectives are
+  hub-and-spoke exchanges of small pickled objects (latency ~0.1 ms): rendezvous, barrier, max / gather of scalars,
+  broadcast of the 128-byte RCCL id.  The [nll, count, grad] all-reduce itself goes over RCCL (RcclComm)."""
+
+  def __init__(self, rank: int, world_size: int, port: int, addr: str = '127.0.0.1', scan: int = 0, token: str = '',
+               timeout: float = 120.0):
+    self.rank, self.world_size = int(rank), int(world_size)
+    self._peers: List[socket.socket] = []
+    self._hub = None
+    hello = (_MAGIC, self.world_size, token)
+    deadline = time.time() + timeout
+    ports = list(range(port, port + max(scan, 1)))
+    if self.rank == 0:
+      srv = None
+      for p in ports:
+        try:
+          srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+          srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+          srv.bind((addr, p))
+          break
+        except OSError:
+          srv.close(); srv = None
+      if srv is None:
+        raise RuntimeError(f'SocketGroup: no free port in {ports[0]}..{ports[-1]}')
+      srv.listen(self.world_size + 8)
+      srv.settimeout(1.0)
+      by_rank = {}
+      while len(by_rank) < self.world_size - 1:
+        if time.time() > deadline:
+          raise TimeoutError(f'SocketGroup: {len(by_rank) + 1} of {self.world_size} ranks arrived')
+        try:
+          conn, _ = srv.accept()
+        except socket.timeout:
+          continue
+        try:
+          conn.settimeout(10.0)
+          _send_msg(conn, hello)
+          r = _recv_msg(conn)
+          if not (isinstance(r, tuple) and r[0] == _MAGIC and 0 < r[1] < self.world_size):
+            raise ValueError('bad greeting')
+          conn.settimeout(timeout)
+          conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+          by_rank[r[1]] = conn
+        except Exception:  # pylint: disable=broad-except   (a stray connection: not one of ours)
+          conn.close()
+      srv.close()
+      self._peers = [by_rank[r] for r in range(1, self.world_size)]
+    else:
+      while self._hub is None:
+        if time.time() > deadline:
+          raise TimeoutError('SocketGroup: hub (rank 0) not found')
+        for p in ports:
+          try:
+            c = socket.create_connection((addr, p), timeout=2.0)
+            c.settimeout(5.0)
+            if _recv_msg(c) != hello:
+              c.close(); continue
+            _send_msg(c, (_MAGIC, self.rank))
+            c.settimeout(timeout)
+            c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+            self._hub = c
+            break
+          except Exception:  # pylint: disable=broad-except   (nobody / somebody else on that port)
+            continue
+        if self._hub is None:
+          time.sleep(0.05)
+
+  def allgather(self, obj):
+    """Every rank's `obj`, in rank order, on every rank."""
+    if self.world_size == 1:
+      return [obj]
+    if self.rank == 0:
+      out = [obj] + [_recv_msg(c) for c in self._peers]
+      for c in self._peers:
+        _send_msg(c, out)
+      return out
+    _send_msg(self._hub, obj)
+    return _recv_msg(self._hub)
+
+  def barrier(self):
+    self.allgather(None)
+
+  def allreduce_max(self, value: float) -> float:
+    return float(max(self.allgather(float(value))))
+
+  def bcast_bytes(self, data: bytes) -> bytes:
+    """Rank 0's bytes on every rank (the RCCL unique id)."""
+    return self.allgather(data if self.rank == 0 else None)[0]
+
+  def close(self):
+    for c in self._peers + ([self._hub] if self._hub is not None else []):
+      try:
+        c.close()
+      except OSError:
+        pass
+    self._peers, self._hub = [], None
+
+
+class SocketComm:
+  """Sum-all-reduce of a small float64 buffer through the SocketGroup hub (host memory, no GPU involved)."""
+
+  def __init__(self, group: SocketGroup):
+    self.group = group
+    self.rank, self.world_size = group.rank, group.world_size
+
+  def allreduce_sum(self, buf: np.ndarray) -> np.ndarray:
+    parts = self.group.allgather(np.ascontiguousarray(buf, dtype=np.float64))
+    out = np.zeros_like(parts[0])
+    for p in parts:          # rank order on every rank: bitwise identical results everywhere
+      out = out + p
+    return out
 
 
 class LocalComm:

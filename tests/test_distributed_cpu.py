@@ -62,3 +62,59 @@ def test_sharded_objective_matches_single_process(tmp_path):
   for r in (r0, r1):
     assert abs(float(r['value']) - val) <= 1e-12 * abs(val)
     np.testing.assert_allclose(r['grad'], helpers.flatten(g), rtol=1e-11, atol=1e-12)
+
+
+# ---- the torch-free process group (hyperbo_amd.parallel.SocketGroup / SocketComm) --------------------------------
+def _socket_worker(rank, world, port, out_dir):
+  sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
+  import helpers
+  from hyperbo_amd import parallel
+  from hyperbo_amd.basics import definitions as defs
+  from oracle import hyperbo_oracle as o
+  assert 'torch' not in sys.modules
+  group = parallel.SocketGroup(rank, world, port, scan=8, token='unit-test')
+  uid = group.bcast_bytes(bytes(range(128)) if rank == 0 else b'')
+  group.barrier()
+  mx = group.allreduce_max(10.0 - rank)
+  rng = np.random.default_rng(0)
+  model = helpers.make_model(rng, 'constant', False, 2)
+  sizes = [9, 14]                      # two tasks, three ranks: the last rank's shard is empty
+  full = {i: defs.SubDataset(*helpers.synthetic_task(rng, n, 2)) for i, n in enumerate(sizes)}
+  mine = parallel.shard_dataset(full, rank, world)
+  params = o.GPParams(model=model)
+  nll_sum, grad_sum = 0.0, np.zeros(helpers.flatten(model).size)
+  for k, s in mine.items():
+    v, g = o.nll_sub_dataset_value_and_grad(o.constant, o.squared_exponential, params, s.x, s.y, o.DEFAULT_WARP_FUNC)
+    nll_sum += v; grad_sum += helpers.flatten(g)
+  value, grad, count = parallel.sharded_mean_nll(nll_sum, len(mine), grad_sum, parallel.SocketComm(group))
+  np.savez(os.path.join(out_dir, f's{rank}.npz'), value=value, grad=grad, count=count, ntasks=len(mine), mx=mx,
+           uid_ok=(uid == bytes(range(128))), torch_loaded=('torch' in sys.modules))
+  group.barrier()
+  group.close()
+
+
+def test_socket_group_sharded_objective_three_ranks_two_tasks(tmp_path):
+  """world_size 3 over localhost sockets, no torch: rendezvous past an occupied port, byte broadcast, max, and the
+  [nll, count, grad] sum with one EMPTY shard must equal the single-process mean over the two tasks."""
+  import multiprocessing as mp
+  sys.path.insert(0, os.path.join(ROOT, 'tests'))
+  import helpers
+  from oracle import hyperbo_oracle as o
+  blocker = socket.socket(); blocker.bind(('127.0.0.1', 0)); port = blocker.getsockname()[1]   # hub must skip this one
+  ctx = mp.get_context('spawn')
+  procs = [ctx.Process(target=_socket_worker, args=(r, 3, port, str(tmp_path))) for r in range(3)]
+  [p.start() for p in procs]
+  [p.join(120) for p in procs]
+  blocker.close()
+  assert all(p.exitcode == 0 for p in procs)
+  res = [np.load(tmp_path / f's{r}.npz') for r in range(3)]
+  assert sorted(int(r['ntasks']) for r in res) == [0, 1, 1]
+  rng = np.random.default_rng(0)
+  model = helpers.make_model(rng, 'constant', False, 2)
+  full = {i: o.SubDataset(*helpers.synthetic_task(rng, n, 2)) for i, n in enumerate([9, 14])}
+  val, g = o.nll_value_and_grad(o.constant, o.squared_exponential, o.GPParams(model=model), full, o.DEFAULT_WARP_FUNC)
+  for r in res:
+    assert int(r['count']) == 2 and float(r['mx']) == 10.0 and bool(r['uid_ok']) and not bool(r['torch_loaded'])
+    assert abs(float(r['value']) - val) <= 1e-12 * abs(val)
+    np.testing.assert_allclose(r['grad'], helpers.flatten(g), rtol=1e-11, atol=1e-12)
+  assert np.array_equal(res[0]['grad'], res[1]['grad']) and np.array_equal(res[0]['grad'], res[2]['grad'])   # rank-order sum: bitwise equal

@@ -1053,3 +1053,85 @@ def test_incremental_cache_append_matches_refactorisation(gpu_ctx, kname, mlp, m
   mu, _ = m.predict(xq, 0)
   mu_o, _ = o.predict(mo, ko, po, x[:50], y[:50], xq, WFO)
   assert helpers.rel_err(mu, mu_o) < 1e-8
+
+
+# ---- multi-GPU plumbing: libhbo's RCCL binding and the self-spawning bench ------------------------------------------
+def test_rccl_single_rank_allreduce(gpu_ctx):
+  """hbo_comm_* with nranks = 1 (what tools/rccl_smoke.py does): id, init, all-reduce (identity), destroy, re-init."""
+  from hyperbo_amd import parallel
+  for _ in range(2):
+    comm = parallel.RcclComm(gpu_ctx, 0, 1, lambda b: b)
+    x = np.arange(37, dtype=np.float64) * 0.5 - 3
+    y = comm.allreduce_sum(x)
+    assert np.array_equal(x, y)
+    for _ in range(3):
+      y = comm.allreduce_sum(y)
+    assert np.array_equal(x, y)
+    comm.close()
+
+
+_RCCL_2RANK = r"""
+import os, sys, json
+import numpy as np
+sys.path.insert(0, os.environ['HBO_ROOT']); sys.path.insert(0, os.path.join(os.environ['HBO_ROOT'], 'tests'))
+import helpers
+from hyperbo_amd import _native as nat, parallel
+from hyperbo_amd.basics import definitions as defs
+from hyperbo_amd.gp_utils import kernel, mean, objectives, utils
+rank, world = int(os.environ['RANK']), 2
+group = parallel.SocketGroup(rank, world, int(os.environ['HBO_TEST_PORT']), token='rccl2')
+ctx = nat.default_context()
+comm = parallel.RcclComm(ctx, rank, world, group.bcast_bytes)
+rng = np.random.default_rng(7)
+model = helpers.make_model(rng, 'constant', False, 3)
+full = {i: defs.SubDataset(*helpers.synthetic_task(rng, n, 3)) for i, n in enumerate([300, 170, 260, 90, 410])}
+mine = parallel.shard_dataset(full, rank, world)
+v, g = objectives.nll_value_and_grad(mean.constant, kernel.squared_exponential, defs.GPParams(model=model), mine, utils.DEFAULT_WARP_FUNC, comm=comm)
+out = {'value': v, 'grad': helpers.flatten(g).tolist(), 'torch': 'torch' in sys.modules}
+if rank == 0:
+  v1, g1 = objectives.nll_value_and_grad(mean.constant, kernel.squared_exponential, defs.GPParams(model=model), full, utils.DEFAULT_WARP_FUNC)
+  out['single'] = v1; out['single_grad'] = helpers.flatten(g1).tolist()
+group.barrier(); comm.close(); group.close()
+print(json.dumps(out))
+"""
+
+
+def test_rccl_two_rank_sharded_objective(gpu_ctx):
+  """Two ranks on two GPUs: RcclComm (unique id over the socket group, ncclAllReduce over xGMI) inside
+  nll_value_and_grad(comm=...) must reproduce the single-process mean NLL and gradient.  Needs >= 2 devices."""
+  import json, socket, subprocess, sys
+  from hyperbo_amd import _native as nat
+  if nat.lib().hbo_device_count() < 2:
+    pytest.skip('needs two GPUs (the multi-GPU box of the driver)')
+  s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  procs = [subprocess.Popen([sys.executable, '-c', _RCCL_2RANK], stdout=subprocess.PIPE, text=True,
+                            env=dict(os.environ, RANK=str(r), HBO_DEVICE=str(r), HBO_TEST_PORT=str(port), HBO_ROOT=root))
+           for r in range(2)]
+  outs = [json.loads(p.communicate(timeout=300)[0].strip().splitlines()[-1]) for p in procs]
+  assert all(p.returncode == 0 for p in procs)
+  for o_ in outs:
+    assert not o_['torch']
+    assert abs(o_['value'] - outs[0]['single']) <= 1e-11 * abs(outs[0]['single'])
+    np.testing.assert_allclose(o_['grad'], outs[0]['single_grad'], rtol=1e-9, atol=1e-11)
+
+
+def test_bench_spawns_its_own_ranks_without_torch(gpu_ctx):
+  """`python bench.py --gpus 2` with no launcher: two ranks, n_gpus = 2 in the JSON line, no torch in the ranks.  On a
+  one-GPU box both ranks share the device and the all-reduce falls back to host sockets (RCCL refuses duplicate GPUs);
+  on the driver's multi-GPU box the same command reports comm = rccl (libhbo, xGMI)."""
+  import json, subprocess, sys
+  from hyperbo_amd import _native as nat
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'RANK', 'LOCAL_RANK', 'HBO_DEVICE')}
+  r = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1',
+                      '--no-cpu-baseline', '--no-extra', '--n', '2048'], env=env, stdout=subprocess.PIPE, text=True, timeout=600)
+  assert r.returncode == 0, r.stdout
+  assert len(r.stdout.strip().splitlines()) == 1, r.stdout      # ONE JSON line on stdout, nothing else
+  line = json.loads(r.stdout.strip())
+  assert line['n_gpus'] == 2 and line['torch_imported'] is False
+  mt = line['multitask']
+  assert mt['local_tasks'] == 32 and mt['comm_us'] is not None
+  assert abs(mt['nll_unperturbed'] - mt['nll_oracle_fixture']) <= 1e-9 * abs(mt['nll_oracle_fixture'])
+  if nat.lib().hbo_device_count() >= 2:
+    assert mt['comm'].startswith('rccl (libhbo')
