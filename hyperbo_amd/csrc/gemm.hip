@@ -294,12 +294,18 @@ __device__ __forceinline__ void gemm_tile(const TileJob<T>& job, unsigned char* 
   stage_store<T, BKC, TM>(sB0, rb, tid);
   __syncthreads();
 
-  const int my_cu = job.yield_flag ? cu_token() : 0;
+  // Yield poll, software-pipelined: the table entry of this CU is loaded at the top of a K step -- ahead of the slab
+  // prefetch, so it has arrived, at no cost, by the time the prefetch is waited for -- and looked at at the top of the
+  // NEXT step (a poll that is waited for on the spot costs an L2 round trip per K step: N = 16384 lost 0.9 % to it).
+  const int* const yslot = job.yield_flag ? job.yield_flag + cu_token() : nullptr;
+  int ypoll = 0;
   for (int kt = 0; kt < nk; ++kt) {
-    if (job.yield_flag) {
+    if (yslot) {
       // a panel-chain workgroup is running on this CU: stay off its MFMA / LDS paths until it is done (bounded wait)
-      for (int spin = 0; spin < 256 && __hip_atomic_load(job.yield_flag + my_cu, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0; ++spin)
-        __builtin_amdgcn_s_sleep(16);
+      if (ypoll != 0)
+        for (int spin = 0; spin < 256 && __hip_atomic_load(yslot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0; ++spin)
+          __builtin_amdgcn_s_sleep(16);
+      ypoll = __hip_atomic_load(yslot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     const T* cA = (kt & 1) ? sA1 : sA0;
     const T* cB = (kt & 1) ? sB1 : sB0;
