@@ -43,6 +43,24 @@ int main(int argc, char** argv) {
     char nm[64]; snprintf(nm, 64, "syrk K=%d dbg=%d", kt * 128, dbg);
     timeit(nm, a, dim3(nblk + 1 - kt, nblk - kt, 1), m * (m + 1) / 2 * 128.0 * 128 * 2 * 128 * kt);
   }
+  { // the shipped bulk trailing update: persistent, tiles from a counter, K = 384 / 512 over the trailing matrix after 6 / 24 panels
+    int* ctr; CK(hipMalloc(&ctr, 64 * sizeof(int)));
+    for (int pf : {32, 0})
+    for (int kt : {3, 4})
+    for (int c0 : {6, 24}) {
+      GemmArgs a = {}; a.tasks = d; a.mode = GEMM_SYRK; a.p0 = c0 - kt; a.kt = kt; a.c_lo = c0; a.c_hi = nblk; a.aug = 1;
+      a.persistent = pf ? 2 * (256 - pf) : 0; a.work_counter = pf ? ctr : nullptr;
+      double m = nblk - c0;
+      char nm[64]; snprintf(nm, 64, "bulk K=%d m=%d %s", kt * 128, (int)m, pf ? "persistent" : "plain");
+      float best = 1e9;
+      for (int rep = 0; rep < 6; ++rep) {
+        CK(hipMemsetAsync(ctr, 0, 64 * sizeof(int), 0));
+        CK(hipEventRecord(e0)); launch_gemm(HBO_F64, a, dim3(nblk + 1 - c0, nblk - c0, 1), 0); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1)); if (rep && ms < best) best = ms;
+      }
+      printf("%-28s %8.3f ms  %6.1f TFLOP/s\n", nm, best, (m * (m + 1) / 2 + m) * 128.0 * 128 * 2 * 128 * kt / best / 1e9);
+    }
+  }
   { GemmArgs a = {}; a.tasks = d; a.mode = GEMM_LAUUM;
     timeit("lauum", a, dim3(nblk, nblk, 1), (double)n * n * n / 3); }
   { double tot = 0; float msum = 0;
