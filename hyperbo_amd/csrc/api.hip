@@ -30,6 +30,7 @@ struct hbo_ctx {
   int opt_trtri_gran = 0;    // panels between two launches of the inverse's computable pieces during the factorisation (0: auto)
   int opt_small_nblk = 32;   // matrices up to this many 128-blocks use 64x64 GEMM tiles in trtri / lauum
   int opt_persist_free = -1; // bulk trailing update runs as 2*(CUs - this) persistent workgroups (-1: auto, see run_potrf)
+  int opt_post_chunk = 8192;   // posterior / acquisition: candidates per pass (the cross-Gram workspace is npad x this, whatever M)
   int opt_trtri_at = 0;        // single matrix: panel count (in 64ths of the block count) after which the inverse starts beside the chain (0: 13/16)
   int opt_trtri_small_wgs = 2; // ... and workgroups per CU of their 64-tile form
   int opt_trtri_free = 48;   // CUs the inverse products that co-run with the panel chain leave free (0: one tile per workgroup)
@@ -88,7 +89,7 @@ static inline int64_t padded_ld(int64_t extent, int dtype) { return extent + 128
 
 // grow-only scratch buffer for `slot`; nullptr on allocation failure (ctx->err is set)
 enum WsSlot { WS_XQ = 1, WS_MU0, WS_KD, WS_MU, WS_VAR, WS_ACQ, WS_K, WS_COLSQ, WS_V, WS_KQQ, WS_COV,
-              WS_AP_KX, WS_AP_L, WS_AP_W, WS_AP_MU, WS_AP_KD, WS_COUNTERS,
+              WS_AP_KX, WS_AP_L, WS_AP_W, WS_AP_MU, WS_AP_KD, WS_COUNTERS, WS_MUPART,
               WS_AG_K, WS_AG_L, WS_AG_B, WS_AG_GF, WS_AG_DMU, WS_AG_GX, WS_AG_T0, WS_AG_T1, WS_AG_DW, WS_FQ0 /* + layer */ };
 static void* ws_get(hbo_ctx* c, int slot, size_t bytes) {
   auto& e = c->ws[slot];
@@ -216,6 +217,7 @@ extern "C" int hbo_set_option(hbo_ctx* c, const char* name, int64_t value) {
   if (!strcmp(name, "cu_yield")) { if (value < 0 || value > 2) return fail(c, HBO_ERR_ARG, "cu_yield in 0..2"); c->opt_cu_yield = (int)value; return HBO_OK; }
   if (!strcmp(name, "trtri_gran")) { if (value < 0) return fail(c, HBO_ERR_ARG, "trtri_gran >= 0"); c->opt_trtri_gran = (int)value; return HBO_OK; }
   if (!strcmp(name, "small_nblk")) { c->opt_small_nblk = (int)value; return HBO_OK; }
+  if (!strcmp(name, "post_chunk")) { if (value < 128 || value > 65536) return fail(c, HBO_ERR_ARG, "post_chunk in 128..65536"); c->opt_post_chunk = (int)value; return HBO_OK; }
   if (!strcmp(name, "trtri_at")) { if (value < 0 || value > 63) return fail(c, HBO_ERR_ARG, "trtri_at in 0..63"); c->opt_trtri_at = (int)value; return HBO_OK; }
   if (!strcmp(name, "trtri_small_wgs")) { if (value < 1 || value > 4) return fail(c, HBO_ERR_ARG, "trtri_small_wgs in 1..4"); c->opt_trtri_small_wgs = (int)value; return HBO_OK; }
   if (!strcmp(name, "trtri_free")) { if (value < 0 || value > 200) return fail(c, HBO_ERR_ARG, "trtri_free in 0..200"); c->opt_trtri_free = (int)value; return HBO_OK; }
@@ -1173,93 +1175,132 @@ static int posterior(hbo_ctx* c, const hbo_model* m, hbo_cache* k, const void* x
   const int dtype = m->dtype;
   if (k && (k->dtype != dtype || k->D != m->input_dim)) return fail(c, HBO_ERR_ARG, "posterior: cache/model mismatch");
   const size_t es = esize(dtype);
-  hipStream_t st = c->stream;
   const int fdim = feature_dim(m), fm = mean_feature_dim(m);
-  const int64_t CH = 65536;  // candidates per pass (bounds the cross-Gram workspace)
+  // Candidates are STREAMED: chunks of `CH` queries, so that the cross-Gram workspace (npad x CH) does not grow with M
+  // (gp.py:295-305 materialises all of Kxq; at cfg 3 that is 16384 x 65536 fp32 = 4.3 GB).  Two workspaces alternate:
+  // upload + features + cross Gram of chunk i+1 run on a second stream beside the triangular product of chunk i; the
+  // results of all chunks are gathered in M-sized vectors and come back in one copy.  full_cov keeps a single pass.
+  const int64_t CH = full_cov ? 65536 : std::max<int64_t>(c->opt_post_chunk, HBO_TILE);
+  if (full_cov && M > CH) { return fail(c, HBO_ERR_UNSUPPORTED, "posterior: full_cov limited to 65536 queries"); }
   const int64_t mc_max = std::min<int64_t>(M, CH);
+  const int nbuf = (!full_cov && M > CH) ? 2 : 1;
   const int mpad_max = round_up(mc_max, HBO_TILE);
   const int64_t ldq_max = padded_ld(mpad_max, dtype);
-  void *d_xq = nullptr, *d_mu0 = nullptr, *d_kd = nullptr, *d_mu = nullptr, *d_var = nullptr, *d_acq = nullptr;
-  void *d_K = nullptr, *d_colsq = nullptr, *d_V = nullptr, *d_Kqq = nullptr, *d_cov = nullptr;
-  void* fq_acts[HBO_MAX_MLP_LAYERS] = {nullptr};
-  std::vector<void*> to_free;
-  auto cleanup = [&]() {};   // buffers are ctx-owned scratch (ws_get)
-#define HIPCHK_P(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) { c->err = std::string(#call " failed: ") + hipGetErrorString(e__); cleanup(); return HBO_ERR_HIP; } } while (0)
-  if (full_cov && M > CH) { return fail(c, HBO_ERR_UNSUPPORTED, "posterior: full_cov limited to 65536 queries"); }
-  { d_xq = ws_get(c, WS_XQ, (size_t)mc_max * m->input_dim * es); if (!d_xq) return HBO_ERR_HIP; }
-  { d_mu0 = ws_get(c, WS_MU0, (size_t)mc_max * es); if (!d_mu0) return HBO_ERR_HIP; }
-  { d_kd = ws_get(c, WS_KD, (size_t)mc_max * es); if (!d_kd) return HBO_ERR_HIP; }
-  { d_mu = ws_get(c, WS_MU, (size_t)mc_max * es); if (!d_mu) return HBO_ERR_HIP; }
-  { d_var = ws_get(c, WS_VAR, (size_t)mc_max * es); if (!d_var) return HBO_ERR_HIP; }
-  if (acq_out) { d_acq = ws_get(c, WS_ACQ, (size_t)mc_max * es); if (!d_acq) return HBO_ERR_HIP; }
-  if (needs_mlp(m)) for (int l = 0; l < m->n_layers; ++l) { fq_acts[l] = ws_get(c, WS_FQ0 + l, (size_t)mc_max * m->features[l] * es); if (!fq_acts[l]) return HBO_ERR_HIP; }
+  hipStream_t sa = c->stream, sb = nbuf == 2 ? c->stream2 : c->stream;
+  char *d_xq = nullptr, *d_mu0 = nullptr, *d_kd = nullptr, *d_K = nullptr, *d_colsq = nullptr, *d_mupart = nullptr;
+  void *d_mu = nullptr, *d_var = nullptr, *d_acq = nullptr, *d_V = nullptr, *d_Kqq = nullptr, *d_cov = nullptr;
+  char* fq_acts[HBO_MAX_MLP_LAYERS] = {nullptr};
+  size_t fq_stride[HBO_MAX_MLP_LAYERS] = {0};
+#define HIPCHK_P(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) { c->err = std::string(#call " failed: ") + hipGetErrorString(e__); return HBO_ERR_HIP; } } while (0)
+  auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+  const size_t vec_b = al((size_t)mc_max * es);
+  // the queries go up in ONE copy (M x D elements: small beside the N x CH workspace): a pageable host-to-device copy
+  // inside the chunk loop waits for the products in flight on the other stream -- it serialised the two streams and
+  // took cfg 3 from 142 to 197 ms
+  { d_xq = (char*)ws_get(c, WS_XQ, (size_t)M * m->input_dim * es); if (!d_xq) return HBO_ERR_HIP; }
+  HIPCHK_P(hipMemcpyAsync(d_xq, xq, (size_t)M * m->input_dim * es, hipMemcpyHostToDevice, sa));
+  { d_mu0 = (char*)ws_get(c, WS_MU0, vec_b * nbuf); if (!d_mu0) return HBO_ERR_HIP; }
+  { d_kd = (char*)ws_get(c, WS_KD, vec_b * nbuf); if (!d_kd) return HBO_ERR_HIP; }
+  { d_mu = ws_get(c, WS_MU, (size_t)M * es); if (!d_mu) return HBO_ERR_HIP; }
+  { d_var = ws_get(c, WS_VAR, (size_t)M * es); if (!d_var) return HBO_ERR_HIP; }
+  if (acq_out) { d_acq = ws_get(c, WS_ACQ, (size_t)M * es); if (!d_acq) return HBO_ERR_HIP; }
+  if (needs_mlp(m)) for (int l = 0; l < m->n_layers; ++l) {
+    fq_stride[l] = al((size_t)mc_max * m->features[l] * es);
+    fq_acts[l] = (char*)ws_get(c, WS_FQ0 + l, fq_stride[l] * nbuf); if (!fq_acts[l]) return HBO_ERR_HIP;
+  }
   TaskHost* t = k ? k->t : nullptr;
+  size_t K_b = 0, colsq_b = 0;
   if (k) {
-    { d_K = ws_get(c, WS_K, (size_t)t->npad * ldq_max * es); if (!d_K) return HBO_ERR_HIP; }
-    { d_colsq = ws_get(c, WS_COLSQ, (size_t)t->nblk * ldq_max * es); if (!d_colsq) return HBO_ERR_HIP; }
+    K_b = al((size_t)t->npad * ldq_max * es); colsq_b = al((size_t)t->nblk * ldq_max * es);
+    { d_K = (char*)ws_get(c, WS_K, K_b * nbuf); if (!d_K) return HBO_ERR_HIP; }
+    { d_colsq = (char*)ws_get(c, WS_COLSQ, colsq_b * nbuf); if (!d_colsq) return HBO_ERR_HIP; }
+    { d_mupart = (char*)ws_get(c, WS_MUPART, colsq_b * nbuf); if (!d_mupart) return HBO_ERR_HIP; }
     if (full_cov) { d_V = ws_get(c, WS_V, (size_t)t->npad * ldq_max * es); if (!d_V) return HBO_ERR_HIP; }
   }
   if (full_cov) { { d_Kqq = ws_get(c, WS_KQQ, (size_t)M * M * es); if (!d_Kqq) return HBO_ERR_HIP; } { d_cov = ws_get(c, WS_COV, (size_t)M * M * es); if (!d_cov) return HBO_ERR_HIP; } }
   const bool bad = k && k->info != INT_MAX;
+  hipEvent_t ev_ready[2] = {nullptr, nullptr}, ev_free[2] = {nullptr, nullptr};
+  size_t evi = 0;
+  if (nbuf == 2) {   // the side stream starts behind whatever the main stream still holds (model upload)
+    hipEvent_t e = pool_event(c, evi++); hipEventRecord(e, sa); hipStreamWaitEvent(sb, e, 0);
+  }
 
-  for (int64_t q0 = 0; q0 < M; q0 += CH) {
+  int64_t chunk = 0;
+  for (int64_t q0 = 0; q0 < M; q0 += CH, ++chunk) {
+    const int b = (int)(chunk % nbuf);
     const int64_t mc = std::min<int64_t>(CH, M - q0);
     const int mpad = round_up(mc, HBO_TILE);
     const int64_t ldq = padded_ld(mpad, dtype);
-    HIPCHK_P(hipMemcpyAsync(d_xq, (const char*)xq + (size_t)q0 * m->input_dim * es, (size_t)mc * m->input_dim * es, hipMemcpyHostToDevice, st));
+    char* xq_d = d_xq + (size_t)q0 * m->input_dim * es; char* mu0_d = d_mu0 + b * vec_b; char* kd_d = d_kd + b * vec_b;
+    // ---- producer side (sb): inputs, features, prior mean / variance, cross Gram into workspace b ----
+    if (ev_free[b]) hipStreamWaitEvent(sb, ev_free[b], 0);   // workspace b was read by the products of chunk - 2
     const void* fq_last = nullptr;
-    { ProfScope ps(c, "features", 1);
-      if (needs_mlp(m)) { run_mlp(c, m, d_xq, mc, fq_acts); fq_last = fq_acts[m->n_layers - 1]; } }
-    const void* Fq = m->kernel_uses_mlp ? fq_last : d_xq;
-    const void* Fmq = (m->mean_id == HBO_MEAN_LINEAR) ? d_xq : (m->mean_id == HBO_MEAN_LINEAR_MLP ? fq_last : nullptr);
-    launch_mean(dtype, Fmq, mc, fm, c->d_model, d_mu0, st);
-    launch_kdiag(dtype, Fq, mc, fdim, c->d_model, d_kd, st);
+    { ProfScope ps(c, "features", 1, sb);
+      if (needs_mlp(m)) {
+        void* acts[HBO_MAX_MLP_LAYERS];
+        for (int l = 0; l < m->n_layers; ++l) acts[l] = fq_acts[l] + b * fq_stride[l];
+        const void* in = xq_d; int fin = m->input_dim;
+        for (int l = 0; l < m->n_layers; ++l) { launch_dense_tanh(dtype, in, c->d_mlp_w[l], c->d_mlp_b[l], acts[l], mc, fin, m->features[l], sb); in = acts[l]; fin = m->features[l]; }
+        fq_last = acts[m->n_layers - 1];
+      } }
+    const void* Fq = m->kernel_uses_mlp ? fq_last : xq_d;
+    const void* Fmq = (m->mean_id == HBO_MEAN_LINEAR) ? (const void*)xq_d : (m->mean_id == HBO_MEAN_LINEAR_MLP ? fq_last : nullptr);
+    launch_mean(dtype, Fmq, mc, fm, c->d_model, mu0_d, sb);
+    launch_kdiag(dtype, Fq, mc, fdim, c->d_model, kd_d, sb);
+    void* mu_d = (char*)d_mu + (size_t)q0 * es; void* var_d = (char*)d_var + (size_t)q0 * es;
+    void* acq_d = d_acq ? (char*)d_acq + (size_t)q0 * es : nullptr;
     if (!k) {  // prior branch (gp.py:275-282)
-      if (mu_out) HIPCHK_P(hipMemcpyAsync((char*)mu_out + (size_t)q0 * es, d_mu0, (size_t)mc * es, hipMemcpyDeviceToHost, st));
+      HIPCHK_P(hipMemcpyAsync(mu_d, mu0_d, (size_t)mc * es, hipMemcpyDeviceToDevice, sb));
       if (full_cov) {
         GramArgs g = {}; g.kernel_id = c->h_model->kernel_id; g.x1 = Fq; g.x2 = Fq; g.out = d_cov; g.n1 = mc; g.n2 = mc; g.ldo = mc; g.fdim = fdim;
-        launch_gram(dtype, g, c->d_model, dim3((unsigned)((mc + 127) / 128), (unsigned)((mc + 127) / 128), 1), st);
-        if (var_out) HIPCHK_P(hipMemcpyAsync(var_out, d_cov, (size_t)M * M * es, hipMemcpyDeviceToHost, st));
-      } else if (var_out) {
-        HIPCHK_P(hipMemcpyAsync((char*)var_out + (size_t)q0 * es, d_kd, (size_t)mc * es, hipMemcpyDeviceToHost, st));
+        launch_gram(dtype, g, c->d_model, dim3((unsigned)((mc + 127) / 128), (unsigned)((mc + 127) / 128), 1), sb);
+      } else {
+        HIPCHK_P(hipMemcpyAsync(var_d, kd_d, (size_t)mc * es, hipMemcpyDeviceToDevice, sb));
       }
       if (acq_out) {   // acquisition on the prior
         PostArgs pa = {}; pa.Kxq = nullptr; pa.n = 0; pa.nblk = 0; pa.ldq = ldq; pa.alpha = nullptr; pa.colsq = nullptr;
-        pa.kdiag = d_kd; pa.muq = d_mu0; pa.acq_out = d_acq; pa.M = mc; pa.acq_id = acq_id; pa.param = param; pa.add_noise = add_noise; pa.scale = scale;
-        launch_post_epilogue(dtype, pa, st);
-        HIPCHK_P(hipMemcpyAsync((char*)acq_out + (size_t)q0 * es, d_acq, (size_t)mc * es, hipMemcpyDeviceToHost, st));
+        pa.kdiag = kd_d; pa.muq = mu0_d; pa.acq_out = acq_d; pa.M = mc; pa.acq_id = acq_id; pa.param = param; pa.add_noise = add_noise; pa.scale = scale;
+        launch_post_epilogue(dtype, pa, sb);
       }
-      HIPCHK_P(hipStreamSynchronize(st));
+      if (nbuf == 2) { ev_free[b] = pool_event(c, evi++); hipEventRecord(ev_free[b], sb); }
       continue;
     }
-    { ProfScope ps(c, "cross_gram", 1);
-      GramArgs g = {}; g.kernel_id = c->h_model->kernel_id; g.x1 = k->h_desc.F; g.x2 = Fq; g.out = d_K; g.n1 = t->n; g.n2 = mc; g.ldo = ldq;
+    char* K_d = d_K + b * K_b; char* colsq_d = d_colsq + b * colsq_b;
+    { ProfScope ps(c, "cross_gram", 1, sb);
+      GramArgs g = {}; g.kernel_id = c->h_model->kernel_id; g.x1 = k->h_desc.F; g.x2 = Fq; g.out = K_d; g.n1 = t->n; g.n2 = mc; g.ldo = ldq;
       g.n1pad = t->npad; g.n2pad = mpad; g.fdim = fdim; g.symmetric = 0; g.padded = 1;
-      launch_gram(dtype, g, c->d_model, dim3(mpad / HBO_TILE, t->nblk, 1), st); }
-    { ProfScope ps(c, "post_gemm", 1);
-      GemmArgs a = {}; a.tasks = k->d_desc; a.mode = GEMM_POST; a.B = d_K; a.ldb = ldq; a.V = full_cov ? d_V : nullptr; a.colsq = d_colsq;
-      launch_gemm(dtype, a, dim3(mpad / HBO_TILE, t->nblk, 1), st); }
-    { ProfScope ps(c, "post_epilogue", 1);
-      PostArgs pa = {}; pa.Kxq = d_K; pa.ldq = ldq; pa.npad = t->npad; pa.n = (int)t->n; pa.nblk = t->nblk; pa.alpha = t->svec; pa.colsq = d_colsq;
-      pa.kdiag = d_kd; pa.muq = d_mu0; pa.mu_out = d_mu; pa.var_out = d_var; pa.acq_out = d_acq; pa.M = mc;
+      launch_gram(dtype, g, c->d_model, dim3(mpad / HBO_TILE, t->nblk, 1), sb); }
+    if (nbuf == 2) { ev_ready[b] = pool_event(c, evi++); hipEventRecord(ev_ready[b], sb); hipStreamWaitEvent(sa, ev_ready[b], 0); }
+    // ---- consumer side (sa): V = L^-1 Kxq on MFMA (column sums of squares), then mean / variance / acquisition ----
+    { ProfScope ps(c, "post_gemm", 1, sa);
+      GemmArgs a = {}; a.tasks = k->d_desc; a.mode = GEMM_POST; a.B = K_d; a.ldb = ldq; a.V = full_cov ? d_V : nullptr; a.colsq = colsq_d;
+      launch_gemm(dtype, a, dim3(mpad / HBO_TILE, t->nblk, 1), sa); }
+    { ProfScope ps(c, "post_epilogue", 1, sa);
+      PostArgs pa = {}; pa.Kxq = K_d; pa.ldq = ldq; pa.npad = t->npad; pa.n = (int)t->n; pa.nblk = t->nblk; pa.alpha = t->svec; pa.colsq = colsq_d; pa.mupart = d_mupart + b * colsq_b;
+      pa.kdiag = kd_d; pa.muq = mu0_d; pa.mu_out = mu_d; pa.var_out = var_d; pa.acq_out = acq_d; pa.M = mc;
       pa.acq_id = acq_id; pa.param = param; pa.add_noise = add_noise; pa.scale = scale;
-      launch_post_epilogue(dtype, pa, st); }
-    if (mu_out) HIPCHK_P(hipMemcpyAsync((char*)mu_out + (size_t)q0 * es, d_mu, (size_t)mc * es, hipMemcpyDeviceToHost, st));
+      launch_post_epilogue(dtype, pa, sa); }
+    if (nbuf == 2) { ev_free[b] = pool_event(c, evi++); hipEventRecord(ev_free[b], sa); }
     if (full_cov) {
       GramArgs g = {}; g.kernel_id = c->h_model->kernel_id; g.x1 = Fq; g.x2 = Fq; g.out = d_Kqq; g.n1 = mc; g.n2 = mc; g.ldo = mc; g.fdim = fdim;
-      launch_gram(dtype, g, c->d_model, dim3((unsigned)((mc + 127) / 128), (unsigned)((mc + 127) / 128), 1), st);
-      launch_fullcov(dtype, d_V, ldq, t->npad, d_Kqq, mc, d_cov, st);
-      if (var_out) HIPCHK_P(hipMemcpyAsync(var_out, d_cov, (size_t)M * M * es, hipMemcpyDeviceToHost, st));
-    } else if (var_out) {
-      HIPCHK_P(hipMemcpyAsync((char*)var_out + (size_t)q0 * es, d_var, (size_t)mc * es, hipMemcpyDeviceToHost, st));
+      launch_gram(dtype, g, c->d_model, dim3((unsigned)((mc + 127) / 128), (unsigned)((mc + 127) / 128), 1), sa);
+      launch_fullcov(dtype, d_V, ldq, t->npad, d_Kqq, mc, d_cov, sa);
     }
-    if (acq_out) HIPCHK_P(hipMemcpyAsync((char*)acq_out + (size_t)q0 * es, d_acq, (size_t)mc * es, hipMemcpyDeviceToHost, st));
-    HIPCHK_P(hipStreamSynchronize(st));
   }
+  if (nbuf == 2) {   // join: everything the side stream produced (the prior branch runs there entirely)
+    hipEvent_t e = pool_event(c, evi++); hipEventRecord(e, sb); hipStreamWaitEvent(sa, e, 0);
+  }
+  if (mu_out) HIPCHK_P(hipMemcpyAsync(mu_out, d_mu, (size_t)M * es, hipMemcpyDeviceToHost, sa));
+  if (var_out) {
+    if (full_cov) HIPCHK_P(hipMemcpyAsync(var_out, d_cov, (size_t)M * M * es, hipMemcpyDeviceToHost, sa));
+    else HIPCHK_P(hipMemcpyAsync(var_out, d_var, (size_t)M * es, hipMemcpyDeviceToHost, sa));
+  }
+  if (acq_out) HIPCHK_P(hipMemcpyAsync(acq_out, d_acq, (size_t)M * es, hipMemcpyDeviceToHost, sa));
+  HIPCHK_P(hipStreamSynchronize(sa));
+  if (nbuf == 2) HIPCHK_P(hipStreamSynchronize(sb));
   HIPCHK_P(hipGetLastError());
 #undef HIPCHK_P
   prof_collect(c);
-  cleanup();
   if (bad) {
     if (mu_out) fill_nan(mu_out, (size_t)M, dtype);
     if (var_out) fill_nan(var_out, full_cov ? (size_t)M * M : (size_t)M, dtype);

@@ -915,6 +915,28 @@ __global__ void add_inplace_kernel(double* dst, const double* src, int64_t count
   if (idx < count) dst[idx] += src[idx];
 }
 
+// mupart[b][q] = sum over the 128 rows i of row block b of Kxq[i][q] * alpha[i]: the posterior mean's product
+// Kxq^T alpha (gp.py:300) split by row block, so that its parallelism is (row blocks x queries) -- one thread per
+// query walking all n rows takes ~6 ms whatever the number of queries (latency-bound), which an 8192-candidate
+// chunk paid in full
+template <typename T>
+__global__ void post_mupart_kernel(const T* __restrict__ K, int64_t ldq, int n, const T* __restrict__ al, T* mupart, int64_t M) {
+  const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int b = blockIdx.y;
+  if (q >= M) return;
+  const int i0 = b * HBO_TILE, i1 = min(i0 + HBO_TILE, n);
+  T s0 = (T)0, s1 = (T)0, s2 = (T)0, s3 = (T)0;
+  int i = i0;
+  for (; i + 3 < i1; i += 4) {
+    s0 += K[(int64_t)i * ldq + q] * al[i];
+    s1 += K[(int64_t)(i + 1) * ldq + q] * al[i + 1];
+    s2 += K[(int64_t)(i + 2) * ldq + q] * al[i + 2];
+    s3 += K[(int64_t)(i + 3) * ldq + q] * al[i + 3];
+  }
+  for (; i < i1; ++i) s0 += K[(int64_t)i * ldq + q] * al[i];
+  mupart[(int64_t)b * ldq + q] = (s0 + s1) + (s2 + s3);
+}
+
 template <typename T>
 __global__ void post_epilogue_kernel(PostArgs a) {
   const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -922,7 +944,12 @@ __global__ void post_epilogue_kernel(PostArgs a) {
   const T* K = static_cast<const T*>(a.Kxq);
   const T* al = static_cast<const T*>(a.alpha);
   T mu = (T)0;
-  for (int64_t i = 0; i < a.n; ++i) mu += K[i * a.ldq + q] * al[i];
+  if (a.mupart) {   // per-row-block partial sums of Kxq^T alpha (post_mupart_kernel)
+    const T* mp = static_cast<const T*>(a.mupart);
+    for (int b = 0; b < a.nblk; ++b) mu += mp[(int64_t)b * a.ldq + q];
+  } else {
+    for (int64_t i = 0; i < a.n; ++i) mu += K[i * a.ldq + q] * al[i];
+  }
   mu += static_cast<const T*>(a.muq)[q];
   T var = static_cast<const T*>(a.kdiag)[q];
   const T* cs = static_cast<const T*>(a.colsq);
@@ -1182,6 +1209,11 @@ void launch_add_inplace(double* dst, const double* src, int64_t count, hipStream
 void launch_post_epilogue(int dtype, const PostArgs& a, hipStream_t st) {
   if (a.M <= 0) return;
   dim3 grid((unsigned)((a.M + 255) / 256));
+  if (a.mupart && a.Kxq && a.n > 0) {
+    dim3 g2(grid.x, (unsigned)a.nblk);
+    if (dtype == HBO_F64) hipLaunchKernelGGL((post_mupart_kernel<double>), g2, dim3(256), 0, st, static_cast<const double*>(a.Kxq), a.ldq, a.n, static_cast<const double*>(a.alpha), static_cast<double*>(a.mupart), a.M);
+    else hipLaunchKernelGGL((post_mupart_kernel<float>), g2, dim3(256), 0, st, static_cast<const float*>(a.Kxq), a.ldq, a.n, static_cast<const float*>(a.alpha), static_cast<float*>(a.mupart), a.M);
+  }
   if (dtype == HBO_F64) hipLaunchKernelGGL((post_epilogue_kernel<double>), grid, dim3(256), 0, st, a);
   else hipLaunchKernelGGL((post_epilogue_kernel<float>), grid, dim3(256), 0, st, a);
 }

@@ -156,6 +156,7 @@ struct PostArgs {
   const void* Kxq; int64_t ldq; int npad; int n; int nblk;   // cross Gram (npad x ldq)
   const void* alpha;    // kinvy [npad] (first column)
   const void* colsq;    // partial [nblk][ldq]
+  void* mupart;         // scratch [nblk][ldq] for the row-block partial sums of Kxq^T alpha (null: one thread per query walks all rows)
   const void* kdiag;    // prior variance at the queries [M]
   const void* muq;      // prior mean at the queries [M]
   void* mu_out; void* var_out; void* acq_out;

@@ -190,6 +190,9 @@ int hbo_profile_get(hbo_ctx* ctx, char names[][32], double* ms, int32_t* launche
  *   persist_free  -1..200 CUs the persistent bulk trailing update leaves to the panel chain (-1 = auto: 48 / 32)
  *   cu_yield       0..2  background GEMM workgroups (bulk update, overlapped inverse) pause at a K step while a panel-chain
  *                        workgroup runs on their CU: 1 = potf2 only, 2 = trsm and the chain's column updates too
+ *   post_chunk     128..65536 posterior / acquisition: query candidates per pass (cross-Gram workspace = npad x post_chunk
+ *                        elements whatever M; two workspaces alternate so that the Gram build of a chunk runs beside the
+ *                        triangular product of the previous one)
  *   trtri_at       0..63 single matrix: the inverse starts beside the chain after this many 64ths of the panels (0 = auto)
  *   trtri_small_wgs 1..4 workgroups per CU of the 64-tile form of the co-running inverse products
  *   lookahead      0/1   panel chain on its own stream, one group ahead of the bulk update

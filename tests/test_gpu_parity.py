@@ -1135,3 +1135,48 @@ def test_bench_spawns_its_own_ranks_without_torch(gpu_ctx):
   assert abs(mt['nll_unperturbed'] - mt['nll_oracle_fixture']) <= 1e-9 * abs(mt['nll_oracle_fixture'])
   if nat.lib().hbo_device_count() >= 2:
     assert mt['comm'].startswith('rccl (libhbo')
+
+
+def test_streamed_posterior_chunks_match_single_pass(gpu_ctx):
+  """The candidates are processed in chunks (two alternating cross-Gram workspaces, Gram build of chunk i+1 beside the
+  triangular product of chunk i): every chunk size -- one pass, ragged last chunk, 128-candidate chunks -- must give
+  bit-identical mean / variance / EI, with data and on the prior branch, fp64 and fp32."""
+  defs, _, acfun, gp, kernel, mean, _, utils = _native()
+  rng = np.random.default_rng(31)
+  d = 5
+  model = helpers.make_model(rng, 'linear_mlp', True, d)
+  x, y = helpers.synthetic_task(rng, 700, d)
+  xq = rng.uniform(size=(1000, d))
+  for dtype in (np.float64, np.float32):
+    cast = lambda t: {k: cast(v) for k, v in t.items()} if isinstance(t, dict) else np.asarray(t, dtype=dtype)
+    g = gp.GP({0: defs.SubDataset(x.astype(dtype), y.astype(dtype)), 1: defs.SubDataset(np.zeros((0, d), dtype), np.zeros((0, 1), dtype))},
+              mean.linear_mlp, kernel.matern52_mlp, defs.GPParams(model=cast(model), config={'mlp_features': helpers.MLP_FEATURES}),
+              utils.DEFAULT_WARP_FUNC)
+    ref = None
+    try:
+      for chunk in (65536, 512, 384, 128):
+        gpu_ctx.set_option('post_chunk', chunk)
+        cur = (g.predict(xq.astype(dtype), 0), acfun.expected_improvement(model=g, sub_dataset_key=0, x_queries=xq.astype(dtype)),
+               g.predict(xq.astype(dtype), 1), acfun.ucb(model=g, sub_dataset_key=1, x_queries=xq.astype(dtype)))
+        flat = [cur[0][0], cur[0][1], cur[1], cur[2][0], cur[2][1], cur[3]]
+        assert all(np.isfinite(a).all() for a in flat)
+        if ref is None:
+          ref = flat
+        else:
+          for a, b in zip(flat, ref):
+            assert np.array_equal(a, b), chunk
+    finally:
+      gpu_ctx.set_option('post_chunk', 8192)
+  if dtype == np.float32:
+    pass
+  # against the oracle (fp64) with small chunks
+  gpu_ctx.set_option('post_chunk', 256)
+  try:
+    g64 = gp.GP({0: defs.SubDataset(x, y)}, mean.linear_mlp, kernel.matern52_mlp,
+                defs.GPParams(model=model, config={'mlp_features': helpers.MLP_FEATURES}), utils.DEFAULT_WARP_FUNC)
+    mu, var = g64.predict(xq, 0, with_noise=False, unbiased=False)
+  finally:
+    gpu_ctx.set_option('post_chunk', 8192)
+  po = o.GPParams(model=model, config={'mlp_features': helpers.MLP_FEATURES})
+  mu_o, var_o = o.predict(o.linear_mlp, o.matern52_mlp, po, x, y, xq, WFO)
+  assert helpers.rel_err(mu, mu_o) < 1e-9 and helpers.rel_err(var, var_o) < 1e-8

@@ -14,11 +14,14 @@ __global__ void fill(double* p, size_t n, unsigned seed) {
 int main(int argc, char** argv) {
   int n = argc > 1 ? atoi(argv[1]) : 8192;
   int nblk = n / 128; int64_t ld = n + 16;
+  // HBO_BENCH_LD=<elements>: override the leading dimension (e.g. 16: every row aliases the same 128 bytes -> all operand
+  // traffic hits in L1/L2: the compute-bound speed of a kernel, numerically meaningless)
+  const char* ldenv = getenv("HBO_BENCH_LD");
   double *A, *W, *S;
   size_t na = (size_t)(n + 128) * ld;
   CK(hipMalloc(&A, na * 8)); CK(hipMalloc(&W, na * 8)); CK(hipMalloc(&S, na * 8));
   fill<<<(na + 255) / 256, 256>>>(A, na, 1); fill<<<(na + 255) / 256, 256>>>(W, na, 2); fill<<<(na + 255) / 256, 256>>>(S, na, 3);
-  TaskDesc h = {}; h.A = A; h.W = W; h.S = S; h.n = n; h.npad = n; h.nblk = nblk; h.m = 1; h.ld = ld;
+  TaskDesc h = {}; h.A = A; h.W = W; h.S = S; h.n = n; h.npad = n; h.nblk = nblk; h.m = 1; h.ld = ldenv ? atoll(ldenv) : ld;
   TaskDesc* d; CK(hipMalloc(&d, sizeof h)); CK(hipMemcpy(d, &h, sizeof h, hipMemcpyHostToDevice));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   auto timeit = [&](const char* name, GemmArgs a, dim3 grid, double flops) {
