@@ -296,12 +296,12 @@ def main():
     # HBM traffic per launch from committed rocprofv3 PMC passes of this same command (separate
     # --pmc FETCH_SIZE / WRITE_SIZE runs; FETCH_SIZE doubled per MI355X_MICROARCH.md: on gfx950 it
     # reports half the bytes of wide coalesced streaming reads).  bench.py cannot run rocprof itself.
-    pmc_path = os.path.join(ROOT, 'profiles', 'r01_pmc_hbm.json')
+    pmc_path = os.path.join(ROOT, 'profiles', 'r02_pmc_hbm.json')   # re-collected for this round's build (tools/pmc_to_json.py)
     if os.path.exists(pmc_path):
       pmc = json.load(open(pmc_path)).get('gemm_kernel<double, true, true, 128>')
       if pmc:
         roofline['traffic'] = int((2 * pmc['FETCH_SIZE_KB'] + pmc['WRITE_SIZE_KB']) * 1024)
-        roofline['traffic_note'] = 'bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024, profiles/r01_pmc_hbm.json'
+        roofline['traffic_note'] = 'bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024, profiles/r02_pmc_hbm.json'
   stages = {k: round(v[0] / stage_evals, 4) for k, v in stage_prof.items()}   # separate pass with all stage events on
   ctx.profile_enable(0)
   roofline_potrf = None
