@@ -1,6 +1,6 @@
 // C ABI of libhbo (see include/hbo.h): context, device memory, orchestration of the HIP kernels
 // for the GP hot path, profiling with HIP events, and the RCCL all-reduce used by task sharding.
-#include "hbo_internal.h"
+#include "ctx.h"
 
 #include <dlfcn.h>
 #include <limits.h>
@@ -14,73 +14,8 @@
 #include <string>
 #include <vector>
 
-static thread_local std::string g_err;
+thread_local std::string hbo_g_err;
 
-struct ProfEntry { const char* name; hipEvent_t e0, e1; };
-
-struct hbo_ctx {
-  int device = 0;
-  hipStream_t stream = nullptr;
-  hipStream_t stream2 = nullptr;   // panel stream of the look-ahead Cholesky (high priority)
-  hipStream_t stream4 = nullptr;   // early part of trtri, overlapped with the tail of potrf
-  int opt_cu_yield = 2;      // background GEMM workgroups pause while a panel-chain workgroup runs on their CU (single matrix,
-                             // look-ahead): 1 = potf2 only, 2 = trsm and the chain's column updates too
-  int* d_yield = nullptr;    // per-CU table (cu_token() -> panel-chain workgroups running there)
-  int* gemm_yield = nullptr; // run_potrf -> trtri_level: GemmArgs::yield_flag of the launches that co-run with the panel chain
-  int opt_trtri_gran = 0;    // panels between two launches of the inverse's computable pieces during the factorisation (0: auto)
-  int opt_small_nblk = 32;   // matrices up to this many 128-blocks use 64x64 GEMM tiles in trtri / lauum
-  int opt_persist_free = -1; // bulk trailing update runs as 2*(CUs - this) persistent workgroups (-1: auto, see run_potrf)
-  int opt_post_chunk = 8192;   // posterior / acquisition: candidates per pass (the cross-Gram workspace is npad x this, whatever M)
-  int opt_trtri_at = 0;        // single matrix: panel count (in 64ths of the block count) after which the inverse starts beside the chain (0: 13/16)
-  int opt_trtri_small_wgs = 2; // ... and workgroups per CU of their 64-tile form
-  int opt_trtri_free = 48;   // CUs the inverse products that co-run with the panel chain leave free (0: one tile per workgroup)
-  int* trtri_counters = nullptr; int trtri_counter_next = 0;   // run_potrf -> trtri_level: tile counters of those launches
-  int n_cus = 256;
-  std::vector<hipEvent_t> ev_pool;
-  std::map<int, std::pair<void*, size_t>> ws;   // grow-only device scratch buffers by slot (no per-call hipMalloc/hipFree)
-  int opt_lookahead = 1;
-  int opt_f1_on_chain = 1;         // F1 on the panel stream (no event hops around it)
-  int opt_dynamic_tiles = 1;       // persistent bulk update draws its tiles from a counter
-  int opt_overlap_trtri = 1;
-  std::string err;
-  ModelDev* h_model = nullptr;      // pinned: uploaded without a staging copy or a synchronisation
-  void* hp_stage = nullptr; size_t hp_stage_bytes = 0;   // pinned staging (descriptors up, results down)
-  hipEvent_t ev_upload = nullptr;   // last host->device copy out of the pinned buffers
-  ModelDev* d_model = nullptr;
-  void* d_mlp_w[HBO_MAX_MLP_LAYERS] = {nullptr};
-  void* d_mlp_b[HBO_MAX_MLP_LAYERS] = {nullptr};
-  size_t mlp_w_bytes[HBO_MAX_MLP_LAYERS] = {0};
-  size_t mlp_b_bytes[HBO_MAX_MLP_LAYERS] = {0};
-  int opt_group = 0;         // 128-wide panels per trailing update (K = 128*group); 0: auto, see run_potrf
-  int prof_level = 0;
-  std::vector<ProfEntry> prof_pending;
-  std::vector<hipEvent_t> prof_events; size_t prof_next = 0;   // event pool of the timing scopes
-  std::vector<std::string> prof_names;
-  std::vector<double> prof_ms;
-  std::vector<int> prof_count;
-  // RCCL
-  void* rccl_lib = nullptr;
-  void* comm = nullptr;
-  double* d_comm_buf = nullptr;
-  int comm_buf_count = 0;
-};
-
-#define HIPCHK(ctx, call)                                                                     \
-  do {                                                                                        \
-    hipError_t e__ = (call);                                                                  \
-    if (e__ != hipSuccess) {                                                                  \
-      char buf__[512];                                                                        \
-      snprintf(buf__, sizeof buf__, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e__),   \
-               __FILE__, __LINE__);                                                           \
-      if (ctx) (ctx)->err = buf__; else g_err = buf__;                                        \
-      return HBO_ERR_HIP;                                                                     \
-    }                                                                                         \
-  } while (0)
-
-static int fail(hbo_ctx* ctx, int code, const std::string& msg) {
-  if (ctx) ctx->err = msg; else g_err = msg;
-  return code;
-}
 static inline size_t esize(int dtype) { return dtype == HBO_F64 ? 8 : 4; }
 static inline int round_up(int64_t n, int q) { return (int)(((n + q - 1) / q) * q); }
 // leading dimension: padded extent + 128 bytes, so that rows do not sit at a power-of-two stride
@@ -155,7 +90,7 @@ extern "C" int hbo_device_count(void) {
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
   return n;
 }
-extern "C" const char* hbo_last_error(hbo_ctx* ctx) { return ctx ? ctx->err.c_str() : g_err.c_str(); }
+extern "C" const char* hbo_last_error(hbo_ctx* ctx) { return ctx ? ctx->err.c_str() : hbo_g_err.c_str(); }
 
 extern "C" int hbo_ctx_create(int device, hbo_ctx** out) {
   if (!out) return fail(nullptr, HBO_ERR_ARG, "hbo_ctx_create: out is null");
@@ -177,7 +112,7 @@ extern "C" int hbo_ctx_create(int device, hbo_ctx** out) {
   if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_model, sizeof(ModelDev), hipHostMallocDefault);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_upload, hipEventDisableTiming);
   if (e != hipSuccess) {
-    g_err = std::string("hbo_ctx_create: ") + hipGetErrorString(e);
+    hbo_g_err = std::string("hbo_ctx_create: ") + hipGetErrorString(e);
     delete c;
     (void)nullctx;
     return HBO_ERR_HIP;
@@ -1569,71 +1504,4 @@ extern "C" int hbo_spd_solve(hbo_ctx* c, int dtype, const void* a, int64_t n, co
   }
   cleanup();
   return bad ? HBO_NOT_PD : HBO_OK;
-}
-
-// ---- RCCL (loaded lazily; libhbo itself does not link against it) ----------------------------
-struct hbo_nccl_id { char internal[HBO_UNIQUE_ID_BYTES]; };
-typedef int (*fn_ncclAllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t);
-typedef int (*fn_ncclCommDestroy)(void*);
-typedef const char* (*fn_ncclGetErrorString)(int);
-
-static void* rccl_open() {
-  static void* lib = nullptr;
-  if (lib) return lib;
-  for (const char* name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
-    lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
-    if (lib) break;
-  }
-  return lib;
-}
-
-extern "C" int hbo_comm_unique_id(void* out128) {
-  if (!out128) return HBO_ERR_ARG;
-  void* lib = rccl_open();
-  if (!lib) return fail(nullptr, HBO_ERR_COMM, "librccl.so not found");
-  auto f = (int (*)(hbo_nccl_id*))dlsym(lib, "ncclGetUniqueId");
-  if (!f) return fail(nullptr, HBO_ERR_COMM, "ncclGetUniqueId not found");
-  hbo_nccl_id id; memset(&id, 0, sizeof id);
-  int rc = f(&id);
-  if (rc != 0) return fail(nullptr, HBO_ERR_COMM, "ncclGetUniqueId failed");
-  memcpy(out128, &id, HBO_UNIQUE_ID_BYTES);
-  return HBO_OK;
-}
-extern "C" int hbo_comm_init(hbo_ctx* c, int rank, int nranks, const void* unique_id128) {
-  if (!c || !unique_id128 || nranks <= 0 || rank < 0 || rank >= nranks) return fail(c, HBO_ERR_ARG, "hbo_comm_init: bad argument");
-  HIPCHK(c, hipSetDevice(c->device));
-  void* lib = rccl_open();
-  if (!lib) return fail(c, HBO_ERR_COMM, "librccl.so not found");
-  c->rccl_lib = lib;
-  auto f = (int (*)(void**, int, hbo_nccl_id, int))dlsym(lib, "ncclCommInitRank");
-  if (!f) return fail(c, HBO_ERR_COMM, "ncclCommInitRank not found");
-  hbo_nccl_id id; memcpy(&id, unique_id128, HBO_UNIQUE_ID_BYTES);
-  int rc = f(&c->comm, nranks, id, rank);
-  if (rc != 0) { c->comm = nullptr; return fail(c, HBO_ERR_COMM, "ncclCommInitRank failed with code " + std::to_string(rc)); }
-  return HBO_OK;
-}
-extern "C" int hbo_comm_allreduce_sum(hbo_ctx* c, double* buf, int32_t count) {
-  if (!c || !buf || count <= 0) return fail(c, HBO_ERR_ARG, "hbo_comm_allreduce_sum: bad argument");
-  if (!c->comm) return fail(c, HBO_ERR_COMM, "hbo_comm_allreduce_sum: communicator not initialised");
-  HIPCHK(c, hipSetDevice(c->device));
-  if (c->comm_buf_count < count) { if (c->d_comm_buf) hipFree(c->d_comm_buf); HIPCHK(c, hipMalloc((void**)&c->d_comm_buf, sizeof(double) * count)); c->comm_buf_count = count; }
-  auto f = (fn_ncclAllReduce)dlsym(c->rccl_lib, "ncclAllReduce");
-  if (!f) return fail(c, HBO_ERR_COMM, "ncclAllReduce not found");
-  HIPCHK(c, hipMemcpyAsync(c->d_comm_buf, buf, sizeof(double) * count, hipMemcpyHostToDevice, c->stream));
-  const int ncclFloat64 = 8, ncclSum = 0;
-  int rc = f(c->d_comm_buf, c->d_comm_buf, (size_t)count, ncclFloat64, ncclSum, c->comm, c->stream);
-  if (rc != 0) return fail(c, HBO_ERR_COMM, "ncclAllReduce failed with code " + std::to_string(rc));
-  HIPCHK(c, hipMemcpyAsync(buf, c->d_comm_buf, sizeof(double) * count, hipMemcpyDeviceToHost, c->stream));
-  HIPCHK(c, hipStreamSynchronize(c->stream));
-  return HBO_OK;
-}
-extern "C" int hbo_comm_destroy(hbo_ctx* c) {
-  if (!c) return HBO_OK;
-  if (c->comm && c->rccl_lib) {
-    auto f = (fn_ncclCommDestroy)dlsym(c->rccl_lib, "ncclCommDestroy");
-    if (f) f(c->comm);
-  }
-  c->comm = nullptr;
-  if (c->d_comm_buf) { hipFree(c->d_comm_buf); c->d_comm_buf = nullptr; c->comm_buf_count = 0; }
-  return HBO_OK;
 }

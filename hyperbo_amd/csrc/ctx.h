@@ -1,0 +1,79 @@
+// Context object of libhbo and the error plumbing shared by its host translation units (api.hip: the C ABI and the
+// orchestration of the kernels; comm.hip: the RCCL binding).
+#pragma once
+#include "hbo_internal.h"
+
+#include <stdio.h>
+
+#include <map>
+#include <string>
+#include <utility>
+#include <vector>
+
+extern thread_local std::string hbo_g_err;   // last error of ctx-less calls (hbo_last_error(NULL))
+
+struct ProfEntry { const char* name; hipEvent_t e0, e1; };
+
+struct hbo_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  hipStream_t stream2 = nullptr;   // panel stream of the look-ahead Cholesky (high priority)
+  hipStream_t stream4 = nullptr;   // early part of trtri, overlapped with the tail of potrf
+  int opt_cu_yield = 2;      // background GEMM workgroups pause while a panel-chain workgroup runs on their CU (single matrix,
+                             // look-ahead): 1 = potf2 only, 2 = trsm and the chain's column updates too
+  int* d_yield = nullptr;    // per-CU table (cu_token() -> panel-chain workgroups running there)
+  int* gemm_yield = nullptr; // run_potrf -> trtri_level: GemmArgs::yield_flag of the launches that co-run with the panel chain
+  int opt_trtri_gran = 0;    // panels between two launches of the inverse's computable pieces during the factorisation (0: auto)
+  int opt_small_nblk = 32;   // matrices up to this many 128-blocks use 64x64 GEMM tiles in trtri / lauum
+  int opt_persist_free = -1; // bulk trailing update runs as 2*(CUs - this) persistent workgroups (-1: auto, see run_potrf)
+  int opt_post_chunk = 8192;   // posterior / acquisition: candidates per pass (the cross-Gram workspace is npad x this, whatever M)
+  int opt_trtri_at = 0;        // single matrix: panel count (in 64ths of the block count) after which the inverse starts beside the chain (0: 5/8)
+  int opt_trtri_small_wgs = 2; // ... and workgroups per CU of their 64-tile form
+  int opt_trtri_free = 48;   // CUs the inverse products that co-run with the panel chain leave free (0: one tile per workgroup)
+  int* trtri_counters = nullptr; int trtri_counter_next = 0;   // run_potrf -> trtri_level: tile counters of those launches
+  int n_cus = 256;
+  std::vector<hipEvent_t> ev_pool;
+  std::map<int, std::pair<void*, size_t>> ws;   // grow-only device scratch buffers by slot (no per-call hipMalloc/hipFree)
+  int opt_lookahead = 1;
+  int opt_f1_on_chain = 1;         // F1 on the panel stream (no event hops around it)
+  int opt_dynamic_tiles = 1;       // persistent bulk update draws its tiles from a counter
+  int opt_overlap_trtri = 1;
+  std::string err;
+  ModelDev* h_model = nullptr;      // pinned: uploaded without a staging copy or a synchronisation
+  void* hp_stage = nullptr; size_t hp_stage_bytes = 0;   // pinned staging (descriptors up, results down)
+  hipEvent_t ev_upload = nullptr;   // last host->device copy out of the pinned buffers
+  ModelDev* d_model = nullptr;
+  void* d_mlp_w[HBO_MAX_MLP_LAYERS] = {nullptr};
+  void* d_mlp_b[HBO_MAX_MLP_LAYERS] = {nullptr};
+  size_t mlp_w_bytes[HBO_MAX_MLP_LAYERS] = {0};
+  size_t mlp_b_bytes[HBO_MAX_MLP_LAYERS] = {0};
+  int opt_group = 0;         // 128-wide panels per trailing update (K = 128*group); 0: auto, see run_potrf
+  int prof_level = 0;
+  std::vector<ProfEntry> prof_pending;
+  std::vector<hipEvent_t> prof_events; size_t prof_next = 0;   // event pool of the timing scopes
+  std::vector<std::string> prof_names;
+  std::vector<double> prof_ms;
+  std::vector<int> prof_count;
+  // RCCL
+  void* rccl_lib = nullptr;
+  void* comm = nullptr;
+  double* d_comm_buf = nullptr;
+  int comm_buf_count = 0;
+};
+
+#define HIPCHK(ctx, call)                                                                     \
+  do {                                                                                        \
+    hipError_t e__ = (call);                                                                  \
+    if (e__ != hipSuccess) {                                                                  \
+      char buf__[512];                                                                        \
+      snprintf(buf__, sizeof buf__, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e__),   \
+               __FILE__, __LINE__);                                                           \
+      if (ctx) (ctx)->err = buf__; else hbo_g_err = buf__;                                        \
+      return HBO_ERR_HIP;                                                                     \
+    }                                                                                         \
+  } while (0)
+
+static inline int fail(hbo_ctx* ctx, int code, const std::string& msg) {
+  if (ctx) ctx->err = msg; else hbo_g_err = msg;
+  return code;
+}

@@ -33,13 +33,10 @@ template <> struct Mma<float> {
 };
 
 // LDS strides (elements).  k-contiguous operand: [128][SKC]; m-contiguous operand: [BKE][SMC].
-//   f64: SKC = 18 (== 2 mod 32 -> conflict-free ds_read_b64 fragment reads), f32: SKC = 36.
-//   SMC = 144 (== 16 mod 32) for both.  Both layouts take 18432 bytes per operand stage.
-#ifdef HBO_SKC17
+//   f64: SKC = 17 (odd stride: the k-contiguous ds_read_b64 fragment reads spread over the banks; the staging stores become
+//   pairs of 8-byte writes -- 18, with 16-byte stores and two-way read conflicts, measured equal or slower), f32: SKC = 36.
+//   SMC = 144 (== 16 mod 32) for both.  Both layouts take at most 18432 bytes per operand stage.
 template <typename T> __device__ __host__ constexpr int skc() { return sizeof(T) == 8 ? 17 : 36; }
-#else
-template <typename T> __device__ __host__ constexpr int skc() { return sizeof(T) == 8 ? 18 : 36; }
-#endif
 template <int TM> __device__ __host__ constexpr int smc() { return TM + 16; }   // == 16 mod 32
 constexpr int OPERAND_BYTES = 18432;  // >= 128*skc*sizeof(T) and BKE*SMC*sizeof(T)
 constexpr int OPERAND_BYTES_64 = 10240;   // 64-tiles: max(64*skc, BKE*80) elements

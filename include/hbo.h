@@ -193,14 +193,14 @@ int hbo_profile_get(hbo_ctx* ctx, char names[][32], double* ms, int32_t* launche
  *   post_chunk     128..65536 posterior / acquisition: query candidates per pass (cross-Gram workspace = npad x post_chunk
  *                        elements whatever M; two workspaces alternate so that the Gram build of a chunk runs beside the
  *                        triangular product of the previous one)
- *   trtri_at       0..63 single matrix: the inverse starts beside the chain after this many 64ths of the panels (0 = auto)
+ *   trtri_at       0..63 single matrix: the inverse starts beside the chain after this many 64ths of the panels (0 = auto: 5/8)
  *   trtri_small_wgs 1..4 workgroups per CU of the 64-tile form of the co-running inverse products
  *   lookahead      0/1   panel chain on its own stream, one group ahead of the bulk update
  *   f1_on_chain    0/1   next group's column update launched on the panel stream
  *   dynamic_tiles  0/1   persistent bulk update draws tiles from a counter
  *   overlap_trtri  0/1   inverse walks the block tree while the factorisation runs
  *   trtri_gran     >=0   panels between two launches of the inverse's computable pieces (0 = auto: every 4 panels
- *                        for a batch, once after 13/16 of the panels for a single matrix)
+ *                        for a batch, once after 5/8 of the panels for a single matrix)
  *   trtri_free     0..200 CUs left free by the inverse products that co-run with the panel chain (persistent form,
  *                        tiles from a counter; 0 = one tile per workgroup)
  *   small_nblk     int   matrices up to this many blocks use 64x64 tiles in trtri / lauum */
