@@ -152,6 +152,7 @@ extern "C" int hbo_set_option(hbo_ctx* c, const char* name, int64_t value) {
   if (!strcmp(name, "cu_yield")) { if (value < 0 || value > 2) return fail(c, HBO_ERR_ARG, "cu_yield in 0..2"); c->opt_cu_yield = (int)value; return HBO_OK; }
   if (!strcmp(name, "trtri_gran")) { if (value < 0) return fail(c, HBO_ERR_ARG, "trtri_gran >= 0"); c->opt_trtri_gran = (int)value; return HBO_OK; }
   if (!strcmp(name, "small_nblk")) { c->opt_small_nblk = (int)value; return HBO_OK; }
+  if (!strcmp(name, "lauum_split")) { c->opt_lauum_split = value ? 1 : 0; return HBO_OK; }
   if (!strcmp(name, "post_chunk")) { if (value < 128 || value > 65536) return fail(c, HBO_ERR_ARG, "post_chunk in 128..65536"); c->opt_post_chunk = (int)value; return HBO_OK; }
   if (!strcmp(name, "trtri_at")) { if (value < 0 || value > 63) return fail(c, HBO_ERR_ARG, "trtri_at in 0..63"); c->opt_trtri_at = (int)value; return HBO_OK; }
   if (!strcmp(name, "trtri_small_wgs")) { if (value < 1 || value > 4) return fail(c, HBO_ERR_ARG, "trtri_small_wgs in 1..4"); c->opt_trtri_small_wgs = (int)value; return HBO_OK; }
@@ -535,11 +536,23 @@ static void run_trtri(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks
   TrtriProgress fresh;
   trtri_advance(c, dtype, d_tasks, ntasks, max_nblk, max_nblk, c->stream, pg ? *pg : fresh);
 }
-static void run_lauum(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, int max_nblk) {
-  ProfScope ps(c, "lauum", 2);
+// K^-1 = W^T W on the lower tiles.  `split` > 0: the two-launch form -- `phase` 1 (the leading split x split tiles over the rows
+// below split, i.e. W11^T W11) may run as soon as W11 is final, phase 2 accumulates the rest (see GemmArgs::lsplit).
+static void run_lauum(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, int max_nblk, int split = 0, int phase = 0,
+                      hipStream_t st = nullptr) {
+  ProfScope ps(c, "lauum", 2, st ? st : c->stream);
   GemmArgs a = {}; a.tasks = d_tasks; a.mode = GEMM_LAUUM;
   a.small_tiles = max_nblk <= c->opt_small_nblk;
-  launch_gemm(dtype, a, dim3(max_nblk, max_nblk, ntasks), c->stream);
+  if (split > 0 && !a.small_tiles) { a.lsplit = split; a.lphase = phase; }
+  const int rows = (a.lphase == 1) ? split : max_nblk;
+  launch_gemm(dtype, a, dim3(rows, rows, ntasks), st ? st : c->stream);
+}
+// leading block count whose inverse W[0:split, 0:split] is complete once block columns [0, cfin) of L have been walked by
+// trtri_advance: the largest power of two <= cfin that is at most half the matrix (no tree node straddles it)
+static int lauum_split_for(int cfin, int max_nblk) {
+  int s = 1;
+  while (2 * s <= cfin && 4 * s <= max_nblk) s *= 2;
+  return (s >= 8 && s <= cfin) ? s : 0;
 }
 
 // ---- datasets ----------------------------------------------------------------------------
@@ -547,7 +560,7 @@ struct TaskHost {
   int64_t n = 0; int m = 0; int npad = 0, nblk = 0; int64_t ld = 0;
   void* X = nullptr; void* ysum = nullptr;
   void* ydiv = nullptr;   // (m+1) x n rows for the divergence objectives: (y_a - mean_a y)/sqrt(m), then -mean_a y
-  void* A = nullptr; void* W = nullptr; void* S = nullptr; void* svec = nullptr; int svec_cols = 0;
+  void* A = nullptr; void* W = nullptr; void* S = nullptr; void* wscr = nullptr; void* svec = nullptr; int svec_cols = 0;
   double* dmu = nullptr; double* fnorm = nullptr;
   double* dF = nullptr; double* dtmp = nullptr; size_t dF_elems = 0;   // MLP backward workspaces
   FeatBuf feat;
@@ -570,7 +583,7 @@ struct hbo_dataset {
 
 static void free_task(TaskHost* t) {
   if (!t) return;
-  for (void* p : {t->X, t->ysum, t->ydiv, t->A, t->W, t->S, t->svec, (void*)t->dmu, (void*)t->fnorm, (void*)t->dF, (void*)t->dtmp}) if (p) hipFree(p);
+  for (void* p : {t->X, t->ysum, t->ydiv, t->A, t->W, t->S, t->wscr, t->svec, (void*)t->dmu, (void*)t->fnorm, (void*)t->dF, (void*)t->dtmp}) if (p) hipFree(p);
   delete t;
 }
 
@@ -643,6 +656,7 @@ static int ensure_task_workspace(hbo_ctx* c, int dtype, TaskHost* t, bool need_S
   if (!t->A) HIPCHK(c, hipMalloc(&t->A, (size_t)(t->npad + HBO_TILE) * ld * es));
   if (!t->W) { HIPCHK(c, hipMalloc(&t->W, (size_t)t->npad * ld * es)); HIPCHK(c, hipMemsetAsync(t->W, 0, (size_t)t->npad * ld * es, c->stream)); }
   if (need_S && !t->S) HIPCHK(c, hipMalloc(&t->S, (size_t)t->npad * ld * es));
+  if (!t->wscr) HIPCHK(c, hipMalloc(&t->wscr, (size_t)((t->npad + 511) / 512) * ld * es));
   if (t->svec_cols < naug_cols) {
     if (t->svec) { HIPCHK(c, hipStreamSynchronize(c->stream)); hipFree(t->svec); t->svec = nullptr; }
     HIPCHK(c, hipMalloc(&t->svec, (size_t)t->npad * es * naug_cols));
@@ -658,7 +672,7 @@ enum { ROLE_FACTOR = 100 };
 
 static void fill_desc(TaskDesc& d, TaskHost* t, const hbo_model* m, int dtype, int role) {
   memset(&d, 0, sizeof d);
-  d.A = t->A; d.W = t->W; d.S = t->S; d.X = t->X; d.ysum = t->ysum; d.svec = t->svec;
+  d.A = t->A; d.W = t->W; d.S = t->S; d.wscr = t->wscr; d.X = t->X; d.ysum = t->ysum; d.svec = t->svec;
   d.dmu = t->dmu; d.fnorm = t->fnorm;
   const double mm = (double)t->m;
   switch (role) {
@@ -788,11 +802,22 @@ extern "C" int hbo_objective(hbo_ctx* c, const hbo_model* m_in, hbo_dataset* ds,
     const size_t pb = sizeof(double) * stride_task * T;
     if (ds->partials_bytes < pb) { if (ds->d_partials) hipFree(ds->d_partials); HIPCHK(c, hipMalloc((void**)&ds->d_partials, pb)); ds->partials_bytes = pb; }
     if (!euc) {
+      // The tail of the inverse is a chain of small dependent products (the tree over the last panels) before its top-level
+      // product: the machine is mostly idle for ~0.5 ms.  The part of K^-1 = W^T W that only needs W11 (final since the
+      // overlapped inverse walked the leading blocks) runs beside it on the side stream.
+      const int lsplit = (T == 1 && early_trtri && c->opt_lauum_split && max_nblk > c->opt_small_nblk) ? lauum_split_for(trtri_pg.diag, max_nblk) : 0;
+      hipEvent_t ev_l1 = nullptr;
+      if (lsplit > 0) {
+        hipEvent_t e0 = pool_event(c, 0); hipEventRecord(e0, st); hipStreamWaitEvent(c->stream4, e0, 0);
+        { ProfScope ps(c, "lauum_early", 1, c->stream4); run_lauum(c, dtype, ds->d_desc, T, max_nblk, lsplit, 1, c->stream4); }
+        ev_l1 = pool_event(c, 1); hipEventRecord(ev_l1, c->stream4);
+      }
       { ProfScope ps(c, "trtri", 1);
         run_trtri(c, dtype, ds->d_desc, T, max_nblk, &trtri_pg); }
+      if (ev_l1) hipStreamWaitEvent(st, ev_l1, 0);
       { ProfScope ps(c, "wt_z", 1);
         for (int b = 0; b < max_naug; ++b) launch_wt_z(dtype, ds->d_desc, T, max_nblk, b, b, max_npad, st); }
-      { ProfScope ps(c, "lauum", 1); run_lauum(c, dtype, ds->d_desc, T, max_nblk); }
+      { ProfScope ps(c, "lauum", 1); run_lauum(c, dtype, ds->d_desc, T, max_nblk, lsplit, lsplit > 0 ? 2 : 0); }
     }
     { ProfScope ps(c, "grad_contract", 1);
       launch_dmu(dtype, ds->d_desc, T, obj, st);
@@ -1455,7 +1480,7 @@ extern "C" int hbo_spd_solve(hbo_ctx* c, int dtype, const void* a, int64_t n, co
   launch_fill_spd(dtype, d_a, n, t->A, t->ld, t->npad, st);
   launch_set_aug(dtype, d_b, n, b ? mcols : 0, t->A, t->ld, t->npad, st);
   TaskDesc h; memset(&h, 0, sizeof h);
-  h.A = t->A; h.W = t->W; h.S = t->S; h.svec = t->svec; h.n = (int)n; h.npad = t->npad; h.nblk = t->nblk; h.m = t->m; h.ld = t->ld;
+  h.A = t->A; h.W = t->W; h.S = t->S; h.wscr = t->wscr; h.svec = t->svec; h.n = (int)n; h.npad = t->npad; h.nblk = t->nblk; h.m = t->m; h.ld = t->ld;
   h.naug = t->m;
   HIPCHK_S(hipMalloc((void**)&d_desc, sizeof h));
   HIPCHK_S(hipMalloc((void**)&d_info, sizeof(int)));

@@ -26,6 +26,8 @@ struct hbo_ctx {
   int opt_trtri_gran = 0;    // panels between two launches of the inverse's computable pieces during the factorisation (0: auto)
   int opt_small_nblk = 32;   // matrices up to this many 128-blocks use 64x64 GEMM tiles in trtri / lauum
   int opt_persist_free = -1; // bulk trailing update runs as 2*(CUs - this) persistent workgroups (-1: auto, see run_potrf)
+  int opt_lauum_split = 0;     // single matrix: W11^T W11 of K^-1 = W^T W runs beside the tail of the inverse (two-launch lauum; measured
+                               // neutral: N = 8192 11.68 -> 11.78 ms -- the tail of the inverse slows by what the early part saves)
   int opt_post_chunk = 8192;   // posterior / acquisition: candidates per pass (the cross-Gram workspace is npad x this, whatever M)
   int opt_trtri_at = 0;        // single matrix: panel count (in 64ths of the block count) after which the inverse starts beside the chain (0: 5/8)
   int opt_trtri_small_wgs = 2; // ... and workgroups per CU of their 64-tile form

@@ -291,7 +291,7 @@ __global__ __launch_bounds__(256) void wtz_partial_kernel(const TaskDesc* tasks,
   if (cb >= t.nblk || (!xover && aug_row >= t.naug)) return;
   const int64_t row_lo = (int64_t)rc * 512;
   if (row_lo >= t.npad) return;
-  T* part = static_cast<T*>(t.S) + (int64_t)rc * t.ld + (int64_t)cb * HBO_TILE;
+  T* part = static_cast<T*>(t.wscr) + (int64_t)rc * t.ld + (int64_t)cb * HBO_TILE;
   const int col = threadIdx.x & 127, half = threadIdx.x >> 7;
   T acc = (T)0;
   if (row_lo + 512 > (int64_t)cb * HBO_TILE) {  // chunk reaches the lower triangle
@@ -327,7 +327,7 @@ __global__ void wtz_final_kernel(const TaskDesc* tasks, int out_col, int out_ld,
   const TaskDesc& t = tasks[blockIdx.z];
   const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= t.npad || (!oover && out_col >= t.naug)) return;
-  const T* part = static_cast<const T*>(t.S);
+  const T* part = static_cast<const T*>(t.wscr);
   const int nrc = (t.npad + 511) / 512;
   T s = (T)0;
   for (int rc = 0; rc < nrc; ++rc) s += part[(int64_t)rc * t.ld + j];

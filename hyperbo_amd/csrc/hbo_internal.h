@@ -22,6 +22,7 @@ struct TaskDesc {
   void* A;           // (npad+128) x ld : Gram+jitter -> L (lower)
   void* W;           // npad x ld       : L^-1 (lower, zeros above)
   void* S;           // npad x ld       : scratch (trtri temp) -> K^-1 (lower tiles)
+  void* wscr;        // ceil(npad/512) x ld : partial sums of W^T z (its own buffer: S may already hold a part of K^-1)
   const void* X;     // n x D inputs
   const void* F;     // n x fdim kernel features (== X when the kernel has no MLP)
   const void* Fm;    // n x fmean features feeding a linear mean (X or MLP output) or null
@@ -73,6 +74,9 @@ struct GemmArgs {
   int pgx, pgy;     // persistent TRTRI: the tile grid the workgroups walk (set by launch_gemm)
   int* work_counter; // persistent SYRK: zero-initialised tile counter -> workgroups draw tiles dynamically (a faster
                      // workgroup takes more of them) instead of striding over them; null: static stride
+  int lsplit, lphase; // LAUUM in two launches (128-tiles): phase 1 = tiles i, j < lsplit summed over the rows k < lsplit*128 only
+                      // (needs W[0:lsplit, 0:lsplit], final early), phase 2 = every tile over the rest of its rows, accumulating
+                      // into the phase-1 tiles; lphase 0 = one launch over everything
   int dbg;          // HBO_GEMM_TIMING builds: 1 -> this launch records per-workgroup wall-clock stamps
   int* yield_flag;  // non-null (background launches: bulk update, overlapped inverse): per-CU table indexed by cu_token(); a
                     // workgroup sleeps at a K step while the entry of the CU it runs on is non-zero -- a panel-chain kernel
@@ -132,7 +136,7 @@ void launch_mean(int dtype, const void* fm, int64_t n, int fmean, const ModelDev
 void launch_aug_rows(int dtype, const TaskDesc* tasks, int ntasks, int max_npad, const ModelDev* md, hipStream_t st);
 void launch_nll_reduce(int dtype, const TaskDesc* tasks, int ntasks, const int* info, double* out,
                        hipStream_t st);
-// s = W^T z_a (z_a = augmented row a of A) -> tasks[t].svec[out_col*out_ld + j]; uses S as scratch
+// s = W^T z_a (z_a = augmented row a of A) -> tasks[t].svec[out_col*out_ld + j]; uses wscr as scratch
 // xover / oover (single task only): explicit input vector [npad] / output vector [npad]
 void launch_wt_z(int dtype, const TaskDesc* tasks, int ntasks, int max_nblk, int aug_row, int out_col,
                  int out_ld, hipStream_t st, const void* xover = nullptr, void* oover = nullptr);

@@ -190,6 +190,8 @@ int hbo_profile_get(hbo_ctx* ctx, char names[][32], double* ms, int32_t* launche
  *   persist_free  -1..200 CUs the persistent bulk trailing update leaves to the panel chain (-1 = auto: 48 / 32)
  *   cu_yield       0..2  background GEMM workgroups (bulk update, overlapped inverse) pause at a K step while a panel-chain
  *                        workgroup runs on their CU: 1 = potf2 only, 2 = trsm and the chain's column updates too
+ *   lauum_split    0/1   single matrix: the W11^T W11 part of K^-1 = W^T W runs beside the tail of the inverse (default 0:
+ *                        measured neutral)
  *   post_chunk     128..65536 posterior / acquisition: query candidates per pass (cross-Gram workspace = npad x post_chunk
  *                        elements whatever M; two workspaces alternate so that the Gram build of a chunk runs beside the
  *                        triangular product of the previous one)

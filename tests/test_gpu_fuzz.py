@@ -184,11 +184,16 @@ OPTION_SETS = [
     {'potrf_group': 1}, {'potrf_group': 2}, {'potrf_group': 4}, {'potrf_group': 8},
     {'persist_free': 0}, {'persist_free': 128}, {'dynamic_tiles': 0}, {'f1_on_chain': 0},
     {'trtri_gran': 1}, {'trtri_gran': 2}, {'trtri_gran': 5}, {'trtri_gran': 64},
-    {'small_nblk': 0}, {'small_nblk': 4}, {'cu_yield': 0},
+    {'small_nblk': 0}, {'small_nblk': 4}, {'cu_yield': 0}, {'cu_yield': 1},
     {'lookahead': 0, 'potrf_group': 3, 'small_nblk': 0},
+    # round 2: persistent co-running inverse products, their start point, the two-launch lauum, streamed posterior
+    {'trtri_free': 0}, {'trtri_free': 120, 'small_nblk': 0}, {'trtri_small_wgs': 4}, {'trtri_small_wgs': 1, 'trtri_free': 200},
+    {'trtri_at': 12}, {'trtri_at': 60, 'small_nblk': 0}, {'lauum_split': 1, 'small_nblk': 0}, {'lauum_split': 1, 'small_nblk': 0, 'trtri_at': 48},
+    {'post_chunk': 128},
 ]
 DEFAULTS = {'lookahead': 1, 'overlap_trtri': 1, 'potrf_group': 0, 'persist_free': -1, 'dynamic_tiles': 1, 'f1_on_chain': 1,
-            'trtri_gran': 0, 'small_nblk': 32, 'cu_yield': 1}
+            'trtri_gran': 0, 'small_nblk': 32, 'cu_yield': 2, 'trtri_free': 48, 'trtri_small_wgs': 2, 'trtri_at': 0,
+            'lauum_split': 0, 'post_chunk': 8192}
 
 
 @pytest.mark.parametrize('opts', OPTION_SETS, ids=lambda o_: ','.join(f'{k}={v}' for k, v in o_.items()))
