@@ -38,6 +38,42 @@ static void* ws_get(hbo_ctx* c, int slot, size_t bytes) {
   return e.first;
 }
 
+// ---- pooled device buffers of datasets and caches (see hbo_ctx::pool_free) ---------------------
+static hipError_t dev_alloc(hbo_ctx* c, void** out, size_t bytes, int cls = 0, bool* reused = nullptr) {
+  if (reused) *reused = false;
+  if (bytes == 0) bytes = 16;
+  if (c) {
+    auto it = c->pool_free.find({cls, bytes});
+    if (it != c->pool_free.end() && !it->second.empty()) {
+      *out = it->second.back(); it->second.pop_back();
+      c->pool_bytes -= bytes;
+      c->pool_live[*out] = {cls, bytes};
+      if (reused) *reused = true;
+      return hipSuccess;
+    }
+  }
+  hipError_t e = hipMalloc(out, bytes);
+  if (e != hipSuccess && c && c->pool_bytes) {   // out of memory with buffers parked: release them and retry
+    for (auto& kv : c->pool_free) for (void* p : kv.second) hipFree(p);
+    c->pool_free.clear(); c->pool_bytes = 0;
+    e = hipMalloc(out, bytes);
+  }
+  if (e == hipSuccess && c) c->pool_live[*out] = {cls, bytes};
+  return e;
+}
+static void dev_free(hbo_ctx* c, void* p) {
+  if (!p) return;
+  if (c) {
+    auto it = c->pool_live.find(p);
+    if (it != c->pool_live.end()) {
+      const std::pair<int, size_t> key = it->second;
+      c->pool_live.erase(it);
+      if (c->pool_bytes + key.second <= c->pool_cap) { c->pool_free[key].push_back(p); c->pool_bytes += key.second; return; }
+    }
+  }
+  hipFree(p);
+}
+
 // ---- profiling ---------------------------------------------------------------------------
 // Timing scopes: HIP events recorded on the stream the kernels are launched on.  Events come from a pool owned by
 // the context (creating and destroying ~80 events per evaluation cost 0.4 ms of host time).  prof_level < 0 is the
@@ -135,6 +171,8 @@ extern "C" int hbo_ctx_destroy(hbo_ctx* c) {
   if (c->hp_stage) hipHostFree(c->hp_stage);
   if (c->ev_upload) hipEventDestroy(c->ev_upload);
   for (auto& kv : c->ws) if (kv.second.first) hipFree(kv.second.first);
+  for (auto& kv : c->pool_free) for (void* p : kv.second) hipFree(p);
+  c->pool_free.clear(); c->pool_live.clear(); c->pool_bytes = 0;
   for (hipEvent_t ev : c->ev_pool) hipEventDestroy(ev);
   if (c->stream4) hipStreamDestroy(c->stream4);
   if (c->stream2) hipStreamDestroy(c->stream2);
@@ -558,6 +596,7 @@ static int lauum_split_for(int cfin, int max_nblk) {
 // ---- datasets ----------------------------------------------------------------------------
 struct TaskHost {
   int64_t n = 0; int m = 0; int npad = 0, nblk = 0; int64_t ld = 0;
+  bool owns_inputs = true;   // false: X / ysum / ydiv point into the dataset's single input block
   void* X = nullptr; void* ysum = nullptr;
   void* ydiv = nullptr;   // (m+1) x n rows for the divergence objectives: (y_a - mean_a y)/sqrt(m), then -mean_a y
   void* A = nullptr; void* W = nullptr; void* S = nullptr; void* wscr = nullptr; void* svec = nullptr; int svec_cols = 0;
@@ -570,6 +609,7 @@ struct hbo_dataset {
   std::vector<TaskHost*> tasks;
   std::vector<TaskDesc> h_desc;
   TaskDesc* d_desc = nullptr;
+  void* d_inputs = nullptr;   // x, column sums of y and divergence rows of every task (one upload)
   // results of one evaluation, one device block = one copy back: [value T][gradient T x out_stride][info T (int)]
   double* d_pack = nullptr; size_t pack_bytes = 0;
   int* d_info = nullptr;
@@ -581,16 +621,21 @@ struct hbo_dataset {
   bool has_S = false;
 };
 
-static void free_task(TaskHost* t) {
+static void free_task(hbo_ctx* c, TaskHost* t) {
   if (!t) return;
-  for (void* p : {t->X, t->ysum, t->ydiv, t->A, t->W, t->S, t->wscr, t->svec, (void*)t->dmu, (void*)t->fnorm, (void*)t->dF, (void*)t->dtmp}) if (p) hipFree(p);
+  if (t->owns_inputs) for (void* p : {t->X, t->ysum, t->ydiv}) dev_free(c, p);
+  for (void* p : {t->A, t->W, t->S, t->wscr, t->svec, (void*)t->dmu, (void*)t->fnorm}) dev_free(c, p);
+  for (void* p : {(void*)t->dF, (void*)t->dtmp}) if (p) hipFree(p);
   delete t;
 }
 
 extern "C" int hbo_dataset_free(hbo_ctx* c, hbo_dataset* ds) {
   if (!ds) return HBO_OK;
   if (c) hipSetDevice(c->device);
-  for (TaskHost* t : ds->tasks) free_task(t);
+  // (the buffers go back to the pool while kernels of the last evaluation may still run only if a call returned without
+  //  draining its streams -- none does: every entry point synchronises before it returns)
+  for (TaskHost* t : ds->tasks) free_task(c, t);
+  dev_free(c, ds->d_inputs);
   for (void* p : {(void*)ds->d_desc, (void*)ds->d_pack, (void*)ds->d_partials, (void*)ds->d_mlpgrad}) if (p) hipFree(p);
   delete ds;
   return HBO_OK;
@@ -605,28 +650,49 @@ extern "C" int hbo_dataset_create(hbo_ctx* c, int dtype, int input_dim, const hb
   hbo_dataset* ds = new hbo_dataset();
   ds->dtype = dtype; ds->D = input_dim;
   const size_t es = esize(dtype);
+  // All inputs of all tasks travel in ONE block: laid out in a pinned staging buffer (x, the column sums of y, the
+  // divergence rows), one host-to-device copy, the tasks point into the block.  (Three synchronous copies per task cost
+  // ~1 ms for 24 small tasks -- what an Adam step of GP.train() pays when it re-samples its batch, gp.py:101-111.)
+  auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+  size_t total = 0;
   for (int k = 0; k < n_tasks; ++k) {
     const hbo_task& tk = tasks[k];
     if (tk.n <= 0) continue;  // objectives.py:184-185: empty sub-datasets are skipped
     if (tk.m <= 0 || !tk.x || !tk.y) { hbo_dataset_free(c, ds); return fail(c, HBO_ERR_ARG, "hbo_dataset_create: bad task"); }
+    total += al((size_t)tk.n * input_dim * es) + al((size_t)tk.n * es);
+    if (tk.m + 1 <= HBO_TILE) total += al((size_t)(tk.m + 1) * tk.n * es);
+  }
+  unsigned char* stage = nullptr;
+  if (total) {
+    HIPCHK(c, hipEventSynchronize(c->ev_upload));   // the pinned buffer may still feed an earlier upload
+    stage = static_cast<unsigned char*>(pinned_stage(c, total));
+    hipError_t e = stage ? dev_alloc(c, &ds->d_inputs, total) : hipErrorOutOfMemory;
+    if (e != hipSuccess) { hbo_dataset_free(c, ds); return fail(c, HBO_ERR_HIP, std::string("hbo_dataset_create: ") + hipGetErrorString(e)); }
+  }
+  size_t off = 0;
+  for (int k = 0; k < n_tasks; ++k) {
+    const hbo_task& tk = tasks[k];
+    if (tk.n <= 0) continue;
     TaskHost* t = new TaskHost();
     ds->tasks.push_back(t);
+    t->owns_inputs = false;
     t->n = tk.n; t->m = tk.m; t->npad = round_up(tk.n, HBO_TILE); t->nblk = t->npad / HBO_TILE; t->ld = padded_ld(t->npad, dtype);
-    // ysum on the host (sum over columns, in double then cast)
-    std::vector<unsigned char> ys((size_t)tk.n * es);
+    t->X = (char*)ds->d_inputs + off;
+    memcpy(stage + off, tk.x, (size_t)tk.n * input_dim * es);
+    off += al((size_t)tk.n * input_dim * es);
+    // ysum (sum over columns, in double then cast)
+    t->ysum = (char*)ds->d_inputs + off;
     for (int64_t i = 0; i < tk.n; ++i) {
-      double s = 0;
-      for (int a = 0; a < tk.m; ++a) s += host_elem(tk.y, dtype, i * tk.m + a);
-      if (dtype == HBO_F64) ((double*)ys.data())[i] = s; else ((float*)ys.data())[i] = (float)s;
+      double sum = 0;
+      for (int a = 0; a < tk.m; ++a) sum += host_elem(tk.y, dtype, i * tk.m + a);
+      if (dtype == HBO_F64) ((double*)(stage + off))[i] = sum; else ((float*)(stage + off))[i] = (float)sum;
     }
-    hipError_t e = hipMalloc(&t->X, (size_t)tk.n * input_dim * es);
-    if (e == hipSuccess) e = hipMalloc(&t->ysum, (size_t)tk.n * es);
-    if (e == hipSuccess) e = hipMemcpy(t->X, tk.x, (size_t)tk.n * input_dim * es, hipMemcpyHostToDevice);
-    if (e == hipSuccess) e = hipMemcpy(t->ysum, ys.data(), (size_t)tk.n * es, hipMemcpyHostToDevice);
-    if (e == hipSuccess && tk.m + 1 <= HBO_TILE) {
+    off += al((size_t)tk.n * es);
+    if (tk.m + 1 <= HBO_TILE) {
       // sample statistics of objectives.py:57-58: mu_data = mean over the m aligned columns, cov_data =
       // (1/m) sum_a yc_a yc_a^T (jnp.cov(bias=True)); kept as its m rank-1 factors.
-      std::vector<unsigned char> yd((size_t)(tk.m + 1) * tk.n * es);
+      t->ydiv = (char*)ds->d_inputs + off;
+      unsigned char* yd = stage + off;
       const double rs = 1.0 / sqrt((double)tk.m);
       for (int64_t i = 0; i < tk.n; ++i) {
         double mu0 = 0;
@@ -634,14 +700,17 @@ extern "C" int hbo_dataset_create(hbo_ctx* c, int dtype, int input_dim, const hb
         mu0 /= tk.m;
         for (int a = 0; a <= tk.m; ++a) {
           const double v = a < tk.m ? (host_elem(tk.y, dtype, i * tk.m + a) - mu0) * rs : -mu0;
-          if (dtype == HBO_F64) ((double*)yd.data())[(size_t)a * tk.n + i] = v; else ((float*)yd.data())[(size_t)a * tk.n + i] = (float)v;
+          if (dtype == HBO_F64) ((double*)yd)[(size_t)a * tk.n + i] = v; else ((float*)yd)[(size_t)a * tk.n + i] = (float)v;
         }
       }
-      e = hipMalloc(&t->ydiv, yd.size());
-      if (e == hipSuccess) e = hipMemcpy(t->ydiv, yd.data(), yd.size(), hipMemcpyHostToDevice);
+      off += al((size_t)(tk.m + 1) * tk.n * es);
     }
-    if (e != hipSuccess) { hbo_dataset_free(c, ds); return fail(c, HBO_ERR_HIP, std::string("hbo_dataset_create: ") + hipGetErrorString(e)); }
     ds->max_nblk = std::max(ds->max_nblk, t->nblk);
+  }
+  if (total) {
+    hipError_t e = hipMemcpyAsync(ds->d_inputs, stage, total, hipMemcpyHostToDevice, c->stream);
+    if (e == hipSuccess) e = hipEventRecord(c->ev_upload, c->stream);
+    if (e != hipSuccess) { hbo_dataset_free(c, ds); return fail(c, HBO_ERR_HIP, std::string("hbo_dataset_create: ") + hipGetErrorString(e)); }
   }
   ds->ntasks = (int)ds->tasks.size();
   // largest tasks first: their tiles are dispatched first
@@ -653,17 +722,21 @@ extern "C" int hbo_dataset_create(hbo_ctx* c, int dtype, int input_dim, const hb
 static int ensure_task_workspace(hbo_ctx* c, int dtype, TaskHost* t, bool need_S, int naug_cols) {
   const size_t es = esize(dtype);
   const size_t ld = (size_t)t->ld;
-  if (!t->A) HIPCHK(c, hipMalloc(&t->A, (size_t)(t->npad + HBO_TILE) * ld * es));
-  if (!t->W) { HIPCHK(c, hipMalloc(&t->W, (size_t)t->npad * ld * es)); HIPCHK(c, hipMemsetAsync(t->W, 0, (size_t)t->npad * ld * es, c->stream)); }
-  if (need_S && !t->S) HIPCHK(c, hipMalloc(&t->S, (size_t)t->npad * ld * es));
-  if (!t->wscr) HIPCHK(c, hipMalloc(&t->wscr, (size_t)((t->npad + 511) / 512) * ld * es));
+  if (!t->A) HIPCHK(c, dev_alloc(c, &t->A, (size_t)(t->npad + HBO_TILE) * ld * es));
+  if (!t->W) {   // a W that served the same shape before still has its zeros above the diagonal
+    bool reused = false;
+    HIPCHK(c, dev_alloc(c, &t->W, (size_t)t->npad * ld * es, dtype == HBO_F64 ? 2 : 1, &reused));
+    if (!reused) HIPCHK(c, hipMemsetAsync(t->W, 0, (size_t)t->npad * ld * es, c->stream));
+  }
+  if (need_S && !t->S) HIPCHK(c, dev_alloc(c, &t->S, (size_t)t->npad * ld * es));
+  if (!t->wscr) HIPCHK(c, dev_alloc(c, &t->wscr, (size_t)((t->npad + 511) / 512) * ld * es));
   if (t->svec_cols < naug_cols) {
-    if (t->svec) { HIPCHK(c, hipStreamSynchronize(c->stream)); hipFree(t->svec); t->svec = nullptr; }
-    HIPCHK(c, hipMalloc(&t->svec, (size_t)t->npad * es * naug_cols));
+    if (t->svec) { HIPCHK(c, hipStreamSynchronize(c->stream)); dev_free(c, t->svec); t->svec = nullptr; }
+    HIPCHK(c, dev_alloc(c, &t->svec, (size_t)t->npad * es * naug_cols));
     HIPCHK(c, hipMemsetAsync(t->svec, 0, (size_t)t->npad * es * naug_cols, c->stream));
     t->svec_cols = naug_cols;
   }
-  if (!t->dmu) { HIPCHK(c, hipMalloc((void**)&t->dmu, (size_t)t->npad * sizeof(double))); HIPCHK(c, hipMalloc((void**)&t->fnorm, 2 * sizeof(double))); }
+  if (!t->dmu) { HIPCHK(c, dev_alloc(c, (void**)&t->dmu, (size_t)t->npad * sizeof(double))); HIPCHK(c, dev_alloc(c, (void**)&t->fnorm, 2 * sizeof(double))); }
   return HBO_OK;
 }
 
@@ -913,7 +986,7 @@ struct hbo_cache {
 extern "C" int hbo_cache_free(hbo_ctx* c, hbo_cache* k) {
   if (!k) return HBO_OK;
   if (c) hipSetDevice(c->device);
-  free_task(k->t);
+  free_task(c, k->t);
   for (void* p : {(void*)k->d_desc, (void*)k->d_info, k->resid, k->zvec}) if (p) hipFree(p);
   delete k;
   return HBO_OK;
@@ -936,13 +1009,13 @@ extern "C" int hbo_factor(hbo_ctx* c, const hbo_model* m, const void* x, int64_t
   t->n = n; t->m = mcols; t->npad = round_up(n, HBO_TILE); t->nblk = t->npad / HBO_TILE; t->ld = padded_ld(t->npad, dtype);
   auto bail = [&](int code) { hbo_cache_free(c, k); return code; };
 #define HIPCHK_K(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) { c->err = std::string(#call " failed: ") + hipGetErrorString(e__); return bail(HBO_ERR_HIP); } } while (0)
-  HIPCHK_K(hipMalloc(&t->X, (size_t)t->npad * m->input_dim * es));   // capacity npad rows (row appends)
+  HIPCHK_K(dev_alloc(c, &t->X, (size_t)t->npad * m->input_dim * es));   // capacity npad rows (row appends)
   HIPCHK_K(hipMemcpy(t->X, x, (size_t)n * m->input_dim * es, hipMemcpyHostToDevice));
   // y^T (m x n) so that aug row a = column a of y
   std::vector<unsigned char> yt((size_t)n * mcols * es);
   for (int64_t i = 0; i < n; ++i)
     for (int a = 0; a < mcols; ++a) memcpy(yt.data() + ((size_t)a * n + i) * es, (const unsigned char*)y + ((size_t)i * mcols + a) * es, es);
-  HIPCHK_K(hipMalloc(&t->ysum, (size_t)n * mcols * es));
+  HIPCHK_K(dev_alloc(c, &t->ysum, (size_t)n * mcols * es));
   HIPCHK_K(hipMemcpy(t->ysum, yt.data(), (size_t)n * mcols * es, hipMemcpyHostToDevice));
   rc = ensure_task_workspace(c, dtype, t, true, mcols);
   if (rc) return bail(rc);
@@ -1470,7 +1543,7 @@ extern "C" int hbo_spd_solve(hbo_ctx* c, int dtype, const void* a, int64_t n, co
   TaskHost* t = new TaskHost();
   t->n = n; t->m = b ? mcols : 1; t->npad = round_up(n, HBO_TILE); t->nblk = t->npad / HBO_TILE; t->ld = padded_ld(t->npad, dtype);
   void *d_a = nullptr, *d_b = nullptr, *d_tmp = nullptr; TaskDesc* d_desc = nullptr; int* d_info = nullptr;
-  auto cleanup = [&]() { free_task(t); for (void* p : {d_a, d_b, d_tmp, (void*)d_desc, (void*)d_info}) if (p) hipFree(p); };
+  auto cleanup = [&]() { free_task(c, t); for (void* p : {d_a, d_b, d_tmp, (void*)d_desc, (void*)d_info}) if (p) hipFree(p); };
 #define HIPCHK_S(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) { c->err = std::string(#call " failed: ") + hipGetErrorString(e__); cleanup(); return HBO_ERR_HIP; } } while (0)
   const bool need_inv = inv_out != nullptr || x_out != nullptr;
   { int rc = ensure_task_workspace(c, dtype, t, need_inv, t->m); if (rc) { cleanup(); return rc; } }

@@ -36,6 +36,14 @@ struct hbo_ctx {
   int n_cus = 256;
   std::vector<hipEvent_t> ev_pool;
   std::map<int, std::pair<void*, size_t>> ws;   // grow-only device scratch buffers by slot (no per-call hipMalloc/hipFree)
+  // Device buffers of freed datasets / caches, kept for the next one of the same shape (dev_alloc / dev_free in api.hip):
+  // GP.train()'s Adam loop re-creates its sub-sampled batch every step (gp.py:101-111) and 64 tasks x 8 buffers of
+  // hipMalloc + hipFree cost 40 of its 50 ms.  Key: (class, bytes); class 1 / 2 = an fp32 / fp64 inverse factor W, whose
+  // "zeros above the diagonal" survive a reuse in the same role only.
+  std::map<std::pair<int, size_t>, std::vector<void*>> pool_free;
+  std::map<void*, std::pair<int, size_t>> pool_live;
+  size_t pool_bytes = 0;                       // bytes parked in pool_free
+  size_t pool_cap = (size_t)48 << 30;
   int opt_lookahead = 1;
   int opt_f1_on_chain = 1;         // F1 on the panel stream (no event hops around it)
   int opt_dynamic_tiles = 1;       // persistent bulk update draws its tiles from a counter

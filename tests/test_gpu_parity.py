@@ -1180,3 +1180,37 @@ def test_streamed_posterior_chunks_match_single_pass(gpu_ctx):
   po = o.GPParams(model=model, config={'mlp_features': helpers.MLP_FEATURES})
   mu_o, var_o = o.predict(o.linear_mlp, o.matern52_mlp, po, x, y, xq, WFO)
   assert helpers.rel_err(mu, mu_o) < 1e-9 and helpers.rel_err(var, var_o) < 1e-8
+
+
+def test_pooled_device_buffers_are_safe_to_reuse(gpu_ctx):
+  """Datasets and caches hand their device buffers back to a pool on close (GP.train()'s Adam loop re-creates its
+  sub-sampled batch every step, gp.py:101-111); the next dataset of the same shape takes them over -- including the
+  inverse factor W, whose zeros above the diagonal are only valid for the same size and dtype.  Alternating shapes, dtypes,
+  objectives and a posterior cache must all still match the oracle."""
+  defs, linalg, acfun, gp, kernel, mean, objectives, utils = _native()
+  rng = np.random.default_rng(41)
+  d = 3
+  model = helpers.make_model(rng, 'constant', False, d)
+  po = o.GPParams(model=model)
+  wf = utils.DEFAULT_WARP_FUNC
+  cast32 = lambda t: {k: cast32(v) for k, v in t.items()} if isinstance(t, dict) else np.asarray(t, dtype=np.float32)
+  plan = [(300, np.float64), (300, np.float64), (180, np.float64), (300, np.float32), (180, np.float32), (300, np.float64), (428, np.float64), (300, np.float64)]
+  for step, (n, dt) in enumerate(plan):
+    data = {k: helpers.synthetic_task(rng, n + 17 * k, d) for k in range(3)}
+    dso = {k: o.SubDataset(x, y) for k, (x, y) in data.items()}
+    dsn = {k: defs.SubDataset(x.astype(dt), y.astype(dt)) for k, (x, y) in data.items()}
+    pn = defs.GPParams(model=cast32(model) if dt == np.float32 else model)
+    vo, go = o.nll_value_and_grad(o.constant, o.matern32, po, dso, WFO)
+    dev = objectives.DeviceDataset(dsn)
+    vn, gn = objectives.nll_value_and_grad(mean.constant, kernel.matern32, pn, dev, wf)
+    dev.close()
+    tol_v, tol_g = (1e-10, 1e-8) if dt == np.float64 else (3e-4, 1e-2)
+    assert abs(vn - vo) <= tol_v * max(abs(vo), 1.0), (step, n, dt)
+    fo, fn = helpers.flatten(go), helpers.flatten(gn)
+    assert np.max(np.abs(fo - fn)) <= tol_g * np.max(np.abs(fo)), (step, n, dt)
+    if dt == np.float64:   # a posterior cache (its own X / W / S buffers) in between
+      x, y = data[0]
+      h = linalg.factor(mean.constant, kernel.matern32, pn, x, y, wf)
+      chol, kinvy, _ = h.export(); h.close()
+      co, ko, _ = o.solve_gp_linear_system(o.constant, o.matern32, po, x, y, WFO)
+      assert helpers.rel_err(chol, co) < 1e-10 and helpers.rel_err(kinvy, ko) < 1e-8
