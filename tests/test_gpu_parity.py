@@ -1214,3 +1214,61 @@ def test_pooled_device_buffers_are_safe_to_reuse(gpu_ctx):
       chol, kinvy, _ = h.export(); h.close()
       co, ko, _ = o.solve_gp_linear_system(o.constant, o.matern32, po, x, y, WFO)
       assert helpers.rel_err(chol, co) < 1e-10 and helpers.rel_err(kinvy, ko) < 1e-8
+
+
+# ---- fp32 (the reference's DEFAULT dtype: JAX without x64) across the whole registry -----------------------------------
+_FP32_ERR = {}
+
+
+@pytest.mark.parametrize('kname', helpers.KERNELS)
+@pytest.mark.parametrize('mlp', [False, True])
+@pytest.mark.parametrize('mname', helpers.MEANS)
+def test_fp32_registry_value_grad_posterior_vs_oracle(gpu_ctx, kname, mlp, mname):
+  """Every kernel x MLP-or-not x mean of the closed registry in float32 -- the dtype the reference runs in unless
+  JAX_ENABLE_X64 is set: NLL (two ragged tasks), ALL gradient leaves, posterior mean / variance and EI against the fp64
+  oracle evaluated on the SAME float32-rounded inputs and parameters.  Tolerances: a float32 Cholesky of a jittered Gram
+  matrix with noise variance 0.13 (cond ~1e3), about ten times the worst error measured on MI355X (value 7e-7, gradient
+  6e-6, mean 4e-5, variance 5e-6): value 1e-5, gradient 1e-4 of max|g|, mean 5e-4, variance 1e-4, EI 2e-3."""
+  defs, _, acfun, gp, kernel, mean, objectives, utils = _native()
+  rng = np.random.default_rng(51)
+  d = 3
+  model = helpers.make_model(rng, mname, mlp, d)
+  cast32 = lambda t: {k: cast32(v) for k, v in t.items()} if isinstance(t, dict) else np.asarray(t, dtype=np.float32)
+  up64 = lambda t: {k: up64(v) for k, v in t.items()} if isinstance(t, dict) else np.asarray(t, dtype=np.float64)
+  m32 = cast32(model)
+  data = {k: tuple(a.astype(np.float32) for a in helpers.synthetic_task(rng, n, d)) for k, n in enumerate((260, 131))}
+  cfg = {'mlp_features': helpers.MLP_FEATURES}
+  po = o.GPParams(model=up64(m32), config=dict(cfg)); pn = defs.GPParams(model=m32, config=dict(cfg))
+  dso = {k: o.SubDataset(x.astype(np.float64), y.astype(np.float64)) for k, (x, y) in data.items()}
+  dsn = {k: defs.SubDataset(x, y) for k, (x, y) in data.items()}
+  ko = getattr(o, kname + ('_mlp' if mlp else '')); kn = getattr(kernel, kname + ('_mlp' if mlp else ''))
+  mo, mn = getattr(o, mname), getattr(mean, mname)
+  wf = utils.DEFAULT_WARP_FUNC
+  vo, go = o.nll_value_and_grad(mo, ko, po, dso, WFO)
+  vn, gn = objectives.nll_value_and_grad(mn, kn, pn, dsn, wf)
+  fo, fn = helpers.flatten(go), helpers.flatten(gn)
+  e_val = abs(vn - vo) / max(abs(vo), 1.0)
+  e_grad = np.max(np.abs(fo - fn)) / np.max(np.abs(fo))
+  x, y = data[0]
+  xq = rng.uniform(size=(64, d)).astype(np.float32)
+  g32 = gp.GP(dsn, mn, kn, pn, wf)
+  mu, var = g32.predict(xq, 0)
+  ei = acfun.expected_improvement(model=g32, sub_dataset_key=0, x_queries=xq)
+  assert mu.dtype == np.float32 and var.dtype == np.float32 and ei.dtype == np.float32
+  mu_o, var_o = o.predict(mo, ko, po, x.astype(np.float64), y.astype(np.float64), xq.astype(np.float64), WFO)
+  mu_o, var_o = o.gp_predict_postprocess(po, dso, mu_o, var_o, WFO, False, True, True)
+  ei_o = o.expected_improvement_sub(mu_o, np.sqrt(var_o), float(np.max(y)))
+  e_mu = np.max(np.abs(mu - mu_o)) / max(np.max(np.abs(mu_o)), 1.0)
+  e_var = np.max(np.abs(var - var_o)) / np.max(np.abs(var_o))
+  e_ei = np.max(np.abs(ei - ei_o)) / max(np.max(np.abs(ei_o)), 1e-3)
+  _FP32_ERR[(kname, mlp, mname)] = (e_val, e_grad, e_mu, e_var, e_ei)
+  assert e_val <= 1e-5 and e_grad <= 1e-4 and e_mu <= 5e-4 and e_var <= 1e-4 and e_ei <= 2e-3, _FP32_ERR[(kname, mlp, mname)]
+
+
+def test_fp32_registry_error_summary(gpu_ctx):
+  """Prints the worst float32 errors of the sweep above (run with -s); fails only if the sweep did not run."""
+  if not _FP32_ERR:
+    pytest.skip('run together with test_fp32_registry_value_grad_posterior_vs_oracle')
+  worst = np.max(np.array(list(_FP32_ERR.values())), axis=0)
+  print('fp32 worst relative errors (value, grad, mu, var, ei):', ' '.join('%.2e' % w for w in worst))
+  assert len(_FP32_ERR) == 32
