@@ -191,6 +191,16 @@ extern "C" int hbo_set_option(hbo_ctx* c, const char* name, int64_t value) {
   if (!strcmp(name, "trtri_gran")) { if (value < 0) return fail(c, HBO_ERR_ARG, "trtri_gran >= 0"); c->opt_trtri_gran = (int)value; return HBO_OK; }
   if (!strcmp(name, "small_nblk")) { c->opt_small_nblk = (int)value; return HBO_OK; }
   if (!strcmp(name, "lauum_split")) { c->opt_lauum_split = value ? 1 : 0; return HBO_OK; }
+  if (!strcmp(name, "pool_cap_mb")) {
+    if (value < 0) return fail(c, HBO_ERR_ARG, "pool_cap_mb >= 0");
+    c->pool_cap = (size_t)value << 20;
+    if (c->pool_bytes > c->pool_cap) {   // trim: release everything parked (simple and rare)
+      hipSetDevice(c->device);
+      for (auto& kv : c->pool_free) for (void* p : kv.second) hipFree(p);
+      c->pool_free.clear(); c->pool_bytes = 0;
+    }
+    return HBO_OK;
+  }
   if (!strcmp(name, "post_chunk")) { if (value < 128 || value > 65536) return fail(c, HBO_ERR_ARG, "post_chunk in 128..65536"); c->opt_post_chunk = (int)value; return HBO_OK; }
   if (!strcmp(name, "trtri_at")) { if (value < 0 || value > 63) return fail(c, HBO_ERR_ARG, "trtri_at in 0..63"); c->opt_trtri_at = (int)value; return HBO_OK; }
   if (!strcmp(name, "trtri_small_wgs")) { if (value < 1 || value > 4) return fail(c, HBO_ERR_ARG, "trtri_small_wgs in 1..4"); c->opt_trtri_small_wgs = (int)value; return HBO_OK; }

@@ -192,6 +192,8 @@ int hbo_profile_get(hbo_ctx* ctx, char names[][32], double* ms, int32_t* launche
  *                        workgroup runs on their CU: 1 = potf2 only, 2 = trsm and the chain's column updates too
  *   lauum_split    0/1   single matrix: the W11^T W11 part of K^-1 = W^T W runs beside the tail of the inverse (default 0:
  *                        measured neutral)
+ *   pool_cap_mb    >=0   device buffers of freed datasets / caches are parked for the next one of the same shape (GP.train()
+ *                        re-creates its sub-sampled batch every step); at most this many MB stay parked (default 49152; 0 = off)
  *   post_chunk     128..65536 posterior / acquisition: query candidates per pass (cross-Gram workspace = npad x post_chunk
  *                        elements whatever M; two workspaces alternate so that the Gram build of a chunk runs beside the
  *                        triangular product of the previous one)
