@@ -31,12 +31,29 @@ int main(int argc, char** argv) {
     for (int i = 0; i < reps; ++i) launch_gemm(HBO_F64, a, grid, 0);
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
-    printf("%-28s %8.3f ms  %6.1f TFLOP/s (algorithmic)\n", name, ms, flops / ms / 1e9);
+    printf("%-36s %8.3f ms  %6.1f TFLOP/s (algorithmic)\n", name, ms, flops / ms / 1e9);
   };
   if (argc > 2) {  // single-kernel mode for PMC runs: syrk K=1024 without C traffic
     GemmArgs a = {}; a.tasks = d; a.mode = GEMM_SYRK; a.p0 = 0; a.kt = 8; a.c_lo = 8; a.c_hi = nblk; a.aug = 1 | 4;
     double m = nblk - 8;
     timeit("syrk K=1024 dbg=4", a, dim3(nblk + 1 - 8, nblk - 8, 1), m * (m + 1) / 2 * 128.0 * 128 * 2 * 128 * 8);
+    return 0;
+  }
+  if (argc > 1 && getenv("HBO_BENCH_CHAIN")) {   // the panel chain's own GEMM launches, alone on the machine (latency, not throughput)
+    {
+    for (int p : {6, 30, 50})
+      for (int kt : {1, 2}) {
+        GemmArgs a = {}; a.tasks = d; a.mode = GEMM_SYRK; a.p0 = p - kt; a.kt = kt; a.c_lo = p; a.c_hi = p + 1; a.aug = 1; a.small_tiles = 1;
+        char nm[64]; snprintf(nm, 64, "column update p=%d K=%d", p, kt * 128);
+        timeit(nm, a, dim3(nblk + 1 - p, 1, 1), (double)(nblk + 1 - p) * 128.0 * 128 * 2 * 128 * kt);
+      }
+    for (int g1 : {6, 30, 51}) {
+      GemmArgs a = {}; a.tasks = d; a.mode = GEMM_SYRK; a.p0 = g1 - 3; a.kt = 3; a.c_lo = g1; a.c_hi = g1 + 3; a.aug = 1;
+      a.small_tiles = (int64_t)(nblk + 1 - a.c_lo) * 3 < 600;
+      char nm[64]; snprintf(nm, 64, "F1 g1=%d K=384", g1);
+      timeit(nm, a, dim3(nblk + 1 - g1, 3, 1), (double)(3 * (nblk + 1 - g1) - 3) * 128.0 * 128 * 2 * 384);
+    }
+    }
     return 0;
   }
   for (int dbg : {0, 2, 4})
@@ -61,7 +78,7 @@ int main(int argc, char** argv) {
         CK(hipEventRecord(e0)); launch_gemm(HBO_F64, a, dim3(nblk + 1 - c0, nblk - c0, 1), 0); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1)); if (rep && ms < best) best = ms;
       }
-      printf("%-28s %8.3f ms  %6.1f TFLOP/s\n", nm, best, (m * (m + 1) / 2 + m) * 128.0 * 128 * 2 * 128 * kt / best / 1e9);
+      printf("%-36s %8.3f ms  %6.1f TFLOP/s\n", nm, best, (m * (m + 1) / 2 + m) * 128.0 * 128 * 2 * 128 * kt / best / 1e9);
     }
   }
   { GemmArgs a = {}; a.tasks = d; a.mode = GEMM_LAUUM;
@@ -78,6 +95,6 @@ int main(int argc, char** argv) {
         printf("  trtri s=%2d mode %d: %.3f ms\n", s, mode, ms);
       }
     }
-    printf("%-28s %8.3f ms  %6.1f TFLOP/s (algorithmic, N^3/3 minus diag blocks)\n", "trtri levels", msum, (double)n * n * n / 3 / msum / 1e9); }
+    printf("%-36s %8.3f ms  %6.1f TFLOP/s (algorithmic, N^3/3 minus diag blocks)\n", "trtri levels", msum, (double)n * n * n / 3 / msum / 1e9); }
   return 0;
 }
