@@ -23,7 +23,7 @@ static inline int round_up(int64_t n, int q) { return (int)(((n + q - 1) / q) * 
 static inline int64_t padded_ld(int64_t extent, int dtype) { return extent + 128 / (int64_t)esize(dtype); }
 
 // grow-only scratch buffer for `slot`; nullptr on allocation failure (ctx->err is set)
-enum WsSlot { WS_XQ = 1, WS_MU0, WS_KD, WS_MU, WS_VAR, WS_ACQ, WS_K, WS_COLSQ, WS_V, WS_KQQ, WS_COV,
+enum WsSlot { WS_K3 = 40, WS_XQ = 1, WS_MU0, WS_KD, WS_MU, WS_VAR, WS_ACQ, WS_K, WS_COLSQ, WS_V, WS_KQQ, WS_COV,
               WS_AP_KX, WS_AP_L, WS_AP_W, WS_AP_MU, WS_AP_KD, WS_COUNTERS, WS_MUPART,
               WS_AG_K, WS_AG_L, WS_AG_B, WS_AG_GF, WS_AG_DMU, WS_AG_GX, WS_AG_T0, WS_AG_T1, WS_AG_DW, WS_FQ0 /* + layer */ };
 static void* ws_get(hbo_ctx* c, int slot, size_t bytes) {
@@ -201,6 +201,7 @@ extern "C" int hbo_set_option(hbo_ctx* c, const char* name, int64_t value) {
     }
     return HBO_OK;
   }
+  if (!strcmp(name, "post_bf16x3")) { c->opt_post_bf16x3 = value != 0; return HBO_OK; }
   if (!strcmp(name, "post_chunk")) { if (value < 128 || value > 65536) return fail(c, HBO_ERR_ARG, "post_chunk in 128..65536"); c->opt_post_chunk = (int)value; return HBO_OK; }
   if (!strcmp(name, "trtri_at")) { if (value < 0 || value > 63) return fail(c, HBO_ERR_ARG, "trtri_at in 0..63"); c->opt_trtri_at = (int)value; return HBO_OK; }
   if (!strcmp(name, "trtri_small_wgs")) { if (value < 1 || value > 4) return fail(c, HBO_ERR_ARG, "trtri_small_wgs in 1..4"); c->opt_trtri_small_wgs = (int)value; return HBO_OK; }
@@ -991,13 +992,15 @@ struct hbo_cache {
   int* d_info = nullptr; int info = INT_MAX;
   void* resid = nullptr;   // m x npad : y - mu
   void* zvec = nullptr;    // m x npad : z = L^-1 (y - mu), kept for O(N^2) row appends
+  // fp32 caches: W = L^-1 split into three bf16 planes for the posterior product (post3.hip), built at the first use
+  unsigned short* w3 = nullptr; size_t w3_elems = 0; bool w3_valid = false;
 };
 
 extern "C" int hbo_cache_free(hbo_ctx* c, hbo_cache* k) {
   if (!k) return HBO_OK;
   if (c) hipSetDevice(c->device);
   free_task(c, k->t);
-  for (void* p : {(void*)k->d_desc, (void*)k->d_info, k->resid, k->zvec}) if (p) hipFree(p);
+  for (void* p : {(void*)k->d_desc, (void*)k->d_info, k->resid, k->zvec, (void*)k->w3}) if (p) hipFree(p);
   delete k;
   return HBO_OK;
 }
@@ -1076,6 +1079,7 @@ extern "C" int hbo_cache_append(hbo_ctx* c, const hbo_model* m, hbo_cache* k, co
   if (k->dtype != m->dtype || k->D != m->input_dim) return fail(c, HBO_ERR_ARG, "hbo_cache_append: cache/model mismatch");
   if (k->info != INT_MAX) return HBO_NOT_PD;
   if (t->n + n_new > t->npad) return fail(c, HBO_ERR_UNSUPPORTED, "hbo_cache_append: capacity exhausted (re-factorise)");
+  k->w3_valid = false;   // W changes: its bf16 planes are rebuilt at the next posterior call
   int rc = upload_model(c, m);
   if (rc) return rc;
   const int dtype = k->dtype; const size_t es = esize(dtype);
@@ -1261,6 +1265,26 @@ static int posterior(hbo_ctx* c, const hbo_model* m, hbo_cache* k, const void* x
     if (full_cov) { d_V = ws_get(c, WS_V, (size_t)t->npad * ldq_max * es); if (!d_V) return HBO_ERR_HIP; }
   }
   if (full_cov) { { d_Kqq = ws_get(c, WS_KQQ, (size_t)M * M * es); if (!d_Kqq) return HBO_ERR_HIP; } { d_cov = ws_get(c, WS_COV, (size_t)M * M * es); if (!d_cov) return HBO_ERR_HIP; } }
+  // fp32: the product runs on the bf16 matrix cores from exact three-way splits of both operands (post3.hip)
+  const bool use3 = k && dtype == HBO_F32 && c->opt_post_bf16x3 && !full_cov;
+  unsigned short* d_K3 = nullptr; size_t k3_b = 0;
+  const int nkb = k ? t->npad / 16 : 0;
+  if (use3) {
+    k3_b = al((size_t)mpad_max * t->npad * 3 * sizeof(unsigned short));   // (mpad / 128) x nkb blocks of 3 x 128 x 16
+    d_K3 = (unsigned short*)ws_get(c, WS_K3, k3_b * nbuf); if (!d_K3) return HBO_ERR_HIP;
+    if (!k->w3_valid) {
+      const size_t elems = (size_t)t->npad * t->npad * 3;
+      if (!k->w3 || k->w3_elems != elems) {
+        if (k->w3) hipFree(k->w3);
+        k->w3 = nullptr;
+        HIPCHK_P(hipMalloc((void**)&k->w3, elems * sizeof(unsigned short)));
+        k->w3_elems = elems;
+      }
+      ProfScope ps(c, "split_w", 1, sa);
+      launch_split3_rows(static_cast<const float*>(t->W), t->ld, t->nblk, k->w3, nkb, sa);
+      k->w3_valid = true;
+    }
+  }
   const bool bad = k && k->info != INT_MAX;
   hipEvent_t ev_ready[2] = {nullptr, nullptr}, ev_free[2] = {nullptr, nullptr};
   size_t evi = 0;
@@ -1313,9 +1337,20 @@ static int posterior(hbo_ctx* c, const hbo_model* m, hbo_cache* k, const void* x
       GramArgs g = {}; g.kernel_id = c->h_model->kernel_id; g.x1 = k->h_desc.F; g.x2 = Fq; g.out = K_d; g.n1 = t->n; g.n2 = mc; g.ldo = ldq;
       g.n1pad = t->npad; g.n2pad = mpad; g.fdim = fdim; g.symmetric = 0; g.padded = 1;
       launch_gram(dtype, g, c->d_model, dim3(mpad / HBO_TILE, t->nblk, 1), sb); }
+    unsigned short* K3_d = use3 ? d_K3 + (size_t)b * (k3_b / sizeof(unsigned short)) : nullptr;
+    if (use3) {
+      ProfScope ps(c, "split_kxq", 1, sb);
+      launch_split3_transpose(reinterpret_cast<const float*>(K_d), ldq, t->npad, mpad, K3_d, nkb, sb);
+    }
     if (nbuf == 2) { ev_ready[b] = pool_event(c, evi++); hipEventRecord(ev_ready[b], sb); hipStreamWaitEvent(sa, ev_ready[b], 0); }
     // ---- consumer side (sa): V = L^-1 Kxq on MFMA (column sums of squares), then mean / variance / acquisition ----
-    { ProfScope ps(c, "post_gemm", 1, sa);
+    if (use3) {
+      ProfScope ps(c, "post_gemm", 1, sa);
+      Post3Args a = {}; a.Wp = k->w3; a.Kp = K3_d; a.nkb = nkb;
+      a.colsq = reinterpret_cast<float*>(colsq_d); a.ldc = ldq; a.V = nullptr; a.ldv = 0; a.nblk = t->nblk;
+      launch_post3(a, mpad / HBO_TILE, sa);
+    } else {
+      ProfScope ps(c, "post_gemm", 1, sa);
       GemmArgs a = {}; a.tasks = k->d_desc; a.mode = GEMM_POST; a.B = K_d; a.ldb = ldq; a.V = full_cov ? d_V : nullptr; a.colsq = colsq_d;
       launch_gemm(dtype, a, dim3(mpad / HBO_TILE, t->nblk, 1), sa); }
     { ProfScope ps(c, "post_epilogue", 1, sa);

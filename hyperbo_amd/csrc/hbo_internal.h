@@ -169,6 +169,19 @@ struct PostArgs {
 };
 void launch_post_epilogue(int dtype, const PostArgs& a, hipStream_t st);
 
+// ---- fp32 posterior product on the bf16 matrix cores (post3.hip) --------------------------------
+struct Post3Args {
+  const unsigned short* Wp;   // W = L^-1 split into bf16 panel blocks (layout: post3.hip), npad rows, k up to npad
+  const unsigned short* Kp;   // Kxq^T split the same way: rows = candidates of the chunk, k = training points
+  int nkb;                    // npad / 16: blocks of k per 128-row tile (both operands)
+  float* colsq; int64_t ldc;  // [nblk][ldc] per-row-block column sums of V^2 (may be null)
+  float* V; int64_t ldv;      // optional V output (npad x ldv)
+  int nblk;
+};
+void launch_split3_rows(const float* in, int64_t ld, int row_tiles, unsigned short* out, int nkb, hipStream_t st);
+void launch_split3_transpose(const float* in, int64_t ld, int krows, int jcols, unsigned short* out, int nkb, hipStream_t st);
+void launch_post3(const Post3Args& a, int col_tiles, hipStream_t st);
+
 struct AcqGradArgs {
   const void* Fq; const void* F; int fdim; int64_t n; int npad;   // kernel features: queries [M][fdim], training [n][fdim]
   const void* Kq; const void* L; const void* B;   // [M][npad]: k(x_q, X), W k, W^T W k  (null when n == 0)

@@ -1,0 +1,227 @@
+// fp32 posterior product V = W Kxq on the bf16 matrix cores ("bf16x3"), gfx950.
+//
+// hyperbo/gp_utils/gp.py:295-305 solves L V = Kxq (solve_triangular) for the predictive variance; here W = L^-1 is cached and
+// V = W Kxq is a triangular GEMM of N^2 M flops -- at the reference's default dtype (fp32) 1.76e13 flops at cfg 3, bound by the
+// fp32 MFMA rate (157 TFLOP/s dense).  The bf16 MFMA runs at 16x that rate, and an fp32 number is EXACTLY the sum of three
+// bf16 numbers (24 significand bits = 8 + 8 + 8, same exponent range):  x = x0 + x1 + x2,  x0 = bf16(x), x1 = bf16(x - x0),
+// x2 = bf16(x - x0 - x1).  With both operands split, the six products of weight >= 2^-16 relative to the leading one,
+//     a0 b0 + (a0 b1 + a1 b0) + (a0 b2 + a1 b1 + a2 b0),
+// are formed exactly by the bf16 MFMA (8 x 8 bit products) and accumulated in its fp32 accumulator; the three dropped ones
+// weigh <= 2^-24 -- the rounding an fp32 FMA commits on every product anyway.  Six bf16 MFMAs (32 cycles each for 32x32x16)
+// replace eight fp32 MFMAs (64 cycles each for 32x32x2): 2.7x the rate at fp32 accuracy (measured against the fp64 path in
+// tests/test_gpu_parity.py).  Operands are split once: W per factorisation (split3_rows), the cross-Gram per candidate chunk,
+// transposed on the way so that both operands are k-contiguous (split3_transpose), into a blocked layout that makes every
+// pipeline stage of the product a contiguous read.
+#include "hbo_internal.h"
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned short u16;
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));   // (native vector: HIP's uint4 is a union-backed struct that kept the staging registers in scratch memory)
+
+__device__ __forceinline__ u16 bf_bits(__bf16 v) { return __builtin_bit_cast(u16, v); }
+
+// x = h + m + l exactly (round-to-nearest-even at every step; the remainders are exact in fp32)
+__device__ __forceinline__ void split3(float x, u16& h, u16& m, u16& l) {
+  const __bf16 bh = (__bf16)x;
+  const float r1 = x - (float)bh;
+  const __bf16 bm = (__bf16)r1;
+  const float r2 = r1 - (float)bm;
+  const __bf16 bl = (__bf16)r2;
+  h = bf_bits(bh); m = bf_bits(bm); l = bf_bits(bl);
+}
+
+struct alignas(16) U16x8 { u16 v[8]; };
+
+// Layout of a split operand ("panel blocks"): for every 128-row tile R and every block KB of 16 values of k, the three planes
+// of the 128 x 16 block are stored back to back, each as [row][16 k] (4 KB):
+//     element (row, k, plane p)  ->  ((R * nkb + KB) * 3 + p) * 2048 + (row % 128) * 16 + k % 16,   nkb = Kpad / 16.
+// One pipeline stage of the product kernel is then 3 x 4 KB of contiguous memory per operand (256 threads x 16 bytes per
+// plane): the first version kept row-major planes and fetched 32 bytes out of every 128-byte line per stage (40 TFLOP/s).
+constexpr int P3_CHUNK = HBO_TILE * 16;   // elements of one plane of one block
+
+// in: rows x ld fp32 (row-major, k = column).  One workgroup = one 128-row tile x four k blocks; only blocks up to the row
+// tile's own diagonal block are written (W is lower triangular, zeros above the diagonal inside the diagonal blocks).
+__global__ __launch_bounds__(256) void split3_rows_kernel(const float* __restrict__ in, int64_t ld, u16* __restrict__ out, int nkb) {
+  const int R = blockIdx.y, kb0 = blockIdx.x * 4;
+  if (kb0 >= (R + 1) * (HBO_TILE / 16)) return;
+  const int row = threadIdx.x >> 1, half = threadIdx.x & 1;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int kb = kb0 + q;
+    const float* src = in + (int64_t)(R * HBO_TILE + row) * ld + kb * 16 + half * 8;
+    const float4 a = *reinterpret_cast<const float4*>(src);
+    const float4 b = *reinterpret_cast<const float4*>(src + 4);
+    const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    U16x8 h, m, l;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) split3(x[e], h.v[e], m.v[e], l.v[e]);
+    u16* o = out + ((int64_t)R * nkb + kb) * 3 * P3_CHUNK + threadIdx.x * 8;
+    *reinterpret_cast<U16x8*>(o) = h;
+    *reinterpret_cast<U16x8*>(o + P3_CHUNK) = m;
+    *reinterpret_cast<U16x8*>(o + 2 * P3_CHUNK) = l;
+  }
+}
+
+// in: krows x ld fp32 with k = ROW (the cross-Gram Kxq: k = training point, column j = candidate); out: panel blocks of the
+// transpose (row = j).  64 (k) x 64 (j) tiles through LDS.
+__global__ __launch_bounds__(256) void split3_transpose_kernel(const float* __restrict__ in, int64_t ld, u16* __restrict__ out, int nkb) {
+  __shared__ float tile[64][65];
+  const int k0 = blockIdx.y * 64, j0 = blockIdx.x * 64;
+  const int tid = threadIdx.x;
+  {
+    const int c = (tid & 15) * 4, r = tid >> 4;   // 16 threads x float4 per row of 64, 16 rows per pass
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 v = *reinterpret_cast<const float4*>(in + (int64_t)(k0 + r + 16 * q) * ld + j0 + c);
+      tile[r + 16 * q][c] = v.x; tile[r + 16 * q][c + 1] = v.y; tile[r + 16 * q][c + 2] = v.z; tile[r + 16 * q][c + 3] = v.w;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int item = tid + 256 * q;          // 4 k blocks x 64 rows j x 2 halves: consecutive items -> consecutive 16 bytes
+    const int kbl = item >> 7, j = (item & 127) >> 1, half = item & 1;
+    const int ko = kbl * 16 + half * 8;
+    U16x8 h, m, l;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) split3(tile[ko + e][j], h.v[e], m.v[e], l.v[e]);
+    const int jr = j0 + j;
+    u16* o = out + ((int64_t)(jr / HBO_TILE) * nkb + (k0 / 16 + kbl)) * 3 * P3_CHUNK + (jr % HBO_TILE) * 16 + half * 8;
+    *reinterpret_cast<U16x8*>(o) = h;
+    *reinterpret_cast<U16x8*>(o + P3_CHUNK) = m;
+    *reinterpret_cast<U16x8*>(o + 2 * P3_CHUNK) = l;
+  }
+}
+
+// ---- the product ---------------------------------------------------------------------------------------------------------
+// One workgroup = one 128 x 128 tile of V (rows i of W, columns j of the chunk), four waves in 2 x 2, each 64 x 64 = 2 x 2 MFMA
+// tiles of 32 x 32 (64 accumulator registers).  One pipeline stage = 16 values of k = one MFMA depth: per operand and plane
+// 128 rows x 32 bytes, staged through LDS with a 48-byte row stride (16 lanes x ds_read_b128 cover all 64 banks once).
+// Two stages of 2 operands x 3 planes: 73.7 KB, two workgroups per CU.
+constexpr int P3_ROW = 48;                     // bytes per LDS row
+constexpr int P3_ARR = 128 * P3_ROW;           // one operand plane of one stage
+constexpr int POST3_LDS_BYTES = 2 * 2 * 3 * P3_ARR;
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void post3_kernel(Post3Args g) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int i = g.nblk - 1 - (int)blockIdx.y;   // long rows first
+  const int jq = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l32 = lane & 31, lh = lane >> 5;
+  auto arr = [&](int st, int op, int p) { return smem + (size_t)((st * 2 + op) * 3 + p) * P3_ARR; };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  // staging: thread -> (row, 16-byte half of the stage's 32 bytes)
+  const int srow = tid >> 1, shalf = tid & 1;
+  const u16* ga = g.Wp + (int64_t)i * g.nkb * 3 * P3_CHUNK + tid * 8;
+  const u16* gb = g.Kp + (int64_t)jq * g.nkb * 3 * P3_CHUNK + tid * 8;
+  const int soff = srow * P3_ROW + shalf * 16;
+  // Global loads run four stages ahead of their use, in registers: one stage is only 24 MFMAs per wave (768 cycles, 0.3 us),
+  // far less than a memory round trip -- with a single stage in flight the kernel ran at the latency of its loads (72 TFLOP/s).
+  struct Slot { u32x4 a0, a1, a2, b0, b1, b2; };
+  Slot s0, s1, s2, s3;   // (named, not an array: an array indexed through the unrolled loop ended up in scratch memory)
+#define P3_GLOAD(KT, S)                                                              \
+  {                                                                                  \
+    const u16* pa_ = ga + (int64_t)(KT) * 3 * P3_CHUNK;                              \
+    const u16* pb_ = gb + (int64_t)(KT) * 3 * P3_CHUNK;                              \
+    S.a0 = *reinterpret_cast<const u32x4*>(pa_);                                     \
+    S.b0 = *reinterpret_cast<const u32x4*>(pb_);                                     \
+    S.a1 = *reinterpret_cast<const u32x4*>(pa_ + P3_CHUNK);                          \
+    S.b1 = *reinterpret_cast<const u32x4*>(pb_ + P3_CHUNK);                          \
+    S.a2 = *reinterpret_cast<const u32x4*>(pa_ + 2 * P3_CHUNK);                      \
+    S.b2 = *reinterpret_cast<const u32x4*>(pb_ + 2 * P3_CHUNK);                      \
+  }
+#define P3_SSTORE(ST, S)                                                             \
+  {                                                                                  \
+    *reinterpret_cast<u32x4*>(arr(ST, 0, 0) + soff) = S.a0;                          \
+    *reinterpret_cast<u32x4*>(arr(ST, 1, 0) + soff) = S.b0;                          \
+    *reinterpret_cast<u32x4*>(arr(ST, 0, 1) + soff) = S.a1;                          \
+    *reinterpret_cast<u32x4*>(arr(ST, 1, 1) + soff) = S.b1;                          \
+    *reinterpret_cast<u32x4*>(arr(ST, 0, 2) + soff) = S.a2;                          \
+    *reinterpret_cast<u32x4*>(arr(ST, 1, 2) + soff) = S.b2;                          \
+  }
+  // one pipeline stage: refill slot S_FILL (its data went to LDS one stage ago) with stage kt + 4, run the 24 MFMAs of the
+  // stage in LDS buffer CUR, move slot S_NEXT (stage kt + 1, loaded three stages ago) into the other LDS buffer
+#define P3_STAGE(KT, CUR, S_FILL, S_NEXT)                                                                         \
+  {                                                                                                               \
+    const int kt_ = (KT);                                                                                         \
+    if (kt_ + 4 < nk) P3_GLOAD(kt_ + 4, S_FILL)                                                                   \
+    bf16x8 fa[3][2], fb[3][2];                                                                                    \
+    _Pragma("unroll") for (int p = 0; p < 3; ++p)                                                                 \
+    _Pragma("unroll") for (int t = 0; t < 2; ++t) {                                                               \
+      fa[p][t] = *reinterpret_cast<const bf16x8*>(arr(CUR, 0, p) + foff_a + t * 32 * P3_ROW);                     \
+      fb[p][t] = *reinterpret_cast<const bf16x8*>(arr(CUR, 1, p) + foff_b + t * 32 * P3_ROW);                     \
+    }                                                                                                             \
+    constexpr int PA[6] = {2, 0, 1, 1, 0, 0};   /* smallest products first */                                     \
+    constexpr int PB[6] = {0, 2, 1, 0, 1, 0};                                                                     \
+    _Pragma("unroll") for (int q = 0; q < 6; ++q)                                                                 \
+    _Pragma("unroll") for (int a = 0; a < 2; ++a)                                                                 \
+    _Pragma("unroll") for (int b = 0; b < 2; ++b)                                                                 \
+      acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA[q]][a], fb[PB[q]][b], acc[a][b], 0, 0, 0);        \
+    if (kt_ + 1 < nk) P3_SSTORE((CUR) ^ 1, S_NEXT)                                                                \
+    __syncthreads();                                                                                              \
+  }
+  const int nk = (i + 1) * HBO_TILE / 16;   // a multiple of 8
+  const int foff_a = (wm * 64 + l32) * P3_ROW + lh * 16;
+  const int foff_b = (wn * 64 + l32) * P3_ROW + lh * 16;
+  P3_GLOAD(0, s0) P3_GLOAD(1, s1) P3_GLOAD(2, s2) P3_GLOAD(3, s3)
+  P3_SSTORE(0, s0)
+  __syncthreads();
+  for (int kt0 = 0; kt0 < nk; kt0 += 4) {
+    P3_STAGE(kt0, 0, s0, s1)
+    P3_STAGE(kt0 + 1, 1, s1, s2)
+    P3_STAGE(kt0 + 2, 0, s2, s3)
+    P3_STAGE(kt0 + 3, 1, s3, s0)
+  }
+#undef P3_STAGE
+#undef P3_GLOAD
+#undef P3_SSTORE
+  if (g.colsq) {
+    float* red = reinterpret_cast<float*>(smem);   // [4 waves][64]  (the k loop ended with a barrier)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      float s = 0.f;
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) s += acc[a][b][r] * acc[a][b][r];
+      s += __shfl_xor(s, 32);
+      if (lh == 0) red[wave * 64 + b * 32 + l32] = s;
+    }
+    __syncthreads();
+    if (tid < 128) {
+      const int wn2 = tid >> 6, c = tid & 63;
+      g.colsq[(int64_t)i * g.ldc + (int64_t)jq * HBO_TILE + tid] = red[(0 * 2 + wn2) * 64 + c] + red[(1 * 2 + wn2) * 64 + c];
+    }
+  }
+}
+
+}  // namespace
+
+void launch_split3_rows(const float* in, int64_t ld, int row_tiles, unsigned short* out, int nkb, hipStream_t st) {
+  if (row_tiles <= 0) return;
+  hipLaunchKernelGGL(split3_rows_kernel, dim3((nkb + 3) / 4, row_tiles), dim3(256), 0, st, in, ld, out, nkb);
+}
+void launch_split3_transpose(const float* in, int64_t ld, int krows, int jcols, unsigned short* out, int nkb, hipStream_t st) {
+  if (krows <= 0 || jcols <= 0) return;
+  hipLaunchKernelGGL(split3_transpose_kernel, dim3(jcols / 64, krows / 64), dim3(256), 0, st, in, ld, out, nkb);
+}
+void launch_post3(const Post3Args& a, int col_tiles, hipStream_t st) {
+  static bool attr = false;
+  if (!attr) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&post3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, POST3_LDS_BYTES);
+    attr = true;
+  }
+  hipLaunchKernelGGL(post3_kernel, dim3(col_tiles, a.nblk), dim3(256), POST3_LDS_BYTES, st, a);
+}

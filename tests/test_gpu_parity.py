@@ -1272,3 +1272,47 @@ def test_fp32_registry_error_summary(gpu_ctx):
   worst = np.max(np.array(list(_FP32_ERR.values())), axis=0)
   print('fp32 worst relative errors (value, grad, mu, var, ei):', ' '.join('%.2e' % w for w in worst))
   assert len(_FP32_ERR) == 32
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('kname', ['squared_exponential', 'matern32', 'matern52', 'dot_product'])
+def test_fp32_posterior_on_bf16_matrix_cores_is_as_accurate_as_fp32_mfma(gpu_ctx, kname):
+  """fp32 caches run the posterior product V = L^-1 Kxq on the bf16 MFMA from exact three-way splits of both operands
+  (csrc/post3.hip; gp.py:295-305 is the reference's solve).  Claim under test: the result is fp32-accurate -- its error
+  against the fp64 path is not larger than that of the fp32-MFMA product it replaces (same inputs, option off) -- for every
+  kernel of the registry, ragged sizes, several chunks; and the planes of W follow a row append of the cache."""
+  defs, _, acfun, gp, kernel, mean, _, utils = _native()
+  rng = np.random.default_rng(77)
+  d, n, M = 6, 1300, 900
+  isp = lambda v: np.log(np.expm1(np.asarray(v, dtype=np.float64)))
+  model = {'lengthscale': isp(np.full(d, 0.8)), 'signal_variance': isp(1.2), 'noise_variance': isp(3e-2), 'constant': np.array(0.3),
+           'dot_prod_sigma': isp(1.5), 'dot_prod_bias': np.array(0.4)}
+  x = rng.uniform(size=(n, d)); y = np.sin(3.0 * x[:, :2].sum(axis=1, keepdims=True)) + 0.1 * rng.normal(size=(n, 1))
+  xq = rng.uniform(size=(M, d))
+  cov = getattr(kernel, kname)
+  out = {}
+  try:
+    gpu_ctx.set_option('post_chunk', 384)
+    for name, dt, opt in (('f64', np.float64, 0), ('mfma', np.float32, 0), ('bf16x3', np.float32, 1)):
+      gpu_ctx.set_option('post_bf16x3', opt)
+      cast = lambda t: {k: cast(v) for k, v in t.items()} if isinstance(t, dict) else np.asarray(t, dtype=dt)
+      g = gp.GP({0: defs.SubDataset(x[:n - 40].astype(dt), y[:n - 40].astype(dt))}, mean.constant, cov, defs.GPParams(model=cast(model)),
+                utils.DEFAULT_WARP_FUNC)
+      mu, var = g.predict(xq.astype(dt), 0)
+      ei = acfun.expected_improvement(model=g, sub_dataset_key=0, x_queries=xq.astype(dt))
+      # the cache grows by 40 rows (O(N^2) append): W changes, its bf16 planes must be rebuilt
+      g.update_sub_dataset(defs.SubDataset(x[n - 40:].astype(dt), y[n - 40:].astype(dt)), 0, is_append=True)
+      mu2, var2 = g.predict(xq.astype(dt), 0)
+      out[name] = [np.asarray(a, np.float64).ravel() for a in (mu, var, ei, mu2, var2)]
+  finally:
+    gpu_ctx.set_option('post_bf16x3', 1)
+    gpu_ctx.set_option('post_chunk', 8192)
+  for j, what in enumerate(('mean', 'variance', 'EI', 'mean after append', 'variance after append')):
+    ref = out['f64'][j]
+    scale = max(np.abs(ref).max(), 1e-6)
+    e_mfma = np.abs(out['mfma'][j] - ref).max() / scale
+    e_b3 = np.abs(out['bf16x3'][j] - ref).max() / scale
+    assert np.isfinite(out['bf16x3'][j]).all(), what
+    # fp32-level agreement with fp64, and no worse than the fp32-MFMA product (1.5x + 2 ulp of slack for the max statistic)
+    assert e_b3 <= 1.5 * e_mfma + 2.4e-7, (kname, what, e_b3, e_mfma)
+    assert e_b3 < 2e-3, (kname, what, e_b3)
