@@ -7,7 +7,6 @@
 // Replaces what jax.scipy.linalg.cholesky lowers to (hyperbo/basics/linalg.py:31,134).
 #include "hbo_internal.h"
 #include <limits.h>
-#include <cstdlib>
 
 namespace {
 
@@ -366,7 +365,7 @@ __global__ __launch_bounds__(256) void potf2_kernel(const TaskDesc* tasks, int p
 }
 
 template <typename T>
-constexpr int trsm_lds_bytes(int nw = 4) { return (28 + 8 + nw) * TILE_ELEMS * (int)sizeof(T); }   // 4 waves: 87 KB fp64, fits beside one GEMM workgroup
+constexpr int trsm_lds_bytes() { return (28 + 8 + 4) * TILE_ELEMS * (int)sizeof(T); }   // 87 KB fp64: fits beside one GEMM workgroup
 __device__ __forceinline__ int strict_index(int I, int J) { return I * (I - 1) / 2 + J; }
 
 // grid.x = 64-row group, grid.y = (IDENT ? diagonal block p : unused), grid.z = task
@@ -374,8 +373,7 @@ __device__ __forceinline__ int strict_index(int I, int J) { return I * (I - 1) /
 // L_pp and its leaf inverses into LDS first -- a caller that walks several row groups of the same panel (chain.hip)
 // stages once.
 template <typename T, bool IDENT>
-__device__ __forceinline__ void trsm_body(const TaskDesc& t, int p, int64_t row0, unsigned char* smem, bool stage, int nparts = 1,
-                                          int64_t row_end = INT64_MAX) {
+__device__ __forceinline__ void trsm_body(const TaskDesc& t, int p, int64_t row0, unsigned char* smem, bool stage) {
   typedef typename Mma<T>::acc_t acc_t;
   T* sLt = reinterpret_cast<T*>(smem);          // 28 packed strictly-lower tiles of L_pp
   T* sWi = sLt + 28 * TILE_ELEMS;               // 8 leaf inverses (stand in for the diagonal tiles)
@@ -387,66 +385,34 @@ __device__ __forceinline__ void trsm_body(const TaskDesc& t, int p, int64_t row0
   const T* Wb = static_cast<const T*>(t.W) + (int64_t)p * NB * ld + (int64_t)p * NB;
 
   const int64_t wrow0 = row0 + wave * 16;                 // this wave's 16 rows
-  const bool active = wrow0 < row_end;                    // (wide workgroups: the last one may reach past the panel's rows)
   const int rg = IDENT ? (int)((wrow0 - (int64_t)p * NB) >> 4) : 0;  // row group inside the block
   T* Ap = IDENT ? nullptr : static_cast<T*>(t.A) + wrow0 * ld + (int64_t)p * NB;
   T* Wout = IDENT ? static_cast<T*>(t.W) + (int64_t)p * NB * ld + (int64_t)p * NB : nullptr;
 
   // the wave's 16 x 128 panel rows, all eight tiles in flight before L_pp is staged
   acc_t areg[8];
-  if (active) {
 #pragma unroll
-    for (int jb = 0; jb < 8; ++jb)
+  for (int jb = 0; jb < 8; ++jb)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = Mma<T>::crow(lane, r);
-        if (IDENT) areg[jb][r] = (rg == jb && row == l15) ? (T)1 : (T)0;
-        else areg[jb][r] = gld(Ap + (int64_t)row * ld + jb * 16 + l15);
-      }
-  }
+    for (int r = 0; r < 4; ++r) {
+      const int row = Mma<T>::crow(lane, r);
+      if (IDENT) areg[jb][r] = (rg == jb && row == l15) ? (T)1 : (T)0;
+      else areg[jb][r] = gld(Ap + (int64_t)row * ld + jb * 16 + l15);
+    }
   // stage L_pp (lower tiles) and the leaf inverses: thread = one element of each 16x16 tile
   if (stage) {
-    const int i = (tid & 255) >> 4, j = tid & 15;
-    if (nparts == 1) {
-      int tile = 0;
+    const int i = tid >> 4, j = tid & 15;
+    int tile = 0;
 #pragma unroll
-      for (int I = 1; I < 8; ++I)
+    for (int I = 1; I < 8; ++I)
 #pragma unroll
-        for (int J = 0; J < I; ++J, ++tile)
-          sLt[tile * TILE_ELEMS + i * TS + j] = gld(Lb + (int64_t)(I * 16 + i) * ld + J * 16 + j);
+      for (int J = 0; J < I; ++J, ++tile)
+        sLt[tile * TILE_ELEMS + i * TS + j] = gld(Lb + (int64_t)(I * 16 + i) * ld + J * 16 + j);
 #pragma unroll
-      for (int b = 0; b < 8; ++b)
-        sWi[b * TILE_ELEMS + i * TS + j] = gld(Wb + (int64_t)(b * 16 + i) * ld + b * 16 + j);
-    } else {
-      // nparts groups of 256 threads take the tiles round-robin (branch-free: every load is in flight before the first store)
-      const int part = tid >> 8;
-      T v[16];
-#pragma unroll
-      for (int k = 0; k < 14; ++k)
-        if (k * nparts < 28) {
-          const int tile = k * nparts + part;
-          int I = 1;
-          while ((I + 1) * I / 2 <= tile) ++I;          // strict_index(I, 0) <= tile < strict_index(I + 1, 0)
-          const int J = tile - I * (I - 1) / 2;
-          v[k] = gld(Lb + (int64_t)(I * 16 + i) * ld + J * 16 + j);
-        }
-      T w[4];
-#pragma unroll
-      for (int k = 0; k < 4; ++k)
-        if (k * nparts < 8) {
-          const int b = k * nparts + part;
-          w[k] = gld(Wb + (int64_t)(b * 16 + i) * ld + b * 16 + j);
-        }
-#pragma unroll
-      for (int k = 0; k < 14; ++k)
-        if (k * nparts < 28) sLt[(k * nparts + part) * TILE_ELEMS + i * TS + j] = v[k];
-#pragma unroll
-      for (int k = 0; k < 4; ++k)
-        if (k * nparts < 8) sWi[(k * nparts + part) * TILE_ELEMS + i * TS + j] = w[k];
-    }
+    for (int b = 0; b < 8; ++b)
+      sWi[b * TILE_ELEMS + i * TS + j] = gld(Wb + (int64_t)(b * 16 + i) * ld + b * 16 + j);
   }
   if (stage) __syncthreads();
-  if (!active) return;
 
   T* sc = sSc + wave * TILE_ELEMS;   // wave-private: LDS ops of one wave execute in order
   T xneg[8][4];                      // -X in A-operand layout, per 16-column block
@@ -507,13 +473,8 @@ __device__ __forceinline__ void trsm_body(const TaskDesc& t, int p, int64_t row0
     }
   }
 }
-// NW = waves per workgroup (16 panel rows each).  Every workgroup stages all of L_pp (78 KB, for 64 KB of panel rows at
-// NW = 4) and, at one workgroup per CU, every SIMD runs ONE wave's dependent MFMA chain.  A single matrix wants the rows
-// spread over as many CUs as possible (NW = 4: 8 waves were 12 % slower end to end, profiles/r02_potrf_chain.md); a batch
-// oversubscribes every CU anyway (64 tasks: 1900 workgroups of 64 rows per panel), and there wide workgroups share the
-// staging between more rows and keep several chains per SIMD in flight.
-template <typename T, bool IDENT, int NW = 4>
-__global__ __launch_bounds__(64 * NW) void trsm_kernel(const TaskDesc* tasks, int p_arg, int* yield_tab) {
+template <typename T, bool IDENT>
+__global__ __launch_bounds__(256) void trsm_kernel(const TaskDesc* tasks, int p_arg, int* yield_tab) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __builtin_amdgcn_s_setprio(3);                // critical path: outrank co-resident GEMM waves
   const TaskDesc& t = tasks[blockIdx.z];
@@ -528,7 +489,7 @@ __global__ __launch_bounds__(64 * NW) void trsm_kernel(const TaskDesc* tasks, in
   }
 #endif
   // first row handled by this workgroup
-  int64_t row0, row_end = INT64_MAX;
+  int64_t row0;
   if (IDENT) {
     row0 = (int64_t)p * NB + (int64_t)blockIdx.x * 64;            // blockIdx.x in {0,1}
   } else {
@@ -537,13 +498,12 @@ __global__ __launch_bounds__(64 * NW) void trsm_kernel(const TaskDesc* tasks, in
     // workgroup i runs on XCD (i + const) mod 8 whatever the load: in a ragged batch the rows that exist are the low ones in
     // every task, so the row index is rotated by the task index to spread them over the XCDs
     const int64_t bx = ((int64_t)blockIdx.x + 3 * (int64_t)blockIdx.z) % gridDim.x;
-    if (bx * (16 * NW) >= nrows) return;
-    row0 = first + bx * (16 * NW);
-    row_end = first + nrows;
+    if (bx * 64 >= nrows) return;
+    row0 = first + bx * 64;
   }
   int tok = 0;
   if (yield_tab && threadIdx.x == 0) tok = yield_enter(yield_tab);
-  trsm_body<T, IDENT>(t, p, row0, smem, true, NW / 4, row_end);
+  trsm_body<T, IDENT>(t, p, row0, smem, true);
   if (yield_tab) {
     __syncthreads();
     if (threadIdx.x == 0) yield_leave(yield_tab, tok);
@@ -554,11 +514,8 @@ __global__ __launch_bounds__(64 * NW) void trsm_kernel(const TaskDesc* tasks, in
 }
 
 #ifndef HBO_DEVICE_ONLY
-int g_trsm_batch_waves = 16;   // waves per panel-solve workgroup for batches (HBO_TRSM_BATCH_WAVES: experiment switch)
 template <typename T>
 void set_attrs() {
-  static bool env_read = false;
-  if (!env_read) { const char* e = getenv("HBO_TRSM_BATCH_WAVES"); if (e) g_trsm_batch_waves = atoi(e); env_read = true; }
   static bool done = false;
   if (done) return;
   hipFuncSetAttribute(reinterpret_cast<const void*>(&potf2_kernel<T>),
@@ -567,10 +524,6 @@ void set_attrs() {
                       hipFuncAttributeMaxDynamicSharedMemorySize, trsm_lds_bytes<T>());
   hipFuncSetAttribute(reinterpret_cast<const void*>(&trsm_kernel<T, true>),
                       hipFuncAttributeMaxDynamicSharedMemorySize, trsm_lds_bytes<T>());
-  hipFuncSetAttribute(reinterpret_cast<const void*>(&trsm_kernel<T, false, 8>),
-                      hipFuncAttributeMaxDynamicSharedMemorySize, trsm_lds_bytes<T>(8));
-  hipFuncSetAttribute(reinterpret_cast<const void*>(&trsm_kernel<T, false, 16>),
-                      hipFuncAttributeMaxDynamicSharedMemorySize, trsm_lds_bytes<T>(16));
   done = true;
 }
 
@@ -585,16 +538,8 @@ void trsm_t(const TaskDesc* tasks, int ntasks, int p, int max_nblk, hipStream_t 
   set_attrs<T>();
   const int nrows = (max_nblk + 1 - (p + 1)) * NB;
   if (nrows <= 0) return;
-  const int nw = ntasks > 1 ? g_trsm_batch_waves : 4;
-  if (nw == 16)
-    hipLaunchKernelGGL((trsm_kernel<T, false, 16>), dim3((nrows + 255) / 256, 1, ntasks), dim3(1024), trsm_lds_bytes<T>(16), st,
-                       tasks, p, (int*)nullptr);
-  else if (nw == 8)   // (nrows is a multiple of 128)
-    hipLaunchKernelGGL((trsm_kernel<T, false, 8>), dim3(nrows / 128, 1, ntasks), dim3(512), trsm_lds_bytes<T>(8), st,
-                       tasks, p, (int*)nullptr);
-  else
-    hipLaunchKernelGGL((trsm_kernel<T, false>), dim3(nrows / 64, 1, ntasks), dim3(256), trsm_lds_bytes<T>(), st,
-                       tasks, p, ntasks == 1 ? yield_tab : nullptr);
+  hipLaunchKernelGGL((trsm_kernel<T, false>), dim3(nrows / 64, 1, ntasks), dim3(256), trsm_lds_bytes<T>(), st,
+                     tasks, p, ntasks == 1 ? yield_tab : nullptr);
 }
 template <typename T>
 void trtri_diag_t(const TaskDesc* tasks, int ntasks, int p_lo, int p_hi, hipStream_t st) {
