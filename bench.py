@@ -38,6 +38,7 @@ sys.path.insert(0, ROOT)
 
 FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X datasheet; confirmed 77.1 by tools/mfma_probe.hip (64 cyc/instr)
 FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md
+BF16_MFMA_PEAK_TFLOPS = 2500.0   # dense bf16 MFMA (MI355X_MICROARCH.md)
 
 
 def inv_softplus(v):
@@ -144,11 +145,17 @@ def bench_cfg3(ctx):
   tf, te, pf, pe = best
   post_ms = pe['post_gemm'][0]
   post_tf = float(n) * n * m / (post_ms * 1e-3) / 1e12
+  # the fp32 product runs on the bf16 matrix cores: both operands split exactly into three bf16 pieces, six bf16 MFMAs per
+  # fp32 product (csrc/post3.hip) -- executed bf16 flops = 6 x the algorithmic fp32 flops
   return {'workload': 'cfg3: Matern-5/2 o tanh-MLP(32->64) + linear_mlp mean, N=16384, fp32, factor + EI over 65536 candidates',
           'factor_ms': round(tf * 1e3, 2), 'potrf_ms': round(pf['potrf'][0], 2), 'trtri_ms': round(pf['trtri'][0], 2),
           'ei_ms': round(te * 1e3, 2), 'post_gemm_ms': round(post_ms, 2), 'post_gemm_tflops': round(post_tf, 1),
-          'frac_fp32': round(post_tf / FP32_MFMA_PEAK_TFLOPS, 4), 'ei_flops': float(n) * n * m,
-          'note': 'wall times include the host<->device copies of x_query / EI; post_gemm = V = L^-1 Kxq on fp32 MFMA'}
+          'post_gemm_path': 'bf16x3 (exact 3-way split of fp32 operands, 6 bf16 MFMAs per product, fp32 accumulate)',
+          'frac_fp32': round(post_tf / FP32_MFMA_PEAK_TFLOPS, 4),
+          'frac_bf16_executed': round(6.0 * post_tf / BF16_MFMA_PEAK_TFLOPS, 4), 'ei_flops': float(n) * n * m,
+          'note': 'wall times include the host<->device copies of x_query / EI; post_gemm = V = L^-1 Kxq (algorithmic fp32 flops N^2 M); '
+                  'frac_fp32 is against the fp32 MFMA peak this path no longer uses (> 1 = beyond that roofline), '
+                  'frac_bf16_executed = 6 x algorithmic flops against the dense bf16 MFMA peak'}
 
 
 def bench_cfg5(ctx):

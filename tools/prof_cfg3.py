@@ -6,7 +6,8 @@ from hyperbo_amd import _native as nat
 from hyperbo_amd.basics import definitions as defs
 from hyperbo_amd.bo_utils import acfun
 from hyperbo_amd.gp_utils import gp, kernel, mean, utils
-dt = np.float32 if (len(sys.argv) < 2 or sys.argv[1] == 'f32') else np.float64
+dt = np.float64 if (len(sys.argv) > 1 and sys.argv[1] == 'f64') else np.float32
+opts = [a.split('=') for a in sys.argv[1:] if '=' in a]   # context options: name=value
 rng = np.random.Generator(np.random.PCG64(3))
 d, f, n, M = 32, 64, 16384, 65536
 isp = lambda v: np.log(np.expm1(np.asarray(v, dtype=np.float64)))
@@ -18,6 +19,7 @@ x = rng.uniform(size=(n, d)).astype(dt); y = (np.sin(x[:, :4].sum(axis=1, keepdi
 xq = rng.uniform(size=(M, d)).astype(dt)
 g = gp.GP({0: defs.SubDataset(x, y)}, mean.linear_mlp, kernel.matern52_mlp, defs.GPParams(model=to(model), config={'mlp_features': (f,)}), utils.DEFAULT_WARP_FUNC)
 ctx = nat.default_context(); ctx.profile_enable(1)
+for k_, v_ in opts: ctx.set_option(k_, int(v_))
 for it in range(3):
     g.update_model_params(g.params.model)   # drop the cache -> refactor
     t0 = time.perf_counter(); g.setup_predictor(0); t1 = time.perf_counter()
