@@ -1266,24 +1266,28 @@ static int posterior(hbo_ctx* c, const hbo_model* m, hbo_cache* k, const void* x
   }
   if (full_cov) { { d_Kqq = ws_get(c, WS_KQQ, (size_t)M * M * es); if (!d_Kqq) return HBO_ERR_HIP; } { d_cov = ws_get(c, WS_COV, (size_t)M * M * es); if (!d_cov) return HBO_ERR_HIP; } }
   // fp32: the product runs on the bf16 matrix cores from exact three-way splits of both operands (post3.hip)
-  const bool use3 = k && dtype == HBO_F32 && c->opt_post_bf16x3 && !full_cov;
+  bool use3 = k && dtype == HBO_F32 && c->opt_post_bf16x3 && !full_cov;
   unsigned short* d_K3 = nullptr; size_t k3_b = 0;
   const int nkb = k ? t->npad / 16 : 0;
-  if (use3) {
-    k3_b = al((size_t)mpad_max * t->npad * 3 * sizeof(unsigned short));   // (mpad / 128) x nkb blocks of 3 x 128 x 16
-    d_K3 = (unsigned short*)ws_get(c, WS_K3, k3_b * nbuf); if (!d_K3) return HBO_ERR_HIP;
-    if (!k->w3_valid) {
-      const size_t elems = (size_t)t->npad * t->npad * 3;
-      if (!k->w3 || k->w3_elems != elems) {
-        if (k->w3) hipFree(k->w3);
-        k->w3 = nullptr;
-        HIPCHK_P(hipMalloc((void**)&k->w3, elems * sizeof(unsigned short)));
-        k->w3_elems = elems;
-      }
+  if (use3 && !k->w3_valid) {
+    // the split copy of W costs 1.5 x its bytes: when the device cannot spare them the fp32-MFMA product takes over
+    const size_t elems = (size_t)t->npad * t->npad * 3;
+    if (!k->w3 || k->w3_elems != elems) {
+      if (k->w3) hipFree(k->w3);
+      k->w3 = nullptr; k->w3_elems = 0;
+      if (hipMalloc((void**)&k->w3, elems * sizeof(unsigned short)) != hipSuccess) { (void)hipGetLastError(); k->w3 = nullptr; use3 = false; }
+      else k->w3_elems = elems;
+    }
+    if (use3) {
       ProfScope ps(c, "split_w", 1, sa);
       launch_split3_rows(static_cast<const float*>(t->W), t->ld, t->nblk, k->w3, nkb, sa);
       k->w3_valid = true;
     }
+  }
+  if (use3) {
+    k3_b = al((size_t)mpad_max * t->npad * 3 * sizeof(unsigned short));   // (mpad / 128) x nkb blocks of 3 x 128 x 16
+    d_K3 = (unsigned short*)ws_get(c, WS_K3, k3_b * nbuf);
+    if (!d_K3) { c->err.clear(); use3 = false; }
   }
   const bool bad = k && k->info != INT_MAX;
   hipEvent_t ev_ready[2] = {nullptr, nullptr}, ev_free[2] = {nullptr, nullptr};
