@@ -1316,3 +1316,33 @@ def test_fp32_posterior_on_bf16_matrix_cores_is_as_accurate_as_fp32_mfma(gpu_ctx
     # fp32-level agreement with fp64, and no worse than the fp32-MFMA product (1.5x + 2 ulp of slack for the max statistic)
     assert e_b3 <= 1.5 * e_mfma + 2.4e-7, (kname, what, e_b3, e_mfma)
     assert e_b3 < 2e-3, (kname, what, e_b3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('n,M', [(1, 1), (5, 3), (128, 128), (129, 1), (130, 257), (511, 130), (2049, 129)])
+def test_fp32_posterior_bf16x3_edge_sizes(gpu_ctx, n, M):
+  """Block-boundary sizes of the bf16 matrix-core product (one training point, exactly one 128-block, one past a block, a single
+  candidate, ragged chunks): same mean, variance and EI as the fp32-MFMA product to fp32 rounding."""
+  defs, _, acfun, gp, kernel, mean, _, utils = _native()
+  rng = np.random.default_rng(1000 * n + M)
+  d = 3
+  isp = lambda v: np.log(np.expm1(np.asarray(v, dtype=np.float64)))
+  model = {k: np.asarray(v, np.float32) for k, v in
+           {'lengthscale': isp(np.full(d, 0.6)), 'signal_variance': isp(1.0), 'noise_variance': isp(1e-2), 'constant': np.array(0.1)}.items()}
+  x = rng.uniform(size=(n, d)).astype(np.float32); y = np.sin(x.sum(1, keepdims=True)).astype(np.float32)
+  xq = rng.uniform(size=(M, d)).astype(np.float32)
+  out = []
+  try:
+    gpu_ctx.set_option('post_chunk', 128)
+    for opt in (0, 1):
+      gpu_ctx.set_option('post_bf16x3', opt)
+      g = gp.GP({0: defs.SubDataset(x, y)}, mean.constant, kernel.matern52, defs.GPParams(model=model), utils.DEFAULT_WARP_FUNC)
+      mu, var = g.predict(xq, 0)
+      ei = acfun.expected_improvement(model=g, sub_dataset_key=0, x_queries=xq)
+      out.append([np.asarray(a, np.float64).ravel() for a in (mu, var, ei)])
+  finally:
+    gpu_ctx.set_option('post_bf16x3', 1)
+    gpu_ctx.set_option('post_chunk', 8192)
+  for a, b, what in zip(out[0], out[1], ('mean', 'variance', 'EI')):
+    assert np.isfinite(b).all(), what
+    assert np.abs(a - b).max() <= 2e-5 * max(1.0, np.abs(a).max()), (what, np.abs(a - b).max())
