@@ -201,6 +201,7 @@ extern "C" int hbo_set_option(hbo_ctx* c, const char* name, int64_t value) {
     }
     return HBO_OK;
   }
+  if (!strcmp(name, "bulk_tail")) { c->opt_bulk_tail = (int)value; return HBO_OK; }
   if (!strcmp(name, "post_bf16x3")) { c->opt_post_bf16x3 = value != 0; return HBO_OK; }
   if (!strcmp(name, "post_chunk")) { if (value < 128 || value > 65536) return fail(c, HBO_ERR_ARG, "post_chunk in 128..65536"); c->opt_post_chunk = (int)value; return HBO_OK; }
   if (!strcmp(name, "trtri_at")) { if (value < 0 || value > 63) return fail(c, HBO_ERR_ARG, "trtri_at in 0..63"); c->opt_trtri_at = (int)value; return HBO_OK; }
@@ -490,8 +491,15 @@ static void run_potrf(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks
             // (for large trailing matrices the bulk update dominates and gets the whole machine)
             a.persistent = (ntasks == 1 && persist_free > 0 && ntiles > pblocks && m <= 96) ? pblocks : 0;
             a.work_counter = (a.persistent && counters && n_counter < 128) ? counters + n_counter++ : nullptr;
+            a.n_big = 0;
+            if (a.persistent && a.work_counter && !a.small_tiles && c->opt_bulk_tail) {
+              // a partly filled last round (fewer than half of the workgroups would get a 128-tile) runs on 64-tiles
+              const int64_t rem = ntiles % pblocks;
+              if (c->opt_bulk_tail == 2) a.n_big = (int)std::max<int64_t>(ntiles - pblocks, 1);
+              else if (rem > 0 && rem * 2 <= pblocks) a.n_big = (int)(ntiles - rem);
+            }
             launch_gemm(dtype, a, dim3(max_nblk + 1 - a.c_lo, a.c_hi - a.c_lo, ntasks), sb);
-            a.persistent = 0; a.work_counter = nullptr;
+            a.persistent = 0; a.work_counter = nullptr; a.n_big = 0;
           }
           hipEvent_t e2 = pool_event(c, evi++);
           hipEventRecord(e2, sb);

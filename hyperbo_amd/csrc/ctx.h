@@ -29,6 +29,7 @@ struct hbo_ctx {
   int opt_lauum_split = 0;     // single matrix: W11^T W11 of K^-1 = W^T W runs beside the tail of the inverse (two-launch lauum; measured
                                // neutral: N = 8192 11.68 -> 11.78 ms -- the tail of the inverse slows by what the early part saves)
   int opt_post_chunk = 8192;   // posterior / acquisition: candidates per pass (the cross-Gram workspace is npad x this, whatever M)
+  int opt_bulk_tail = 1;       // persistent bulk update: 64-tiles for a partly filled last round (1), for the whole last round (2), never (0)
   int opt_post_bf16x3 = 1;     // fp32 posterior product on the bf16 matrix cores (three-way exact split of both operands, post3.hip); 0: fp32 MFMA
   int opt_trtri_at = 0;        // single matrix: panel count (in 64ths of the block count) after which the inverse starts beside the chain (0: 5/8)
   int opt_trtri_small_wgs = 2; // ... and workgroups per CU of their 64-tile form

@@ -457,6 +457,18 @@ __global__ __launch_bounds__(256, TM == 64 ? 4 : 2) void gemm_kernel(GemmArgs g)
         tix = s_tix;
         __syncthreads();
       }
+      if (TM == 128 && g.n_big > 0 && tix >= g.n_big) {
+        // the tail of the launch on 64-tiles: big tile n_big + s / 4, quadrant s % 4
+        const int s4 = tix - g.n_big;
+        if (!decode_syrk_linear<T, 128>(g, g.n_big + (s4 >> 2), job)) break;
+        const int qr = (s4 >> 1) & 1, qc = s4 & 1;
+        const int64_t ldq = job.lda;
+        job.A += (int64_t)qr * 64 * ldq;
+        job.B += (int64_t)qc * 64 * ldq;
+        job.C += (int64_t)qr * 64 * ldq + qc * 64;
+        gemm_tile<T, AKC, BKC, 64>(job, smem);
+        continue;
+      }
       if (!decode_syrk_linear<T, TM>(g, tix, job)) break;
       gemm_tile<T, AKC, BKC, TM>(job, smem);
 #ifdef HBO_GEMM_TIMING

@@ -71,6 +71,8 @@ struct GemmArgs {
   int aug;       // SYRK: 1 -> include the augmented tile-row
   int small_tiles;  // 1 -> 64x64 output tiles (SYRK / TRTRI / LAUUM; grid is given in 128-tile units)
   int persistent;   // >0 -> that many persistent workgroups loop over the tiles (SYRK; TRTRI on 128-tiles with a work_counter)
+  int n_big;        // persistent SYRK on 128-tiles: tiles [0, n_big) of the linear order run as 128-tiles, the rest as four 64-tiles
+                    // each (0 = all of them as 128-tiles): the last, partly filled round of a launch balances at a quarter of the grain
   int pgx, pgy;     // persistent TRTRI: the tile grid the workgroups walk (set by launch_gemm)
   int* work_counter; // persistent SYRK: zero-initialised tile counter -> workgroups draw tiles dynamically (a faster
                      // workgroup takes more of them) instead of striding over them; null: static stride
