@@ -197,6 +197,8 @@ int hbo_profile_get(hbo_ctx* ctx, char names[][32], double* ms, int32_t* launche
  *   post_chunk     128..65536 posterior / acquisition: query candidates per pass (cross-Gram workspace = npad x post_chunk
  *                        elements whatever M; two workspaces alternate so that the Gram build of a chunk runs beside the
  *                        triangular product of the previous one)
+ *   bulk_tail      0..2  single matrix: a partly filled last round of the persistent bulk trailing update (fewer than half of
+ *                        its workgroups would draw a 128-tile) runs on 64-tiles; 2 = the whole last round; 0 = never.  Default 1
  *   post_bf16x3    0/1   fp32 caches: the posterior product V = L^-1 Kxq runs on the bf16 matrix cores from exact three-way
  *                        splits of both operands (six bf16 MFMAs per fp32 product, fp32 accumulate: fp32-accurate, 1.3x the
  *                        speed of the fp32-MFMA product); costs 1.5 x the bytes of W once per cache.  Default 1; full_cov uses fp32 MFMA

@@ -190,10 +190,12 @@ OPTION_SETS = [
     {'trtri_free': 0}, {'trtri_free': 120, 'small_nblk': 0}, {'trtri_small_wgs': 4}, {'trtri_small_wgs': 1, 'trtri_free': 200},
     {'trtri_at': 12}, {'trtri_at': 60, 'small_nblk': 0}, {'lauum_split': 1, 'small_nblk': 0}, {'lauum_split': 1, 'small_nblk': 0, 'trtri_at': 48},
     {'post_chunk': 128},
+    # 64-tile tail of the persistent bulk update: off, whole last round, and with fewer reserved CUs (other remainders)
+    {'bulk_tail': 0}, {'bulk_tail': 2, 'small_nblk': 0}, {'bulk_tail': 1, 'persist_free': 64, 'small_nblk': 0}, {'bulk_tail': 2, 'persist_free': 200, 'small_nblk': 0},
 ]
 DEFAULTS = {'lookahead': 1, 'overlap_trtri': 1, 'potrf_group': 0, 'persist_free': -1, 'dynamic_tiles': 1, 'f1_on_chain': 1,
             'trtri_gran': 0, 'small_nblk': 32, 'cu_yield': 2, 'trtri_free': 48, 'trtri_small_wgs': 2, 'trtri_at': 0,
-            'lauum_split': 0, 'post_chunk': 8192}
+            'lauum_split': 0, 'post_chunk': 8192, 'bulk_tail': 1}
 
 
 @pytest.mark.parametrize('opts', OPTION_SETS, ids=lambda o_: ','.join(f'{k}={v}' for k, v in o_.items()))

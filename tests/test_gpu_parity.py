@@ -385,6 +385,18 @@ def test_cfg2_full_size_value_and_full_gradient(gpu_ctx):
     vals.append(objectives.neg_log_marginal_likelihood(mean.constant, kernel.squared_exponential, pm, dev, utils.DEFAULT_WARP_FUNC))
   num = (vals[0] - vals[1]) / (2 * h)
   assert abs(num - fn @ direction) <= 1e-5 * abs(num) + 1e-6
+  # the 64-tile tail of the persistent bulk update (only launches of >= 600 128-tiles have one): off, default rule, whole last
+  # round, and with other numbers of reserved CUs (other remainders) -- same value and gradient
+  try:
+    for opts in ({'bulk_tail': 0}, {'bulk_tail': 2}, {'bulk_tail': 1, 'persist_free': 64}, {'bulk_tail': 2, 'persist_free': 100}):
+      for k_, v_ in opts.items():
+        gpu_ctx.set_option(k_, v_)
+      v2, g2 = objectives.nll_value_and_grad(mean.constant, kernel.squared_exponential, pn, dev, utils.DEFAULT_WARP_FUNC)
+      assert abs(v2 - v) <= 1e-11 * abs(v), opts
+      assert np.max(np.abs(helpers.flatten(g2) - fn)) <= 1e-9 * np.max(np.abs(fn)), opts
+  finally:
+    gpu_ctx.set_option('bulk_tail', 1)
+    gpu_ctx.set_option('persist_free', -1)
   dev.close()
 
 
