@@ -182,7 +182,7 @@ extern "C" int hbo_ctx_destroy(hbo_ctx* c) {
 }
 extern "C" int hbo_set_option(hbo_ctx* c, const char* name, int64_t value) {
   if (!c || !name) return HBO_ERR_ARG;
-  if (!strcmp(name, "potrf_group")) { if (value < 0 || value > 8) return fail(c, HBO_ERR_ARG, "potrf_group in 0..8 (0: auto)"); c->opt_group = (int)value; return HBO_OK; }
+  if (!strcmp(name, "potrf_group")) { if (value < 0 || value > 16) return fail(c, HBO_ERR_ARG, "potrf_group in 0..16 (0: auto)"); c->opt_group = (int)value; return HBO_OK; }
   if (!strcmp(name, "overlap_trtri")) { c->opt_overlap_trtri = value ? 1 : 0; return HBO_OK; }
   if (!strcmp(name, "dynamic_tiles")) { c->opt_dynamic_tiles = value ? 1 : 0; return HBO_OK; }
   if (!strcmp(name, "f1_on_chain")) { c->opt_f1_on_chain = value ? 1 : 0; return HBO_OK; }
@@ -388,7 +388,8 @@ static void run_potrf(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks
   //   N = 4096: (4, 32) 3.61, (3, 32) 3.54, (3, 64) 3.51;   N = 8192: (4, 32) 13.49, (3, 32) 13.34, (3, 64) 13.25,
   //   (3, 96) 13.43, (2, 64) 13.57, (5, 32) 13.61;   N = 16384: (4, 32) 78.4, (3, 32) 79.1, (3, 64) 79.5
   const bool small_mat = max_nblk <= 96;
-  const int q = c->opt_group > 0 ? c->opt_group : (small_mat ? 3 : 4);
+  //   round 2, N = 65536: group 4 / 6 / 8 / 12 / 16: 60.2 / 60.7 / 62.0 / 62.6 / 62.0 TFLOP/s; N = 32768: 4 / 6 / 8: 56.8 / 57.2 / 57.9; N = 16384: 48.1 / 47.4 / 47.8
+  const int q = c->opt_group > 0 ? c->opt_group : (small_mat ? 3 : (max_nblk >= 256 ? 8 : 4));
   //   with the CU yield (below): N = 8192 (3, 64) 12.58, (3, 48) 12.52, (3, 32) 12.61, (3, 16) 13.24, (4, 48) 12.66
   //   round 2 (chain kernels mark their CUs, background workgroups there pause): 32 beats 48 at N = 8192 (11.73 / 11.81)
   const int persist_free = c->opt_persist_free >= 0 ? c->opt_persist_free : 32;

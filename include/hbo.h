@@ -186,7 +186,7 @@ int hbo_profile_get(hbo_ctx* ctx, char names[][32], double* ms, int32_t* launche
 
 /* Scheduling knobs (integers by name); the defaults are the measured best, the knobs exist for A/B runs
  * (tools/ab_opt.py).  Unknown names are an error.
- *   potrf_group    0..8  128-wide panels per trailing update, K = 128*group (0 = auto: 3 up to 96 blocks, else 4)
+ *   potrf_group    0..16 128-wide panels per trailing update, K = 128*group (0 = auto: 3 up to 96 blocks, 4 up to 255, else 8)
  *   persist_free  -1..200 CUs the persistent bulk trailing update leaves to the panel chain (-1 = auto: 48 / 32)
  *   cu_yield       0..2  background GEMM workgroups (bulk update, overlapped inverse) pause at a K step while a panel-chain
  *                        workgroup runs on their CU: 1 = potf2 only, 2 = trsm and the chain's column updates too
