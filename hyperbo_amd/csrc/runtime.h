@@ -1,0 +1,112 @@
+// Host-side runtime helpers shared by the translation units of libhbo (api.hip: the C ABI; sched.hip: the launch schedules):
+// element sizes and padded leading dimensions, grow-only workspaces, the pooled device buffers of datasets and caches, and
+// the HIP-event profiling scopes.
+#pragma once
+#include "ctx.h"
+
+#include <string.h>
+
+#include <string>
+
+static inline size_t esize(int dtype) { return dtype == HBO_F64 ? 8 : 4; }
+static inline int round_up(int64_t n, int q) { return (int)(((n + q - 1) / q) * q); }
+// leading dimension: padded extent + 128 bytes, so that rows do not sit at a power-of-two stride
+// (a 64 KiB row stride maps every row of a k-contiguous tile onto the same L2/HBM channel)
+static inline int64_t padded_ld(int64_t extent, int dtype) { return extent + 128 / (int64_t)esize(dtype); }
+
+// grow-only scratch buffer for `slot`; nullptr on allocation failure (ctx->err is set)
+enum WsSlot { WS_K3 = 40, WS_XQ = 1, WS_MU0, WS_KD, WS_MU, WS_VAR, WS_ACQ, WS_K, WS_COLSQ, WS_V, WS_KQQ, WS_COV,
+              WS_AP_KX, WS_AP_L, WS_AP_W, WS_AP_MU, WS_AP_KD, WS_COUNTERS, WS_MUPART,
+              WS_AG_K, WS_AG_L, WS_AG_B, WS_AG_GF, WS_AG_DMU, WS_AG_GX, WS_AG_T0, WS_AG_T1, WS_AG_DW, WS_FQ0 /* + layer */ };
+static inline void* ws_get(hbo_ctx* c, int slot, size_t bytes) {
+  auto& e = c->ws[slot];
+  if (e.second < bytes || !e.first) {
+    if (e.first) hipFree(e.first);
+    e.first = nullptr; e.second = 0;
+    hipError_t err = hipMalloc(&e.first, bytes ? bytes : 16);
+    if (err != hipSuccess) { c->err = std::string("hipMalloc failed: ") + hipGetErrorString(err); e.first = nullptr; return nullptr; }
+    e.second = bytes;
+  }
+  return e.first;
+}
+
+// ---- pooled device buffers of datasets and caches (see hbo_ctx::pool_free) ---------------------
+static inline hipError_t dev_alloc(hbo_ctx* c, void** out, size_t bytes, int cls = 0, bool* reused = nullptr) {
+  if (reused) *reused = false;
+  if (bytes == 0) bytes = 16;
+  if (c) {
+    auto it = c->pool_free.find({cls, bytes});
+    if (it != c->pool_free.end() && !it->second.empty()) {
+      *out = it->second.back(); it->second.pop_back();
+      c->pool_bytes -= bytes;
+      c->pool_live[*out] = {cls, bytes};
+      if (reused) *reused = true;
+      return hipSuccess;
+    }
+  }
+  hipError_t e = hipMalloc(out, bytes);
+  if (e != hipSuccess && c && c->pool_bytes) {   // out of memory with buffers parked: release them and retry
+    for (auto& kv : c->pool_free) for (void* p : kv.second) hipFree(p);
+    c->pool_free.clear(); c->pool_bytes = 0;
+    e = hipMalloc(out, bytes);
+  }
+  if (e == hipSuccess && c) c->pool_live[*out] = {cls, bytes};
+  return e;
+}
+static inline void dev_free(hbo_ctx* c, void* p) {
+  if (!p) return;
+  if (c) {
+    auto it = c->pool_live.find(p);
+    if (it != c->pool_live.end()) {
+      const std::pair<int, size_t> key = it->second;
+      c->pool_live.erase(it);
+      if (c->pool_bytes + key.second <= c->pool_cap) { c->pool_free[key].push_back(p); c->pool_bytes += key.second; return; }
+    }
+  }
+  hipFree(p);
+}
+
+// ---- profiling ---------------------------------------------------------------------------
+// Timing scopes: HIP events recorded on the stream the kernels are launched on.  Events come from a pool owned by
+// the context (creating and destroying ~80 events per evaluation cost 0.4 ms of host time).  prof_level < 0 is the
+// "roofline only" mode of bench.py: just the launches of the dominant kernel (scopes named syrk_bulk) are bracketed.
+static inline hipEvent_t prof_event(hbo_ctx* c) {
+  if (c->prof_next == c->prof_events.size()) {
+    hipEvent_t ev;
+    hipEventCreate(&ev);
+    c->prof_events.push_back(ev);
+  }
+  return c->prof_events[c->prof_next++];
+}
+struct ProfScope {
+  hbo_ctx* c; bool on; ProfEntry e; hipStream_t st;
+  ProfScope(hbo_ctx* ctx, const char* name, int level, hipStream_t stream = nullptr)
+      : c(ctx), on(ctx->prof_level >= level || (ctx->prof_level < 0 && !strcmp(name, "syrk_bulk"))),
+        st(stream ? stream : ctx->stream) {
+    if (!on) return;
+    e.name = name;
+    e.e0 = prof_event(c); e.e1 = prof_event(c);
+    hipEventRecord(e.e0, st);
+  }
+  ~ProfScope() {
+    if (!on) return;
+    hipEventRecord(e.e1, st);
+    c->prof_pending.push_back(e);
+  }
+};
+static inline void prof_begin(hbo_ctx* c) {
+  c->prof_names.clear(); c->prof_ms.clear(); c->prof_count.clear();
+  c->prof_pending.clear();
+  c->prof_next = 0;
+}
+static inline void prof_collect(hbo_ctx* c) {  // stream must be synchronised
+  for (auto& p : c->prof_pending) {
+    float ms = 0;
+    hipEventElapsedTime(&ms, p.e0, p.e1);
+    size_t k = 0;
+    for (; k < c->prof_names.size(); ++k) if (c->prof_names[k] == p.name) break;
+    if (k == c->prof_names.size()) { c->prof_names.push_back(p.name); c->prof_ms.push_back(0); c->prof_count.push_back(0); }
+    c->prof_ms[k] += ms; c->prof_count[k] += 1;
+  }
+  c->prof_pending.clear();
+}

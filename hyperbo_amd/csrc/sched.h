@@ -1,0 +1,13 @@
+// Launch schedules of the blocked factorisation, the block-recursive inverse and K^-1 = W^T W (sched.hip).
+#pragma once
+#include "runtime.h"
+
+// progress of the block-recursive inverse (see trtri_advance)
+struct TrtriProgress { int diag = 0; int a[12] = {0}; int b[12] = {0}; };
+
+hipEvent_t pool_event(hbo_ctx* c, size_t i);
+void run_potrf(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, int max_nblk, int* d_info, TrtriProgress* early = nullptr);
+void trtri_advance(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, int max_nblk, int cfin, hipStream_t st, TrtriProgress& pg);
+void run_trtri(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, int max_nblk, TrtriProgress* pg = nullptr);
+void run_lauum(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, int max_nblk, int split = 0, int phase = 0, hipStream_t st = nullptr);
+int lauum_split_for(int cfin, int max_nblk);

@@ -1,0 +1,253 @@
+// Launch schedules: the right-looking blocked Cholesky with look-ahead (panel chain on its own stream, bulk trailing update
+// persistent beside it), the block-recursive inverse W = L^-1 walked while the factorisation still runs, and K^-1 = W^T W.
+// Everything here decides WHICH kernels of gemm.hip / chol.hip run on WHICH stream in WHAT order; the measurements behind
+// the choices are in profiles/r01_potrf_chain.md and profiles/r02_potrf_chain.md.
+#include "sched.h"
+
+#include <algorithm>
+
+// ---- blocked factorisation drivers -----------------------------------------------------------
+
+hipEvent_t pool_event(hbo_ctx* c, size_t i) {
+  while (c->ev_pool.size() <= i) {
+    hipEvent_t ev;
+    hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+    c->ev_pool.push_back(ev);
+  }
+  return c->ev_pool[i];
+}
+
+
+// Right-looking blocked Cholesky with look-ahead.  Panels are 128 wide; `group` consecutive panels
+// are factored left-looking (the later ones first receive the group's earlier panels: syrk_col),
+// then one trailing update with K = 128*group is applied.  The trailing update is split in two
+// launches: F1 updates only the NEXT group's block columns, F2 the rest; the next group's panel
+// work (potf2 -> trsm, the serial chain) runs on a second stream as soon as F1 is done, so F2
+// -- the bulk of the flops -- overlaps it.
+void run_potrf(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, int max_nblk, int* d_info, TrtriProgress* early) {
+  // panels per trailing update and CUs the persistent bulk update leaves to the panel chain.  Measured (NLL+grad, ms):
+  //   N = 4096: (4, 32) 3.61, (3, 32) 3.54, (3, 64) 3.51;   N = 8192: (4, 32) 13.49, (3, 32) 13.34, (3, 64) 13.25,
+  //   (3, 96) 13.43, (2, 64) 13.57, (5, 32) 13.61;   N = 16384: (4, 32) 78.4, (3, 32) 79.1, (3, 64) 79.5
+  const bool small_mat = max_nblk <= 96;
+  //   round 2, N = 65536: group 4 / 6 / 8 / 12 / 16: 60.2 / 60.7 / 62.0 / 62.6 / 62.0 TFLOP/s; N = 32768: 4 / 6 / 8: 56.8 / 57.2 / 57.9; N = 16384: 48.1 / 47.4 / 47.8
+  const int q = c->opt_group > 0 ? c->opt_group : (small_mat ? 3 : (max_nblk >= 256 ? 8 : 4));
+  //   with the CU yield (below): N = 8192 (3, 64) 12.58, (3, 48) 12.52, (3, 32) 12.61, (3, 16) 13.24, (4, 48) 12.66
+  //   round 2 (chain kernels mark their CUs, background workgroups there pause): 32 beats 48 at N = 8192 (11.73 / 11.81)
+  const int persist_free = c->opt_persist_free >= 0 ? c->opt_persist_free : 32;
+  hipStream_t sm = c->stream;
+  // (a single block column has no trailing matrix to look ahead over: it stays on the caller's stream)
+  const bool la = c->opt_lookahead != 0 && max_nblk > 1;
+  hipStream_t sp = la ? c->stream2 : c->stream;
+  hipStream_t sb = sm;   // bulk updates share the main stream (CU-masked queues were measured slower)
+  size_t evi = 0;
+  if (la) { hipEvent_t e = pool_event(c, evi++); hipEventRecord(e, sm); hipStreamWaitEvent(sp, e, 0); }
+  hipEvent_t ev_f1 = nullptr, ev_f2 = nullptr;
+  // early inverse: a batch takes every piece as soon as four more panels are final (16.9 against 17.35 ms for 64 tasks
+  // of ~2000 points, 3.77 against 3.92 for 8); one large matrix only at half time -- more launches on the side stream
+  // take slots from the panel chain (N = 8192: 13.63 ms at 32 panels, 13.8 at 4, 14.0 at 2)
+  int tgran = c->opt_trtri_gran;
+  // (one large matrix, measured later with the CU yield below: a single call after 13/16 of the panels instead of half --
+  //  N = 8192, call after panel 32 / 40 / 44 / 48 / 52 / 56 / 60: 12.42 / 12.37 / 12.34 / 12.25 / 12.21 / 12.30 / 12.50 ms)
+  int early_at = -1;   // single-task form: the one panel count after which the side stream gets its work
+  if (tgran <= 0) {
+    tgran = 4;
+    if (ntasks == 1) {
+      // (round 2, with the persistent / yielding forms of the co-running products -- they no longer stall the chain --
+      //  N = 8192, (start after panel, CUs left free by the inverse, by the bulk update): (40, 48, 32) 11.73 ms,
+      //  (36, 64, 32) 11.74, (40, 32, 32) 11.80, (44, 48, 32) 11.92, (52, 16, 48) 12.27, (48, 96, 32) 12.37)
+      early_at = c->opt_trtri_at > 0 ? std::min(c->opt_trtri_at * max_nblk / 64, max_nblk - 1) : (max_nblk * 5 / 8) & ~3;
+      if (early_at < 4) early_at = -1;
+      tgran = 1 << 30;
+    }
+  }
+  // (up to 96 blocks: N = 4096 3.37 -> 3.29 ms, N = 8192 12.61 -> 12.52; N = 16384 loses 0.9 % to the polling)
+  int* const yield_flag = (la && ntasks == 1 && c->opt_cu_yield && small_mat) ? c->d_yield : nullptr;
+  if (yield_flag) hipMemsetAsync(yield_flag, 0, sizeof(int) * HBO_YIELD_TAB_ENTRIES, sm);
+  int* const chain_mark = (yield_flag && c->opt_cu_yield >= 2) ? yield_flag : nullptr;   // the chain's wide kernels mark their CUs too
+  c->gemm_yield = yield_flag;
+  // one tile counter per bulk launch (dynamic tile assignment of the persistent form), zeroed up front
+  int* counters = c->opt_dynamic_tiles ? (int*)ws_get(c, WS_COUNTERS, sizeof(int) * 256) : nullptr;
+  int n_counter = 0;
+  if (counters) hipMemsetAsync(counters, 0, sizeof(int) * 256, sm);
+  c->trtri_counters = counters ? counters + 128 : nullptr;   // second half: the persistent inverse products (trtri_level)
+  c->trtri_counter_next = 0;
+  for (int g0 = 0; g0 < max_nblk; g0 += q) {
+    const int g1 = std::min(g0 + q, max_nblk);
+    const int g2 = std::min(g1 + q, max_nblk);
+    if (la && ev_f1) hipStreamWaitEvent(sp, ev_f1, 0);
+    for (int p = g0; p < g1; ++p) {
+      if (p > g0) {  // left-looking update of block column p with the group's earlier panels
+        ProfScope ps(c, "syrk_col", 2, sp);
+        GemmArgs a = {}; a.tasks = d_tasks; a.mode = GEMM_SYRK; a.p0 = g0; a.kt = p - g0; a.c_lo = p; a.c_hi = p + 1; a.aug = 1; a.small_tiles = 1;
+        a.yield_mark = chain_mark;
+        launch_gemm(dtype, a, dim3(max_nblk + 1 - p, 1, ntasks), sp);
+      }
+      { ProfScope ps(c, "potf2", 2, sp); launch_potf2(dtype, d_tasks, ntasks, p, d_info, sp, yield_flag); }
+      { ProfScope ps(c, "trsm", 2, sp); launch_trsm(dtype, d_tasks, ntasks, p, max_nblk, sp, chain_mark); }
+      if (early && ((p + 1) % tgran == 0 || p + 1 == early_at) && p + 1 < max_nblk) {
+        // block columns 0..p of L are final: everything of the inverse that only needs them goes to a side stream
+        // (the panel chain leaves most of the machine idle in the second half of the factorisation)
+        hipEvent_t e = pool_event(c, evi++);
+        hipEventRecord(e, sp);
+        hipStreamWaitEvent(c->stream4, e, 0);
+        ProfScope ps(c, "trtri_early", 1, c->stream4);
+        trtri_advance(c, dtype, d_tasks, ntasks, max_nblk, p + 1, c->stream4, *early);
+      }
+    }
+    // F1 (next group's block columns) is on the critical path: with look-ahead it is launched on the panel stream
+    // itself -- no cross-stream event hop before and after it -- once the previous bulk update, which wrote the same
+    // tiles, is done (ev_f2); the main stream only learns that F1 is finished (ev_f1) to start F2 behind it.
+    hipStream_t s1 = (la && c->opt_f1_on_chain) ? sp : sm;
+    if (la && s1 == sm) { hipEvent_t e = pool_event(c, evi++); hipEventRecord(e, sp); hipStreamWaitEvent(sm, e, 0); }
+    if (g1 < max_nblk) {
+      GemmArgs a = {}; a.tasks = d_tasks; a.mode = GEMM_SYRK; a.p0 = g0; a.kt = g1 - g0; a.aug = 1;
+      {
+        // F1 is a chain kernel when it runs on the panel stream: it marks its CUs instead of polling
+        a.yield_flag = (la && c->opt_f1_on_chain && chain_mark) ? nullptr : yield_flag;
+        a.yield_mark = (la && c->opt_f1_on_chain) ? chain_mark : nullptr;
+        if (s1 == sp && ev_f2) hipStreamWaitEvent(sp, ev_f2, 0);
+        ProfScope ps(c, "syrk_trailing", 1, s1);
+        a.c_lo = g1; a.c_hi = la ? g2 : max_nblk;
+        // few tiles (one group's block columns, or a small remainder): 64x64 tiles for latency
+        a.small_tiles = (int64_t)(max_nblk + 1 - a.c_lo) * (a.c_hi - a.c_lo) * ntasks < 600;
+        launch_gemm(dtype, a, dim3(max_nblk + 1 - a.c_lo, a.c_hi - a.c_lo, ntasks), s1);
+      }
+      if (la) {
+        ev_f1 = pool_event(c, evi++);
+        hipEventRecord(ev_f1, s1);
+        if (s1 == sp) { hipStreamWaitEvent(sm, ev_f1, 0); ev_f1 = nullptr; }   // the panel stream continues in order
+        if (g2 < max_nblk) {
+          // F2 on the CU-masked bulk stream: after F1(g) (same C columns are not shared, but F2(g)
+          // must precede F1(g+1)/F2(g+1) which accumulate into the same tiles)
+          if (ev_f1) hipStreamWaitEvent(sb, ev_f1, 0);
+          {
+            a.yield_flag = yield_flag; a.yield_mark = nullptr;   // the bulk update is background work
+            a.c_lo = g2; a.c_hi = max_nblk;
+            const int64_t m = max_nblk - g2;
+            a.small_tiles = m * (m + 1) / 2 * ntasks < 600;
+            // "syrk_bulk" = the 128x128-tile bulk trailing update (the roofline kernel of bench.py)
+            ProfScope ps(c, a.small_tiles ? "syrk_trailing" : "syrk_bulk", 1, sb);
+            // persistent form (single task, enough tiles to fill the machine): leave CUs for the panel chain
+            const int64_t ntiles = (m * (m + 1) / 2 + m) * (a.small_tiles ? 4 : 1);
+            const int pblocks = 2 * (c->n_cus - persist_free);
+            // (for large trailing matrices the bulk update dominates and gets the whole machine)
+            a.persistent = (ntasks == 1 && persist_free > 0 && ntiles > pblocks && m <= 96) ? pblocks : 0;
+            a.work_counter = (a.persistent && counters && n_counter < 128) ? counters + n_counter++ : nullptr;
+            a.n_big = 0;
+            if (a.persistent && a.work_counter && !a.small_tiles && c->opt_bulk_tail) {
+              // a partly filled last round (fewer than half of the workgroups would get a 128-tile) runs on 64-tiles
+              const int64_t rem = ntiles % pblocks;
+              if (c->opt_bulk_tail == 2) a.n_big = (int)std::max<int64_t>(ntiles - pblocks, 1);
+              else if (rem > 0 && rem * 2 <= pblocks) a.n_big = (int)(ntiles - rem);
+            }
+            launch_gemm(dtype, a, dim3(max_nblk + 1 - a.c_lo, a.c_hi - a.c_lo, ntasks), sb);
+            a.persistent = 0; a.work_counter = nullptr; a.n_big = 0;
+          }
+          hipEvent_t e2 = pool_event(c, evi++);
+          hipEventRecord(e2, sb);
+          hipStreamWaitEvent(sm, e2, 0);   // later F1 / final consumers on the main stream
+          ev_f2 = e2;
+        }
+      }
+    }
+  }
+  c->gemm_yield = nullptr;
+  c->trtri_counters = nullptr;
+  if (la) { hipEvent_t e = pool_event(c, evi++); hipEventRecord(e, sp); hipStreamWaitEvent(sm, e, 0); }   // join
+  if (early) {   // the rest of the inverse (main stream) needs the early part
+    hipEvent_t e = pool_event(c, evi++);
+    hipEventRecord(e, c->stream4);
+    hipStreamWaitEvent(sm, e, 0);
+  }
+}
+// One level of the recursive inverse restricted to the groups [grp_lo, grp_hi) (a group = 2s blocks):
+//   mode A: S21 = L21 W11,  mode B: W21 = -W22 S21.
+static void trtri_level(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, int max_nblk, int s,
+                        int grp_lo, int grp_hi, bool do_a, bool do_b, hipStream_t st) {
+  const int ngroups = grp_hi - grp_lo;
+  if (ngroups <= 0) return;
+  GemmArgs a = {}; a.tasks = d_tasks; a.p0 = s; a.grp_lo = grp_lo;
+  // few or short tiles (small levels, small / batched matrices): 64x64 tiles -- a lone 128-tile runs
+  // its K loop latency-bound, four 64-tiles expose 4x the parallelism for the same flops
+  a.small_tiles = (max_nblk <= c->opt_small_nblk) || ((int64_t)ngroups * s * s * ntasks < 600);
+  a.yield_flag = (st == c->stream4) ? c->gemm_yield : nullptr;
+  // products that co-run with the panel chain (single matrix, side stream): persistent, 2 workgroups on all but
+  // `trtri_free` CUs, tiles from a counter -- see gemm_kernel
+  const bool corun = st == c->stream4 && ntasks == 1 && c->opt_trtri_free > 0 && c->trtri_counters;
+  // The dispatcher spreads a grid over the CUs breadth-first, so "free CUs" really means free room on every CU: a panel
+  // kernel (potf2 78 KB, trsm 87 KB of LDS, 128 VGPRs) fits beside ONE 128-tile workgroup (72 KB) or TWO 64-tile
+  // workgroups (2 x 40 KB), not beside more -- with 4 x (CUs - free) 64-tile workgroups every CU held three or four of
+  // them and potf2 waited 330 us for the whole launch to end (rocprofv3 kernel trace, profiles/r02_potrf_chain.md)
+  const int pblocks = (a.small_tiles ? c->opt_trtri_small_wgs : 2) * (c->n_cus - c->opt_trtri_free);
+  const int tmul = a.small_tiles ? 4 : 1;
+  ProfScope ps(c, "trtri_gemm", 2, st);
+  // Rows of the last group's lower half that exist in the largest task: workgroups beyond them would be dispatched
+  // only to exit, which is not free (56 ns each: at the top level of a batch of 64 matrices of <= 19 blocks, 13 of
+  // the 16 tile rows are empty and the launch took 4.3 ms instead of 0.8).
+  const int vlast = std::min(s, max_nblk - ((grp_hi - 1) * 2 * s + s));
+  if (vlast <= 0 && ngroups == 1) return;
+  const int xa = (ngroups - 1) * s + std::max(vlast, 0);
+  a.c_hi = grp_hi - 1; a.c_lo = std::max(vlast, 0);   // TRTRI_A: last group and its launched tile rows
+  auto persist = [&](int64_t tiles) {
+    a.persistent = 0; a.work_counter = nullptr;
+    if (corun && tiles > pblocks && c->trtri_counter_next < 128) { a.persistent = pblocks; a.work_counter = c->trtri_counters + c->trtri_counter_next++; }
+  };
+  if (do_a && xa > 0) { a.mode = GEMM_TRTRI_A; persist((int64_t)xa * s * tmul); launch_gemm(dtype, a, dim3(xa, s, ntasks), st); }
+  if (do_b) {
+    a.mode = GEMM_TRTRI_B;
+    const int vy = ngroups == 1 ? vlast : s;
+    a.kt = vy;   // valid tile rows when there is a single group (blockIdx.y counts down from them)
+    persist((int64_t)ngroups * s * vy * tmul);
+    launch_gemm(dtype, a, dim3(ngroups * s, vy, ntasks), st);
+  }
+}
+
+// W = L^-1 by recursive doubling over the block tree: level s merges pairs of inverted s-block diagonal pieces,
+//   S21 = L21 W11 (A),  W21 = -W22 S21 (B)   for every group g = blocks [2sg, 2sg + 2s).
+// A of a group only needs the block columns below 2sg + s of L, B those below the group's end, so the tree can be
+// walked while the factorisation is still running: trtri_advance(cfin) launches -- level by level, which is also the
+// dependency order on one stream -- every piece that has become computable now that block columns [0, cfin) are
+// final and was not launched before.  run_potrf calls it on a side stream after every fourth panel (the second half
+// of the factorisation is bound by the serial panel chain and leaves most CUs idle); the last call, with
+// cfin = max_nblk on the main stream, launches what is left (for a 64-block matrix: the B products on the right
+// spine of the tree, 1.25 of the inverse's 3.7 ms).
+void trtri_advance(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, int max_nblk, int cfin,
+                          hipStream_t st, TrtriProgress& pg) {
+  if (cfin > pg.diag) {
+    ProfScope ps(c, "trtri_diag", 2, st);
+    launch_trtri_diag(dtype, d_tasks, ntasks, pg.diag, cfin, st);
+    pg.diag = cfin;
+  }
+  int li = 0;
+  for (int s = 1; s < max_nblk && li < 12; s *= 2, ++li) {
+    // groups with a lower half: g*2s + s < max_nblk
+    const int ngrp = (max_nblk - s + 2 * s - 1) / (2 * s);
+    // A: left half final (cfin >= g*2s + s);  B: whole group final (cfin >= min(g*2s + 2s, max_nblk))
+    int na = cfin >= s ? (cfin - s) / (2 * s) + 1 : 0;
+    int nb = cfin >= max_nblk ? ngrp : cfin / (2 * s);
+    na = std::min(na, ngrp); nb = std::min(nb, ngrp);
+    if (na > pg.a[li]) { trtri_level(c, dtype, d_tasks, ntasks, max_nblk, s, pg.a[li], na, true, false, st); pg.a[li] = na; }
+    if (nb > pg.b[li]) { trtri_level(c, dtype, d_tasks, ntasks, max_nblk, s, pg.b[li], nb, false, true, st); pg.b[li] = nb; }
+  }
+}
+void run_trtri(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, int max_nblk, TrtriProgress* pg) {
+  TrtriProgress fresh;
+  trtri_advance(c, dtype, d_tasks, ntasks, max_nblk, max_nblk, c->stream, pg ? *pg : fresh);
+}
+// K^-1 = W^T W on the lower tiles.  `split` > 0: the two-launch form -- `phase` 1 (the leading split x split tiles over the rows
+// below split, i.e. W11^T W11) may run as soon as W11 is final, phase 2 accumulates the rest (see GemmArgs::lsplit).
+void run_lauum(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, int max_nblk, int split, int phase, hipStream_t st) {
+  ProfScope ps(c, "lauum", 2, st ? st : c->stream);
+  GemmArgs a = {}; a.tasks = d_tasks; a.mode = GEMM_LAUUM;
+  a.small_tiles = max_nblk <= c->opt_small_nblk;
+  if (split > 0 && !a.small_tiles) { a.lsplit = split; a.lphase = phase; }
+  const int rows = (a.lphase == 1) ? split : max_nblk;
+  launch_gemm(dtype, a, dim3(rows, rows, ntasks), st ? st : c->stream);
+}
+// leading block count whose inverse W[0:split, 0:split] is complete once block columns [0, cfin) of L have been walked by
+// trtri_advance: the largest power of two <= cfin that is at most half the matrix (no tree node straddles it)
+int lauum_split_for(int cfin, int max_nblk) {
+  int s = 1;
+  while (2 * s <= cfin && 4 * s <= max_nblk) s *= 2;
+  return (s >= 8 && s <= cfin) ? s : 0;
+}
