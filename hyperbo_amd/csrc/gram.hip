@@ -724,17 +724,44 @@ __global__ void dense_bwd_in_kernel(const double* __restrict__ dz, const T* __re
 // per task: reduce tile partials and apply the chain-rule factors; also mean-parameter grads.
 // out layout per task (doubles): [lengthscale(n_ls)] [signal_variance] [noise_variance] [constant]
 //                                [dot_prod_sigma] [dot_prod_bias] [linear_kernel(fmean)] [linear_bias]
+// Column sums of the per-tile partials of a large matrix in two steps: GRAD_PRE workgroups per task each sum every
+// GRAD_PRE-th slot (fixed order: deterministic), grad_finalize_kernel then reads GRAD_PRE rows instead of nblk (nblk + 1)
+// (one workgroup walking the 4160 slots of a 64-block matrix took 72 us).
+constexpr int GRAD_PRE = HBO_GRAD_PRE_ROWS;
+__global__ __launch_bounds__(256) void grad_prereduce_kernel(const TaskDesc* tasks, int nacc, const double* partials, int64_t stride_task,
+                                                             double* pre) {
+  __shared__ double s_part[4][HBO_MAX_FEATURE_DIM + 4];
+  const TaskDesc& t = tasks[blockIdx.y];
+  const double* part = partials + (int64_t)blockIdx.y * stride_task;
+  const int ntile = t.nblk * (t.nblk + 1);
+  // thread = (slot lane, column): 256 / 32 = 8 slots in flight per pass over up to 32 columns at a time
+  for (int q0 = 0; q0 < nacc; q0 += 32) {
+    const int col = q0 + (threadIdx.x & 31), sl = threadIdx.x >> 5;
+    double acc = 0;
+    if (col < nacc)
+      for (int tl = blockIdx.x + GRAD_PRE * sl; tl < ntile; tl += GRAD_PRE * 8) acc += part[(int64_t)tl * nacc + col];
+    // sum the 8 slot lanes (two per wave: lanes l and l + 32)
+    acc += __shfl_xor(acc, 32);
+    if ((threadIdx.x & 63) < 32 && col < nacc) s_part[threadIdx.x >> 6][col] = acc;
+    __syncthreads();
+    if (threadIdx.x < 32 && col < nacc)
+      pre[((int64_t)blockIdx.y * GRAD_PRE + blockIdx.x) * nacc + col] = (s_part[0][col] + s_part[1][col]) + (s_part[2][col] + s_part[3][col]);
+    __syncthreads();
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void grad_finalize_kernel(const TaskDesc* tasks, const ModelDev* __restrict__ md,
                                                             int fdim, int nacc, int obj, const double* partials,
                                                             int64_t stride_task, double* out, int out_stride,
-                                                            double* value_out) {
+                                                            double* value_out, int pre_rows) {
   __shared__ double sred[4];
   __shared__ double s_scale;
   const TaskDesc& t = tasks[blockIdx.x];
   const double* part = partials + (int64_t)blockIdx.x * stride_task;
   double* o = out + (int64_t)blockIdx.x * out_stride;
-  const int ntile = t.nblk * (t.nblk + 1);   // two 64-row half-tile slots per lower 128x128 tile
+  // two 64-row half-tile slots per lower 128x128 tile -- or the pre_rows rows grad_prereduce_kernel left
+  const int ntile = pre_rows > 0 ? pre_rows : t.nblk * (t.nblk + 1);
   const int n_ls = md->n_ls;
   const bool is_dot = (md->kernel_id == HBO_KERNEL_DOT);
   int pos = 0;
@@ -1142,10 +1169,15 @@ void launch_dmu(int dtype, const TaskDesc* tasks, int ntasks, int obj, hipStream
 }
 void launch_grad_finalize(int dtype, const TaskDesc* tasks, int ntasks, const ModelDev* md, int kernel_id,
                           int fdim, int obj, const double* partials, int64_t stride_task, double* out,
-                          int out_stride, double* value_out, hipStream_t st) {
+                          int out_stride, double* value_out, hipStream_t st, double* pre, int max_nblk) {
   const int nacc = grad_nacc(kernel_id, fdim);
-  if (dtype == HBO_F64) hipLaunchKernelGGL((grad_finalize_kernel<double>), dim3(ntasks), dim3(256), 0, st, tasks, md, fdim, nacc, obj, partials, stride_task, out, out_stride, value_out);
-  else hipLaunchKernelGGL((grad_finalize_kernel<float>), dim3(ntasks), dim3(256), 0, st, tasks, md, fdim, nacc, obj, partials, stride_task, out, out_stride, value_out);
+  int pre_rows = 0;
+  if (pre && max_nblk * (max_nblk + 1) >= 1024) {   // large matrices: column sums in two steps
+    hipLaunchKernelGGL(grad_prereduce_kernel, dim3(GRAD_PRE, ntasks), dim3(256), 0, st, tasks, nacc, partials, stride_task, pre);
+    partials = pre; stride_task = (int64_t)GRAD_PRE * nacc; pre_rows = GRAD_PRE;
+  }
+  if (dtype == HBO_F64) hipLaunchKernelGGL((grad_finalize_kernel<double>), dim3(ntasks), dim3(256), 0, st, tasks, md, fdim, nacc, obj, partials, stride_task, out, out_stride, value_out, pre_rows);
+  else hipLaunchKernelGGL((grad_finalize_kernel<float>), dim3(ntasks), dim3(256), 0, st, tasks, md, fdim, nacc, obj, partials, stride_task, out, out_stride, value_out, pre_rows);
 }
 void launch_scale_dF(const TaskDesc* tasks, int ntasks, int64_t max_n, int fdim, hipStream_t st) {
   dim3 grid((unsigned)((max_n * fdim + 255) / 256), 1, ntasks);

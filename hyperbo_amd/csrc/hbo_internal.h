@@ -150,7 +150,8 @@ void launch_dmu(int dtype, const TaskDesc* tasks, int ntasks, int obj, hipStream
 // value_out (nullable, EUC): per-task objective value |mu1-mu0| + |C0-K1|_F
 void launch_grad_finalize(int dtype, const TaskDesc* tasks, int ntasks, const ModelDev* md, int kernel_id,
                           int fdim, int obj, const double* partials, int64_t stride_task, double* out,
-                          int out_stride, double* value_out, hipStream_t st);
+                          int out_stride, double* value_out, hipStream_t st, double* pre = nullptr, int max_nblk = 0);
+constexpr int HBO_GRAD_PRE_ROWS = 32;   // rows of the pre-reduction buffer per task (`pre`: ntasks x 32 x nacc doubles)
 void launch_scale_dF(const TaskDesc* tasks, int ntasks, int64_t max_n, int fdim, hipStream_t st);
 void launch_grad_feat(int dtype, const TaskDesc* tasks, int ntasks, int max_nblk, const ModelDev* md, int kernel_id,
                       int fdim, int obj, hipStream_t st);
