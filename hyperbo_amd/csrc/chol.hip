@@ -365,7 +365,16 @@ __global__ __launch_bounds__(256) void potf2_kernel(const TaskDesc* tasks, int p
 }
 
 template <typename T>
-constexpr int trsm_lds_bytes() { return (28 + 8 + 4) * TILE_ELEMS * (int)sizeof(T); }   // 87 KB fp64: fits beside one GEMM workgroup
+constexpr int trsm_tile() { return sizeof(T) == 8 ? 256 : TILE_ELEMS; }
+// element (r, c) of a 16 x 16 tile of the panel solve.  fp64: unpadded rows, the column XOR-ed with 2 (r / 2) -- every access
+// pattern of trsm_body (one row per 16 lanes; MFMA operand fragments: 16 rows x 2 columns per half-wave; accumulator layout:
+// 2 rows x 16 columns per half-wave) then covers all banks once, and the 40 tiles take exactly 80 KB: TWO workgroups fit on a
+// CU the bulk update leaves free (with padded 17-column rows, 87 KB, one did: 35 us per panel solve beside the bulk update,
+// 10-13 us alone).  fp32 keeps the padded rows (43.5 KB).
+template <typename T>
+__device__ __forceinline__ int trsm_at(int r, int c) { return sizeof(T) == 8 ? r * 16 + (c ^ ((r >> 1) << 1)) : r * TS + c; }
+template <typename T>
+constexpr int trsm_lds_bytes() { return (28 + 8 + 4) * trsm_tile<T>() * (int)sizeof(T); }   // fp64: 80 KB (also fits beside one GEMM workgroup)
 __device__ __forceinline__ int strict_index(int I, int J) { return I * (I - 1) / 2 + J; }
 
 // grid.x = 64-row group, grid.y = (IDENT ? diagonal block p : unused), grid.z = task
@@ -375,9 +384,10 @@ __device__ __forceinline__ int strict_index(int I, int J) { return I * (I - 1) /
 template <typename T, bool IDENT>
 __device__ __forceinline__ void trsm_body(const TaskDesc& t, int p, int64_t row0, unsigned char* smem, bool stage) {
   typedef typename Mma<T>::acc_t acc_t;
+  constexpr int TE = trsm_tile<T>();
   T* sLt = reinterpret_cast<T*>(smem);          // 28 packed strictly-lower tiles of L_pp
-  T* sWi = sLt + 28 * TILE_ELEMS;               // 8 leaf inverses (stand in for the diagonal tiles)
-  T* sSc = sWi + 8 * TILE_ELEMS;                // 4 per-wave scratch tiles
+  T* sWi = sLt + 28 * TE;                       // 8 leaf inverses (stand in for the diagonal tiles)
+  T* sSc = sWi + 8 * TE;                        // 4 per-wave scratch tiles
   const int64_t ld = t.ld;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, lq = lane >> 4;
@@ -407,14 +417,14 @@ __device__ __forceinline__ void trsm_body(const TaskDesc& t, int p, int64_t row0
     for (int I = 1; I < 8; ++I)
 #pragma unroll
       for (int J = 0; J < I; ++J, ++tile)
-        sLt[tile * TILE_ELEMS + i * TS + j] = gld(Lb + (int64_t)(I * 16 + i) * ld + J * 16 + j);
+        sLt[tile * TE + trsm_at<T>(i, j)] = gld(Lb + (int64_t)(I * 16 + i) * ld + J * 16 + j);
 #pragma unroll
     for (int b = 0; b < 8; ++b)
-      sWi[b * TILE_ELEMS + i * TS + j] = gld(Wb + (int64_t)(b * 16 + i) * ld + b * 16 + j);
+      sWi[b * TE + trsm_at<T>(i, j)] = gld(Wb + (int64_t)(b * 16 + i) * ld + b * 16 + j);
   }
   if (stage) __syncthreads();
 
-  T* sc = sSc + wave * TILE_ELEMS;   // wave-private: LDS ops of one wave execute in order
+  T* sc = sSc + wave * TE;   // wave-private: LDS ops of one wave execute in order
   T xneg[8][4];                      // -X in A-operand layout, per 16-column block
 #pragma unroll
   for (int jb = 0; jb < 8; ++jb) {
@@ -424,10 +434,10 @@ __device__ __forceinline__ void trsm_body(const TaskDesc& t, int p, int64_t row0
 #pragma unroll
     for (int kb = 0; kb < 8; ++kb) {
       if (kb < jb) {
-        const T* lt = sLt + strict_index(jb, kb) * TILE_ELEMS;
+        const T* lt = sLt + strict_index(jb, kb) * TE;
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
-          const T bfrag = lt[l15 * TS + kk * 4 + lq];   // B[k][j] = L[jb*16+j][kb*16+k]
+          const T bfrag = lt[trsm_at<T>(l15, kk * 4 + lq)];   // B[k][j] = L[jb*16+j][kb*16+k]
           if (kb & 1) acc2 = Mma<T>::mma(xneg[kb][kk], bfrag, acc2);
           else acc = Mma<T>::mma(xneg[kb][kk], bfrag, acc);
         }
@@ -438,17 +448,17 @@ __device__ __forceinline__ void trsm_body(const TaskDesc& t, int p, int64_t row0
     // T (C layout) -> scratch -> A layout
     __builtin_amdgcn_wave_barrier();
 #pragma unroll
-    for (int r = 0; r < 4; ++r) sc[Mma<T>::crow(lane, r) * TS + l15] = acc[r];
+    for (int r = 0; r < 4; ++r) sc[trsm_at<T>(Mma<T>::crow(lane, r), l15)] = acc[r];
     __builtin_amdgcn_wave_barrier();
     T ta[4];
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) ta[kk] = sc[l15 * TS + kk * 4 + lq];
+    for (int kk = 0; kk < 4; ++kk) ta[kk] = sc[trsm_at<T>(l15, kk * 4 + lq)];
     // X[:,jb] = T * Winv_jb^T
     acc_t x = (acc_t){0, 0, 0, 0};
-    const T* wt = sWi + jb * TILE_ELEMS;
+    const T* wt = sWi + jb * TE;
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
-      const T bfrag = wt[l15 * TS + kk * 4 + lq];       // B[k][j] = Winv[j][k]
+      const T bfrag = wt[trsm_at<T>(l15, kk * 4 + lq)];       // B[k][j] = Winv[j][k]
       x = Mma<T>::mma(ta[kk], bfrag, x);
     }
     // store
@@ -466,10 +476,10 @@ __device__ __forceinline__ void trsm_body(const TaskDesc& t, int p, int64_t row0
       // X (C layout) -> scratch -> negated A layout for later column blocks
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
-      for (int r = 0; r < 4; ++r) sc[Mma<T>::crow(lane, r) * TS + l15] = x[r];
+      for (int r = 0; r < 4; ++r) sc[trsm_at<T>(Mma<T>::crow(lane, r), l15)] = x[r];
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
-      for (int kk = 0; kk < 4; ++kk) xneg[jb][kk] = -sc[l15 * TS + kk * 4 + lq];
+      for (int kk = 0; kk < 4; ++kk) xneg[jb][kk] = -sc[trsm_at<T>(l15, kk * 4 + lq)];
     }
   }
 }
