@@ -47,6 +47,16 @@ __device__ __forceinline__ float swap16(float v) {
 __device__ __forceinline__ float readlane_t(float v, int lane) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
+// value held by lane `src` (any lane -> any lane, through the LDS crossbar)
+__device__ __forceinline__ double lane_gather(double v, int src) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_ds_bpermute(src << 2, lo);
+  hi = __builtin_amdgcn_ds_bpermute(src << 2, hi);
+  return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ float lane_gather(float v, int src) {
+  return __int_as_float(__builtin_amdgcn_ds_bpermute(src << 2, __float_as_int(v)));
+}
 
 // packed 16x16 tiles, row stride 17
 constexpr int TS = 17;
@@ -78,6 +88,91 @@ __device__ __forceinline__ float fast_rsqrt(float d) { return rsqrt(d); }
 // potf2).  The inverse rides in its shadow: V starts as I and takes the same eliminations, V -= f (inv * V[j,:]); row j
 // of V is final after step j-1 and never touched again, and M = L^-1 = diag(1/L_jj) V.  Its MFMA is independent of the
 // S chain and issues while the next pivot is being prepared.
+// Four columns per step, no masks, results written as they become final (HBO_LEAF4, default).  The 4x4 pivot block
+// P = S[j..j+3][j..j+3] reaches every lane through ten readlanes and its Cholesky factor (l10 l20 l30 l21 l31 l32, four
+// inverse pivots) is computed redundantly by all lanes; rows j..j+3 of S and of V are gathered into every lane group
+// (ds_bpermute), each lane forms the four elimination vectors f_t = (s_t - sum_{u<t} l_tu f_u) / pivot_t, lane group q feeds
+// f_q as K slice q and ONE MFMA applies the four rank-1 updates (a second one takes V along).  f_q IS column j+q of L (its
+// diagonal entry included) and h_q = inv_q (v_q - ...) IS row j+q of M = L^-1: lane group q stores them on the spot.  The
+// updates therefore need no masks: entry (r, c) of S or V only sees a[r] and b[c], so what the un-masked vectors write into
+// rows / columns that are already final is never read again (the tile's upper triangle holds leftovers; the final store of L
+// zeroes it, M's upper triangle is exactly zero), and the per-column scaling pass at the end is gone.  A pivot <= 0 or NaN
+// needs no branch either: v_rsq of it is NaN or inf, the Newton correction turns inf into NaN (0 * inf), NaN spreads --
+// the failing column is read off the inverse pivots afterwards.  Two columns per step with masks: 4084 cycles per leaf.
+#ifndef HBO_LEAF4
+#define HBO_LEAF4 1
+#endif
+template <typename T>
+__device__ __forceinline__ int leaf_cholesky4(typename Mma<T>::acc_t& acc, T* dt, T* sM, T* dinv_out, T* Wg, int64_t ldw, int lane) {
+  typedef typename Mma<T>::acc_t acc_t;
+  constexpr bool F64 = sizeof(T) == 8;
+  const int l15 = lane & 15, lq = lane >> 4;
+  acc_t vinv;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) vinv[r] = (Mma<T>::crow(lane, r) == l15) ? (T)1 : (T)0;
+#pragma unroll
+  for (int j = 0; j < 16; j += 4) {
+    // fp64: row = lq + 4 reg -> rows j+a sit in register j/4 of lane group a;  fp32: row = 4 lq + reg -> rows j+a sit in
+    // register a of lane group j/4
+    const int g0 = j >> 2;
+    T s[4], v[4];
+    T p00, p10, p11, p20, p21, p22, p30, p31, p32, p33;
+    if constexpr (F64) {
+      const T own = acc[g0], vown = vinv[g0];
+      p00 = readlane_t(own, j);
+      p10 = readlane_t(own, 16 + j); p11 = readlane_t(own, 16 + j + 1);
+      p20 = readlane_t(own, 32 + j); p21 = readlane_t(own, 32 + j + 1); p22 = readlane_t(own, 32 + j + 2);
+      p30 = readlane_t(own, 48 + j); p31 = readlane_t(own, 48 + j + 1); p32 = readlane_t(own, 48 + j + 2); p33 = readlane_t(own, 48 + j + 3);
+#pragma unroll
+      for (int a = 0; a < 4; ++a) { s[a] = lane_gather(own, 16 * a + l15); v[a] = lane_gather(vown, 16 * a + l15); }
+    } else {
+      const int base = 16 * g0;
+      p00 = readlane_t(acc[0], base + j);
+      p10 = readlane_t(acc[1], base + j); p11 = readlane_t(acc[1], base + j + 1);
+      p20 = readlane_t(acc[2], base + j); p21 = readlane_t(acc[2], base + j + 1); p22 = readlane_t(acc[2], base + j + 2);
+      p30 = readlane_t(acc[3], base + j); p31 = readlane_t(acc[3], base + j + 1); p32 = readlane_t(acc[3], base + j + 2); p33 = readlane_t(acc[3], base + j + 3);
+#pragma unroll
+      for (int a = 0; a < 4; ++a) { s[a] = lane_gather(acc[a], base + l15); v[a] = lane_gather(vinv[a], base + l15); }
+    }
+    // ---- Cholesky of the pivot block (all lanes, same values).  fp32: rsqrt(0) = inf has no Newton step to turn it into NaN
+    auto inv_sqrt = [](T d) -> T {
+      if constexpr (F64) return fast_rsqrt(d);
+      else return d > (T)0 ? fast_rsqrt(d) : (T)NAN;
+    };
+    const T i0 = inv_sqrt(p00);
+    const T l10 = p10 * i0, l20 = p20 * i0, l30 = p30 * i0;
+    const T i1 = inv_sqrt(fma(-l10, l10, p11));
+    const T l21 = fma(-l20, l10, p21) * i1, l31 = fma(-l30, l10, p31) * i1;
+    const T i2 = inv_sqrt(fma(-l21, l21, fma(-l20, l20, p22)));
+    const T l32 = fma(-l31, l21, fma(-l30, l20, p32)) * i2;
+    const T i3 = inv_sqrt(fma(-l32, l32, fma(-l31, l31, fma(-l30, l30, p33))));
+    dinv_out[j] = i0; dinv_out[j + 1] = i1; dinv_out[j + 2] = i2; dinv_out[j + 3] = i3;
+    // ---- columns j..j+3 of L and the matching K slices of the update
+    const T f0 = s[0] * i0;
+    const T f1 = fma(-l10, f0, s[1]) * i1;
+    const T f2 = fma(-l21, f1, fma(-l20, f0, s[2])) * i2;
+    const T f3 = fma(-l32, f2, fma(-l31, f1, fma(-l30, f0, s[3]))) * i3;
+    const T a = (lq == 0) ? f0 : (lq == 1 ? f1 : (lq == 2 ? f2 : f3));
+    acc = Mma<T>::mma(-a, a, acc);
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- rows j..j+3 of M = L^-1
+    const T h0 = v[0] * i0;
+    const T h1 = fma(-l10, h0, v[1]) * i1;
+    const T h2 = fma(-l21, h1, fma(-l20, h0, v[2])) * i2;
+    const T h3 = fma(-l32, h2, fma(-l31, h1, fma(-l30, h0, v[3]))) * i3;
+    const T b = (lq == 0) ? h0 : (lq == 1 ? h1 : (lq == 2 ? h2 : h3));
+    vinv = Mma<T>::mma(-a, b, vinv);
+    dt[l15 * TS + j + lq] = a;                       // L[l15][j + lq]
+    sM[(j + lq) * TS + l15] = b;                     // M[j + lq][l15]
+    gst(Wg + (int64_t)(j + lq) * ldw + l15, b);      // leaf inverse (lower triangular; zeros above the diagonal)
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  // first column whose pivot was not positive (or NaN): its inverse pivot is NaN
+  const T mine = dinv_out[l15];                      // (this wave's own stores: LDS operations of a wave stay in order)
+  const unsigned long long badmask = __ballot(!(mine < (T)INFINITY)) & 0xFFFFull;
+  return badmask ? (int)__builtin_ctzll(badmask) : -1;
+}
+
 template <typename T>
 __device__ __forceinline__ int leaf_cholesky(typename Mma<T>::acc_t& acc, typename Mma<T>::acc_t& vinv, T* dinv_out,
                                              int lane) {
@@ -249,9 +344,14 @@ __device__ __forceinline__ void potf2_body(const TaskDesc& t, int p, int* info_s
 
   auto factor_leaf = [&](int jb) {   // wave 0 only
     T* dt = sT + tri_index(jb, jb) * TILE_ELEMS;
-    acc_t acc, vinv;
+    acc_t acc;
 #pragma unroll
     for (int r = 0; r < 4; ++r) acc[r] = dt[Mma<T>::crow(lane, r) * TS + l15];
+#if HBO_LEAF4
+    const int bad = leaf_cholesky4<T>(acc, dt, sM, sDinv + jb * 16, Wb + (int64_t)(jb * 16) * ld + jb * 16, ld, lane);
+    if (bad >= 0 && lane == 0) atomicMin(info_slot, p * NB + jb * 16 + bad + 1);
+#else
+    acc_t vinv;
     const int bad = leaf_cholesky<T>(acc, vinv, sDinv + jb * 16, lane);
     if (bad >= 0 && lane == 0) atomicMin(info_slot, p * NB + jb * 16 + bad + 1);
 #pragma unroll
@@ -261,6 +361,7 @@ __device__ __forceinline__ void potf2_body(const TaskDesc& t, int p, int* info_s
       sM[row * TS + l15] = vinv[r];
       gst(Wb + (int64_t)(jb * 16 + row) * ld + jb * 16 + l15, vinv[r]);   // leaf inverse (lower triangular)
     }
+#endif
   };
   auto solve_tile = [&](int jb, int R) {   // rows of tile (R, jb): X = A M^T, in place
     T* xt = sT + tri_index(R, jb) * TILE_ELEMS;
@@ -281,6 +382,28 @@ __device__ __forceinline__ void potf2_body(const TaskDesc& t, int p, int* info_s
     for (int kk = 0; kk < 4; ++kk) acc = Mma<T>::mma(-at[l15 * TS + kk * 4 + lq], bt[l15 * TS + kk * 4 + lq], acc);
 #pragma unroll
     for (int r = 0; r < 4; ++r) ct[Mma<T>::crow(lane, r) * TS + l15] = acc[r];
+  };
+
+  auto update_tile2 = [&](int jb, int I0, int J0, int I1, int J1) {   // two independent tiles, interleaved
+    T* c0 = sT + tri_index(I0, J0) * TILE_ELEMS;
+    T* c1 = sT + tri_index(I1, J1) * TILE_ELEMS;
+    const T* a0 = sT + tri_index(I0, jb) * TILE_ELEMS;
+    const T* b0 = sT + tri_index(J0, jb) * TILE_ELEMS;
+    const T* a1 = sT + tri_index(I1, jb) * TILE_ELEMS;
+    const T* b1 = sT + tri_index(J1, jb) * TILE_ELEMS;
+    acc_t x0, x1;
+    T fa0[4], fb0[4], fa1[4], fb1[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { x0[r] = c0[Mma<T>::crow(lane, r) * TS + l15]; x1[r] = c1[Mma<T>::crow(lane, r) * TS + l15]; }
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      fa0[kk] = -a0[l15 * TS + kk * 4 + lq]; fb0[kk] = b0[l15 * TS + kk * 4 + lq];
+      fa1[kk] = -a1[l15 * TS + kk * 4 + lq]; fb1[kk] = b1[l15 * TS + kk * 4 + lq];
+    }
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) { x0 = Mma<T>::mma(fa0[kk], fb0[kk], x0); x1 = Mma<T>::mma(fa1[kk], fb1[kk], x1); }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { c0[Mma<T>::crow(lane, r) * TS + l15] = x0[r]; c1[Mma<T>::crow(lane, r) * TS + l15] = x1[r]; }
   };
 
   STAMP(1);
@@ -309,18 +432,33 @@ __device__ __forceinline__ void potf2_body(const TaskDesc& t, int p, int* info_s
     STAMP(3 + 3 * jb);
     if (jb == nleaf - 1) break;   // (the rows below the last data leaf are zero: (B) left them zero)
     // ---- (C) trailing update; wave 0 owns the next diagonal tile and factors it right away ----
-    if (wave == 0) {
-      update_tile(jb, jb + 1, jb + 1);
-      factor_leaf(jb + 1);
-      STAMP(4 + 3 * jb);
-    } else {
+    {
       const int m = nleaf - 1 - jb;
-      const int ntiles = m * (m + 1) / 2;
-      for (int tix = wave; tix < ntiles; tix += 3) {   // tix 0 is the (jb+1,jb+1) tile: skipped
+      const int ntiles = m * (m + 1) / 2;            // tile 0 is (jb+1, jb+1): wave 0's
+      // the leaf costs about four tile updates: while more than ~13 other tiles remain (the first two steps of a full
+      // block) wave 0 takes the last n0 of them after its leaf, so that all four waves finish together
+      const int n0 = (ntiles - 1 > 13) ? (ntiles - 1 - 13) / 4 : 0;
+      const int nshared = ntiles - n0;               // tiles [1, nshared) go round the waves 1..3
+      auto tile_of = [&](int tix, int& I, int& J) {
         int ii = 0;
         while ((ii + 1) * (ii + 2) / 2 <= tix) ++ii;
-        const int jj = tix - ii * (ii + 1) / 2;
-        update_tile(jb, jb + 1 + ii, jb + 1 + jj);
+        I = jb + 1 + ii; J = jb + 1 + tix - ii * (ii + 1) / 2;
+      };
+      if (wave == 0) {
+        update_tile(jb, jb + 1, jb + 1);
+        factor_leaf(jb + 1);
+        STAMP(4 + 3 * jb);
+        for (int tix = nshared; tix < ntiles; ++tix) { int I, J; tile_of(tix, I, J); update_tile(jb, I, J); }
+      } else {
+        // two tiles per pass: their LDS round trips and MFMAs interleave (one tile at a time ran at the latency of its
+        // own load -> 4 MFMA -> store chain, ~1000 cycles per tile)
+        int tix = wave;
+        for (; tix + 3 < nshared; tix += 6) {
+          int I0, J0, I1, J1;
+          tile_of(tix, I0, J0); tile_of(tix + 3, I1, J1);
+          update_tile2(jb, I0, J0, I1, J1);
+        }
+        if (tix < nshared) { int I, J; tile_of(tix, I, J); update_tile(jb, I, J); }
       }
     }
     __syncthreads();

@@ -3,6 +3,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <climits>
+#include <cmath>
+#include <vector>
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1);} } while (0)
 __global__ void fill_spd(double* p, int64_t n, int64_t ld) {
   int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -22,6 +24,30 @@ int main(int argc, char** argv) {
   TaskDesc* d; CK(hipMalloc(&d, sizeof h)); CK(hipMemcpy(d, &h, sizeof h, hipMemcpyHostToDevice));
   int* info; CK(hipMalloc(&info, 4)); int inf = INT_MAX; CK(hipMemcpy(info, &inf, 4, hipMemcpyHostToDevice));
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  {  // correctness of one potf2 against a host Cholesky of the same diagonal block (and of the leaf inverses)
+    const int pb = 3;
+    std::vector<double> blk(128 * 128), Lg(128 * 128), Wg(128 * 128);
+    CK(hipMemcpy2D(blk.data(), 128 * 8, A + (size_t)pb * 128 * ld + pb * 128, ld * 8, 128 * 8, 128, hipMemcpyDeviceToHost));
+    launch_potf2(HBO_F64, d, 1, pb, info, 0, nullptr); CK(hipDeviceSynchronize());
+    CK(hipMemcpy2D(Lg.data(), 128 * 8, A + (size_t)pb * 128 * ld + pb * 128, ld * 8, 128 * 8, 128, hipMemcpyDeviceToHost));
+    CK(hipMemcpy2D(Wg.data(), 128 * 8, W + (size_t)pb * 128 * ld + pb * 128, ld * 8, 128 * 8, 128, hipMemcpyDeviceToHost));
+    std::vector<double> Lh(blk);
+    for (int j = 0; j < 128; ++j) {
+      double dd = Lh[j * 128 + j];
+      for (int k = 0; k < j; ++k) dd -= Lh[j * 128 + k] * Lh[j * 128 + k];
+      dd = sqrt(dd); Lh[j * 128 + j] = dd;
+      for (int i = j + 1; i < 128; ++i) { double v = Lh[i * 128 + j]; for (int k = 0; k < j; ++k) v -= Lh[i * 128 + k] * Lh[j * 128 + k]; Lh[i * 128 + j] = v / dd; }
+    }
+    double eL = 0, eW = 0, eU = 0;
+    for (int i = 0; i < 128; ++i) for (int j = 0; j < 128; ++j) { if (j <= i) eL = fmax(eL, fabs(Lg[i * 128 + j] - Lh[i * 128 + j])); else if (j / 16 == i / 16) eU = fmax(eU, fabs(Lg[i * 128 + j])); }
+    for (int b = 0; b < 8; ++b)   // leaf inverse times leaf = identity
+      for (int i = 0; i < 16; ++i) for (int j = 0; j < 16; ++j) {
+        double sum = 0;
+        for (int k = 0; k < 16; ++k) sum += Wg[(b * 16 + i) * 128 + b * 16 + k] * (k >= j ? Lh[(b * 16 + k) * 128 + b * 16 + j] : 0.0);
+        eW = fmax(eW, fabs(sum - (i == j ? 1.0 : 0.0)));
+      }
+    printf("potf2 check: max |L - L_host| = %.3e, max |upper of diagonal tiles| = %.3e, max |M L_leaf - I| = %.3e\n", eL, eU, eW);
+  }
   const int reps = 20;
   // potf2 on (fresh copies of) the same diagonal block: p cycles over blocks so data stays SPD-ish
   launch_potf2(HBO_F64, d, 1, 0, info, 0, nullptr); CK(hipDeviceSynchronize());
