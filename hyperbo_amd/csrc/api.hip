@@ -107,6 +107,18 @@ extern "C" int hbo_set_option(hbo_ctx* c, const char* name, int64_t value) {
   if (!strcmp(name, "trtri_at")) { if (value < 0 || value > 63) return fail(c, HBO_ERR_ARG, "trtri_at in 0..63"); c->opt_trtri_at = (int)value; return HBO_OK; }
   if (!strcmp(name, "trtri_small_wgs")) { if (value < 1 || value > 4) return fail(c, HBO_ERR_ARG, "trtri_small_wgs in 1..4"); c->opt_trtri_small_wgs = (int)value; return HBO_OK; }
   if (!strcmp(name, "trtri_free")) { if (value < 0 || value > 200) return fail(c, HBO_ERR_ARG, "trtri_free in 0..200"); c->opt_trtri_free = (int)value; return HBO_OK; }
+  if (!strcmp(name, "dag")) { if (value < 0 || value > 2) return fail(c, HBO_ERR_ARG, "dag in 0..2"); c->opt_dag = (int)value; c->dag_broken = 0; return HBO_OK; }
+  if (!strcmp(name, "dag_f1_small")) { c->opt_dag_f1_small = (int)value; return HBO_OK; }
+  if (!strcmp(name, "dag_join")) { c->opt_dag_join = value ? 1 : 0; return HBO_OK; }
+  if (!strcmp(name, "dag_reserve")) { if (value < 0 || value > 4) return fail(c, HBO_ERR_ARG, "dag_reserve in 0..4 (CUs per shader engine)"); c->opt_dag_reserve = (int)value; return HBO_OK; }
+  if (!strcmp(name, "dag_near64")) { if (value < 0 || value > 2) return fail(c, HBO_ERR_ARG, "dag_near64 in 0..2"); c->opt_dag_near64 = (int)value; return HBO_OK; }
+  if (!strcmp(name, "dag_trtri")) { if (value < 0 || value > 64) return fail(c, HBO_ERR_ARG, "dag_trtri in 0..64"); c->opt_dag_trtri = (int)value; return HBO_OK; }
+  if (!strcmp(name, "dag_spin_us")) { if (value < 0 || value > 1000) return fail(c, HBO_ERR_ARG, "dag_spin_us in 0..1000"); c->opt_dag_spin_us = (int)value; return HBO_OK; }
+  if (!strcmp(name, "dag_idle_sleep")) { if (value < 0 || value > 1000) return fail(c, HBO_ERR_ARG, "dag_idle_sleep in 0..1000"); c->opt_dag_idle_sleep = (int)value; return HBO_OK; }
+  if (!strcmp(name, "dag_dbg")) { c->opt_dag_dbg = (int)value; return HBO_OK; }
+  if (!strcmp(name, "dag_max_nblk")) { c->opt_dag_max_nblk = (int)value; return HBO_OK; }
+  if (!strcmp(name, "dag_min_nblk")) { c->opt_dag_min_nblk = (int)value; return HBO_OK; }
+  if (!strcmp(name, "dag_timeout_ms")) { if (value < 1 || value > 60000) return fail(c, HBO_ERR_ARG, "dag_timeout_ms in 1..60000"); c->opt_dag_timeout_ms = (int)value; return HBO_OK; }
   if (!strcmp(name, "persist_free")) { if (value < -1 || value > 200) return fail(c, HBO_ERR_ARG, "persist_free in -1..200 (-1: auto)"); c->opt_persist_free = (int)value; return HBO_OK; }
   return fail(c, HBO_ERR_ARG, std::string("unknown option ") + name);
 }
@@ -533,7 +545,11 @@ extern "C" int hbo_objective(hbo_ctx* c, const hbo_model* m_in, hbo_dataset* ds,
       GramArgs g = {}; g.kernel_id = c->h_model->kernel_id; g.tasks = ds->d_desc; g.fdim = feature_dim(m); g.symmetric = 1; g.padded = 1;
       launch_gram(dtype, g, c->d_model, dim3(max_nblk, max_nblk, T), st);
     }
-    { ProfScope ps(c, "potrf", 1); run_potrf(c, dtype, ds->d_desc, T, max_nblk, ds->d_info, early_trtri ? &trtri_pg : nullptr); }
+    {
+      std::vector<int> h_nblk(T);
+      for (int k = 0; k < T; ++k) h_nblk[k] = ds->h_desc[k].nblk;
+      ProfScope ps(c, "potrf", 1); run_potrf(c, dtype, ds->d_desc, T, max_nblk, ds->d_info, early_trtri ? &trtri_pg : nullptr, h_nblk.data());
+    }
     // the small reductions (log-determinant + quadratic form now, alpha = W^T z and d nll / d mu after the inverse) run on
     // the idle panel stream beside the inverse and K^-1 = W^T W instead of between them (0.14 ms at cfg 2)
     side = (want_grad && obj == OBJ_NLL && c->opt_lookahead) ? c->stream2 : st;
@@ -618,6 +634,9 @@ extern "C" int hbo_objective(hbo_ctx* c, const hbo_model* m_in, hbo_dataset* ds,
   HIPCHK(c, hipStreamSynchronize(st));
   HIPCHK(c, hipGetLastError());
   prof_collect(c);
+  // the resident tile-task schedule ran out of its wall-clock bound (it never has; a hang would be a dead GPU): the context
+  // falls back to the launch schedule for good and this evaluation is repeated on it
+  if (dag_aborted(c)) { if (getenv("HBO_DAG_WATCH")) fprintf(stderr, "[dag] aborted: repeating on the launch schedule\n"); return hbo_objective(c, m_in, ds, objective, nll_sum, nll_per_task, grad_sum); }
 
   bool notpd = false;
   double total = 0;
@@ -730,6 +749,7 @@ extern "C" int hbo_factor(hbo_ctx* c, const hbo_model* m, const void* x, int64_t
   HIPCHK_K(hipStreamSynchronize(st));
   HIPCHK_K(hipGetLastError());
   prof_collect(c);
+  if (dag_aborted(c)) { hbo_cache_free(c, k); return hbo_factor(c, m, x, n, y, mcols, out); }
 #undef HIPCHK_K
   *out = k;
   return k->info != INT_MAX ? HBO_NOT_PD : HBO_OK;

@@ -85,6 +85,10 @@ struct GemmArgs {
                     // (potf2, trsm, the chain's column updates) is running there and would otherwise share MFMA / LDS with it
   int* yield_mark;  // non-null (launches ON the panel chain): the same table; every workgroup counts itself in and out
   int grp_lo;       // TRTRI: first group (of size 2s blocks) handled by this launch
+  // resident bulk schedule (dag.hip): a SYRK launch of the panel stream waits, tile by tile, until the tile-task workgroups
+  // have applied the earlier groups' bulk updates to it: dag_ctr[dag_off + task * dag_stride + r * dag_M + c] >= dag_need
+  // (r, c in 128-units; dag_ctr null or dag_need 0: no wait)
+  int* dag_ctr; int dag_off, dag_stride, dag_M, dag_need; long long dag_timeout;
   void* B;       // POST: Kxq (npad x ldb)
   int64_t ldb;
   void* V;       // POST: optional V output (npad x ldb), may be null
@@ -113,10 +117,14 @@ __device__ __forceinline__ void yield_leave(int* tab, int tok) {
 // ---- launchers (defined in the .hip files) ---------------------------------------------
 void launch_gemm(int dtype, const GemmArgs& a, dim3 grid, hipStream_t st);
 
-void launch_potf2(int dtype, const TaskDesc* tasks, int ntasks, int p, int* info, hipStream_t st, int* yield_flag = nullptr);
-void launch_trsm(int dtype, const TaskDesc* tasks, int ntasks, int p, int max_nblk, hipStream_t st, int* yield_tab = nullptr);
+// `cs` (dag.h) non-null: the kernels poll / bump the dependency counters of the resident tile-task schedule
+struct ChainSync;
+void launch_potf2(int dtype, const TaskDesc* tasks, int ntasks, int p, int* info, hipStream_t st, int* yield_flag = nullptr,
+                  const ChainSync* cs = nullptr);
+void launch_trsm(int dtype, const TaskDesc* tasks, int ntasks, int p, int max_nblk, hipStream_t st, int* yield_tab = nullptr,
+                 const ChainSync* cs = nullptr);
 // inverses of the diagonal blocks p in [p_lo, p_hi)
-void launch_trtri_diag(int dtype, const TaskDesc* tasks, int ntasks, int p_lo, int p_hi, hipStream_t st);
+void launch_trtri_diag(int dtype, const TaskDesc* tasks, int ntasks, int p_lo, int p_hi, hipStream_t st, const ChainSync* cs = nullptr);
 
 struct GramArgs {
   const TaskDesc* tasks;   // batched symmetric mode (tasks != null): out = tasks[z].A, x = tasks[z].F

@@ -24,7 +24,12 @@ hipEvent_t pool_event(hbo_ctx* c, size_t i) {
 // launches: F1 updates only the NEXT group's block columns, F2 the rest; the next group's panel
 // work (potf2 -> trsm, the serial chain) runs on a second stream as soon as F1 is done, so F2
 // -- the bulk of the flops -- overlaps it.
-void run_potrf(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, int max_nblk, int* d_info, TrtriProgress* early) {
+void run_potrf(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, int max_nblk, int* d_info, TrtriProgress* early,
+               const int* h_nblk) {
+  c->dag_ctr_last = nullptr;
+  if (c->opt_dag && !c->dag_broken && c->opt_lookahead && max_nblk >= c->opt_dag_min_nblk && max_nblk <= c->opt_dag_max_nblk &&
+      (ntasks == 1 || h_nblk) && run_potrf_dag(c, dtype, d_tasks, ntasks, max_nblk, h_nblk, d_info, early))
+    return;
   // panels per trailing update and CUs the persistent bulk update leaves to the panel chain.  Measured (NLL+grad, ms):
   //   N = 4096: (4, 32) 3.61, (3, 32) 3.54, (3, 64) 3.51;   N = 8192: (4, 32) 13.49, (3, 32) 13.34, (3, 64) 13.25,
   //   (3, 96) 13.43, (2, 64) 13.57, (5, 32) 13.61;   N = 16384: (4, 32) 78.4, (3, 32) 79.1, (3, 64) 79.5
