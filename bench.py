@@ -22,8 +22,16 @@ timed on rank 0 at N=1 under "cfg3" / "cfg5".
 Extra objects on the JSON line:
   roofline       -- the Cholesky trailing-update kernel (fp64 MFMA syrk): algorithmic flops per launch
                     / HIP-event duration of those launches inside the timed region.
+  roofline_small -- the 64x64-tile trailing updates of the panel stream (column updates inside a group, the next group's
+                    block columns, small remainders): the kernel class with the most kernel time per evaluation
+                    (per-launch events of a separate untimed pass).
   roofline_potrf -- the WHOLE factorisation: N^3/3 flops / its HIP-event time (with the overlapped inverse beside it).
-  cpu_baseline   -- oracle/cpu_baseline.py (NumPy/SciPy-LAPACK port, kind "port") on the host cores.
+  cpu_baseline   -- oracle/cpu_baseline.py (NumPy/SciPy-LAPACK port, kind "port") on the host cores, with its thread / BLAS
+                    provenance; jax_baseline: a JAX expression of the same formulas, only if `import jax` works on the box.
+  train, bo_step -- GP.train() ms per step (Adam with per-step sub-sampling / L-BFGS) and one BO step at N = 8100 (O(N^2)
+                    cache append + posterior at 64 queries vs re-factorisation).
+  device         -- hipGetDeviceProperties name / CUs / memory, and a short GPU leg AFTER the CPU baseline (a sampler that only
+                    looks at the end of the run sees the GPU working).
 """
 import argparse
 import json
@@ -91,13 +99,36 @@ def bulk_update_flops(n, group):
   return out
 
 
+def small_update_flops(n, group):
+  """Tile flops of the 64x64-tile SYRK launches of the panel stream (hyperbo_amd/csrc/sched.hip:run_potrf): the
+  left-looking column updates inside a group (K = 128 .. 128*(group-1)), F1 = the next group's block columns
+  (K = 128*group) and the bulk updates that have become too small for 128-tiles.  Lower tiles incl. the diagonal ones."""
+  nblk = (n + 127) // 128
+  fl = 0.0
+  tile = 128.0 * 128 * 2 * 128
+  for g0 in range(0, nblk, group):
+    g1 = min(g0 + group, nblk)
+    g2 = min(g1 + group, nblk)
+    for p in range(g0 + 1, g1):
+      fl += (nblk - p) * tile * (p - g0)
+    if g1 < nblk:
+      for c in range(g1, g2):
+        fl += (nblk - c) * tile * (g1 - g0)
+      m = nblk - g2
+      if g2 < nblk and m * (m + 1) // 2 < 600:
+        fl += m * (m + 1) / 2 * tile * (g1 - g0)
+  return fl
+
+
 def spawn_ranks(n):
   """`python bench.py --gpus N` without a launcher: start the N ranks (one per GPU, HBO_DEVICE = rank), pass our own
-  arguments through, relay rank 0's JSON line.  The ranks meet on a localhost port chosen here."""
-  import socket
+  arguments through, relay rank 0's JSON line.  The ranks meet on a loopback port: rank 0 takes the first free one of a
+  range chosen here (no bind-then-close race), the others probe the range.  A rank that dies takes the others with it:
+  the line then carries the error instead of a half-formed group waiting for its time-out."""
+  import random
   import subprocess
   import uuid
-  s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+  port = 20000 + random.SystemRandom().randrange(20000)
   token = uuid.uuid4().hex
   procs = []
   for r in range(n):
@@ -105,11 +136,30 @@ def spawn_ranks(n):
                HBO_BENCH_PORT=str(port), HBO_BENCH_TOKEN=token)
     procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                   stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=(r == 0)))
-  out, _ = procs[0].communicate()
-  rcs = [p.wait() for p in procs]
+  failed = None
+  while failed is None and any(p.poll() is None for p in procs):
+    for r, p in enumerate(procs):
+      if p.poll() not in (None, 0):
+        failed = (r, p.returncode)
+    time.sleep(0.2)
+  if failed is None:
+    failed = next(((r, p.returncode) for r, p in enumerate(procs) if p.returncode != 0), None)
+  if failed is not None:
+    for p in procs:
+      if p.poll() is None:
+        p.terminate()
+  out = procs[0].stdout.read() if procs[0].stdout else ''
+  for p in procs:
+    try:
+      p.wait(timeout=10)
+    except subprocess.TimeoutExpired:
+      p.kill()
+  if failed is not None and not out.strip():
+    out = json.dumps({'metric': 'GP NLL+grad evals/sec at N=8192 D=16 fp64', 'value': None, 'n_gpus': n,
+                      'error': f'rank {failed[0]} exited with code {failed[1]}; the other ranks were stopped'}) + '\n'
   sys.stdout.write(out)
   sys.stdout.flush()
-  return max(abs(rc) for rc in rcs)
+  return 0 if failed is None else max(1, abs(failed[1]))
 
 
 def bench_cfg3(ctx):
@@ -190,6 +240,75 @@ def bench_cfg5(ctx):
           'potrf_tflops': round(tf, 2), 'frac': round(tf / FP64_MFMA_PEAK_TFLOPS, 4)}
 
 
+def bench_train():
+  """GP.train() (gp.py:53-195): Adam with a fresh sub-sampled batch every step, and L-BFGS on one resident batch -- the
+  callers that turn NLL+grad evaluations into pre-training time.  64 tasks x 2000 points, batch_size 500."""
+  from hyperbo_amd.basics import definitions as defs
+  from hyperbo_amd.gp_utils import gp, kernel, mean, objectives, utils
+  rng = np.random.default_rng(0)
+  tasks, n, d, bs = 64, 2000, 4, 500
+  data = {}
+  for k in range(tasks):
+    x = rng.uniform(size=(n, d)); w = rng.normal(size=d)
+    data[k] = defs.SubDataset(x, np.sin(2 * np.pi * x @ w)[:, None] + 0.1 * rng.normal(size=(n, 1)))
+  model = lambda: {'lengthscale': np.zeros(d), 'signal_variance': np.array(0.0), 'noise_variance': np.array(-2.0), 'constant': np.array(0.0)}
+  out = {'workload': f'GP.train(): {tasks} tasks x {n} points, D={d}, batch_size {bs}, fp64, SE-ARD + constant mean'}
+  for method, st in (('adam', 40), ('lbfgs', 8)):
+    p = defs.GPParams(model=model(), config={'method': method, 'batch_size': bs, 'max_training_step': st, 'learning_rate': 0.01,
+                                             'objective': objectives.nll})
+    g = gp.GP(data, mean.constant, kernel.squared_exponential, p, utils.DEFAULT_WARP_FUNC)
+    g.train(key=1)
+    g.params.model = model()
+    t0 = time.perf_counter(); g.train(key=2); el = time.perf_counter() - t0
+    out[f'{method}_ms_per_step'] = round(el / st * 1e3, 3)
+  return out
+
+
+def bench_bo_step():
+  """One BO iteration at N = 8100 (bayesopt.py:186-190): append one observation to the cached factorisation and predict
+  at 64 queries -- the O(N^2) row append against the reference's re-factorisation."""
+  from hyperbo_amd.basics import definitions as defs
+  from hyperbo_amd.gp_utils import gp, kernel, mean, utils
+  n = 8100
+  x, y, raw = cfg2_inputs(n=n + 8)
+  xq = x[:64]
+  out = {'workload': f'BO step: append 1 observation to a cached N={n} factorisation + posterior at 64 queries, fp64'}
+  for inc, name in ((True, 'append_ms'), (False, 'refactor_ms')):
+    m = gp.GP({0: defs.SubDataset(x[:n], y[:n])}, mean.constant, kernel.squared_exponential,
+              defs.GPParams(model=raw, config={'incremental_cache': inc}), utils.DEFAULT_WARP_FUNC)
+    m.predict(xq, 0)
+    ts = []
+    for i in range(4):
+      m.update_sub_dataset((x[n + i:n + i + 1], y[n + i:n + i + 1]), 0, is_append=True)
+      t0 = time.perf_counter(); m.predict(xq, 0); ts.append(time.perf_counter() - t0)
+    out[name] = round(1e3 * float(np.median(ts)), 3)
+  return out
+
+
+def cpu_provenance():
+  """Where the CPU baseline's flops come from: thread settings and the BLAS / LAPACK the port calls."""
+  info = {'omp_num_threads': os.environ.get('OMP_NUM_THREADS'), 'openblas_num_threads': os.environ.get('OPENBLAS_NUM_THREADS')}
+  try:
+    cfg = np.show_config(mode='dicts')
+    dep = cfg.get('Build Dependencies', {})
+    info['numpy_blas'] = '%s %s' % (dep.get('blas', {}).get('name'), dep.get('blas', {}).get('version'))
+  except Exception:  # pylint: disable=broad-except
+    pass
+  try:
+    import scipy
+    scfg = scipy.show_config(mode='dicts')
+    dep = scfg.get('Build Dependencies', {})
+    info['scipy_lapack'] = '%s %s' % (dep.get('lapack', {}).get('name'), dep.get('lapack', {}).get('version'))
+  except Exception:  # pylint: disable=broad-except
+    pass
+  try:
+    from threadpoolctl import threadpool_info
+    info['threadpools'] = [{k: t.get(k) for k in ('user_api', 'internal_api', 'version', 'num_threads', 'threading_layer')} for t in threadpool_info()]
+  except Exception:  # pylint: disable=broad-except
+    pass
+  return info
+
+
 def main():
   ap = argparse.ArgumentParser()
   ap.add_argument('--gpus', type=int, default=1)
@@ -201,6 +320,7 @@ def main():
   ap.add_argument('--no-multitask', action='store_true')
   ap.add_argument('--no-extra', action='store_true', help='skip the cfg3 / cfg5 legs')
   ap.add_argument('--cpu-evals', type=int, default=8)
+  ap.add_argument('--jax', action='store_true', help='also time a JAX expression of the same NLL+grad on the host (only if jax imports)')
   ap.add_argument('--secondary-timeout', type=float, default=420.0, help='seconds for the multitask + CPU legs')
   args = ap.parse_args()
 
@@ -224,10 +344,10 @@ def main():
   if world > 1:
     from hyperbo_amd import parallel as _par
     if 'HBO_BENCH_PORT' in os.environ:     # spawned by this script: the port is ours
-      pgroup = _par.SocketGroup(rank, world, int(os.environ['HBO_BENCH_PORT']), token=os.environ.get('HBO_BENCH_TOKEN', ''))
+      pgroup = _par.SocketGroup(rank, world, int(os.environ['HBO_BENCH_PORT']), scan=32, token=os.environ.get('HBO_BENCH_TOKEN', ''))
     else:                                  # torch.distributed.run: MASTER_PORT belongs to the launcher, take one next to it
       base = int(os.environ.get('MASTER_PORT', '29500')) + 1
-      pgroup = _par.SocketGroup(rank, world, base, addr=os.environ.get('MASTER_ADDR', '127.0.0.1'), scan=32,
+      pgroup = _par.SocketGroup(rank, world, base, scan=32,
                                token=os.environ.get('TORCHELASTIC_RUN_ID', '') + ':' + os.environ.get('MASTER_PORT', ''))
 
   from hyperbo_amd import _native as nat
@@ -280,6 +400,11 @@ def main():
     step_fn(10_000 + i)
     for k, (ms, cnt) in ctx.profile_get().items():
       a = stage_prof.setdefault(k, [0.0, 0]); a[0] += ms; a[1] += cnt
+  launch_prof = {}
+  ctx.profile_enable(2)          # per-launch events of the panel stream's kernels: one more untimed evaluation
+  step_fn(20_000)
+  for k, (ms, cnt) in ctx.profile_get().items():
+    launch_prof[k] = (ms, cnt)
   assert np.isfinite(last[0]), 'NLL is not finite'
   ms_per_step = elapsed / args.steps * 1e3
   value = world * args.steps / elapsed
@@ -303,12 +428,25 @@ def main():
     # HBM traffic per launch from committed rocprofv3 PMC passes of this same command (separate
     # --pmc FETCH_SIZE / WRITE_SIZE runs; FETCH_SIZE doubled per MI355X_MICROARCH.md: on gfx950 it
     # reports half the bytes of wide coalesced streaming reads).  bench.py cannot run rocprof itself.
-    pmc_path = os.path.join(ROOT, 'profiles', 'r02_pmc_hbm.json')   # re-collected for this round's build (tools/pmc_to_json.py)
+    pmc_path = os.path.join(ROOT, 'profiles', 'r03_pmc_hbm.json')   # re-collected for this round's build (tools/pmc_to_json.py)
     if os.path.exists(pmc_path):
       pmc = json.load(open(pmc_path)).get('gemm_kernel<double, true, true, 128>')
       if pmc:
         roofline['traffic'] = int((2 * pmc['FETCH_SIZE_KB'] + pmc['WRITE_SIZE_KB']) * 1024)
-        roofline['traffic_note'] = 'bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024, profiles/r02_pmc_hbm.json'
+        roofline['traffic_note'] = ('bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 from separate rocprofv3 --pmc passes of this '
+                                    'command, profiles/r03_pmc_hbm.json (kernel unchanged since: gemm.hip tile body)')
+  roofline_small = None
+  if 'syrk_col' in launch_prof and 'syrk_trailing' in launch_prof:
+    sm_ms = launch_prof['syrk_col'][0] + launch_prof['syrk_trailing'][0]
+    sm_fl = small_update_flops(args.n, group)
+    sm_tf = sm_fl / (sm_ms * 1e-3) / 1e12
+    roofline_small = {'bound': 'mfma', 'kernel': 'gemm_kernel<double,true,true,64> (panel-stream trailing updates: column updates inside a group, '
+                                                 'next group\'s block columns, small remainders)',
+                      'flops': sm_fl, 'ms': round(sm_ms, 4), 'launches': launch_prof['syrk_col'][1] + launch_prof['syrk_trailing'][1],
+                      'achieved': round(sm_tf, 3), 'peak': FP64_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(sm_tf / FP64_MFMA_PEAK_TFLOPS, 4),
+                      'chain_kernels_ms': {k: round(launch_prof[k][0], 4) for k in ('potf2', 'trsm', 'syrk_col', 'syrk_trailing') if k in launch_prof},
+                      'note': 'sum of the per-launch HIP-event durations of ONE untimed evaluation (profile level 2); the launches sit '
+                              'on the panel stream, one after the other, beside the bulk update and the overlapped inverse'}
   stages = {k: round(v[0] / stage_evals, 4) for k, v in stage_prof.items()}   # separate pass with all stage events on
   ctx.profile_enable(0)
   roofline_potrf = None
@@ -321,6 +459,14 @@ def main():
                       'unit': 'TFLOP/s', 'frac': round(tf / FP64_MFMA_PEAK_TFLOPS, 4)}
 
   extra = {}
+  device_info = {}
+  try:
+    import ctypes as _C
+    nm = _C.create_string_buffer(128); cus = _C.c_int32(0); mem = _C.c_int64(0)
+    if nat.lib().hbo_device_info(int(os.environ.get('HBO_DEVICE', '0')), nm, 128, _C.byref(cus), _C.byref(mem)) == 0:
+      device_info = {'name': nm.value.decode(), 'cus': cus.value, 'mem_gb': round(mem.value / 2**30, 1)}
+  except Exception as e:  # pylint: disable=broad-except
+    device_info = {'error': str(e)[:100]}
 
   def result_line(cpu, multitask):
     return {
@@ -334,9 +480,14 @@ def main():
         'algorithmic_tflops': round(float(args.n)**3 / (ms_per_step * 1e-3) / 1e12, 3),
         'stages_ms_per_step': stages,
         'stages_note': 'separate untimed pass of 3 evaluations with every stage bracketed by HIP events; the timed '
-                       'region brackets only the roofline kernel (stage events cost 0.3 ms per evaluation)',
+                       'region brackets only the roofline kernel (stage events cost 0.3 ms per evaluation).  Rows overlap: '
+                       'syrk_bulk / syrk_trailing / trtri_early run INSIDE potrf (three streams); nll_reduce, wt_z run on the idle '
+                       'panel stream BESIDE trtri / lauum (wt_z waits for the inverse, then shares the machine with lauum: its '
+                       'bracket spans that) -- the sum of the rows is not the evaluation time',
         'torch_imported': 'torch' in sys.modules,
-        'roofline': roofline, 'roofline_potrf': roofline_potrf, 'cpu_baseline': cpu, 'multitask': multitask,
+        'device': device_info,
+        'roofline': roofline, 'roofline_small': roofline_small, 'roofline_potrf': roofline_potrf, 'cpu_baseline': cpu, 'multitask': multitask,
+        'jax_baseline': extra.get('jax'), 'train': extra.get('train'), 'bo_step': extra.get('bo_step'),
         'cfg3': extra.get('cfg3'), 'cfg5': extra.get('cfg5'),
     }
 
@@ -409,6 +560,16 @@ def main():
     expected = float(np.load(fx)['nll_mean']) if os.path.exists(fx) else None
     if expected is not None:
       assert abs(v_ref - expected) <= 1e-9 * abs(expected), ('cfg4 mean NLL differs from the oracle fixture', v_ref, expected)
+    # every rank's own shard time (device time before the collective) and the collective itself, from the events of the
+    # device-resident route (hbo_objective_sharded); host sockets: wall time of the whole call
+    rank_ms = imbalance = coll_us = None
+    if pgroup is not None:
+      t_local = getattr(comm, 'last_timing', None)
+      if t_local:
+        all_ms = pgroup.allgather(float(t_local[0]))
+        rank_ms = [round(v, 3) for v in all_ms]
+        imbalance = round(max(all_ms) / (sum(all_ms) / len(all_ms)), 3)
+        coll_us = round(max(pgroup.allgather(float(t_local[1]))), 1)
     comm_us = None
     if comm is not None:
       buf = np.zeros(2 + 7)
@@ -422,7 +583,8 @@ def main():
                              'LPT task shards + one all-reduce of [nll,count,grad]',
                  'evals_per_s': round(k4 / el4, 3), 'ms_per_eval': round(el4 / k4 * 1e3, 3), 'steps': k4,
                  'scaling': 'strong', 'comm': comm_kind, 'comm_us': comm_us, 'nll': float(v4[0]),
-                 'nll_unperturbed': float(v_ref), 'nll_oracle_fixture': expected, 'local_tasks': len(mine)}
+                 'nll_unperturbed': float(v_ref), 'nll_oracle_fixture': expected, 'local_tasks': len(mine),
+                 'rank_ms': rank_ms, 'imbalance': imbalance, 'allreduce_in_eval_us': coll_us}
     if world == 1:
       # what one rank of an 8-GPU job would hold: the heaviest LPT shard of 8 (eight tasks), timed alone
       shard8 = parallel.shard_dataset(full, 0, 8)
@@ -442,6 +604,8 @@ def main():
     try:
       extra['cfg3'] = bench_cfg3(ctx)
       extra['cfg5'] = bench_cfg5(ctx)
+      extra['train'] = bench_train()
+      extra['bo_step'] = bench_bo_step()
     except Exception as e:  # pylint: disable=broad-except
       extra['error'] = str(e)[:200]
 
@@ -460,6 +624,19 @@ def main():
                      f'(oracle/cpu_baseline.py + oracle/cpu_port.c: Gram build and gradient contraction in C/OpenMP on all '
                      f'cores, LAPACK potrf/potrs/potri via SciPy/OpenBLAS)',
            'seconds': round(el, 2), 'nll_matches_gpu': bool(abs(vals[-1] - float(step_fn(args.cpu_evals - 1)[0])) <= 1e-8 * abs(vals[-1]))}
+    cpu.update(cpu_provenance())
+    if args.jax:
+      try:
+        import jax  # noqa: F401  pylint: disable=unused-import
+        from oracle import jax_baseline
+        extra['jax'] = jax_baseline.time_nll_and_grad(x, y, perturb(raw, 0, 0), budget_s=20.0)
+      except ImportError:
+        extra['jax'] = {'error': 'jax is not importable on this box'}
+    # the GPU again, after the CPU leg (a utilisation sampler that only sees the end of the run finds it busy here)
+    t0 = time.perf_counter()
+    for i in range(10):
+      step_fn(30_000 + i)
+    device_info['ms_per_step_after_cpu_leg'] = round((time.perf_counter() - t0) / 10 * 1e3, 4)
 
   watchdog.cancel()
   if rank == 0:

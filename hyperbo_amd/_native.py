@@ -96,6 +96,9 @@ SIGNATURES = {
     'hbo_comm_init': (C.c_int, [_P, C.c_int, C.c_int, _P]),
     'hbo_comm_allreduce_sum': (C.c_int, [_P, C.POINTER(C.c_double), C.c_int32]),
     'hbo_comm_destroy': (C.c_int, [_P]),
+    'hbo_objective_sharded': (C.c_int, [_P, C.POINTER(Model), _P, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                        C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    'hbo_device_info': (C.c_int, [C.c_int, C.c_char_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]),
 }
 
 _lib = None

@@ -26,6 +26,14 @@ extern "C" int hbo_device_count(void) {
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
   return n;
 }
+extern "C" int hbo_device_info(int device, char* name_out, int32_t cap, int32_t* cus, int64_t* mem_bytes) {
+  hipDeviceProp_t p;
+  if (hipGetDeviceProperties(&p, device) != hipSuccess) return fail(nullptr, HBO_ERR_NODEV, "hbo_device_info: no such device");
+  if (name_out && cap > 0) { snprintf(name_out, (size_t)cap, "%s (%s)", p.name, p.gcnArchName); }
+  if (cus) *cus = p.multiProcessorCount;
+  if (mem_bytes) *mem_bytes = (int64_t)p.totalGlobalMem;
+  return HBO_OK;
+}
 extern "C" const char* hbo_last_error(hbo_ctx* ctx) { return ctx ? ctx->err.c_str() : hbo_g_err.c_str(); }
 
 extern "C" int hbo_ctx_create(int device, hbo_ctx** out) {
@@ -42,8 +50,8 @@ extern "C" int hbo_ctx_create(int device, hbo_ctx** out) {
   if (e == hipSuccess) e = hipStreamCreate(&c->stream);
   if (e == hipSuccess) e = hipStreamCreate(&c->stream2);
   if (e == hipSuccess) e = hipStreamCreate(&c->stream4);
-  if (e == hipSuccess) e = hipMalloc((void**)&c->d_model, sizeof(ModelDev));
-  if (e == hipSuccess) e = hipMalloc((void**)&c->d_yield, sizeof(int) * HBO_YIELD_TAB_ENTRIES);
+  if (e == hipSuccess) e = hbo_malloc(c, (void**)&c->d_model, sizeof(ModelDev));
+  if (e == hipSuccess) e = hbo_malloc(c, (void**)&c->d_yield, sizeof(int) * HBO_YIELD_TAB_ENTRIES);
   if (e == hipSuccess) e = hipMemset(c->d_yield, 0, sizeof(int) * HBO_YIELD_TAB_ENTRIES);
   if (e == hipSuccess) e = hipHostMalloc((void**)&c->h_model, sizeof(ModelDev), hipHostMallocDefault);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_upload, hipEventDisableTiming);
@@ -53,7 +61,12 @@ extern "C" int hbo_ctx_create(int device, hbo_ctx** out) {
     (void)nullctx;
     return HBO_ERR_HIP;
   }
-  { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, device) == hipSuccess) c->n_cus = prop.multiProcessorCount; }
+  { hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
+      c->n_cus = prop.multiProcessorCount;
+      // parked buffers of freed datasets / caches: at most a quarter of the device memory (option pool_cap_mb)
+      c->pool_cap = std::min<size_t>(c->pool_cap, (size_t)prop.totalGlobalMem / 4);
+    } }
   *out = c;
   return HBO_OK;
 }
@@ -74,6 +87,7 @@ extern "C" int hbo_ctx_destroy(hbo_ctx* c) {
   for (auto& kv : c->pool_free) for (void* p : kv.second) hipFree(p);
   c->pool_free.clear(); c->pool_live.clear(); c->pool_bytes = 0;
   for (hipEvent_t ev : c->ev_pool) hipEventDestroy(ev);
+  for (hipEvent_t ev : c->ev_timed) if (ev) hipEventDestroy(ev);
   if (c->stream4) hipStreamDestroy(c->stream4);
   if (c->stream2) hipStreamDestroy(c->stream2);
   if (c->stream) hipStreamDestroy(c->stream);
@@ -96,8 +110,7 @@ extern "C" int hbo_set_option(hbo_ctx* c, const char* name, int64_t value) {
     c->pool_cap = (size_t)value << 20;
     if (c->pool_bytes > c->pool_cap) {   // trim: release everything parked (simple and rare)
       hipSetDevice(c->device);
-      for (auto& kv : c->pool_free) for (void* p : kv.second) hipFree(p);
-      c->pool_free.clear(); c->pool_bytes = 0;
+      pool_release_all(c);
     }
     return HBO_OK;
   }
@@ -200,8 +213,8 @@ static int upload_model(hbo_ctx* c, const hbo_model* m) {
     int fin = m->input_dim;
     for (int l = 0; l < m->n_layers; ++l) {
       const size_t wb = (size_t)fin * m->features[l] * esize(m->dtype), bb = (size_t)m->features[l] * esize(m->dtype);
-      if (c->mlp_w_bytes[l] < wb) { if (c->d_mlp_w[l]) hipFree(c->d_mlp_w[l]); HIPCHK(c, hipMalloc(&c->d_mlp_w[l], wb)); c->mlp_w_bytes[l] = wb; }
-      if (c->mlp_b_bytes[l] < bb) { if (c->d_mlp_b[l]) hipFree(c->d_mlp_b[l]); HIPCHK(c, hipMalloc(&c->d_mlp_b[l], bb)); c->mlp_b_bytes[l] = bb; }
+      if (c->mlp_w_bytes[l] < wb) { if (c->d_mlp_w[l]) hipFree(c->d_mlp_w[l]); HIPCHK(c, hbo_malloc(c, &c->d_mlp_w[l], wb)); c->mlp_w_bytes[l] = wb; }
+      if (c->mlp_b_bytes[l] < bb) { if (c->d_mlp_b[l]) hipFree(c->d_mlp_b[l]); HIPCHK(c, hbo_malloc(c, &c->d_mlp_b[l], bb)); c->mlp_b_bytes[l] = bb; }
       HIPCHK(c, hipMemcpyAsync(c->d_mlp_w[l], m->mlp_kernel[l], wb, hipMemcpyHostToDevice, c->stream));
       HIPCHK(c, hipMemcpyAsync(c->d_mlp_b[l], m->mlp_bias[l], bb, hipMemcpyHostToDevice, c->stream));
       fin = m->features[l];
@@ -257,7 +270,7 @@ struct FeatBuf {   // device activations of one input matrix
     acts.resize(HBO_MAX_MLP_LAYERS, nullptr); bytes.resize(HBO_MAX_MLP_LAYERS, 0);
     for (int l = 0; l < m->n_layers; ++l) {
       const size_t need = (size_t)std::max<int64_t>(n, 1) * m->features[l] * esize(m->dtype);
-      if (bytes[l] < need) { if (acts[l]) hipFree(acts[l]); acts[l] = nullptr; HIPCHK(c, hipMalloc(&acts[l], need)); bytes[l] = need; }
+      if (bytes[l] < need) { if (acts[l]) hipFree(acts[l]); acts[l] = nullptr; HIPCHK(c, hbo_malloc(c, &acts[l], need)); bytes[l] = need; }
     }
     return HBO_OK;
   }
@@ -458,9 +471,16 @@ extern "C" int hbo_nll(hbo_ctx* c, const hbo_model* m, hbo_dataset* ds, double* 
   return hbo_objective(c, m, ds, HBO_OBJ_NLL, nll_sum, nll_per_task, grad_sum);
 }
 
-extern "C" int hbo_objective(hbo_ctx* c, const hbo_model* m_in, hbo_dataset* ds, int objective, double* nll_sum,
-                             double* nll_per_task, double* grad_sum) {
-  if (!c || !ds || !nll_sum || !m_in) return fail(c, HBO_ERR_ARG, "hbo_objective: null argument");
+// Task-sharded form (hbo_objective_sharded): the sums over this rank's tasks are formed on the device, all-reduced in place
+// over the context's RCCL communicator and copied to the host once.
+struct ShardReq { double* count; double* timing; };
+int comm_allreduce_device(hbo_ctx* c, double* d_buf, int count, hipStream_t st);   // comm.hip
+void launch_shard_reduce(const double* nll, const double* grad, const int* info, int T, int out_stride, const int* map,
+                         const double* mlp, const int* mlp_seg, int n_mlp_seg, double* out, int out_count, hipStream_t st);   // gram.hip
+
+static int objective_impl(hbo_ctx* c, const hbo_model* m_in, hbo_dataset* ds, int objective, double* nll_sum,
+                          double* nll_per_task, double* grad_sum, const ShardReq* sh) {
+  if (!c || !nll_sum || !m_in || (!ds && !sh)) return fail(c, HBO_ERR_ARG, "hbo_objective: null argument");
   if (objective != HBO_OBJ_NLL && objective != HBO_OBJ_EKL && objective != HBO_OBJ_EUC) return fail(c, HBO_ERR_ARG, "hbo_objective: unknown objective id");
   HIPCHK(c, hipSetDevice(c->device));
   hbo_model mcopy = *m_in;
@@ -470,18 +490,52 @@ extern "C" int hbo_objective(hbo_ctx* c, const hbo_model* m_in, hbo_dataset* ds,
   const bool euc = obj == OBJ_EUC;
   int rc = validate_model(c, m);
   if (rc) return rc;
-  if (m->dtype != ds->dtype || m->input_dim != ds->D) return fail(c, HBO_ERR_ARG, "hbo_objective: model/dataset dtype or input_dim mismatch");
+  if (ds && ds->ntasks > 0 && (m->dtype != ds->dtype || m->input_dim != ds->D)) return fail(c, HBO_ERR_ARG, "hbo_objective: model/dataset dtype or input_dim mismatch");
   hbo_grad_layout lay;
   hbo_grad_layout_of(m, &lay);
   const bool want_grad = grad_sum != nullptr;
   *nll_sum = 0;
   if (want_grad) for (int i = 0; i < lay.total; ++i) grad_sum[i] = 0;
-  const int T = ds->ntasks;
-  if (T == 0) return HBO_OK;
+  const int T = ds ? ds->ntasks : 0;
+  hipStream_t st = c->stream;
+  // sharded: [nll, count, grad] of the whole job, reduced on the device
+  const int red_count = 2 + (want_grad ? lay.total : 0);
+  auto finish_sharded = [&](double* d_red, hipEvent_t ev0, hipEvent_t ev1) -> int {
+    hipEvent_t ev2 = pool_event_timed(c, 2);
+    int rc = c->comm ? comm_allreduce_device(c, d_red, red_count, st) : HBO_OK;
+    if (rc) return rc;
+    HIPCHK(c, hipEventRecord(ev2, st));
+    double* stage = static_cast<double*>(pinned_stage(c, sizeof(double) * red_count));
+    if (!stage) return fail(c, HBO_ERR_HIP, "hbo_objective_sharded: pinned staging buffer");
+    HIPCHK(c, hipMemcpyAsync(stage, d_red, sizeof(double) * red_count, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    *nll_sum = stage[0];
+    *sh->count = stage[1];
+    if (want_grad) for (int i = 0; i < lay.total; ++i) grad_sum[i] = stage[2 + i];
+    if (sh->timing) {
+      float ms_local = 0, ms_comm = 0;
+      hipEventElapsedTime(&ms_local, ev0, ev1); hipEventElapsedTime(&ms_comm, ev1, ev2);
+      sh->timing[0] = ms_local; sh->timing[1] = 1e3 * ms_comm;
+    }
+    return HBO_OK;
+  };
+  if (T == 0) {
+    if (!sh) return HBO_OK;
+    // a rank beyond the task count: zeros into the collective
+    HIPCHK(c, hipSetDevice(c->device));
+    double* d_red = static_cast<double*>(ws_get(c, WS_SHARD_RED, sizeof(double) * red_count));
+    if (!d_red) return HBO_ERR_HIP;
+    hipEvent_t ev0 = pool_event_timed(c, 0), ev1 = pool_event_timed(c, 1);
+    HIPCHK(c, hipEventRecord(ev0, st));
+    HIPCHK(c, hipMemsetAsync(d_red, 0, sizeof(double) * red_count, st));
+    HIPCHK(c, hipEventRecord(ev1, st));
+    return finish_sharded(d_red, ev0, ev1);
+  }
   if (obj != OBJ_NLL) for (TaskHost* t : ds->tasks) if (!t->ydiv) return fail(c, HBO_ERR_UNSUPPORTED, "hbo_objective: divergence objectives need m + 1 <= 128 aligned columns");
   const int dtype = ds->dtype;
-  hipStream_t st = c->stream;
   prof_begin(c);
+  hipEvent_t ev_sh0 = nullptr;
+  if (sh) { ev_sh0 = pool_event_timed(c, 0); HIPCHK(c, hipEventRecord(ev_sh0, st)); }
   rc = upload_model(c, m);
   if (rc) return rc;
 
@@ -500,20 +554,20 @@ extern "C" int hbo_objective(hbo_ctx* c, const hbo_model* m_in, hbo_dataset* ds,
         if (t->dF) hipFree(t->dF);
         if (t->dtmp) hipFree(t->dtmp);
         t->dF = t->dtmp = nullptr;
-        HIPCHK(c, hipMalloc((void**)&t->dF, need * sizeof(double)));
-        HIPCHK(c, hipMalloc((void**)&t->dtmp, need * sizeof(double)));
+        HIPCHK(c, hbo_malloc(c, (void**)&t->dF, need * sizeof(double)));
+        HIPCHK(c, hbo_malloc(c, (void**)&t->dtmp, need * sizeof(double)));
         t->dF_elems = need;
       }
     }
     fill_desc(ds->h_desc[k], t, m, dtype, obj);
   }
-  if (!ds->d_desc) HIPCHK(c, hipMalloc((void**)&ds->d_desc, sizeof(TaskDesc) * T));
+  if (!ds->d_desc) HIPCHK(c, hbo_malloc(c, (void**)&ds->d_desc, sizeof(TaskDesc) * T));
   const int out_stride = (m->kernel_id == HBO_KERNEL_DOT ? 0 : m->n_lengthscale) + 6 + mean_feature_dim(m);
   const size_t pack_bytes = sizeof(double) * T * (1 + (size_t)out_stride) + sizeof(int) * T;
   if (ds->pack_bytes < pack_bytes) {
     if (ds->d_pack) hipFree(ds->d_pack);
     ds->d_pack = nullptr; ds->pack_bytes = 0;
-    HIPCHK(c, hipMalloc((void**)&ds->d_pack, pack_bytes));
+    HIPCHK(c, hbo_malloc(c, (void**)&ds->d_pack, pack_bytes));
     ds->pack_bytes = pack_bytes;
   }
   ds->d_nll = ds->d_pack; ds->d_gradout = ds->d_pack + T; ds->d_info = reinterpret_cast<int*>(ds->d_pack + T + (size_t)T * out_stride);
@@ -562,7 +616,7 @@ extern "C" int hbo_objective(hbo_ctx* c, const hbo_model* m_in, hbo_dataset* ds,
   const int64_t stride_task = (int64_t)(max_nblk * (max_nblk + 1)) * nacc;   // two half-tile slots per lower tile
   if (want_grad || euc) {   // EUC: the Frobenius norm of the value comes out of the contraction pass
     const size_t pb = sizeof(double) * (stride_task * T + (size_t)HBO_GRAD_PRE_ROWS * nacc * T);   // per-tile partials + their pre-reduction
-    if (ds->partials_bytes < pb) { if (ds->d_partials) hipFree(ds->d_partials); HIPCHK(c, hipMalloc((void**)&ds->d_partials, pb)); ds->partials_bytes = pb; }
+    if (ds->partials_bytes < pb) { if (ds->d_partials) hipFree(ds->d_partials); HIPCHK(c, hbo_malloc(c, (void**)&ds->d_partials, pb)); ds->partials_bytes = pb; }
     if (!euc) {
       // The tail of the inverse is a chain of small dependent products (the tree over the last panels) before its top-level
       // product: the machine is mostly idle for ~0.5 ms.  The part of K^-1 = W^T W that only needs W11 (final since the
@@ -601,7 +655,7 @@ extern "C" int hbo_objective(hbo_ctx* c, const hbo_model* m_in, hbo_dataset* ds,
       size_t tot = 0; int fin0 = m->input_dim;
       std::vector<size_t> woff(L), boff(L);
       for (int l = 0; l < L; ++l) { woff[l] = tot; tot += (size_t)fin0 * m->features[l]; boff[l] = tot; tot += m->features[l]; fin0 = m->features[l]; }
-      if (ds->mlpgrad_elems < tot) { if (ds->d_mlpgrad) hipFree(ds->d_mlpgrad); HIPCHK(c, hipMalloc((void**)&ds->d_mlpgrad, tot * sizeof(double))); ds->mlpgrad_elems = tot; }
+      if (ds->mlpgrad_elems < tot) { if (ds->d_mlpgrad) hipFree(ds->d_mlpgrad); HIPCHK(c, hbo_malloc(c, (void**)&ds->d_mlpgrad, tot * sizeof(double))); ds->mlpgrad_elems = tot; }
       HIPCHK(c, hipMemsetAsync(ds->d_mlpgrad, 0, tot * sizeof(double), st));
       for (int k = 0; k < T; ++k) HIPCHK(c, hipMemsetAsync(ds->tasks[k]->dF, 0, (size_t)ds->tasks[k]->n * flast * sizeof(double), st));
       if (m->kernel_uses_mlp) {
@@ -622,6 +676,48 @@ extern "C" int hbo_objective(hbo_ctx* c, const hbo_model* m_in, hbo_dataset* ds,
       }
     }
   }
+  if (sh) {
+    // [nll, count, grad] of this rank's tasks in the caller's gradient layout, on the device: entry j of a task's gradient block
+    // goes to map[j] (the scatter the host loop below does), the MLP gradient -- already summed over the tasks -- by segments
+    const int n_ls = m->kernel_id == HBO_KERNEL_DOT ? 0 : m->n_lengthscale;
+    const int fm = mean_feature_dim(m);
+    std::vector<int> hmap(out_stride + 3 * 2 * HBO_MAX_MLP_LAYERS, -1);
+    if (want_grad) {
+      for (int d = 0; d < n_ls; ++d) hmap[d] = lay.lengthscale < 0 ? -1 : lay.lengthscale + d;
+      hmap[n_ls] = lay.signal_variance; hmap[n_ls + 1] = lay.noise_variance; hmap[n_ls + 2] = lay.constant;
+      hmap[n_ls + 3] = lay.dot_prod_sigma; hmap[n_ls + 4] = lay.dot_prod_bias;
+      for (int d = 0; d < fm; ++d) hmap[n_ls + 5 + d] = lay.linear_kernel < 0 ? -1 : lay.linear_kernel + d;
+      hmap[n_ls + 5 + fm] = lay.linear_bias;
+    }
+    int nseg = 0;
+    if (want_grad && needs_mlp(m)) {
+      int pos = 0, fin0 = m->input_dim;
+      for (int l = 0; l < m->n_layers; ++l) {
+        const int wn = fin0 * m->features[l], bn = m->features[l];
+        int* sg = hmap.data() + out_stride + 3 * nseg;
+        sg[0] = lay.mlp_kernel[l]; sg[1] = pos; sg[2] = wn; ++nseg; pos += wn;
+        sg += 3; sg[0] = lay.mlp_bias[l]; sg[1] = pos; sg[2] = bn; ++nseg; pos += bn;
+        fin0 = m->features[l];
+      }
+    }
+    int* d_map = static_cast<int*>(ws_get(c, WS_SHARD_MAP, sizeof(int) * hmap.size()));
+    double* d_red = static_cast<double*>(ws_get(c, WS_SHARD_RED, sizeof(double) * red_count));
+    if (!d_map || !d_red) return HBO_ERR_HIP;
+    HIPCHK(c, hipEventSynchronize(c->ev_upload));
+    memcpy(stage, hmap.data(), sizeof(int) * hmap.size());
+    HIPCHK(c, hipMemcpyAsync(d_map, stage, sizeof(int) * hmap.size(), hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipEventRecord(c->ev_upload, st));
+    launch_shard_reduce(ds->d_nll, want_grad ? ds->d_gradout : nullptr, ds->d_info, T, out_stride, d_map, ds->d_mlpgrad, d_map + out_stride, nseg,
+                        d_red, red_count, st);
+    hipEvent_t ev1 = pool_event_timed(c, 1);
+    HIPCHK(c, hipEventRecord(ev1, st));
+    int rcs = finish_sharded(d_red, ev_sh0, ev1);
+    HIPCHK(c, hipGetLastError());
+    prof_collect(c);
+    if (dag_aborted(c)) return objective_impl(c, m_in, ds, objective, nll_sum, nll_per_task, grad_sum, sh);
+    if (rcs) return rcs;
+    return std::isnan(*nll_sum) ? HBO_NOT_PD : HBO_OK;
+  }
   HIPCHK(c, hipMemcpyAsync(stage, ds->d_pack, pack_bytes, hipMemcpyDeviceToHost, st));
   const double* h_nll = reinterpret_cast<const double*>(stage);
   const double* h_grad = h_nll + T;
@@ -636,7 +732,7 @@ extern "C" int hbo_objective(hbo_ctx* c, const hbo_model* m_in, hbo_dataset* ds,
   prof_collect(c);
   // the resident tile-task schedule ran out of its wall-clock bound (it never has; a hang would be a dead GPU): the context
   // falls back to the launch schedule for good and this evaluation is repeated on it
-  if (dag_aborted(c)) { if (getenv("HBO_DAG_WATCH")) fprintf(stderr, "[dag] aborted: repeating on the launch schedule\n"); return hbo_objective(c, m_in, ds, objective, nll_sum, nll_per_task, grad_sum); }
+  if (dag_aborted(c)) return objective_impl(c, m_in, ds, objective, nll_sum, nll_per_task, grad_sum, sh);
 
   bool notpd = false;
   double total = 0;
@@ -670,6 +766,17 @@ extern "C" int hbo_objective(hbo_ctx* c, const hbo_model* m_in, hbo_dataset* ds,
     }
   }
   return notpd ? HBO_NOT_PD : HBO_OK;
+}
+extern "C" int hbo_objective(hbo_ctx* c, const hbo_model* m, hbo_dataset* ds, int objective, double* nll_sum,
+                             double* nll_per_task, double* grad_sum) {
+  if (!ds) return fail(c, HBO_ERR_ARG, "hbo_objective: null argument");
+  return objective_impl(c, m, ds, objective, nll_sum, nll_per_task, grad_sum, nullptr);
+}
+extern "C" int hbo_objective_sharded(hbo_ctx* c, const hbo_model* m, hbo_dataset* ds, int objective, double* value_sum,
+                                     double* count, double* grad_sum, double* timing) {
+  if (!count) return fail(c, HBO_ERR_ARG, "hbo_objective_sharded: null argument");
+  ShardReq sh{count, timing};
+  return objective_impl(c, m, ds, objective, value_sum, nullptr, grad_sum, &sh);
 }
 
 // ---- GPCache -----------------------------------------------------------------------------
@@ -722,10 +829,10 @@ extern "C" int hbo_factor(hbo_ctx* c, const hbo_model* m, const void* x, int64_t
   if (rc) return bail(rc);
   if (needs_mlp(m)) { rc = t->feat.ensure(c, m, t->npad); if (rc) return bail(rc); }
   fill_desc(k->h_desc, t, m, dtype, ROLE_FACTOR);
-  HIPCHK_K(hipMalloc((void**)&k->d_desc, sizeof(TaskDesc)));
-  HIPCHK_K(hipMalloc((void**)&k->d_info, sizeof(int)));
-  HIPCHK_K(hipMalloc(&k->resid, (size_t)mcols * t->npad * es));
-  HIPCHK_K(hipMalloc(&k->zvec, (size_t)mcols * t->npad * es));
+  HIPCHK_K(hbo_malloc(c, (void**)&k->d_desc, sizeof(TaskDesc)));
+  HIPCHK_K(hbo_malloc(c, (void**)&k->d_info, sizeof(int)));
+  HIPCHK_K(hbo_malloc(c, &k->resid, (size_t)mcols * t->npad * es));
+  HIPCHK_K(hbo_malloc(c, &k->zvec, (size_t)mcols * t->npad * es));
   HIPCHK_K(hipMemcpy(k->d_desc, &k->h_desc, sizeof(TaskDesc), hipMemcpyHostToDevice));
   int inf = INT_MAX;
   HIPCHK_K(hipMemcpy(k->d_info, &inf, sizeof(int), hipMemcpyHostToDevice));
@@ -879,7 +986,7 @@ extern "C" int hbo_cache_export(hbo_ctx* c, hbo_cache* k, void* chol_out, void* 
     if (bad) fill_nan(chol_out, (size_t)n * n, k->dtype);
     else {
       void* tmp = nullptr;
-      HIPCHK(c, hipMalloc(&tmp, (size_t)n * n * es));
+      HIPCHK(c, hbo_malloc(c, &tmp, (size_t)n * n * es));
       launch_extract_lower(k->dtype, t->A, t->ld, n, tmp, c->stream);
       hipError_t e = hipMemcpyAsync(chol_out, tmp, (size_t)n * n * es, hipMemcpyDeviceToHost, c->stream);
       if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
@@ -967,7 +1074,7 @@ static int posterior(hbo_ctx* c, const hbo_model* m, hbo_cache* k, const void* x
     if (!k->w3 || k->w3_elems != elems) {
       if (k->w3) hipFree(k->w3);
       k->w3 = nullptr; k->w3_elems = 0;
-      if (hipMalloc((void**)&k->w3, elems * sizeof(unsigned short)) != hipSuccess) { (void)hipGetLastError(); k->w3 = nullptr; use3 = false; }
+      if (hbo_malloc(c, (void**)&k->w3, elems * sizeof(unsigned short)) != hipSuccess) { (void)hipGetLastError(); k->w3 = nullptr; use3 = false; }
       else k->w3_elems = elems;
     }
     if (use3) {
@@ -1216,23 +1323,23 @@ extern "C" int hbo_gram(hbo_ctx* c, const hbo_model* m, const void* x1, int64_t 
   FeatBuf f1, f2;
   auto cleanup = [&]() { for (void* p : {d1, d2, dout}) if (p) hipFree(p); };
 #define HIPCHK_G(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) { c->err = std::string(#call " failed: ") + hipGetErrorString(e__); cleanup(); return HBO_ERR_HIP; } } while (0)
-  HIPCHK_G(hipMalloc(&d1, (size_t)n1 * m->input_dim * es));
+  HIPCHK_G(hbo_malloc(c, &d1, (size_t)n1 * m->input_dim * es));
   HIPCHK_G(hipMemcpyAsync(d1, x1, (size_t)n1 * m->input_dim * es, hipMemcpyHostToDevice, st));
   const void* F1 = d1; const void* F2 = d1;
   if (m->kernel_uses_mlp) { rc = f1.ensure(c, m, n1); if (rc) { cleanup(); return rc; } run_mlp(c, m, d1, n1, f1.acts.data()); F1 = F2 = f1.acts[m->n_layers - 1]; }
   if (x2) {
-    HIPCHK_G(hipMalloc(&d2, (size_t)n2 * m->input_dim * es));
+    HIPCHK_G(hbo_malloc(c, &d2, (size_t)n2 * m->input_dim * es));
     HIPCHK_G(hipMemcpyAsync(d2, x2, (size_t)n2 * m->input_dim * es, hipMemcpyHostToDevice, st));
     F2 = d2;
     if (m->kernel_uses_mlp) { rc = f2.ensure(c, m, n2); if (rc) { cleanup(); return rc; } run_mlp(c, m, d2, n2, f2.acts.data()); F2 = f2.acts[m->n_layers - 1]; }
   }
   const int fdim = feature_dim(m);
   if (diag) {
-    HIPCHK_G(hipMalloc(&dout, (size_t)n1 * es));
+    HIPCHK_G(hbo_malloc(c, &dout, (size_t)n1 * es));
     launch_kdiag(dtype, F1, n1, fdim, c->d_model, dout, st);
     HIPCHK_G(hipMemcpyAsync(out, dout, (size_t)n1 * es, hipMemcpyDeviceToHost, st));
   } else {
-    HIPCHK_G(hipMalloc(&dout, (size_t)n1 * n2 * es));
+    HIPCHK_G(hbo_malloc(c, &dout, (size_t)n1 * n2 * es));
     GramArgs g = {}; g.kernel_id = c->h_model->kernel_id; g.x1 = F1; g.x2 = F2; g.out = dout; g.n1 = n1; g.n2 = n2; g.ldo = n2; g.fdim = fdim;
     launch_gram(dtype, g, c->d_model, dim3((unsigned)((n2 + 127) / 128), (unsigned)((n1 + 127) / 128), 1), st);
     HIPCHK_G(hipMemcpyAsync(out, dout, (size_t)n1 * n2 * es, hipMemcpyDeviceToHost, st));
@@ -1255,8 +1362,8 @@ extern "C" int hbo_mean(hbo_ctx* c, const hbo_model* m, const void* x, int64_t n
   void *dx = nullptr, *dout = nullptr;
   FeatBuf f;
   auto cleanup = [&]() { for (void* p : {dx, dout}) if (p) hipFree(p); };
-  hipError_t e = hipMalloc(&dx, (size_t)n * m->input_dim * es);
-  if (e == hipSuccess) e = hipMalloc(&dout, (size_t)n * es);
+  hipError_t e = hbo_malloc(c, &dx, (size_t)n * m->input_dim * es);
+  if (e == hipSuccess) e = hbo_malloc(c, &dout, (size_t)n * es);
   if (e == hipSuccess) e = hipMemcpyAsync(dx, x, (size_t)n * m->input_dim * es, hipMemcpyHostToDevice, st);
   if (e != hipSuccess) { cleanup(); return fail(c, HBO_ERR_HIP, hipGetErrorString(e)); }
   const void* Fm = (m->mean_id == HBO_MEAN_LINEAR) ? dx : nullptr;
@@ -1288,16 +1395,16 @@ extern "C" int hbo_spd_solve(hbo_ctx* c, int dtype, const void* a, int64_t n, co
 #define HIPCHK_S(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) { c->err = std::string(#call " failed: ") + hipGetErrorString(e__); cleanup(); return HBO_ERR_HIP; } } while (0)
   const bool need_inv = inv_out != nullptr || x_out != nullptr;
   { int rc = ensure_task_workspace(c, dtype, t, need_inv, t->m); if (rc) { cleanup(); return rc; } }
-  HIPCHK_S(hipMalloc(&d_a, (size_t)n * n * es));
+  HIPCHK_S(hbo_malloc(c, &d_a, (size_t)n * n * es));
   HIPCHK_S(hipMemcpyAsync(d_a, a, (size_t)n * n * es, hipMemcpyHostToDevice, st));
-  if (b) { HIPCHK_S(hipMalloc(&d_b, (size_t)n * mcols * es)); HIPCHK_S(hipMemcpyAsync(d_b, b, (size_t)n * mcols * es, hipMemcpyHostToDevice, st)); }
+  if (b) { HIPCHK_S(hbo_malloc(c, &d_b, (size_t)n * mcols * es)); HIPCHK_S(hipMemcpyAsync(d_b, b, (size_t)n * mcols * es, hipMemcpyHostToDevice, st)); }
   launch_fill_spd(dtype, d_a, n, t->A, t->ld, t->npad, st);
   launch_set_aug(dtype, d_b, n, b ? mcols : 0, t->A, t->ld, t->npad, st);
   TaskDesc h; memset(&h, 0, sizeof h);
   h.A = t->A; h.W = t->W; h.S = t->S; h.wscr = t->wscr; h.svec = t->svec; h.n = (int)n; h.npad = t->npad; h.nblk = t->nblk; h.m = t->m; h.ld = t->ld;
   h.naug = t->m;
-  HIPCHK_S(hipMalloc((void**)&d_desc, sizeof h));
-  HIPCHK_S(hipMalloc((void**)&d_info, sizeof(int)));
+  HIPCHK_S(hbo_malloc(c, (void**)&d_desc, sizeof h));
+  HIPCHK_S(hbo_malloc(c, (void**)&d_info, sizeof(int)));
   int inf = INT_MAX;
   HIPCHK_S(hipMemcpyAsync(d_desc, &h, sizeof h, hipMemcpyHostToDevice, st));
   HIPCHK_S(hipMemcpyAsync(d_info, &inf, sizeof(int), hipMemcpyHostToDevice, st));
@@ -1309,7 +1416,7 @@ extern "C" int hbo_spd_solve(hbo_ctx* c, int dtype, const void* a, int64_t n, co
     if (inv_out) { ProfScope ps(c, "lauum", 1); run_lauum(c, dtype, d_desc, 1, t->nblk); }
   }
   HIPCHK_S(hipMemcpyAsync(&inf, d_info, sizeof(int), hipMemcpyDeviceToHost, st));
-  HIPCHK_S(hipMalloc(&d_tmp, (size_t)n * n * es));
+  HIPCHK_S(hbo_malloc(c, &d_tmp, (size_t)n * n * es));
   std::vector<unsigned char> hchol;
   if (chol_out || logdet_half) {
     launch_extract_lower(dtype, t->A, t->ld, n, d_tmp, st);

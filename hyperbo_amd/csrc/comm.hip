@@ -63,6 +63,16 @@ extern "C" int hbo_comm_allreduce_sum(hbo_ctx* c, double* buf, int32_t count) {
   HIPCHK(c, hipStreamSynchronize(c->stream));
   return HBO_OK;
 }
+// in place on a device buffer, on the given stream of the context; nothing is synchronised here
+int comm_allreduce_device(hbo_ctx* c, double* d_buf, int count, hipStream_t st) {
+  if (!c->comm) return fail(c, HBO_ERR_COMM, "all-reduce: communicator not initialised");
+  auto f = (fn_ncclAllReduce)dlsym(c->rccl_lib, "ncclAllReduce");
+  if (!f) return fail(c, HBO_ERR_COMM, "ncclAllReduce not found");
+  const int ncclFloat64 = 8, ncclSum = 0;
+  int rc = f(d_buf, d_buf, (size_t)count, ncclFloat64, ncclSum, c->comm, st);
+  if (rc != 0) return fail(c, HBO_ERR_COMM, "ncclAllReduce failed with code " + std::to_string(rc));
+  return HBO_OK;
+}
 extern "C" int hbo_comm_destroy(hbo_ctx* c) {
   if (!c) return HBO_OK;
   if (c->comm && c->rccl_lib) {

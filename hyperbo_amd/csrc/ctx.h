@@ -37,6 +37,7 @@ struct hbo_ctx {
   int* trtri_counters = nullptr; int trtri_counter_next = 0;   // run_potrf -> trtri_level: tile counters of those launches
   int n_cus = 256;
   std::vector<hipEvent_t> ev_pool;
+  hipEvent_t ev_timed[3] = {nullptr, nullptr, nullptr};   // hbo_objective_sharded: start / local shard done / all-reduce done
   std::map<int, std::pair<void*, size_t>> ws;   // grow-only device scratch buffers by slot (no per-call hipMalloc/hipFree)
   // Device buffers of freed datasets / caches, kept for the next one of the same shape (dev_alloc / dev_free in api.hip):
   // GP.train()'s Adam loop re-creates its sub-sampled batch every step (gp.py:101-111) and 64 tasks x 8 buffers of
@@ -45,7 +46,7 @@ struct hbo_ctx {
   std::map<std::pair<int, size_t>, std::vector<void*>> pool_free;
   std::map<void*, std::pair<int, size_t>> pool_live;
   size_t pool_bytes = 0;                       // bytes parked in pool_free
-  size_t pool_cap = (size_t)48 << 30;
+  size_t pool_cap = (size_t)48 << 30;          // lowered to a quarter of the device memory at context creation
   int opt_lookahead = 1;
   int opt_f1_on_chain = 1;         // F1 on the panel stream (no event hops around it)
   int opt_dynamic_tiles = 1;       // persistent bulk update draws its tiles from a counter

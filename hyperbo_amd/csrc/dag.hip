@@ -469,9 +469,9 @@ bool run_potrf_dag(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, i
     }
     DagHost h;
     build_dag(h, nblk, q, c->opt_dag_near64, cut, c->opt_small_nblk, chain_tasks);
-    if (hipMalloc((void**)&h.d_tasks, sizeof(DagTask) * std::max<size_t>(h.tasks.size(), 1)) != hipSuccess) return false;
-    if (hipMalloc((void**)&h.d_segs, sizeof(DagSeg) * std::max<size_t>(h.segs.size(), 1)) != hipSuccess) return false;
-    if (hipMalloc((void**)&h.d_ctr, sizeof(int) * h.n_ctr) != hipSuccess) return false;
+    if (hbo_malloc(c, (void**)&h.d_tasks, sizeof(DagTask) * std::max<size_t>(h.tasks.size(), 1)) != hipSuccess) return false;
+    if (hbo_malloc(c, (void**)&h.d_segs, sizeof(DagSeg) * std::max<size_t>(h.segs.size(), 1)) != hipSuccess) return false;
+    if (hbo_malloc(c, (void**)&h.d_ctr, sizeof(int) * h.n_ctr) != hipSuccess) return false;
     hipMemcpy(h.d_tasks, h.tasks.data(), sizeof(DagTask) * h.tasks.size(), hipMemcpyHostToDevice);
     hipMemcpy(h.d_segs, h.segs.data(), sizeof(DagSeg) * h.segs.size(), hipMemcpyHostToDevice);
     it = cache.emplace(key, std::move(h)).first;
@@ -495,7 +495,7 @@ bool run_potrf_dag(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, i
 #ifdef HBO_DAG_DEBUG
   {
     static unsigned long long* d_st = nullptr;
-    if (!d_st) hipMalloc((void**)&d_st, sizeof(unsigned long long) * 128 * DAG_STAMPS_PER_PANEL);
+    if (!d_st) hbo_malloc(c, (void**)&d_st, sizeof(unsigned long long) * 128 * DAG_STAMPS_PER_PANEL);
     std::vector<unsigned long long> init(128 * DAG_STAMPS_PER_PANEL);
     for (int i = 0; i < 128 * DAG_STAMPS_PER_PANEL; ++i) { const int k = i % DAG_STAMPS_PER_PANEL; init[i] = (k == 1 || k == 4 || k == 7 || k == 9 || i >= 120 * DAG_STAMPS_PER_PANEL) ? 0ull : ~0ull; }
     hipMemcpyAsync(d_st, init.data(), sizeof(unsigned long long) * init.size(), hipMemcpyHostToDevice, sm);

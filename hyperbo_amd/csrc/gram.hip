@@ -8,6 +8,7 @@
 // mean.py:30-79, basics/linalg.py:36-69 (jitter), objectives.py:144-156 (NLL),
 // gp.py:242-305 (posterior), bo_utils/acfun.py:96-142 (acquisition).
 #include "hbo_internal.h"
+#include <limits.h>
 #include <math.h>
 
 namespace {
@@ -1233,6 +1234,40 @@ void launch_acq_grad_mean(const double* dmu, const ModelDev* md, int64_t M, int 
                           hipStream_t st) {
   if (M * fm <= 0) return;
   hipLaunchKernelGGL(acq_grad_mean_kernel, dim3((unsigned)((M * fm + 255) / 256)), dim3(256), 0, st, dmu, md, M, fm, out, accumulate);
+}
+// [sum of the tasks' values, task count, gradient sum in the caller's layout] of one rank's shard, on the device (what the host loop of
+// hbo_objective does after the copy back: same order of summation).  One workgroup: the vector has a few dozen entries (plus the
+// MLP weights), the task count is at most a few hundred.
+__global__ void shard_reduce_kernel(const double* nll, const double* grad, const int* info, int T, int out_stride, const int* map,
+                                    const double* mlp, const int* seg, int nseg, double* out, int out_count) {
+  const int tid = threadIdx.x;
+  for (int i = tid; i < out_count; i += blockDim.x) out[i] = 0.0;
+  __syncthreads();
+  bool anybad = false;
+  for (int k = 0; k < T; ++k) anybad |= info[k] != INT_MAX;
+  if (tid == 0) {
+    double s = 0.0;
+    for (int k = 0; k < T; ++k) s += nll[k];
+    out[0] = s; out[1] = (double)T;
+  }
+  if (grad) {
+    for (int j = tid; j < out_stride; j += blockDim.x) {
+      const int dst = map[j];
+      if (dst < 0) continue;
+      double s = 0.0;
+      for (int k = 0; k < T; ++k) s += info[k] != INT_MAX ? (double)NAN : grad[(size_t)k * out_stride + j];
+      out[2 + dst] += s;
+    }
+    for (int sgi = 0; sgi < nseg; ++sgi) {
+      const int dst = seg[3 * sgi], src = seg[3 * sgi + 1], len = seg[3 * sgi + 2];
+      if (dst < 0) continue;
+      for (int i = tid; i < len; i += blockDim.x) out[2 + dst + i] = anybad ? (double)NAN : mlp[src + i];
+    }
+  }
+}
+void launch_shard_reduce(const double* nll, const double* grad, const int* info, int T, int out_stride, const int* map,
+                         const double* mlp, const int* mlp_seg, int n_mlp_seg, double* out, int out_count, hipStream_t st) {
+  hipLaunchKernelGGL(shard_reduce_kernel, dim3(1), dim3(256), 0, st, nll, grad, info, T, out_stride, map, mlp, mlp_seg, n_mlp_seg, out, out_count);
 }
 void launch_add_inplace(double* dst, const double* src, int64_t count, hipStream_t st) {
   if (count <= 0) return;

@@ -189,6 +189,19 @@ struct Post3Args {
   float* V; int64_t ldv;      // optional V output (npad x ldv)
   int nblk;
 };
+// fp32 trailing updates of the blocked Cholesky on the bf16 matrix cores (post3.hip: split3_panel_kernel, syrk3_kernel)
+struct Syrk3Args {
+  const TaskDesc* tasks;
+  unsigned short* Xp;        // split copy of the current group's panels: per task, row tile R (0..nblk, nblk = augmented tile-row),
+  int64_t task_stride;       //   k block KB (0..nkb), three planes of 128 x 16 bf16 each; task_stride elements per task
+  int nkb;                   // k blocks per row tile in the buffer (16 panel columns each)
+  // split: columns [kcol0, kcol0 + 16 nk_split) of A go to blocks [kb_off, kb_off + nk_split) of the row tiles r_lo...
+  int kcol0, nk_split, r_lo;
+  // product: C[r, c] -= X[r, kb_off .. kb_off + nk) X[c, ...]^T for the tiles c in [c_lo, c_hi), r in [c, nblk]
+  int kb_off, nk, c_lo, c_hi;
+};
+void launch_split3_panel(const Syrk3Args& a, int row_tiles, int ntasks, hipStream_t st);
+void launch_syrk3(const Syrk3Args& a, int ntiles, int ntasks, hipStream_t st);
 void launch_split3_rows(const float* in, int64_t ld, int row_tiles, unsigned short* out, int nkb, hipStream_t st);
 void launch_split3_transpose(const float* in, int64_t ld, int krows, int jcols, unsigned short* out, int nkb, hipStream_t st);
 void launch_post3(const Post3Args& a, int col_tiles, hipStream_t st);

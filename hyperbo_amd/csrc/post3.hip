@@ -210,6 +210,143 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
 }
 
+
+// ---- the same product for the fp32 trailing updates of the blocked Cholesky ---------------------------------------------
+// C[r, c] -= P[r, :] P[c, :]^T over the K = 16 * nk panel columns of a group: both operands are row tiles of ONE split copy of
+// the group's panels (split3_panel_kernel: rows = matrix rows below the group incl. the augmented tile-row, k = panel column),
+// the tile is read-modified-written once at the end.  hyperbo/basics/linalg.py:29-33 (cholesky) at the reference's default
+// dtype; the panel kernels (potf2, panel solve) stay in fp32 arithmetic.
+__global__ __launch_bounds__(256) void split3_panel_kernel(Syrk3Args g) {
+  // one workgroup = one 128-row tile x four k blocks of the panel columns [kcol0, kcol0 + 16 * nk_split)
+  const TaskDesc& t = g.tasks[blockIdx.z];
+  const int R = g.r_lo + (int)blockIdx.y;
+  if (R > t.nblk) return;                       // (row tile nblk = the augmented tile-row)
+  const float* in = static_cast<const float*>(t.A) + (int64_t)g.kcol0;
+  u16* out = g.Xp + (int64_t)blockIdx.z * g.task_stride;
+  const int row = threadIdx.x >> 1, half = threadIdx.x & 1;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int kb = (int)blockIdx.x * 4 + q;     // block inside the split range
+    if (kb >= g.nk_split) return;
+    const float* src = in + (int64_t)(R * HBO_TILE + row) * t.ld + kb * 16 + half * 8;
+    const float4 a = *reinterpret_cast<const float4*>(src);
+    const float4 b = *reinterpret_cast<const float4*>(src + 4);
+    const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    U16x8 h, m, l;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) split3(x[e], h.v[e], m.v[e], l.v[e]);
+    u16* o = out + ((int64_t)R * g.nkb + g.kb_off + kb) * 3 * P3_CHUNK + threadIdx.x * 8;
+    *reinterpret_cast<U16x8*>(o) = h;
+    *reinterpret_cast<U16x8*>(o + P3_CHUNK) = m;
+    *reinterpret_cast<U16x8*>(o + 2 * P3_CHUNK) = l;
+  }
+}
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void syrk3_kernel(Syrk3Args g) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const TaskDesc& t = g.tasks[blockIdx.z];
+  // tile (r, c) of the trapezoid c in [c_lo, c_hi), r in [c, nblk]: linear index, column-major (consecutive workgroups share B)
+  const int nrt = t.nblk + 1;
+  const int chi = g.c_hi < t.nblk ? g.c_hi : t.nblk;
+  int tix = blockIdx.x, c = g.c_lo;
+  while (c < chi && tix >= nrt - c) { tix -= nrt - c; ++c; }
+  if (c >= chi) return;
+  const int r = c + tix;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l32 = lane & 31, lh = lane >> 5;
+  auto arr = [&](int st, int op, int p) { return smem + (size_t)((st * 2 + op) * 3 + p) * P3_ARR; };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[a][b][q] = 0.f;
+
+  const int srow = tid >> 1, shalf = tid & 1;
+  const u16* xp = g.Xp + (int64_t)blockIdx.z * g.task_stride;
+  const u16* ga = xp + ((int64_t)r * g.nkb + g.kb_off) * 3 * P3_CHUNK + tid * 8;
+  const u16* gb = xp + ((int64_t)c * g.nkb + g.kb_off) * 3 * P3_CHUNK + tid * 8;
+  const int soff = srow * P3_ROW + ((shalf ^ ((srow >> 3) & 1)) * 16);
+  struct Slot { u32x4 a0, a1, a2, b0, b1, b2; };
+  Slot s0, s1, s2, s3;
+#define P3_GLOAD(KT, S)                                                              \
+  {                                                                                  \
+    const u16* pa_ = ga + (int64_t)(KT) * 3 * P3_CHUNK;                              \
+    const u16* pb_ = gb + (int64_t)(KT) * 3 * P3_CHUNK;                              \
+    S.a0 = *reinterpret_cast<const u32x4*>(pa_);                                     \
+    S.b0 = *reinterpret_cast<const u32x4*>(pb_);                                     \
+    S.a1 = *reinterpret_cast<const u32x4*>(pa_ + P3_CHUNK);                          \
+    S.b1 = *reinterpret_cast<const u32x4*>(pb_ + P3_CHUNK);                          \
+    S.a2 = *reinterpret_cast<const u32x4*>(pa_ + 2 * P3_CHUNK);                      \
+    S.b2 = *reinterpret_cast<const u32x4*>(pb_ + 2 * P3_CHUNK);                      \
+  }
+#define P3_SSTORE(ST, S)                                                             \
+  {                                                                                  \
+    *reinterpret_cast<u32x4*>(arr(ST, 0, 0) + soff) = S.a0;                          \
+    *reinterpret_cast<u32x4*>(arr(ST, 1, 0) + soff) = S.b0;                          \
+    *reinterpret_cast<u32x4*>(arr(ST, 0, 1) + soff) = S.a1;                          \
+    *reinterpret_cast<u32x4*>(arr(ST, 1, 1) + soff) = S.b1;                          \
+    *reinterpret_cast<u32x4*>(arr(ST, 0, 2) + soff) = S.a2;                          \
+    *reinterpret_cast<u32x4*>(arr(ST, 1, 2) + soff) = S.b2;                          \
+  }
+#define P3_STAGE(KT, CUR, S_FILL, S_NEXT)                                                                         \
+  {                                                                                                               \
+    const int kt_ = (KT);                                                                                         \
+    if (kt_ + 4 < nk) P3_GLOAD(kt_ + 4, S_FILL)                                                                   \
+    bf16x8 fa[3][2], fb[3][2];                                                                                    \
+    _Pragma("unroll") for (int p = 0; p < 3; ++p)                                                                 \
+    _Pragma("unroll") for (int tt = 0; tt < 2; ++tt) {                                                            \
+      fa[p][tt] = *reinterpret_cast<const bf16x8*>(arr(CUR, 0, p) + foff_a + tt * 32 * P3_ROW);                   \
+      fb[p][tt] = *reinterpret_cast<const bf16x8*>(arr(CUR, 1, p) + foff_b + tt * 32 * P3_ROW);                   \
+    }                                                                                                             \
+    constexpr int PA[6] = {2, 0, 1, 1, 0, 0};   /* smallest products first */                                     \
+    constexpr int PB[6] = {0, 2, 1, 0, 1, 0};                                                                     \
+    _Pragma("unroll") for (int q = 0; q < 6; ++q)                                                                 \
+    _Pragma("unroll") for (int a = 0; a < 2; ++a)                                                                 \
+    _Pragma("unroll") for (int b = 0; b < 2; ++b)                                                                 \
+      acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA[q]][a], fb[PB[q]][b], acc[a][b], 0, 0, 0);        \
+    if (kt_ + 1 < nk) P3_SSTORE((CUR) ^ 1, S_NEXT)                                                                \
+    __syncthreads();                                                                                              \
+  }
+  const int nk = g.nk;                            // a multiple of 4 (one panel = 8 blocks)
+  const int fsw = (lh ^ ((l32 >> 3) & 1)) * 16;
+  const int foff_a = (wm * 64 + l32) * P3_ROW + fsw;
+  const int foff_b = (wn * 64 + l32) * P3_ROW + fsw;
+  P3_GLOAD(0, s0) P3_GLOAD(1, s1) P3_GLOAD(2, s2) P3_GLOAD(3, s3)
+  P3_SSTORE(0, s0)
+  __syncthreads();
+  for (int kt0 = 0; kt0 < nk; kt0 += 4) {
+    P3_STAGE(kt0, 0, s0, s1)
+    P3_STAGE(kt0 + 1, 1, s1, s2)
+    P3_STAGE(kt0 + 2, 0, s2, s3)
+    P3_STAGE(kt0 + 3, 1, s3, s0)
+  }
+#undef P3_STAGE
+#undef P3_GLOAD
+#undef P3_SSTORE
+  // C -= acc.  Accumulator layout of v_mfma_f32_32x32x16_bf16: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
+  float* C = static_cast<float*>(t.A) + (int64_t)r * HBO_TILE * t.ld + (int64_t)c * HBO_TILE;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      float old[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int row = wm * 64 + a * 32 + (q & 3) + 8 * (q >> 2) + 4 * lh;
+        old[q] = gld(C + (int64_t)row * t.ld + wn * 64 + b * 32 + l32);
+      }
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int row = wm * 64 + a * 32 + (q & 3) + 8 * (q >> 2) + 4 * lh;
+        gst(C + (int64_t)row * t.ld + wn * 64 + b * 32 + l32, old[q] - acc[a][b][q]);
+      }
+    }
+}
+
 }  // namespace
 
 void launch_split3_rows(const float* in, int64_t ld, int row_tiles, unsigned short* out, int nkb, hipStream_t st) {
@@ -227,4 +364,18 @@ void launch_post3(const Post3Args& a, int col_tiles, hipStream_t st) {
     attr = true;
   }
   hipLaunchKernelGGL(post3_kernel, dim3(col_tiles, a.nblk), dim3(256), POST3_LDS_BYTES, st, a);
+}
+
+void launch_split3_panel(const Syrk3Args& a, int row_tiles, int ntasks, hipStream_t st) {
+  if (row_tiles <= 0 || a.nk_split <= 0) return;
+  hipLaunchKernelGGL(split3_panel_kernel, dim3((a.nk_split + 3) / 4, row_tiles, ntasks), dim3(256), 0, st, a);
+}
+void launch_syrk3(const Syrk3Args& a, int ntiles, int ntasks, hipStream_t st) {
+  if (ntiles <= 0) return;
+  static bool attr = false;
+  if (!attr) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&syrk3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, POST3_LDS_BYTES);
+    attr = true;
+  }
+  hipLaunchKernelGGL(syrk3_kernel, dim3(ntiles, 1, ntasks), dim3(256), POST3_LDS_BYTES, st, a);
 }

@@ -14,16 +14,29 @@ static inline int round_up(int64_t n, int q) { return (int)(((n + q - 1) / q) * 
 // (a 64 KiB row stride maps every row of a k-contiguous tile onto the same L2/HBM channel)
 static inline int64_t padded_ld(int64_t extent, int dtype) { return extent + 128 / (int64_t)esize(dtype); }
 
+// Every device allocation of the library: out of memory with buffers parked in the pool (dev_free below) -> release them and
+// retry once.  (A training loop with changing batch shapes parks gigabytes; a posterior workspace must not fail beside them.)
+static inline void pool_release_all(hbo_ctx* c);
+static inline hipError_t hbo_malloc(hbo_ctx* c, void** out, size_t bytes) {
+  hipError_t e = hipMalloc(out, bytes ? bytes : 16);
+  if (e == hipErrorOutOfMemory && c && c->pool_bytes) {
+    (void)hipGetLastError();
+    pool_release_all(c);
+    e = hipMalloc(out, bytes ? bytes : 16);
+  }
+  return e;
+}
+
 // grow-only scratch buffer for `slot`; nullptr on allocation failure (ctx->err is set)
 enum WsSlot { WS_K3 = 40, WS_XQ = 1, WS_MU0, WS_KD, WS_MU, WS_VAR, WS_ACQ, WS_K, WS_COLSQ, WS_V, WS_KQQ, WS_COV,
               WS_AP_KX, WS_AP_L, WS_AP_W, WS_AP_MU, WS_AP_KD, WS_COUNTERS, WS_MUPART,
-              WS_AG_K, WS_AG_L, WS_AG_B, WS_AG_GF, WS_AG_DMU, WS_AG_GX, WS_AG_T0, WS_AG_T1, WS_AG_DW, WS_FQ0 /* + layer */ };
+              WS_AG_K, WS_AG_L, WS_AG_B, WS_AG_GF, WS_AG_DMU, WS_AG_GX, WS_AG_T0, WS_AG_T1, WS_AG_DW, WS_SHARD_RED, WS_SHARD_MAP, WS_FQ0 /* + layer */ };
 static inline void* ws_get(hbo_ctx* c, int slot, size_t bytes) {
   auto& e = c->ws[slot];
   if (e.second < bytes || !e.first) {
     if (e.first) hipFree(e.first);
     e.first = nullptr; e.second = 0;
-    hipError_t err = hipMalloc(&e.first, bytes ? bytes : 16);
+    hipError_t err = hbo_malloc(c, &e.first, bytes);
     if (err != hipSuccess) { c->err = std::string("hipMalloc failed: ") + hipGetErrorString(err); e.first = nullptr; return nullptr; }
     e.second = bytes;
   }
@@ -31,6 +44,10 @@ static inline void* ws_get(hbo_ctx* c, int slot, size_t bytes) {
 }
 
 // ---- pooled device buffers of datasets and caches (see hbo_ctx::pool_free) ---------------------
+static inline void pool_release_all(hbo_ctx* c) {
+  for (auto& kv : c->pool_free) for (void* p : kv.second) hipFree(p);
+  c->pool_free.clear(); c->pool_bytes = 0;
+}
 static inline hipError_t dev_alloc(hbo_ctx* c, void** out, size_t bytes, int cls = 0, bool* reused = nullptr) {
   if (reused) *reused = false;
   if (bytes == 0) bytes = 16;
@@ -44,12 +61,7 @@ static inline hipError_t dev_alloc(hbo_ctx* c, void** out, size_t bytes, int cls
       return hipSuccess;
     }
   }
-  hipError_t e = hipMalloc(out, bytes);
-  if (e != hipSuccess && c && c->pool_bytes) {   // out of memory with buffers parked: release them and retry
-    for (auto& kv : c->pool_free) for (void* p : kv.second) hipFree(p);
-    c->pool_free.clear(); c->pool_bytes = 0;
-    e = hipMalloc(out, bytes);
-  }
+  hipError_t e = hbo_malloc(c, out, bytes);
   if (e == hipSuccess && c) c->pool_live[*out] = {cls, bytes};
   return e;
 }
@@ -64,6 +76,12 @@ static inline void dev_free(hbo_ctx* c, void* p) {
     }
   }
   hipFree(p);
+}
+
+// three timing-enabled events of the context (the pool of sched.hip's pool_event is hipEventDisableTiming)
+static inline hipEvent_t pool_event_timed(hbo_ctx* c, int i) {
+  if (!c->ev_timed[i]) hipEventCreate(&c->ev_timed[i]);
+  return c->ev_timed[i];
 }
 
 // ---- profiling ---------------------------------------------------------------------------

@@ -87,6 +87,22 @@ class DeviceDataset:
     except Exception:  # pylint: disable=broad-except
       pass
 
+  def evaluate_sharded(self, mean_func, cov_func, params, warp_func=None, objective=OBJ_NLL, comm=None):
+    """This rank's shard through hbo_objective_sharded: the sums over ALL ranks of `comm`'s communicator, reduced on the device
+    and all-reduced in place (RCCL over xGMI).  Returns (value_sum, task_count, flat grad_sum (warped), BuiltModel)."""
+    input_dim = self.input_dim
+    if self.num_tasks == 0:
+      input_dim = _model.infer_input_dim(mean_func, cov_func, params) or self.input_dim
+    bm = _model.BuiltModel(mean_func, cov_func, params, warp_func, self.dtype, input_dim)
+    val, cnt = C.c_double(0.0), C.c_double(0.0)
+    g = (C.c_double * max(bm.layout.total, 1))()
+    timing = (C.c_double * 2)()
+    self.ctx.check(nat.lib().hbo_objective_sharded(self.ctx.handle, bm.ref(), self._h if self.num_tasks else None, objective,
+                                                   C.byref(val), C.byref(cnt), g, timing))
+    if comm is not None:
+      comm.last_timing = (timing[0], timing[1])
+    return val.value, cnt.value, np.array(list(g)[:bm.layout.total], dtype=np.float64), bm
+
   def evaluate(self, mean_func, cov_func, params, warp_func=None, want_grad=False, per_task=False,
                objective=OBJ_NLL):
     """Returns (value_sum, per_task dict or None, flat grad_sum (warped) or None, BuiltModel)."""
@@ -203,13 +219,17 @@ def nll_value_and_grad(mean_func, cov_func, params, dataset, warp_func=None, exc
   and [nll_sum, count, grad_sum] are sum-all-reduced before the mean over tasks is taken.
   """
   dev, owned = _as_device(dataset, exclude_aligned)
+  native = comm is not None and getattr(comm, 'native_sharded', False)
   try:
-    nll_sum, _, grad, bm = dev.evaluate(mean_func, cov_func, params, warp_func, want_grad=True)
-    count = float(dev.num_tasks)
+    if native:
+      nll_sum, count, grad, bm = dev.evaluate_sharded(mean_func, cov_func, params, warp_func, comm=comm)
+    else:
+      nll_sum, _, grad, bm = dev.evaluate(mean_func, cov_func, params, warp_func, want_grad=True)
+      count = float(dev.num_tasks)
   finally:
     if owned:
       dev.close()
-  if comm is not None:
+  if comm is not None and not native:
     buf = np.concatenate([[nll_sum, count], grad])
     buf = comm.allreduce_sum(buf)
     nll_sum, count, grad = buf[0], buf[1], buf[2:]
@@ -241,16 +261,20 @@ nll_value_and_grad.accepts_device_batch = True
 
 def _divergence(objective_id, mean_func, cov_func, params, dataset, warp_func, want_grad, comm=None):
   dev, owned = _as_device(dataset, True, only_aligned=True)
+  native = want_grad and comm is not None and getattr(comm, 'native_sharded', False)
   try:
-    total, _, grad, bm = dev.evaluate(mean_func, cov_func, params, warp_func, want_grad=want_grad,
-                                      objective=objective_id)
-    count = float(dev.num_tasks)
+    if native:
+      total, count, grad, bm = dev.evaluate_sharded(mean_func, cov_func, params, warp_func, objective=objective_id, comm=comm)
+    else:
+      total, _, grad, bm = dev.evaluate(mean_func, cov_func, params, warp_func, want_grad=want_grad,
+                                        objective=objective_id)
+      count = float(dev.num_tasks)
   finally:
     if owned:
       dev.close()
   if not want_grad:
     return (0. if count == 0 else total / count), None
-  if comm is not None:
+  if comm is not None and not native:
     buf = comm.allreduce_sum(np.concatenate([[total, count], grad]))
     total, count, grad = buf[0], buf[1], buf[2:]
   if count > 0:

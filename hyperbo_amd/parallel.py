@@ -16,7 +16,9 @@ SocketGroup is the torch-free process group of one node (rendezvous, barrier, ma
 from __future__ import annotations
 
 import ctypes as C
-import pickle
+import hashlib
+import hmac
+import os
 import socket
 import struct
 import time
@@ -48,12 +50,75 @@ def shard_dataset(dataset, rank: int, world_size: int, exclude_aligned: bool = T
   return {k: s for k, s in items if k in mine}
 
 
-_MAGIC = b'HBOGRP1\n'
+_MAGIC = b'HBOGRP2\n'
+_MAX_FRAME = 16 << 20   # bytes; the largest legitimate message is a gradient vector or a 128-byte RCCL id
+
+
+# Wire format: typed, length-capped frames -- nothing that arrives on the socket is ever unpickled or evaluated.
+#   frame = b'HB' + type (1 byte) + payload length (u32, little endian) + payload
+#   N none | T true | F false | D float64 | I int64 | S utf-8 string | B bytes | A float64 vector | L list of frames
+def _encode(obj) -> bytes:
+  if obj is None:
+    t, payload = b'N', b''
+  elif obj is True:
+    t, payload = b'T', b''
+  elif obj is False:
+    t, payload = b'F', b''
+  elif isinstance(obj, (bytes, bytearray)):
+    t, payload = b'B', bytes(obj)
+  elif isinstance(obj, str):
+    t, payload = b'S', obj.encode('utf-8')
+  elif isinstance(obj, (int, np.integer)):
+    t, payload = b'I', struct.pack('<q', int(obj))
+  elif isinstance(obj, (float, np.floating)):
+    t, payload = b'D', struct.pack('<d', float(obj))
+  elif isinstance(obj, np.ndarray):
+    t, payload = b'A', np.ascontiguousarray(obj, dtype=np.float64).ravel().tobytes()
+  elif isinstance(obj, (list, tuple)):
+    t, payload = b'L', b''.join(_encode(o) for o in obj)
+  else:
+    raise TypeError(f'SocketGroup cannot send a {type(obj).__name__}')
+  if len(payload) > _MAX_FRAME:
+    raise ValueError('SocketGroup: message too large')
+  return b'HB' + t + struct.pack('<I', len(payload)) + payload
+
+
+def _decode(buf: bytes, pos: int = 0):
+  if buf[pos:pos + 2] != b'HB' or len(buf) < pos + 7:
+    raise ValueError('SocketGroup: malformed frame')
+  t = buf[pos + 2:pos + 3]
+  n, = struct.unpack_from('<I', buf, pos + 3)
+  body = buf[pos + 7:pos + 7 + n]
+  if n > _MAX_FRAME or len(body) != n:
+    raise ValueError('SocketGroup: malformed frame')
+  end = pos + 7 + n
+  if t == b'N':
+    return None, end
+  if t == b'T':
+    return True, end
+  if t == b'F':
+    return False, end
+  if t == b'B':
+    return bytes(body), end
+  if t == b'S':
+    return body.decode('utf-8'), end
+  if t == b'I' and n == 8:
+    return struct.unpack('<q', body)[0], end
+  if t == b'D' and n == 8:
+    return struct.unpack('<d', body)[0], end
+  if t == b'A' and n % 8 == 0:
+    return np.frombuffer(body, dtype=np.float64).copy(), end
+  if t == b'L':
+    out, p = [], 0
+    while p < n:
+      o, p = _decode(body, p)
+      out.append(o)
+    return out, end
+  raise ValueError('SocketGroup: unknown frame type')
 
 
 def _send_msg(sock, obj):
-  data = pickle.dumps(obj, protocol=4)
-  sock.sendall(struct.pack('<Q', len(data)) + data)
+  sock.sendall(_encode(obj))
 
 
 def _recv_exact(sock, n):
@@ -67,25 +132,37 @@ def _recv_exact(sock, n):
 
 
 def _recv_msg(sock):
-  n, = struct.unpack('<Q', _recv_exact(sock, 8))
-  return pickle.loads(_recv_exact(sock, n))
+  head = _recv_exact(sock, 7)
+  if head[:2] != b'HB':
+    raise ValueError('SocketGroup: malformed frame')
+  n, = struct.unpack('<I', head[3:7])
+  if n > _MAX_FRAME:
+    raise ValueError('SocketGroup: frame exceeds the size cap')
+  return _decode(head + _recv_exact(sock, n))[0]
+
+
+def _mac(token: str, *parts: bytes) -> bytes:
+  return hmac.new(token.encode('utf-8'), b'|'.join(parts), hashlib.sha256).digest()
 
 
 class SocketGroup:
-  """Process group of the ranks of ONE node over localhost TCP: rank 0 is the hub.
+  """Process group of the ranks of ONE node over loopback TCP (always 127.0.0.1): rank 0 is the hub.
 
   `port` is where rank 0 listens; with `scan` > 0 rank 0 takes the first free port in [port, port + scan) and the
-  other ranks probe that range for the hub's greeting (magic + world size + `token`) -- so the group can be derived
-  from a launcher's MASTER_PORT (taken by the launcher itself) without a second agreed port.  Collectives are
-  hub-and-spoke exchanges of small pickled objects (latency ~0.1 ms): rendezvous, barrier, max / gather of scalars,
-  broadcast of the 128-byte RCCL id.  The [nll, count, grad] all-reduce itself goes over RCCL (RcclComm)."""
+  other ranks probe that range for the hub -- so the group can be derived from a launcher's MASTER_PORT (taken by the
+  launcher itself) without a second agreed port.  Both sides prove that they hold `token` before anything else is
+  exchanged (HMAC-SHA256 over fresh nonces, in both directions); a rank that is already registered is not replaced.
+  Messages are typed, length-capped frames (None / bool / int / float / str / bytes / float64 vectors / lists of those):
+  nothing received is unpickled.  Collectives are hub-and-spoke exchanges (latency ~0.1 ms): rendezvous, barrier,
+  max / gather of scalars, broadcast of the 128-byte RCCL id.  The [nll, count, grad] all-reduce itself goes over RCCL."""
 
   def __init__(self, rank: int, world_size: int, port: int, addr: str = '127.0.0.1', scan: int = 0, token: str = '',
                timeout: float = 120.0):
+    del addr   # single-node by definition: never listen on, or connect to, anything but loopback
+    addr = '127.0.0.1'
     self.rank, self.world_size = int(rank), int(world_size)
     self._peers: List[socket.socket] = []
     self._hub = None
-    hello = (_MAGIC, self.world_size, token)
     deadline = time.time() + timeout
     ports = list(range(port, port + max(scan, 1)))
     if self.rank == 0:
@@ -112,10 +189,17 @@ class SocketGroup:
           continue
         try:
           conn.settimeout(10.0)
-          _send_msg(conn, hello)
+          nonce_h = os.urandom(16)
+          _send_msg(conn, [_MAGIC, self.world_size, nonce_h])
           r = _recv_msg(conn)
-          if not (isinstance(r, tuple) and r[0] == _MAGIC and 0 < r[1] < self.world_size):
+          if not (isinstance(r, list) and len(r) == 4 and r[0] == _MAGIC and isinstance(r[1], int) and isinstance(r[2], bytes)
+                  and isinstance(r[3], bytes) and 0 < r[1] < self.world_size):
             raise ValueError('bad greeting')
+          if not hmac.compare_digest(r[3], _mac(token, b'client', nonce_h, str(r[1]).encode())):
+            raise ValueError('bad token')
+          if r[1] in by_rank:
+            raise ValueError('rank already registered')   # keep the first one
+          _send_msg(conn, _mac(token, b'hub', r[2]))
           conn.settimeout(timeout)
           conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
           by_rank[r[1]] = conn
@@ -131,9 +215,14 @@ class SocketGroup:
           try:
             c = socket.create_connection((addr, p), timeout=2.0)
             c.settimeout(5.0)
-            if _recv_msg(c) != hello:
+            h = _recv_msg(c)
+            if not (isinstance(h, list) and len(h) == 3 and h[0] == _MAGIC and h[1] == self.world_size and isinstance(h[2], bytes)):
               c.close(); continue
-            _send_msg(c, (_MAGIC, self.rank))
+            nonce_c = os.urandom(16)
+            _send_msg(c, [_MAGIC, self.rank, nonce_c, _mac(token, b'client', h[2], str(self.rank).encode())])
+            proof = _recv_msg(c)
+            if not (isinstance(proof, bytes) and hmac.compare_digest(proof, _mac(token, b'hub', nonce_c))):
+              c.close(); continue   # somebody else's hub (or ours refused us)
             c.settimeout(timeout)
             c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
             self._hub = c
@@ -240,6 +329,11 @@ class RcclComm:
     self.ctx.check(self._nat.lib().hbo_comm_allreduce_sum(
         self.ctx.handle, a.ctypes.data_as(C.POINTER(C.c_double)), a.size), allow_not_pd=False)
     return a
+
+  # objectives.nll_value_and_grad(..., comm=this) takes the device-resident route: hbo_objective_sharded reduces the shard on
+  # the device, all-reduces in place on the context's stream and copies [nll, count, grad] back once
+  native_sharded = True
+  last_timing = None   # (ms of device time on this rank's shard, us of the all-reduce) of the last sharded evaluation
 
   def close(self):
     self._nat.lib().hbo_comm_destroy(self.ctx.handle)

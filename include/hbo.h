@@ -103,6 +103,8 @@ int hbo_ctx_destroy(hbo_ctx* ctx);
 const char* hbo_last_error(hbo_ctx* ctx); /* ctx may be NULL: last error of ctx-less calls */
 const char* hbo_version(void);
 int hbo_device_count(void);
+/* name_out (nullable, cap bytes): marketing / arch name of the device; cus / mem_bytes (nullable): compute units, device memory */
+int hbo_device_info(int device, char* name_out, int32_t cap, int32_t* cus, int64_t* mem_bytes);
 
 int hbo_grad_layout_of(const hbo_model* model, hbo_grad_layout* out);
 
@@ -219,8 +221,17 @@ int hbo_set_option(hbo_ctx* ctx, const char* name, int64_t value);
 #define HBO_UNIQUE_ID_BYTES 128
 int hbo_comm_unique_id(void* out128);
 int hbo_comm_init(hbo_ctx* ctx, int rank, int nranks, const void* unique_id128);
-int hbo_comm_allreduce_sum(hbo_ctx* ctx, double* buf, int32_t count);
+int hbo_comm_allreduce_sum(hbo_ctx* ctx, double* buf, int32_t count);   /* host buffer: up, all-reduce, down (tests, small ad-hoc sums) */
 int hbo_comm_destroy(hbo_ctx* ctx);
+/* The task-sharded objective (objectives.py:181-195 is an independent sum over sub-datasets; `ds` = this rank's shard, may be
+ * NULL / empty: a rank beyond the task count contributes zeros).  Like hbo_objective, but value_sum / count / grad_sum are the sums
+ * over ALL ranks of the communicator bound with hbo_comm_init: every rank reduces its own tasks' [value, count, gradient] on the
+ * device (same summation order as hbo_objective's host loop), ONE ncclAllReduce runs in place on the context's stream (RCCL over
+ * xGMI, no host hop) and the result comes back in one copy.  timing (nullable, 2 doubles): [0] ms of device time this rank spent
+ * on its own shard before the collective, [1] us from there to the end of the all-reduce (HIP events on the context's stream).
+ * Without a communicator the sums are the local ones.  Returns HBO_NOT_PD when the reduced value is NaN. */
+int hbo_objective_sharded(hbo_ctx* ctx, const hbo_model* model, hbo_dataset* ds, int objective, double* value_sum,
+                          double* count, double* grad_sum, double* timing);
 
 #ifdef __cplusplus
 }

@@ -118,3 +118,74 @@ def test_socket_group_sharded_objective_three_ranks_two_tasks(tmp_path):
     assert abs(float(r['value']) - val) <= 1e-12 * abs(val)
     np.testing.assert_allclose(r['grad'], helpers.flatten(g), rtol=1e-11, atol=1e-12)
   assert np.array_equal(res[0]['grad'], res[1]['grad']) and np.array_equal(res[0]['grad'], res[2]['grad'])   # rank-order sum: bitwise equal
+
+
+# ---- SocketGroup: typed frames, mutual token proof, no pickle ------------------------------------------------------
+def test_wire_format_round_trip_and_rejects_garbage():
+  sys.path.insert(0, ROOT)
+  from hyperbo_amd import parallel
+  import inspect
+  assert 'import pickle' not in inspect.getsource(parallel) and 'pickle.loads' not in inspect.getsource(parallel)
+  msg = [None, True, False, 3, -7, 2.5, 'id', bytes(range(40)), np.arange(5, dtype=np.float64), [1, [2.0, b'x']]]
+  out, end = parallel._decode(parallel._encode(msg))
+  assert end == len(parallel._encode(msg))
+  assert out[:8] == msg[:8] and np.array_equal(out[8], msg[8]) and out[9] == [1, [2.0, b'x']]
+  for bad in (b'', b'XX' + b'\0' * 16, b'HBZ\x00\x00\x00\x00', b'HBB\xff\xff\xff\x7f', b'HBD\x03\x00\x00\x00abc'):
+    with pytest.raises(Exception):
+      parallel._decode(bad)
+  with pytest.raises(TypeError):
+    parallel._encode(object())
+
+
+def _hub_proc(port, token, out_path):
+  sys.path.insert(0, ROOT)
+  from hyperbo_amd import parallel
+  g = parallel.SocketGroup(0, 2, port, token=token, timeout=30)
+  res = g.allgather('hub')
+  g.close()
+  open(out_path, 'w').write(repr(res))
+
+
+def test_socket_group_ignores_strangers_and_wrong_tokens(tmp_path):
+  """A connection that sends garbage, one that holds the wrong token and one that claims rank 0 are dropped; the
+  legitimate rank still joins, and a second claim of its rank does not replace it."""
+  import multiprocessing as mp
+  import struct
+  sys.path.insert(0, ROOT)
+  from hyperbo_amd import parallel
+  port = _free_port()
+  out = tmp_path / 'hub.txt'
+  ctx = mp.get_context('spawn')
+  hub = ctx.Process(target=_hub_proc, args=(port, 'secret', str(out)))
+  hub.start()
+  import time
+  def connect():
+    for _ in range(100):
+      try:
+        return socket.create_connection(('127.0.0.1', port), timeout=2.0)
+      except OSError:
+        time.sleep(0.05)
+    raise RuntimeError('hub did not come up')
+  # 1. garbage (what a pickle-based peer would have sent: 8-byte length + payload)
+  s = connect(); s.recv(4096); s.sendall(struct.pack('<Q', 1 << 40) + b'\x80\x04junk'); s.close()
+  # 2. well-formed greeting with the wrong token
+  s = connect(); hello = parallel._recv_msg(s)
+  parallel._send_msg(s, [parallel._MAGIC, 1, b'n' * 16, parallel._mac('wrong', b'client', hello[2], b'1')])
+  s.settimeout(2.0)
+  try:
+    assert s.recv(64) == b''       # the hub closed the connection without answering
+  except (ConnectionError, socket.timeout):
+    pass
+  s.close()
+  # 3. right token, rank out of range
+  s = connect(); hello = parallel._recv_msg(s)
+  parallel._send_msg(s, [parallel._MAGIC, 0, b'n' * 16, parallel._mac('secret', b'client', hello[2], b'0')]); s.close()
+  # 4. a client with the wrong token never accepts the hub either
+  with pytest.raises(TimeoutError):
+    parallel.SocketGroup(1, 2, port, token='wrong', timeout=1.5)
+  # 5. the legitimate rank 1
+  g = parallel.SocketGroup(1, 2, port, token='secret', timeout=30)
+  assert g.allgather('one') == ['hub', 'one']
+  g.close()
+  hub.join(30)
+  assert hub.exitcode == 0 and out.read_text() == "['hub', 'one']"
