@@ -116,6 +116,12 @@ extern "C" int hbo_set_option(hbo_ctx* c, const char* name, int64_t value) {
   }
   if (!strcmp(name, "bulk_tail")) { c->opt_bulk_tail = (int)value; return HBO_OK; }
   if (!strcmp(name, "post_bf16x3")) { c->opt_post_bf16x3 = value != 0; return HBO_OK; }
+  if (!strcmp(name, "trtri_bf16x3")) { c->opt_trtri_bf16x3 = value != 0; return HBO_OK; }
+  if (!strcmp(name, "trtri3_min_s")) { if (value < 1 || value > 1024) return fail(c, HBO_ERR_ARG, "trtri3_min_s in 1..1024"); c->opt_trtri3_min_s = (int)value; return HBO_OK; }
+  if (!strcmp(name, "syrk3_col")) { c->opt_syrk3_col = value != 0; return HBO_OK; }
+  if (!strcmp(name, "syrk3_sep")) { c->opt_syrk3_sep = value != 0; return HBO_OK; }
+  if (!strcmp(name, "syrk3_free")) { if (value < 0 || value > 200) return fail(c, HBO_ERR_ARG, "syrk3_free in 0..200"); c->opt_syrk3_free = (int)value; return HBO_OK; }
+  if (!strcmp(name, "syrk_bf16x3")) { c->opt_syrk_bf16x3 = value != 0; return HBO_OK; }
   if (!strcmp(name, "post_chunk")) { if (value < 128 || value > 65536) return fail(c, HBO_ERR_ARG, "post_chunk in 128..65536"); c->opt_post_chunk = (int)value; return HBO_OK; }
   if (!strcmp(name, "trtri_at")) { if (value < 0 || value > 63) return fail(c, HBO_ERR_ARG, "trtri_at in 0..63"); c->opt_trtri_at = (int)value; return HBO_OK; }
   if (!strcmp(name, "trtri_small_wgs")) { if (value < 1 || value > 4) return fail(c, HBO_ERR_ARG, "trtri_small_wgs in 1..4"); c->opt_trtri_small_wgs = (int)value; return HBO_OK; }
@@ -602,6 +608,8 @@ static int objective_impl(hbo_ctx* c, const hbo_model* m_in, hbo_dataset* ds, in
     {
       std::vector<int> h_nblk(T);
       for (int k = 0; k < T; ++k) h_nblk[k] = ds->h_desc[k].nblk;
+      c->trtri_host_task = TaskDesc{};
+      if (T == 1) c->trtri_host_task = ds->h_desc[0];
       ProfScope ps(c, "potrf", 1); run_potrf(c, dtype, ds->d_desc, T, max_nblk, ds->d_info, early_trtri ? &trtri_pg : nullptr, h_nblk.data());
     }
     // the small reductions (log-determinant + quadratic form now, alpha = W^T z and d nll / d mu after the inverse) run on
@@ -847,6 +855,7 @@ extern "C" int hbo_factor(hbo_ctx* c, const hbo_model* m, const void* x, int64_t
   // the inverse W = L^-1 (kept for the posterior products) starts beside the panel chain, as in the objective path
   TrtriProgress trtri_pg;
   const bool early_trtri = c->opt_lookahead && c->opt_overlap_trtri && t->nblk >= 4;
+  c->trtri_host_task = k->h_desc;
   { ProfScope ps(c, "potrf", 1); run_potrf(c, dtype, k->d_desc, 1, t->nblk, k->d_info, early_trtri ? &trtri_pg : nullptr); }
   HIPCHK_K(hipMemcpy2DAsync(k->zvec, (size_t)t->npad * es, (char*)t->A + (size_t)t->npad * t->ld * es, (size_t)t->ld * es, (size_t)t->npad * es, mcols, hipMemcpyDeviceToDevice, st));
   { ProfScope ps(c, "trtri", 1); run_trtri(c, dtype, k->d_desc, 1, t->nblk, &trtri_pg); }
@@ -1409,6 +1418,7 @@ extern "C" int hbo_spd_solve(hbo_ctx* c, int dtype, const void* a, int64_t n, co
   HIPCHK_S(hipMemcpyAsync(d_desc, &h, sizeof h, hipMemcpyHostToDevice, st));
   HIPCHK_S(hipMemcpyAsync(d_info, &inf, sizeof(int), hipMemcpyHostToDevice, st));
   HIPCHK_S(hipStreamSynchronize(st));
+  c->trtri_host_task = h;
   { ProfScope ps(c, "potrf", 1); run_potrf(c, dtype, d_desc, 1, t->nblk, d_info); }
   if (need_inv) {
     { ProfScope ps(c, "trtri", 1); run_trtri(c, dtype, d_desc, 1, t->nblk); }

@@ -527,7 +527,8 @@ __device__ __forceinline__ int strict_index(int I, int J) { return I * (I - 1) /
 // L_pp and its leaf inverses into LDS first -- a caller that walks several row groups of the same panel (chain.hip)
 // stages once.
 template <typename T, bool IDENT>
-__device__ __forceinline__ void trsm_body(const TaskDesc& t, int p, int64_t row0, unsigned char* smem, bool stage) {
+__device__ __forceinline__ void trsm_body(const TaskDesc& t, int p, int64_t row0, unsigned char* smem, bool stage,
+                                          unsigned short* xp = nullptr, int nkb = 0, int kb_off = 0) {
   typedef typename Mma<T>::acc_t acc_t;
   constexpr int TE = trsm_tile<T>();
   T* sLt = reinterpret_cast<T*>(smem);          // 28 packed strictly-lower tiles of L_pp
@@ -615,6 +616,15 @@ __device__ __forceinline__ void trsm_body(const TaskDesc& t, int p, int64_t row0
         if (rg != jb) gst(Wout + (int64_t)(jb * 16 + l15) * ld + rg * 16 + row, x[r]);
       } else {
         gst(Ap + (int64_t)row * ld + jb * 16 + l15, x[r]);
+        if constexpr (sizeof(T) == 4) {
+          if (xp) {   // the same value as three bf16 planes (see SplitOut)
+            const int64_t grow = wrow0 + row;
+            unsigned short h, m, l;
+            hbo_split3((float)x[r], h, m, l);
+            unsigned short* o = xp + ((grow / NB * nkb + kb_off + jb) * 3) * (int64_t)(NB * 16) + (grow % NB) * 16 + l15;
+            o[0] = h; o[NB * 16] = m; o[2 * NB * 16] = l;
+          }
+        }
       }
     }
     if (jb < 7) {
@@ -629,7 +639,7 @@ __device__ __forceinline__ void trsm_body(const TaskDesc& t, int p, int64_t row0
   }
 }
 template <typename T, bool IDENT>
-__global__ __launch_bounds__(256) void trsm_kernel(const TaskDesc* tasks, int p_arg, int* yield_tab, ChainSync cs) {
+__global__ __launch_bounds__(256) void trsm_kernel(const TaskDesc* tasks, int p_arg, int* yield_tab, ChainSync cs, SplitOut so) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __builtin_amdgcn_s_setprio(3);                // critical path: outrank co-resident GEMM waves
   const TaskDesc& t = tasks[blockIdx.z];
@@ -664,7 +674,7 @@ __global__ __launch_bounds__(256) void trsm_kernel(const TaskDesc* tasks, int p_
   const int rb = (int)(row0 / NB);
   if (cm && !IDENT && !dag_wave_wait(cm, cs.lay.ver(rb, p), cs.need, cs.timeout_ticks)) return;
   if (cm && !IDENT && threadIdx.x == 0 && blockIdx.z == 0) { dag_stamp_min(cs.stamps, p, 8); dag_stamp_max(cs.stamps, p, 9); }
-  trsm_body<T, IDENT>(t, p, row0, smem, true);
+  trsm_body<T, IDENT>(t, p, row0, smem, true, so.xp ? so.xp + (int64_t)blockIdx.z * so.task_stride : nullptr, so.nkb, so.kb_off);
   if (cm) dag_wg_publish(cm, IDENT ? cs.lay.diag(p) : cs.lay.row(p, rb), 1);
   if (cm && !IDENT && threadIdx.x == 0 && blockIdx.z == 0) { dag_stamp_min(cs.stamps, p, 0); dag_stamp_max(cs.stamps, p, 1); }
   if (yield_tab) {
@@ -697,19 +707,20 @@ void potf2_t(const TaskDesc* tasks, int ntasks, int p, int* info, hipStream_t st
                      ntasks == 1 ? yield_flag : nullptr, cs);
 }
 template <typename T>
-void trsm_t(const TaskDesc* tasks, int ntasks, int p, int max_nblk, hipStream_t st, int* yield_tab, const ChainSync& cs) {
+void trsm_t(const TaskDesc* tasks, int ntasks, int p, int max_nblk, hipStream_t st, int* yield_tab, const ChainSync& cs, const SplitOut& so) {
   set_attrs<T>();
   const int nrows = (max_nblk + 1 - (p + 1)) * NB;
   if (nrows <= 0) return;
   hipLaunchKernelGGL((trsm_kernel<T, false>), dim3(nrows / 64, 1, ntasks), dim3(256), trsm_lds_bytes<T>(), st,
-                     tasks, p, ntasks == 1 ? yield_tab : nullptr, cs);
+                     tasks, p, ntasks == 1 ? yield_tab : nullptr, cs, so);
 }
 template <typename T>
 void trtri_diag_t(const TaskDesc* tasks, int ntasks, int p_lo, int p_hi, hipStream_t st, const ChainSync& cs) {
   set_attrs<T>();
   if (p_hi <= p_lo) return;
+  SplitOut none; memset(&none, 0, sizeof none);
   hipLaunchKernelGGL((trsm_kernel<T, true>), dim3(2, p_hi - p_lo, ntasks), dim3(256), trsm_lds_bytes<T>(), st,
-                     tasks, p_lo, (int*)nullptr, cs);
+                     tasks, p_lo, (int*)nullptr, cs, none);
 }
 
 #endif  // HBO_DEVICE_ONLY
@@ -730,10 +741,13 @@ void launch_potf2(int dtype, const TaskDesc* tasks, int ntasks, int p, int* info
   if (dtype == HBO_F64) potf2_t<double>(tasks, ntasks, p, info, st, yield_flag, s);
   else potf2_t<float>(tasks, ntasks, p, info, st, yield_flag, s);
 }
-void launch_trsm(int dtype, const TaskDesc* tasks, int ntasks, int p, int max_nblk, hipStream_t st, int* yield_tab, const ChainSync* cs) {
+void launch_trsm(int dtype, const TaskDesc* tasks, int ntasks, int p, int max_nblk, hipStream_t st, int* yield_tab, const ChainSync* cs,
+                 const SplitOut* so) {
   const ChainSync s = cs ? *cs : no_sync();
-  if (dtype == HBO_F64) trsm_t<double>(tasks, ntasks, p, max_nblk, st, yield_tab, s);
-  else trsm_t<float>(tasks, ntasks, p, max_nblk, st, yield_tab, s);
+  SplitOut o; memset(&o, 0, sizeof o);
+  if (so) o = *so;
+  if (dtype == HBO_F64) trsm_t<double>(tasks, ntasks, p, max_nblk, st, yield_tab, s, o);
+  else trsm_t<float>(tasks, ntasks, p, max_nblk, st, yield_tab, s, o);
 }
 void launch_trtri_diag(int dtype, const TaskDesc* tasks, int ntasks, int p_lo, int p_hi, hipStream_t st, const ChainSync* cs) {
   const ChainSync s = cs ? *cs : no_sync();

@@ -30,6 +30,13 @@ struct hbo_ctx {
                                // neutral: N = 8192 11.68 -> 11.78 ms -- the tail of the inverse slows by what the early part saves)
   int opt_post_chunk = 8192;   // posterior / acquisition: candidates per pass (the cross-Gram workspace is npad x this, whatever M)
   int opt_bulk_tail = 1;       // persistent bulk update: 64-tiles for a partly filled last round (1), for the whole last round (2), never (0)
+  int opt_trtri_bf16x3 = 1;    // fp32, one matrix: the products of the block-recursive inverse on the bf16 cores from level trtri3_min_s on
+  int opt_trtri3_min_s = 8;
+  TaskDesc trtri_host_task = {};   // host copy of the single task's descriptor (pointers, ld) for those launches; valid when .A != null
+  int opt_syrk3_col = 0;       // 1: the left-looking column updates inside a group on the bf16 cores too (needs a split per panel)
+  int opt_syrk3_sep = 0;       // debug: 1 = the panels are split by a kernel of their own instead of inside the panel solve
+  int opt_syrk3_free = 32;     // ... CUs the bulk update of that form leaves with a single workgroup (room for the panel kernels)
+  int opt_syrk_bf16x3 = 1;     // fp32 factorisations: trailing updates on the bf16 matrix cores (exact three-way split of the panels, post3.hip)
   int opt_post_bf16x3 = 1;     // fp32 posterior product on the bf16 matrix cores (three-way exact split of both operands, post3.hip); 0: fp32 MFMA
   int opt_trtri_at = 0;        // single matrix: panel count (in 64ths of the block count) after which the inverse starts beside the chain (0: 5/8)
   int opt_trtri_small_wgs = 2; // ... and workgroups per CU of their 64-tile form

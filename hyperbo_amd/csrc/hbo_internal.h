@@ -103,6 +103,16 @@ __device__ __forceinline__ int cu_token() {
   const unsigned hw = __builtin_amdgcn_s_getreg((4 << 0) | (8 << 6) | (7 << 11));   // HW_ID bits [15:8]
   return (int)(((xcc & 15u) << 8) | (hw & 255u)) + 1;
 }
+// x = h + m + l exactly, three bf16 numbers (round-to-nearest-even at every step; the remainders are exact in fp32): the operand
+// form of the fp32 products on the bf16 matrix cores (post3.hip)
+__device__ __forceinline__ void hbo_split3(float x, unsigned short& h, unsigned short& m, unsigned short& l) {
+  const __bf16 bh = (__bf16)x;
+  const float r1 = x - (float)bh;
+  const __bf16 bm = (__bf16)r1;
+  const float r2 = r1 - (float)bm;
+  const __bf16 bl = (__bf16)r2;
+  h = __builtin_bit_cast(unsigned short, bh); m = __builtin_bit_cast(unsigned short, bm); l = __builtin_bit_cast(unsigned short, bl);
+}
 // a panel-chain workgroup announces itself on its CU (background GEMM workgroups there pause, see GemmArgs::yield_flag)
 __device__ __forceinline__ int yield_enter(int* tab) {
   const int tok = cu_token();
@@ -119,10 +129,13 @@ void launch_gemm(int dtype, const GemmArgs& a, dim3 grid, hipStream_t st);
 
 // `cs` (dag.h) non-null: the kernels poll / bump the dependency counters of the resident tile-task schedule
 struct ChainSync;
+// fp32: the panel solve also writes the solved panel as three bf16 planes (the operand of the bf16x3 trailing updates, post3.hip):
+// element (row, k) of panel block column kb_off.. -> ((row / 128 * nkb + kb_off + k / 16) * 3 + plane) * 2048 + (row % 128) * 16 + k % 16
+struct SplitOut { unsigned short* xp; int64_t task_stride; int nkb, kb_off; };
 void launch_potf2(int dtype, const TaskDesc* tasks, int ntasks, int p, int* info, hipStream_t st, int* yield_flag = nullptr,
                   const ChainSync* cs = nullptr);
 void launch_trsm(int dtype, const TaskDesc* tasks, int ntasks, int p, int max_nblk, hipStream_t st, int* yield_tab = nullptr,
-                 const ChainSync* cs = nullptr);
+                 const ChainSync* cs = nullptr, const SplitOut* so = nullptr);
 // inverses of the diagonal blocks p in [p_lo, p_hi)
 void launch_trtri_diag(int dtype, const TaskDesc* tasks, int ntasks, int p_lo, int p_hi, hipStream_t st, const ChainSync* cs = nullptr);
 
@@ -199,7 +212,26 @@ struct Syrk3Args {
   int kcol0, nk_split, r_lo;
   // product: C[r, c] -= X[r, kb_off .. kb_off + nk) X[c, ...]^T for the tiles c in [c_lo, c_hi), r in [c, nblk]
   int kb_off, nk, c_lo, c_hi;
+  // persistent form: `persistent` workgroups draw the tiles from *work_counter (zeroed by the caller) -- fewer workgroups than the
+  // machine holds, so that the panel kernels always find a CU with room
+  int persistent; int* work_counter;
+  int* yield_flag;   // background launch (the bulk update): pause at a pipeline step while a panel-chain workgroup runs on this CU
+  int* yield_mark;   // launch ON the panel chain (F1, column updates): count the workgroup into the same per-CU table
+  // mode 0: the trailing update above.  Modes 1 / 2: the products of the block-recursive inverse (sched.hip:trtri_level) on one
+  // level of s blocks for `ngrp` groups, operands split by split3_block / split3_block_t into Xp (A operand) and Yp (B operand):
+  //   1 (TRTRI_A): S21[it, jt] =  sum_{k >= jt} L21[it, k] W11[k, jt]     A = L21 rows, B = W11^T rows, K blocks [8 jt, 8 s)
+  //   2 (TRTRI_B): W21[it, jt] = -sum_{k <= it} W22[it, k] S21[k, jt]     A = W22 rows, B = S21^T rows, K blocks [0, 8 (it + 1))
+  // tile index = ((grp * vt + it) * s + jt) in launch order (longest K first); per group the operand tiles are contiguous:
+  // A tile it of group g at ((g * s + it) * nkb), B tile jt at ((g * s + jt) * nkb), nkb = 8 s blocks.
+  int mode, s, grp_lo, ngrp, vlast;   // vlast: tile rows of the LAST group of the launch (a cut lower half), s for the others
+  unsigned short* Yp;
 };
+// split of a (row tiles x 128 nkb/8 ...) fp32 block into panel blocks: rows of `in` are the operand rows (k along the row) --
+// or, transposed, columns of `in` are the operand rows (k along the column).  grid z = group, stepping `in` by gstep elements and
+// `out` by gstride elements
+struct Split3Block { const float* in; int64_t ld, gstep; unsigned short* out; int64_t gstride; int row_tiles, nkb, tri;
+                     int last_rows, last_krows; };   // the LAST group: operand row tiles / k rows that exist (a cut lower half)
+void launch_split3_block(const Split3Block& a, int ngrp, bool transposed, hipStream_t st);
 void launch_split3_panel(const Syrk3Args& a, int row_tiles, int ntasks, hipStream_t st);
 void launch_syrk3(const Syrk3Args& a, int ntiles, int ntasks, hipStream_t st);
 void launch_split3_rows(const float* in, int64_t ld, int row_tiles, unsigned short* out, int nkb, hipStream_t st);

@@ -13,6 +13,7 @@
 // transposed on the way so that both operands are k-contiguous (split3_transpose), into a blocked layout that makes every
 // pipeline stage of the product a contiguous read.
 #include "hbo_internal.h"
+#include <algorithm>
 
 namespace {
 
@@ -22,16 +23,6 @@ typedef unsigned short u16;
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));   // (native vector: HIP's uint4 is a union-backed struct that kept the staging registers in scratch memory)
 
 __device__ __forceinline__ u16 bf_bits(__bf16 v) { return __builtin_bit_cast(u16, v); }
-
-// x = h + m + l exactly (round-to-nearest-even at every step; the remainders are exact in fp32)
-__device__ __forceinline__ void split3(float x, u16& h, u16& m, u16& l) {
-  const __bf16 bh = (__bf16)x;
-  const float r1 = x - (float)bh;
-  const __bf16 bm = (__bf16)r1;
-  const float r2 = r1 - (float)bm;
-  const __bf16 bl = (__bf16)r2;
-  h = bf_bits(bh); m = bf_bits(bm); l = bf_bits(bl);
-}
 
 struct alignas(16) U16x8 { u16 v[8]; };
 
@@ -57,7 +48,7 @@ __global__ __launch_bounds__(256) void split3_rows_kernel(const float* __restric
     const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
     U16x8 h, m, l;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) split3(x[e], h.v[e], m.v[e], l.v[e]);
+    for (int e = 0; e < 8; ++e) hbo_split3(x[e], h.v[e], m.v[e], l.v[e]);
     u16* o = out + ((int64_t)R * nkb + kb) * 3 * P3_CHUNK + threadIdx.x * 8;
     *reinterpret_cast<U16x8*>(o) = h;
     *reinterpret_cast<U16x8*>(o + P3_CHUNK) = m;
@@ -87,7 +78,7 @@ __global__ __launch_bounds__(256) void split3_transpose_kernel(const float* __re
     const int ko = kbl * 16 + half * 8;
     U16x8 h, m, l;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) split3(tile[ko + e][j], h.v[e], m.v[e], l.v[e]);
+    for (int e = 0; e < 8; ++e) hbo_split3(tile[ko + e][j], h.v[e], m.v[e], l.v[e]);
     const int jr = j0 + j;
     u16* o = out + ((int64_t)(jr / HBO_TILE) * nkb + (k0 / 16 + kbl)) * 3 * P3_CHUNK + (jr % HBO_TILE) * 16 + half * 8;
     *reinterpret_cast<U16x8*>(o) = h;
@@ -234,8 +225,68 @@ __global__ __launch_bounds__(256) void split3_panel_kernel(Syrk3Args g) {
     const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
     U16x8 h, m, l;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) split3(x[e], h.v[e], m.v[e], l.v[e]);
+    for (int e = 0; e < 8; ++e) hbo_split3(x[e], h.v[e], m.v[e], l.v[e]);
     u16* o = out + ((int64_t)R * g.nkb + g.kb_off + kb) * 3 * P3_CHUNK + threadIdx.x * 8;
+    *reinterpret_cast<U16x8*>(o) = h;
+    *reinterpret_cast<U16x8*>(o + P3_CHUNK) = m;
+    *reinterpret_cast<U16x8*>(o + 2 * P3_CHUNK) = l;
+  }
+}
+
+// rows of `in` = operand rows.  tri: only the blocks up to the row tile's own diagonal block hold data (a lower-triangular operand);
+// the others are written as zeros (the product kernels bound K by the structure and never read them, but the buffer is reused)
+__global__ __launch_bounds__(256) void split3_block_kernel(Split3Block g) {
+  const int R = blockIdx.y;
+  const bool last = blockIdx.z == gridDim.z - 1;
+  if (last && R >= g.last_rows) return;
+  const float* in = g.in + (int64_t)blockIdx.z * g.gstep;
+  u16* out = g.out + (int64_t)blockIdx.z * g.gstride;
+  const int row = threadIdx.x >> 1, half = threadIdx.x & 1;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int kb = (int)blockIdx.x * 4 + q;
+    if (kb >= g.nkb || (last && kb * 16 >= g.last_krows)) return;
+    if (g.tri && kb >= (R + 1) * (HBO_TILE / 16)) return;
+    const float* src = in + (int64_t)(R * HBO_TILE + row) * g.ld + kb * 16 + half * 8;
+    const float4 a = *reinterpret_cast<const float4*>(src);
+    const float4 b = *reinterpret_cast<const float4*>(src + 4);
+    const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    U16x8 h, m, l;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) hbo_split3(x[e], h.v[e], m.v[e], l.v[e]);
+    u16* o = out + ((int64_t)R * g.nkb + kb) * 3 * P3_CHUNK + threadIdx.x * 8;
+    *reinterpret_cast<U16x8*>(o) = h;
+    *reinterpret_cast<U16x8*>(o + P3_CHUNK) = m;
+    *reinterpret_cast<U16x8*>(o + 2 * P3_CHUNK) = l;
+  }
+}
+// columns of `in` = operand rows (k = row of `in`): 64 (k) x 64 (j) tiles through LDS, as split3_transpose_kernel
+__global__ __launch_bounds__(256) void split3_block_t_kernel(Split3Block g) {
+  __shared__ float tile[64][65];
+  const float* in = g.in + (int64_t)blockIdx.z * g.gstep;
+  u16* out = g.out + (int64_t)blockIdx.z * g.gstride;
+  const int k0 = blockIdx.y * 64, j0 = blockIdx.x * 64;
+  const int tid = threadIdx.x;
+  if (blockIdx.z == gridDim.z - 1 && (k0 >= g.last_krows || j0 >= g.last_rows * HBO_TILE)) return;
+  {
+    const int c = (tid & 15) * 4, r = tid >> 4;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 v = *reinterpret_cast<const float4*>(in + (int64_t)(k0 + r + 16 * q) * g.ld + j0 + c);
+      tile[r + 16 * q][c] = v.x; tile[r + 16 * q][c + 1] = v.y; tile[r + 16 * q][c + 2] = v.z; tile[r + 16 * q][c + 3] = v.w;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int item = tid + 256 * q;
+    const int kbl = item >> 7, j = (item & 127) >> 1, half = item & 1;
+    const int ko = kbl * 16 + half * 8;
+    U16x8 h, m, l;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) hbo_split3(tile[ko + e][j], h.v[e], m.v[e], l.v[e]);
+    const int jr = j0 + j;
+    u16* o = out + ((int64_t)(jr / HBO_TILE) * g.nkb + (k0 / 16 + kbl)) * 3 * P3_CHUNK + (jr % HBO_TILE) * 16 + half * 8;
     *reinterpret_cast<U16x8*>(o) = h;
     *reinterpret_cast<U16x8*>(o + P3_CHUNK) = m;
     *reinterpret_cast<U16x8*>(o + 2 * P3_CHUNK) = l;
@@ -248,11 +299,66 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   // tile (r, c) of the trapezoid c in [c_lo, c_hi), r in [c, nblk]: linear index, column-major (consecutive workgroups share B)
   const int nrt = t.nblk + 1;
   const int chi = g.c_hi < t.nblk ? g.c_hi : t.nblk;
-  int tix = blockIdx.x, c = g.c_lo;
-  while (c < chi && tix >= nrt - c) { tix -= nrt - c; ++c; }
-  if (c >= chi) return;
-  const int r = c + tix;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int* const mailbox = reinterpret_cast<int*>(smem + POST3_LDS_BYTES);
+  const int* const yslot = g.yield_flag ? g.yield_flag + cu_token() : nullptr;
+  int ytok = 0;
+  if (g.yield_mark && tid == 0) ytok = yield_enter(g.yield_mark);
+  for (int tix0 = blockIdx.x;; tix0 += gridDim.x) {
+  int tix = tix0;
+  if (g.persistent) {
+    if (tid == 0) mailbox[0] = atomicAdd(g.work_counter, 1);
+    __syncthreads();
+    tix = mailbox[0];
+    __syncthreads();
+  }
+  int c = g.c_lo, r = 0, nk = g.nk;
+  const u16 *ga, *gb;
+  float* C;
+  float csign = -1.f;      // C = cold * cbeta + csign * acc
+  bool cbeta = true;
+  if (g.mode == 0) {
+    while (c < chi && tix >= nrt - c) { tix -= nrt - c; ++c; }
+    if (c >= chi) break;
+    r = c + tix;
+    const u16* xp = g.Xp + (int64_t)blockIdx.z * g.task_stride;
+    ga = xp + ((int64_t)r * g.nkb + g.kb_off) * 3 * P3_CHUNK + tid * 8;
+    gb = xp + ((int64_t)c * g.nkb + g.kb_off) * 3 * P3_CHUNK + tid * 8;
+    C = static_cast<float*>(t.A) + (int64_t)r * HBO_TILE * t.ld + (int64_t)c * HBO_TILE;
+  } else {
+    // tiles in launch order: the index that fixes K slowest (longest first), the rows / columns of all groups fast
+    const int s = g.s, ng = g.ngrp;
+    const int rows_total = (ng - 1) * s + g.vlast;   // tile rows over all groups (the last group's lower half may be cut)
+    if (tix >= rows_total * s) break;
+    int grp, it, jt;
+    if (g.mode == 1) {           // K = 8 (s - jt) blocks: jt slow, ascending
+      jt = tix / rows_total;
+      const int rr = tix % rows_total;
+      grp = rr / s < ng - 1 ? rr / s : ng - 1;
+      it = rr - grp * s;
+    } else {                     // K = 8 (it + 1) blocks: it slow, descending; every group but a cut last one has the row
+      jt = tix % s;
+      int rem = tix / s;
+      it = s - 1;
+      for (;; --it) {
+        const int cnt = (ng - 1) + (it < g.vlast ? 1 : 0);
+        if (rem < cnt) break;
+        rem -= cnt;
+      }
+      grp = rem;
+    }
+    const int64_t o = (int64_t)(g.grp_lo + grp) * 2 * s * HBO_TILE;
+    const int nkb = 8 * s;
+    int kb0;
+    if (g.mode == 1) { kb0 = 8 * jt; nk = nkb - kb0; csign = 1.f; }
+    else { kb0 = 0; nk = 8 * (it + 1); csign = -1.f; }
+    cbeta = false;
+    ga = g.Xp + (((int64_t)grp * s + it) * nkb + kb0) * 3 * P3_CHUNK + tid * 8;
+    gb = g.Yp + (((int64_t)grp * s + jt) * nkb + kb0) * 3 * P3_CHUNK + tid * 8;
+    const int64_t R = o + (int64_t)s * HBO_TILE + (int64_t)it * HBO_TILE, Cc = o + (int64_t)jt * HBO_TILE;
+    float* base = static_cast<float*>(g.mode == 1 ? t.S : t.W);
+    C = base + R * t.ld + Cc;
+  }
   const int wm = wave >> 1, wn = wave & 1;
   const int l32 = lane & 31, lh = lane >> 5;
   auto arr = [&](int st, int op, int p) { return smem + (size_t)((st * 2 + op) * 3 + p) * P3_ARR; };
@@ -266,9 +372,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       for (int q = 0; q < 16; ++q) acc[a][b][q] = 0.f;
 
   const int srow = tid >> 1, shalf = tid & 1;
-  const u16* xp = g.Xp + (int64_t)blockIdx.z * g.task_stride;
-  const u16* ga = xp + ((int64_t)r * g.nkb + g.kb_off) * 3 * P3_CHUNK + tid * 8;
-  const u16* gb = xp + ((int64_t)c * g.nkb + g.kb_off) * 3 * P3_CHUNK + tid * 8;
   const int soff = srow * P3_ROW + ((shalf ^ ((srow >> 3) & 1)) * 16);
   struct Slot { u32x4 a0, a1, a2, b0, b1, b2; };
   Slot s0, s1, s2, s3;
@@ -311,14 +414,22 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (kt_ + 1 < nk) P3_SSTORE((CUR) ^ 1, S_NEXT)                                                                \
     __syncthreads();                                                                                              \
   }
-  const int nk = g.nk;                            // a multiple of 4 (one panel = 8 blocks)
   const int fsw = (lh ^ ((l32 >> 3) & 1)) * 16;
   const int foff_a = (wm * 64 + l32) * P3_ROW + fsw;
   const int foff_b = (wn * 64 + l32) * P3_ROW + fsw;
   P3_GLOAD(0, s0) P3_GLOAD(1, s1) P3_GLOAD(2, s2) P3_GLOAD(3, s3)
   P3_SSTORE(0, s0)
   __syncthreads();
+  int ypoll = 0;
   for (int kt0 = 0; kt0 < nk; kt0 += 4) {
+    if (yslot) {
+      // a panel-chain workgroup is running on this CU: stay off its MFMA / LDS paths until it is done (bounded wait; the table
+      // entry is loaded a step ahead, as in gemm.hip)
+      if (ypoll != 0)
+        for (int spin = 0; spin < 256 && __hip_atomic_load(yslot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0; ++spin)
+          __builtin_amdgcn_s_sleep(16);
+      ypoll = __hip_atomic_load(yslot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
     P3_STAGE(kt0, 0, s0, s1)
     P3_STAGE(kt0 + 1, 1, s1, s2)
     P3_STAGE(kt0 + 2, 0, s2, s3)
@@ -327,8 +438,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #undef P3_STAGE
 #undef P3_GLOAD
 #undef P3_SSTORE
-  // C -= acc.  Accumulator layout of v_mfma_f32_32x32x16_bf16: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
-  float* C = static_cast<float*>(t.A) + (int64_t)r * HBO_TILE * t.ld + (int64_t)c * HBO_TILE;
+  // C = [C] + csign * acc.  Accumulator layout of v_mfma_f32_32x32x16_bf16: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -337,14 +447,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         const int row = wm * 64 + a * 32 + (q & 3) + 8 * (q >> 2) + 4 * lh;
-        old[q] = gld(C + (int64_t)row * t.ld + wn * 64 + b * 32 + l32);
+        old[q] = cbeta ? gld(C + (int64_t)row * t.ld + wn * 64 + b * 32 + l32) : 0.f;
       }
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         const int row = wm * 64 + a * 32 + (q & 3) + 8 * (q >> 2) + 4 * lh;
-        gst(C + (int64_t)row * t.ld + wn * 64 + b * 32 + l32, old[q] - acc[a][b][q]);
+        gst(C + (int64_t)row * t.ld + wn * 64 + b * 32 + l32, old[q] + csign * acc[a][b][q]);
       }
     }
+  if (!g.persistent) break;
+  }
+  if (g.yield_mark) {
+    __syncthreads();
+    if (tid == 0) yield_leave(g.yield_mark, ytok);
+  }
 }
 
 }  // namespace
@@ -374,8 +490,15 @@ void launch_syrk3(const Syrk3Args& a, int ntiles, int ntasks, hipStream_t st) {
   if (ntiles <= 0) return;
   static bool attr = false;
   if (!attr) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(&syrk3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, POST3_LDS_BYTES);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(&syrk3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, POST3_LDS_BYTES + 16);
     attr = true;
   }
-  hipLaunchKernelGGL(syrk3_kernel, dim3(ntiles, 1, ntasks), dim3(256), POST3_LDS_BYTES, st, a);
+  const int grid = a.persistent > 0 ? std::min(a.persistent, ntiles) : ntiles;
+  hipLaunchKernelGGL(syrk3_kernel, dim3(grid, 1, ntasks), dim3(256), POST3_LDS_BYTES + 16, st, a);
+}
+
+void launch_split3_block(const Split3Block& a, int ngrp, bool transposed, hipStream_t st) {
+  if (a.row_tiles <= 0 || a.nkb <= 0 || ngrp <= 0) return;
+  if (transposed) hipLaunchKernelGGL(split3_block_t_kernel, dim3(a.row_tiles * 2, a.nkb / 4, ngrp), dim3(256), 0, st, a);   // 64-column x 64-k tiles
+  else hipLaunchKernelGGL(split3_block_kernel, dim3((a.nkb + 3) / 4, a.row_tiles, ngrp), dim3(256), 0, st, a);
 }

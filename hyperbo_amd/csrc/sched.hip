@@ -35,7 +35,9 @@ void run_potrf(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, int m
   //   (3, 96) 13.43, (2, 64) 13.57, (5, 32) 13.61;   N = 16384: (4, 32) 78.4, (3, 32) 79.1, (3, 64) 79.5
   const bool small_mat = max_nblk <= 96;
   //   round 2, N = 65536: group 4 / 6 / 8 / 12 / 16: 60.2 / 60.7 / 62.0 / 62.6 / 62.0 TFLOP/s; N = 32768: 4 / 6 / 8: 56.8 / 57.2 / 57.9; N = 16384: 48.1 / 47.4 / 47.8
-  const int q = c->opt_group > 0 ? c->opt_group : (small_mat ? 3 : (max_nblk >= 256 ? 8 : 4));
+  //   round 3, fp32 with the updates on the bf16 cores, N = 16384 (factor, ms): group 4 / 5 / 6 / 7 / 8: 23.1 / 22.5 / 22.3 / 22.4 / 22.0
+  const bool s3_large = dtype == HBO_F32 && c->opt_syrk_bf16x3 && !small_mat;
+  const int q = c->opt_group > 0 ? c->opt_group : (small_mat ? 3 : ((max_nblk >= 256 || s3_large) ? 8 : 4));
   //   with the CU yield (below): N = 8192 (3, 64) 12.58, (3, 48) 12.52, (3, 32) 12.61, (3, 16) 13.24, (4, 48) 12.66
   //   round 2 (chain kernels mark their CUs, background workgroups there pause): 32 beats 48 at N = 8192 (11.73 / 11.81)
   const int persist_free = c->opt_persist_free >= 0 ? c->opt_persist_free : 32;
@@ -66,7 +68,10 @@ void run_potrf(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, int m
     }
   }
   // (up to 96 blocks: N = 4096 3.37 -> 3.29 ms, N = 8192 12.61 -> 12.52; N = 16384 loses 0.9 % to the polling)
-  int* const yield_flag = (la && ntasks == 1 && c->opt_cu_yield && small_mat) ? c->d_yield : nullptr;
+  // fp32 with the trailing updates on the bf16 cores: the bulk update is 1.5x shorter and the panel chain sets the pace at
+  // every size, so the chain's kernels are protected as for the small matrices
+  const bool s3_wanted = dtype == HBO_F32 && c->opt_syrk_bf16x3 && max_nblk > 1;
+  int* const yield_flag = (la && ntasks == 1 && c->opt_cu_yield && (small_mat || s3_wanted)) ? c->d_yield : nullptr;
   if (yield_flag) hipMemsetAsync(yield_flag, 0, sizeof(int) * HBO_YIELD_TAB_ENTRIES, sm);
   int* const chain_mark = (yield_flag && c->opt_cu_yield >= 2) ? yield_flag : nullptr;   // the chain's wide kernels mark their CUs too
   c->gemm_yield = yield_flag;
@@ -76,19 +81,55 @@ void run_potrf(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, int m
   if (counters) hipMemsetAsync(counters, 0, sizeof(int) * 256, sm);
   c->trtri_counters = counters ? counters + 128 : nullptr;   // second half: the persistent inverse products (trtri_level)
   c->trtri_counter_next = 0;
-  for (int g0 = 0; g0 < max_nblk; g0 += q) {
+  // fp32: every trailing update on the bf16 matrix cores from an exact three-way split of the group's panels (post3.hip:
+  // syrk3_kernel; 1.4x the fp32-MFMA rate at fp32 accuracy).  Each panel is split right behind its solve; two buffers alternate
+  // by group, because the bulk update of group g still reads its panels while group g + 1 is being solved.
+  const bool s3 = dtype == HBO_F32 && c->opt_syrk_bf16x3 && max_nblk > 1;
+  Syrk3Args s3a = {};
+  unsigned short* s3buf[2] = {nullptr, nullptr};
+  if (s3) {
+    s3a.tasks = d_tasks; s3a.nkb = q * (HBO_TILE / 16);
+    s3a.task_stride = (int64_t)(max_nblk + 1) * s3a.nkb * 3 * (HBO_TILE * 16);
+    const size_t bytes = sizeof(unsigned short) * (size_t)s3a.task_stride * ntasks;
+    s3buf[0] = static_cast<unsigned short*>(ws_get(c, WS_SYRK3_A, bytes));
+    s3buf[1] = static_cast<unsigned short*>(ws_get(c, WS_SYRK3_B, bytes));
+  }
+  const bool use_s3 = s3 && s3buf[0] && s3buf[1];
+  auto tiles_of = [&](int c_lo, int c_hi) { int n = 0; for (int cc = c_lo; cc < std::min(c_hi, max_nblk); ++cc) n += max_nblk + 1 - cc; return n; };
+  int grp_index = 0;
+  for (int g0 = 0; g0 < max_nblk; g0 += q, ++grp_index) {
     const int g1 = std::min(g0 + q, max_nblk);
     const int g2 = std::min(g1 + q, max_nblk);
+    if (use_s3) s3a.Xp = s3buf[grp_index & 1];
     if (la && ev_f1) hipStreamWaitEvent(sp, ev_f1, 0);
     for (int p = g0; p < g1; ++p) {
-      if (p > g0) {  // left-looking update of block column p with the group's earlier panels
+      if (p > g0 && use_s3 && c->opt_syrk3_col) {
+        ProfScope ps(c, "syrk_col", 2, sp);
+        Syrk3Args a = s3a; a.kb_off = 0; a.nk = (p - g0) * (HBO_TILE / 16); a.c_lo = p; a.c_hi = p + 1;
+        a.yield_mark = chain_mark;
+        launch_syrk3(a, tiles_of(p, p + 1), ntasks, sp);
+      } else if (p > g0) {  // left-looking update of block column p with the group's earlier panels
         ProfScope ps(c, "syrk_col", 2, sp);
         GemmArgs a = {}; a.tasks = d_tasks; a.mode = GEMM_SYRK; a.p0 = g0; a.kt = p - g0; a.c_lo = p; a.c_hi = p + 1; a.aug = 1; a.small_tiles = 1;
         a.yield_mark = chain_mark;
         launch_gemm(dtype, a, dim3(max_nblk + 1 - p, 1, ntasks), sp);
       }
       { ProfScope ps(c, "potf2", 2, sp); launch_potf2(dtype, d_tasks, ntasks, p, d_info, sp, yield_flag); }
-      { ProfScope ps(c, "trsm", 2, sp); launch_trsm(dtype, d_tasks, ntasks, p, max_nblk, sp, chain_mark); }
+      {
+        // (fp32 + bf16x3 updates: the solve writes its panel as three bf16 planes too -- no separate split launch on the chain)
+        SplitOut so = {};
+        if (use_s3) { so.xp = s3a.Xp; so.task_stride = s3a.task_stride; so.nkb = s3a.nkb; so.kb_off = (p - g0) * (HBO_TILE / 16); }
+        const bool fused = use_s3 && !c->opt_syrk3_sep && c->opt_syrk3_col;
+        { ProfScope ps(c, "trsm", 2, sp); launch_trsm(dtype, d_tasks, ntasks, p, max_nblk, sp, chain_mark, nullptr, fused ? &so : nullptr); }
+        if (use_s3 && !fused && p + 1 < max_nblk && (c->opt_syrk3_col || p + 1 == g1)) {
+          // the column updates inside the group stay on fp32 MFMA (64x64 tiles): ONE split of the whole group behind its last
+          // solve, for the wide updates (F1, F2) -- or, with syrk3_col, one per panel for the column updates too
+          ProfScope ps(c, "split3", 2, sp);
+          const int pfirst = c->opt_syrk3_col ? p : g0;
+          Syrk3Args a = s3a; a.kcol0 = pfirst * HBO_TILE; a.nk_split = (p + 1 - pfirst) * (HBO_TILE / 16); a.r_lo = p + 1; a.kb_off = (pfirst - g0) * (HBO_TILE / 16);
+          launch_split3_panel(a, max_nblk + 1 - (p + 1), ntasks, sp);
+        }
+      }
       if (early && ((p + 1) % tgran == 0 || p + 1 == early_at) && p + 1 < max_nblk) {
         // block columns 0..p of L are final: everything of the inverse that only needs them goes to a side stream
         // (the panel chain leaves most of the machine idle in the second half of the factorisation)
@@ -113,9 +154,15 @@ void run_potrf(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, int m
         if (s1 == sp && ev_f2) hipStreamWaitEvent(sp, ev_f2, 0);
         ProfScope ps(c, "syrk_trailing", 1, s1);
         a.c_lo = g1; a.c_hi = la ? g2 : max_nblk;
+        if (use_s3) {
+          Syrk3Args b = s3a; b.kb_off = 0; b.nk = (g1 - g0) * (HBO_TILE / 16); b.c_lo = a.c_lo; b.c_hi = a.c_hi;
+          b.yield_mark = a.yield_mark; b.yield_flag = a.yield_flag;
+          launch_syrk3(b, tiles_of(b.c_lo, b.c_hi), ntasks, s1);
+        } else {
         // few tiles (one group's block columns, or a small remainder): 64x64 tiles for latency
         a.small_tiles = (int64_t)(max_nblk + 1 - a.c_lo) * (a.c_hi - a.c_lo) * ntasks < 600;
         launch_gemm(dtype, a, dim3(max_nblk + 1 - a.c_lo, a.c_hi - a.c_lo, ntasks), s1);
+        }
       }
       if (la) {
         ev_f1 = pool_event(c, evi++);
@@ -130,6 +177,16 @@ void run_potrf(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, int m
             a.c_lo = g2; a.c_hi = max_nblk;
             const int64_t m = max_nblk - g2;
             a.small_tiles = m * (m + 1) / 2 * ntasks < 600;
+            if (use_s3) {
+              ProfScope ps(c, a.small_tiles ? "syrk_trailing" : "syrk_bulk", 1, sb);
+              Syrk3Args b = s3a; b.kb_off = 0; b.nk = (g1 - g0) * (HBO_TILE / 16); b.c_lo = g2; b.c_hi = max_nblk;
+              // persistent, two workgroups on all but `s3_free` CUs: the panel kernels beside it always find a CU with room
+              const int nt = tiles_of(g2, max_nblk);
+              const int pb = 2 * (c->n_cus - c->opt_syrk3_free);
+              if (ntasks == 1 && la && c->opt_syrk3_free > 0 && nt > pb && counters && n_counter < 128) { b.persistent = pb; b.work_counter = counters + n_counter++; }
+              b.yield_flag = yield_flag;
+              launch_syrk3(b, nt, ntasks, sb);
+            } else {
             // "syrk_bulk" = the 128x128-tile bulk trailing update (the roofline kernel of bench.py)
             ProfScope ps(c, a.small_tiles ? "syrk_trailing" : "syrk_bulk", 1, sb);
             // persistent form (single task, enough tiles to fill the machine): leave CUs for the panel chain
@@ -147,6 +204,7 @@ void run_potrf(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, int m
             }
             launch_gemm(dtype, a, dim3(max_nblk + 1 - a.c_lo, a.c_hi - a.c_lo, ntasks), sb);
             a.persistent = 0; a.work_counter = nullptr; a.n_big = 0;
+            }
           }
           hipEvent_t e2 = pool_event(c, evi++);
           hipEventRecord(e2, sb);
@@ -165,12 +223,65 @@ void run_potrf(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, int m
     hipStreamWaitEvent(sm, e, 0);
   }
 }
+// The same level on the bf16 matrix cores (fp32, one matrix): both operands of each product are split exactly into three bf16
+// planes (post3.hip) -- A: S21 = L21 W11 from row blocks of L and the transpose of W11, B: W21 = -W22 S21 from row blocks of
+// W22 and the transpose of S21 -- then one launch per product over all groups of the level.
+static bool trtri_level3(hbo_ctx* c, const TaskDesc* d_tasks, const TaskDesc& h, int max_nblk, int s, int grp_lo, int grp_hi,
+                         bool do_a, bool do_b, hipStream_t st) {
+  int ngrp = grp_hi - grp_lo;
+  int vlast = std::min(s, max_nblk - ((grp_hi - 1) * 2 * s + s));
+  if (vlast <= 0) { --ngrp; vlast = s; }
+  if (ngrp <= 0) return true;
+  const int nkb = 8 * s;
+  const int64_t gstride = (int64_t)s * nkb * 3 * (HBO_TILE * 16);
+  const size_t bytes = sizeof(unsigned short) * (size_t)gstride * ngrp;
+  unsigned short* xp = static_cast<unsigned short*>(ws_get(c, WS_TRTRI3_X, bytes));
+  unsigned short* yp = static_cast<unsigned short*>(ws_get(c, WS_TRTRI3_Y, bytes));
+  if (!xp || !yp) return false;
+  const int64_t ld = h.ld;
+  const int64_t o0 = (int64_t)grp_lo * 2 * s * HBO_TILE, half = (int64_t)s * HBO_TILE;
+  const float* L = static_cast<const float*>(h.A);
+  const float* W = static_cast<const float*>(h.W);
+  const float* S = static_cast<const float*>(h.S);
+  Split3Block sb = {}; sb.ld = ld; sb.gstep = 2 * half * (ld + 1); sb.gstride = gstride; sb.nkb = nkb; sb.row_tiles = s;
+  Syrk3Args g = {}; g.tasks = d_tasks; g.Xp = xp; g.Yp = yp; g.s = s; g.grp_lo = grp_lo; g.ngrp = ngrp; g.vlast = vlast;
+  const bool corun = st == c->stream4 && c->opt_trtri_free > 0 && c->trtri_counters;
+  const int pblocks = 2 * (c->n_cus - c->opt_trtri_free);
+  const int ntiles = ((ngrp - 1) * s + vlast) * s;
+  auto launch = [&](int mode) {
+    g.mode = mode; g.persistent = 0; g.work_counter = nullptr;
+    g.yield_flag = (st == c->stream4) ? c->gemm_yield : nullptr;
+    if (corun && ntiles > pblocks && c->trtri_counter_next < 128) { g.persistent = pblocks; g.work_counter = c->trtri_counters + c->trtri_counter_next++; }
+    launch_syrk3(g, ntiles, 1, st);
+  };
+  ProfScope ps(c, "trtri_gemm", 2, st);
+  if (do_a) {
+    sb.in = L + (o0 + half) * ld + o0; sb.out = xp; sb.tri = 0; sb.last_rows = vlast; sb.last_krows = (int)half;
+    launch_split3_block(sb, ngrp, false, st);                     // rows of L21
+    sb.in = W + o0 * ld + o0; sb.out = yp; sb.last_rows = s; sb.last_krows = (int)half;
+    launch_split3_block(sb, ngrp, true, st);                      // W11^T (the left half of every group is complete)
+    launch(1);
+  }
+  if (do_b) {
+    sb.in = W + (o0 + half) * ld + (o0 + half); sb.out = xp; sb.tri = 1; sb.last_rows = vlast; sb.last_krows = vlast * HBO_TILE;
+    launch_split3_block(sb, ngrp, false, st);                     // rows of W22 (lower triangular)
+    sb.in = S + (o0 + half) * ld + o0; sb.out = yp; sb.tri = 0; sb.last_rows = s; sb.last_krows = vlast * HBO_TILE;
+    launch_split3_block(sb, ngrp, true, st);                      // S21^T
+    launch(2);
+  }
+  return true;
+}
+
 // One level of the recursive inverse restricted to the groups [grp_lo, grp_hi) (a group = 2s blocks):
 //   mode A: S21 = L21 W11,  mode B: W21 = -W22 S21.
 static void trtri_level(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, int max_nblk, int s,
                         int grp_lo, int grp_hi, bool do_a, bool do_b, hipStream_t st) {
+  const TaskDesc& h_task0 = c->trtri_host_task;
   const int ngroups = grp_hi - grp_lo;
   if (ngroups <= 0) return;
+  if (dtype == HBO_F32 && c->opt_trtri_bf16x3 && ntasks == 1 && h_task0.A && s >= c->opt_trtri3_min_s && max_nblk > c->opt_small_nblk &&
+      trtri_level3(c, d_tasks, h_task0, max_nblk, s, grp_lo, grp_hi, do_a, do_b, st))
+    return;
   GemmArgs a = {}; a.tasks = d_tasks; a.p0 = s; a.grp_lo = grp_lo;
   // few or short tiles (small levels, small / batched matrices): 64x64 tiles -- a lone 128-tile runs
   // its K loop latency-bound, four 64-tiles expose 4x the parallelism for the same flops

@@ -568,11 +568,14 @@ def test_cfg3_full_size_against_host_lapack(gpu_ctx):
   assert errs[1][1] <= 1.5 * errs[0][1] + 1e-6 and errs[1][0] <= 1.5 * errs[0][0] + 1e-6, errs
 
 
-def test_ill_conditioned_fp32_cache_explicit_inverse_vs_triangular_solve(gpu_ctx):
-  """The posterior uses V = W Kxq with the explicit W = L^-1 where the reference calls solve_triangular (gp.py:297).  On an
-  ill-conditioned fp32 problem (SE kernel, noise 1e-6 + eps 1e-6, N = 8192: kappa ~ 1e9, far beyond what fp32 resolves) the
-  explicit-inverse route must not be materially worse than the backward-stable route IN THE SAME PRECISION: host LAPACK
-  spotrf + strtrs in fp32, both measured against host LAPACK in fp64."""
+@pytest.mark.parametrize('noise_target', [1e-3, 1e-6])
+def test_ill_conditioned_fp32_cache_explicit_inverse_vs_triangular_solve(gpu_ctx, noise_target):
+  """The posterior uses V = W Kxq with the explicit W = L^-1 where the reference calls solve_triangular (gp.py:297).  On
+  ill-conditioned fp32 problems (SE kernel, N = 8192, noise 1e-3: kappa ~ 1e7, at the edge of what fp32 resolves; noise 1e-6:
+  beyond it) the explicit-inverse route must not be materially worse than the backward-stable route IN THE SAME PRECISION --
+  host LAPACK spotrf + strtrs in fp32 -- both measured against host LAPACK in fp64; and where LAPACK's fp32 factorisation
+  itself breaks down (not positive definite to working precision) the library reports NaN like jax.scipy.linalg.cholesky
+  (linalg.py:29-33), it does not return numbers."""
   defs, _, _, gp, kernel, mean, _, utils = _native()
   rng = np.random.default_rng(19)
   n, M, d = 8192, 512, 6
@@ -580,33 +583,71 @@ def test_ill_conditioned_fp32_cache_explicit_inverse_vs_triangular_solve(gpu_ctx
   y = np.sin(2 * np.pi * x @ w)[:, None] + 0.01 * rng.normal(size=(n, 1))
   xq = rng.uniform(size=(M, d))
   model = {'lengthscale': helpers.inv_softplus(np.full(d, 0.6)), 'signal_variance': helpers.inv_softplus(1.0),
-           'noise_variance': helpers.inv_softplus(1e-6), 'constant': np.array(0.0)}
+           'noise_variance': helpers.inv_softplus(noise_target), 'constant': np.array(0.0)}
   p64 = defs.GPParams(model=model)
   noise = float(np.log1p(np.exp(model['noise_variance'])) + 1e-10)
+  sv = float(np.log1p(np.exp(model['signal_variance'])) + 1e-10)      # k(x, x) of the SE kernel
   k = np.asarray(kernel.squared_exponential(p64, x, warp_func=utils.DEFAULT_WARP_FUNC), dtype=np.float64)
   kxq = np.asarray(kernel.squared_exponential(p64, x, xq, warp_func=utils.DEFAULT_WARP_FUNC), dtype=np.float64)
   kd = k + (noise + 1e-6) * np.eye(n)
-  sv = float(np.log1p(np.exp(model['signal_variance'])) + 1e-10)      # k(x, x) of the SE kernel
   def host(dtype):
     c = spla.cholesky(kd.astype(dtype), lower=True, check_finite=False)
     a = spla.cho_solve((c, True), y.astype(dtype), check_finite=False)
     v = spla.solve_triangular(c, kxq.astype(dtype), lower=True, check_finite=False)
-    mu = kxq.astype(dtype).T @ a
-    var = (sv - np.sum(v.astype(np.float64)**2, axis=0))[:, None]
-    return mu.astype(np.float64), var
+    return (kxq.astype(dtype).T @ a).astype(np.float64), (sv - np.sum(v.astype(np.float64)**2, axis=0))[:, None]
   mu_ref, var_ref = host(np.float64)
-  mu_h32, var_h32 = host(np.float32)
   to32 = lambda t: {k_: to32(v_) for k_, v_ in t.items()} if isinstance(t, dict) else np.asarray(t, dtype=np.float32)
   mu_g, var_g = gp.predict(mean.constant, kernel.squared_exponential, defs.GPParams(model=to32(model)), x.astype(np.float32),
                            y.astype(np.float32), xq.astype(np.float32), warp_func=utils.DEFAULT_WARP_FUNC)
-  e_mu_h = np.max(np.abs(mu_h32 - mu_ref)); e_mu_g = np.max(np.abs(np.asarray(mu_g, dtype=np.float64) - mu_ref))
-  e_var_h = np.max(np.abs(var_h32 - var_ref)); e_var_g = np.max(np.abs(np.asarray(var_g, dtype=np.float64) - var_ref))
-  # both fp32 routes are far from fp64 here (that is the point of the case); the library's must be in the same class
-  if np.isfinite(e_mu_h):      # (LAPACK's fp32 factorisation may itself break down on this matrix)
-    assert np.isfinite(e_mu_g) and e_mu_g <= 10 * e_mu_h + 1e-3, (e_mu_g, e_mu_h)
-    assert e_var_g <= 10 * e_var_h + 1e-3, (e_var_g, e_var_h)
-  else:
-    assert not np.isfinite(e_mu_g) or e_mu_g < 1.0
+  mu_g, var_g = np.asarray(mu_g, dtype=np.float64), np.asarray(var_g, dtype=np.float64)
+  try:
+    mu_h32, var_h32 = host(np.float32)
+  except np.linalg.LinAlgError:
+    # fp32 cannot factor this matrix: NaN from the library as from the reference's jnp cholesky -- or, if the blocked
+    # algorithm's different rounding got through, at least nothing worse than a finite estimate of the right magnitude
+    assert np.isnan(mu_g).all() or np.max(np.abs(mu_g - mu_ref)) < 1.0
+    return
+  e_mu_h, e_mu_g = np.max(np.abs(mu_h32 - mu_ref)), np.max(np.abs(mu_g - mu_ref))
+  e_var_h, e_var_g = np.max(np.abs(var_h32 - var_ref)), np.max(np.abs(var_g - var_ref))
+  assert np.isfinite(e_mu_g) and e_mu_g <= 10 * e_mu_h + 1e-3, (e_mu_g, e_mu_h)
+  assert e_var_g <= 10 * e_var_h + 1e-3, (e_var_g, e_var_h)
+  print(f'noise {noise_target}: |mu - fp64| GPU fp32 {e_mu_g:.3e} vs LAPACK fp32 {e_mu_h:.3e}; |var - fp64| {e_var_g:.3e} vs {e_var_h:.3e}')
+
+
+@pytest.mark.parametrize('n', [1500, 4600])
+def test_fp32_factorisation_on_bf16_matrix_cores_is_as_accurate_as_fp32_mfma(gpu_ctx, n):
+  """The fp32 trailing updates (and, above 32 blocks, the products of the inverse) run on the bf16 matrix cores from exact
+  three-way splits of their operands (post3.hip: syrk3_kernel).  On a matrix of condition number ~1e6 the factor, the solve
+  and the inverse must stay in the accuracy class of the fp32-MFMA kernels against fp64 LAPACK (linalg.py:29-33 in the
+  reference's default dtype).  Measured: well-conditioned matrices come out 3-4x CLOSER to fp64 than with fp32 MFMA (fewer
+  accumulation roundings: 3.7e-6 -> 8.4e-7 at n = 4224, tools/dbg32.py); at kappa = 1e6 the three dropped cross products
+  (weight 2^-24 each, the size of an fp32 rounding) show and the factor is ~2x further (5.7e-5 against 3.0e-5 at n = 1500) --
+  both two orders below kappa * eps.  The bound here is 3x."""
+  _, linalg, *_ = _native()
+  rng = np.random.default_rng(n)
+  q_, _ = np.linalg.qr(rng.normal(size=(n, n)))
+  ev = np.logspace(0, -6, n)                       # kappa = 1e6
+  a64 = (q_ * ev) @ q_.T
+  a64 = 0.5 * (a64 + a64.T)
+  a = a64.astype(np.float32)
+  b = rng.normal(size=(n, 2)).astype(np.float32)
+  a64 = a.astype(np.float64)
+  cref = spla.cholesky(a64, lower=True)
+  xref = spla.cho_solve((cref, True), b.astype(np.float64))
+  iref = np.linalg.inv(a64)
+  err = {}
+  try:
+    for name, on in (('mfma', 0), ('bf16x3', 1)):
+      gpu_ctx.set_option('syrk_bf16x3', on); gpu_ctx.set_option('trtri_bf16x3', on)
+      chol, x = linalg.solve_linear_system(a, b)
+      inv, _ = linalg.spd_inverse(a)
+      assert np.isfinite(chol).all()
+      err[name] = (helpers.rel_err(chol, cref), helpers.rel_err(x, xref), helpers.rel_err(inv, iref))
+  finally:
+    gpu_ctx.set_option('syrk_bf16x3', 1); gpu_ctx.set_option('trtri_bf16x3', 1)
+  for k in range(3):
+    assert err['bf16x3'][k] <= 3.0 * err['mfma'][k] + 1e-7, err
+  assert err['bf16x3'][0] < 1e-3        # kappa * eps_fp32 ~ 6e-2 bounds the solve; the factor itself stays accurate
 
 
 def test_cfg5_full_size_closed_form(gpu_ctx):
@@ -1202,7 +1243,12 @@ def test_sharded_objective_entry_point_reduces_on_the_device(gpu_ctx):
     try:
       v1, g1 = objectives.nll_value_and_grad(mn, kn, p, full, utils.DEFAULT_WARP_FUNC, comm=comm)
       assert comm.last_timing is not None and comm.last_timing[0] > 0 and comm.last_timing[1] >= 0
-      assert v1 == v0 and np.array_equal(helpers.flatten(g1), helpers.flatten(g0))
+      # (MLP gradients are accumulated with fp64 atomics on the device: two evaluations agree to rounding, not to the bit)
+      assert v1 == v0
+      if mlp:
+        np.testing.assert_allclose(helpers.flatten(g1), helpers.flatten(g0), rtol=1e-11, atol=1e-13)
+      else:
+        assert np.array_equal(helpers.flatten(g1), helpers.flatten(g0))
       # an empty shard: zeros, count 0 -> the mean over tasks is defined as 0
       ve, ge = objectives.nll_value_and_grad(mn, kn, p, {}, utils.DEFAULT_WARP_FUNC, comm=comm)
       assert ve == 0.0 and not np.any(helpers.flatten(ge))
@@ -1212,7 +1258,8 @@ def test_sharded_objective_entry_point_reduces_on_the_device(gpu_ctx):
     dev = objectives.DeviceDataset(full)
     s, cnt, gflat, _ = dev.evaluate_sharded(mn, kn, p, utils.DEFAULT_WARP_FUNC)
     s2, _, gflat2, _ = dev.evaluate(mn, kn, p, utils.DEFAULT_WARP_FUNC, want_grad=True)
-    assert cnt == 5.0 and s == s2 and np.array_equal(gflat, gflat2)
+    assert cnt == 5.0 and s == s2
+    np.testing.assert_allclose(gflat, gflat2, rtol=1e-11 if mlp else 0, atol=1e-13 if mlp else 0)
     dev.close()
   # divergence objective through the same path
   al = {i: defs.SubDataset(*helpers.synthetic_task(rng, 120, d, m=3), aligned=i) for i in range(3)}
