@@ -463,7 +463,8 @@ def main():
   try:
     import ctypes as _C
     nm = _C.create_string_buffer(128); cus = _C.c_int32(0); mem = _C.c_int64(0)
-    if nat.lib().hbo_device_info(int(os.environ.get('HBO_DEVICE', '0')), nm, 128, _C.byref(cus), _C.byref(mem)) == 0:
+    ndev = max(nat.lib().hbo_device_count(), 1)
+    if nat.lib().hbo_device_info(int(os.environ.get('HBO_DEVICE', '0')) % ndev, nm, 128, _C.byref(cus), _C.byref(mem)) == 0:
       device_info = {'name': nm.value.decode(), 'cus': cus.value, 'mem_gb': round(mem.value / 2**30, 1)}
   except Exception as e:  # pylint: disable=broad-except
     device_info = {'error': str(e)[:100]}

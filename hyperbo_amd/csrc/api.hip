@@ -28,7 +28,10 @@ extern "C" int hbo_device_count(void) {
 }
 extern "C" int hbo_device_info(int device, char* name_out, int32_t cap, int32_t* cus, int64_t* mem_bytes) {
   hipDeviceProp_t p;
-  if (hipGetDeviceProperties(&p, device) != hipSuccess) return fail(nullptr, HBO_ERR_NODEV, "hbo_device_info: no such device");
+  if (hipGetDeviceProperties(&p, device) != hipSuccess) {
+    (void)hipGetLastError();   // (not sticky: a later HIPCHK(hipGetLastError()) of this thread must not trip over it)
+    return fail(nullptr, HBO_ERR_NODEV, "hbo_device_info: no such device");
+  }
   if (name_out && cap > 0) { snprintf(name_out, (size_t)cap, "%s (%s)", p.name, p.gcnArchName); }
   if (cus) *cus = p.multiProcessorCount;
   if (mem_bytes) *mem_bytes = (int64_t)p.totalGlobalMem;
