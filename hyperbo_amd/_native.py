@@ -92,6 +92,7 @@ SIGNATURES = {
     'hbo_profile_get': (C.c_int, [_P, _P, C.POINTER(C.c_double), C.POINTER(C.c_int32),
                                   C.POINTER(C.c_int32)]),
     'hbo_set_option': (C.c_int, [_P, C.c_char_p, C.c_int64]),
+    'hbo_tune': (C.c_int, [_P, C.c_char_p, C.c_int64]),   # include/hbo_tune.h: measurement hooks, not the boundary
     'hbo_comm_unique_id': (C.c_int, [_P]),
     'hbo_comm_init': (C.c_int, [_P, C.c_int, C.c_int, _P]),
     'hbo_comm_allreduce_sum': (C.c_int, [_P, C.POINTER(C.c_double), C.c_int32]),
@@ -162,8 +163,12 @@ class Context:
       lib().hbo_ctx_destroy(self._h)
       self._h = _P()
 
+  PUBLIC_OPTIONS = ('potrf_group', 'lookahead', 'small_nblk', 'pool_cap_mb', 'post_chunk', 'bf16x3', 'dag', 'dag_timeout_ms')
+
   def set_option(self, name, value):
-    self.check(lib().hbo_set_option(self._h, name.encode(), int(value)))
+    """The options of include/hbo.h; any other name goes to the measurement hook hbo_tune (include/hbo_tune.h)."""
+    f = lib().hbo_set_option if name in self.PUBLIC_OPTIONS else lib().hbo_tune
+    self.check(f(self._h, name.encode(), int(value)))
 
   def profile_enable(self, level):
     self.check(lib().hbo_profile_enable(self._h, int(level)))

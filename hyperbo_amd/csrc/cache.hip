@@ -1,0 +1,472 @@
+// GPCache side of the C ABI: hbo_factor (hyperbo/basics/linalg.py:72-110 behind gp.py:540-560), the O(N^2) row append,
+// and everything that reads a cache -- hbo_predict (gp.py:242-305), hbo_acq (acfun.py:36-142), hbo_acq_grad (bayesopt.py:116-125).
+#include "api_internal.h"
+
+extern "C" int hbo_factor(hbo_ctx* c, const hbo_model* m, const void* x, int64_t n, const void* y, int32_t mcols,
+                          hbo_cache** out) {
+  if (!c || !out || !x || !y) return fail(c, HBO_ERR_ARG, "hbo_factor: null argument");
+  if (n <= 0 || mcols <= 0 || mcols > HBO_TILE) return fail(c, HBO_ERR_ARG, "hbo_factor: need n>0 and 1<=m<=128");
+  HIPCHK(c, hipSetDevice(c->device));
+  prof_begin(c);
+  int rc = upload_model(c, m);
+  if (rc) return rc;
+  const int dtype = m->dtype;
+  const size_t es = esize(dtype);
+  hipStream_t st = c->stream;
+  hbo_cache* k = new hbo_cache();
+  k->dtype = dtype; k->D = m->input_dim; k->m = mcols;
+  TaskHost* t = k->t = new TaskHost();
+  t->n = n; t->m = mcols; t->npad = round_up(n, HBO_TILE); t->nblk = t->npad / HBO_TILE; t->ld = padded_ld(t->npad, dtype);
+  auto bail = [&](int code) { hbo_cache_free(c, k); return code; };
+#define HIPCHK_K(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) { c->err = std::string(#call " failed: ") + hipGetErrorString(e__); return bail(HBO_ERR_HIP); } } while (0)
+  HIPCHK_K(dev_alloc(c, &t->X, (size_t)t->npad * m->input_dim * es));   // capacity npad rows (row appends)
+  HIPCHK_K(hipMemcpy(t->X, x, (size_t)n * m->input_dim * es, hipMemcpyHostToDevice));
+  // y^T (m x n) so that aug row a = column a of y
+  std::vector<unsigned char> yt((size_t)n * mcols * es);
+  for (int64_t i = 0; i < n; ++i)
+    for (int a = 0; a < mcols; ++a) memcpy(yt.data() + ((size_t)a * n + i) * es, (const unsigned char*)y + ((size_t)i * mcols + a) * es, es);
+  HIPCHK_K(dev_alloc(c, &t->ysum, (size_t)n * mcols * es));
+  HIPCHK_K(hipMemcpy(t->ysum, yt.data(), (size_t)n * mcols * es, hipMemcpyHostToDevice));
+  rc = ensure_task_workspace(c, dtype, t, true, mcols);
+  if (rc) return bail(rc);
+  if (needs_mlp(m)) { rc = t->feat.ensure(c, m, t->npad); if (rc) return bail(rc); }
+  fill_desc(k->h_desc, t, m, dtype, ROLE_FACTOR);
+  HIPCHK_K(hbo_malloc(c, (void**)&k->d_desc, sizeof(TaskDesc)));
+  HIPCHK_K(hbo_malloc(c, (void**)&k->d_info, sizeof(int)));
+  HIPCHK_K(hbo_malloc(c, &k->resid, (size_t)mcols * t->npad * es));
+  HIPCHK_K(hbo_malloc(c, &k->zvec, (size_t)mcols * t->npad * es));
+  HIPCHK_K(hipMemcpy(k->d_desc, &k->h_desc, sizeof(TaskDesc), hipMemcpyHostToDevice));
+  int inf = INT_MAX;
+  HIPCHK_K(hipMemcpy(k->d_info, &inf, sizeof(int), hipMemcpyHostToDevice));
+
+  { ProfScope ps(c, "features", 1);
+    if (needs_mlp(m)) run_mlp(c, m, t->X, n, t->feat.acts.data());
+    launch_aug_rows(dtype, k->d_desc, 1, t->npad, c->d_model, st); }
+  HIPCHK_K(hipMemcpy2DAsync(k->resid, (size_t)t->npad * es, (char*)t->A + (size_t)t->npad * t->ld * es, (size_t)t->ld * es, (size_t)t->npad * es, mcols, hipMemcpyDeviceToDevice, st));
+  { ProfScope ps(c, "gram", 1);
+    GramArgs g = {}; g.kernel_id = c->h_model->kernel_id; g.tasks = k->d_desc; g.fdim = feature_dim(m); g.symmetric = 1; g.padded = 1;
+    launch_gram(dtype, g, c->d_model, dim3(t->nblk, t->nblk, 1), st); }
+  // the inverse W = L^-1 (kept for the posterior products) starts beside the panel chain, as in the objective path
+  TrtriProgress trtri_pg;
+  const bool early_trtri = c->opt_lookahead && c->opt_overlap_trtri && t->nblk >= 4;
+  c->trtri_host_task = k->h_desc;
+  { ProfScope ps(c, "potrf", 1); run_potrf(c, dtype, k->d_desc, 1, t->nblk, k->d_info, early_trtri ? &trtri_pg : nullptr); }
+  HIPCHK_K(hipMemcpy2DAsync(k->zvec, (size_t)t->npad * es, (char*)t->A + (size_t)t->npad * t->ld * es, (size_t)t->ld * es, (size_t)t->npad * es, mcols, hipMemcpyDeviceToDevice, st));
+  { ProfScope ps(c, "trtri", 1); run_trtri(c, dtype, k->d_desc, 1, t->nblk, &trtri_pg); }
+  { ProfScope ps(c, "wt_z", 1);
+    for (int a = 0; a < mcols; ++a) launch_wt_z(dtype, k->d_desc, 1, t->nblk, a, a, t->npad, st); }
+  HIPCHK_K(hipMemcpyAsync(&k->info, k->d_info, sizeof(int), hipMemcpyDeviceToHost, st));
+  HIPCHK_K(hipStreamSynchronize(st));
+  HIPCHK_K(hipGetLastError());
+  prof_collect(c);
+  if (dag_aborted(c)) { hbo_cache_free(c, k); return hbo_factor(c, m, x, n, y, mcols, out); }
+#undef HIPCHK_K
+  *out = k;
+  return k->info != INT_MAX ? HBO_NOT_PD : HBO_OK;
+}
+
+// O(N^2) row append (the reference re-factorises from scratch after every BO
+// observation, hyperbo/bo_utils/bayesopt.py:186-190, and notes "One can potentially support rank-1
+// updates", hyperbo/gp_utils/gp.py:284).  For each new point (x*, y*), with W = L^-1 resident:
+//   l = W k(X,x*),  d = sqrt(k(x*,x*) + sigma^2 + eps - l.l),  L' = [[L,0],[l^T,d]],
+//   W' = [[W,0],[-(l^T W)/d, 1/d]],  z' = [z; (r* - l.z)/d],  alpha' = [alpha + w' z'_n ; z'_n/d].
+// Two triangular mat-vecs on the device, O(n) arithmetic on the host.  Returns HBO_ERR_UNSUPPORTED
+// when the padded capacity (npad) is exhausted -- the caller then re-factorises.
+extern "C" int hbo_cache_append(hbo_ctx* c, const hbo_model* m, hbo_cache* k, const void* x_new, int64_t n_new,
+                                const void* y_new) {
+  if (!c || !k || !x_new || !y_new) return fail(c, HBO_ERR_ARG, "hbo_cache_append: null argument");
+  if (n_new <= 0) return HBO_OK;
+  HIPCHK(c, hipSetDevice(c->device));
+  TaskHost* t = k->t;
+  if (k->dtype != m->dtype || k->D != m->input_dim) return fail(c, HBO_ERR_ARG, "hbo_cache_append: cache/model mismatch");
+  if (k->info != INT_MAX) return HBO_NOT_PD;
+  if (t->n + n_new > t->npad) return fail(c, HBO_ERR_UNSUPPORTED, "hbo_cache_append: capacity exhausted (re-factorise)");
+  k->w3_valid = false;   // W changes: its bf16 planes are rebuilt at the next posterior call
+  int rc = upload_model(c, m);
+  if (rc) return rc;
+  const int dtype = k->dtype; const size_t es = esize(dtype);
+  hipStream_t st = c->stream;
+  const int fdim = feature_dim(m), fm = mean_feature_dim(m), mc = k->m;
+  void *d_kx = nullptr, *d_l = nullptr, *d_w = nullptr, *d_mu = nullptr, *d_kd = nullptr;
+  auto cleanup = [&]() {};   // ctx-owned scratch
+#define HIPCHK_A(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) { c->err = std::string(#call " failed: ") + hipGetErrorString(e__); cleanup(); return HBO_ERR_HIP; } } while (0)
+  d_kx = ws_get(c, WS_AP_KX, (size_t)t->npad * es); d_l = ws_get(c, WS_AP_L, (size_t)t->npad * es);
+  d_w = ws_get(c, WS_AP_W, (size_t)t->npad * es); d_mu = ws_get(c, WS_AP_MU, 16); d_kd = ws_get(c, WS_AP_KD, 16);
+  if (!d_kx || !d_l || !d_w || !d_mu || !d_kd) return HBO_ERR_HIP;
+  std::vector<double> l(t->npad), w(t->npad), z((size_t)mc * t->npad), al((size_t)mc * t->npad);
+  std::vector<unsigned char> buf((size_t)t->npad * es * std::max(mc, 1));
+  auto to_host = [&](const void* dev, std::vector<double>& out, size_t count) -> hipError_t {
+    hipError_t e = hipMemcpy(buf.data(), dev, count * es, hipMemcpyDeviceToHost);
+    for (size_t i = 0; i < count; ++i) out[i] = host_elem(buf.data(), dtype, (int64_t)i);
+    return e;
+  };
+  auto to_dev = [&](void* dev, const double* src, size_t count) -> hipError_t {
+    for (size_t i = 0; i < count; ++i) { if (dtype == HBO_F64) ((double*)buf.data())[i] = src[i]; else ((float*)buf.data())[i] = (float)src[i]; }
+    return hipMemcpy(dev, buf.data(), count * es, hipMemcpyHostToDevice);
+  };
+  HIPCHK_A(to_host(k->zvec, z, (size_t)mc * t->npad));
+  HIPCHK_A(to_host(t->svec, al, (size_t)mc * t->npad));
+  int status = HBO_OK;
+  for (int64_t q = 0; q < n_new && status == HBO_OK; ++q) {
+    const int64_t n = t->n;
+    // new input row -> X[n], features -> acts[.][n]
+    void* xrow = (char*)t->X + (size_t)n * m->input_dim * es;
+    HIPCHK_A(hipMemcpyAsync(xrow, (const char*)x_new + (size_t)q * m->input_dim * es, (size_t)m->input_dim * es, hipMemcpyHostToDevice, st));
+    const void* flast = nullptr;
+    if (needs_mlp(m)) {
+      void* rows[HBO_MAX_MLP_LAYERS];
+      for (int lyr = 0; lyr < m->n_layers; ++lyr) rows[lyr] = (char*)t->feat.acts[lyr] + (size_t)n * m->features[lyr] * es;
+      run_mlp(c, m, xrow, 1, rows);
+      flast = rows[m->n_layers - 1];
+    }
+    const void* Fq = m->kernel_uses_mlp ? flast : xrow;
+    const void* Fmq = (m->mean_id == HBO_MEAN_LINEAR) ? xrow : (m->mean_id == HBO_MEAN_LINEAR_MLP ? flast : nullptr);
+    launch_mean(dtype, Fmq, 1, fm, c->d_model, d_mu, st);
+    launch_kdiag(dtype, Fq, 1, fdim, c->d_model, d_kd, st);
+    // k(X, x*)  (n x 1), zero-padded to npad
+    HIPCHK_A(hipMemsetAsync(d_kx, 0, (size_t)t->npad * es, st));
+    { GramArgs g = {}; g.kernel_id = c->h_model->kernel_id; g.x1 = k->h_desc.F; g.x2 = Fq; g.out = d_kx; g.n1 = n; g.n2 = 1; g.ldo = 1; g.fdim = fdim;
+      launch_gram(dtype, g, c->d_model, dim3(1, (unsigned)((n + 127) / 128), 1), st); }
+    // l = W kx ; wl = W^T l
+    launch_tri_matvec(dtype, t->W, t->ld, t->npad, d_kx, t->npad, 1, 0, d_l, t->npad, st);
+    launch_wt_z(dtype, k->d_desc, 1, t->nblk, 0, 0, t->npad, st, d_l, d_w);   // W^T l (two-stage, uses S as scratch)
+    HIPCHK_A(hipStreamSynchronize(st));
+    HIPCHK_A(to_host(d_l, l, (size_t)t->npad));
+    HIPCHK_A(to_host(d_w, w, (size_t)t->npad));
+    std::vector<double> one(1);
+    HIPCHK_A(to_host(d_mu, one, 1)); const double mu_new = one[0];
+    HIPCHK_A(to_host(d_kd, one, 1)); const double kappa = one[0] + m->noise_variance + m->eps;
+    double ll = 0;
+    for (int64_t i = 0; i < n; ++i) ll += l[i] * l[i];
+    const double d2 = kappa - ll;
+    if (!(d2 > 0)) { status = HBO_NOT_PD; k->info = (int)n + 1; break; }
+    const double d = sqrt(d2);
+    for (int64_t i = 0; i < n; ++i) w[i] = -w[i] / d;      // new row of W (columns < n)
+    // write row n of L and of W (identity padding row is overwritten)
+    l[n] = d; w[n] = 1.0 / d;
+    HIPCHK_A(to_dev((char*)t->A + (size_t)n * t->ld * es, l.data(), (size_t)n + 1));
+    HIPCHK_A(to_dev((char*)t->W + (size_t)n * t->ld * es, w.data(), (size_t)n + 1));
+    for (int a = 0; a < mc; ++a) {
+      double* za = z.data() + (size_t)a * t->npad; double* aa = al.data() + (size_t)a * t->npad;
+      const double r_new = host_elem(y_new, dtype, q * mc + a) - mu_new;
+      double lz = 0;
+      for (int64_t i = 0; i < n; ++i) lz += l[i] * za[i];
+      const double zn = (r_new - lz) / d;
+      za[n] = zn;
+      for (int64_t i = 0; i < n; ++i) aa[i] += w[i] * zn;
+      aa[n] = zn / d;
+      // residual buffer (y - mu) gains the new entry
+      double rr = r_new;
+      HIPCHK_A(to_dev((char*)k->resid + ((size_t)a * t->npad + n) * es, &rr, 1));
+    }
+    t->n = n + 1;
+    k->h_desc.n = (int)t->n;
+  }
+  if (status == HBO_OK || status == HBO_NOT_PD) {
+    HIPCHK_A(to_dev(k->zvec, z.data(), (size_t)mc * t->npad));
+    HIPCHK_A(to_dev(t->svec, al.data(), (size_t)mc * t->npad));
+    HIPCHK_A(hipMemcpy(k->d_desc, &k->h_desc, sizeof(TaskDesc), hipMemcpyHostToDevice));
+  }
+  HIPCHK_A(hipGetLastError());
+#undef HIPCHK_A
+  cleanup();
+  return status;
+}
+
+// ---- posterior / acquisition ---------------------------------------------------------------
+static int posterior(hbo_ctx* c, const hbo_model* m, hbo_cache* k, const void* xq, int64_t M, int full_cov,
+                     void* mu_out, void* var_out, void* acq_out, int acq_id, double param, double add_noise,
+                     double scale) {
+  if (!c || !xq) return fail(c, HBO_ERR_ARG, "posterior: null argument");
+  if (M <= 0) return HBO_OK;
+  HIPCHK(c, hipSetDevice(c->device));
+  prof_begin(c);
+  int rc = upload_model(c, m);
+  if (rc) return rc;
+  const int dtype = m->dtype;
+  if (k && (k->dtype != dtype || k->D != m->input_dim)) return fail(c, HBO_ERR_ARG, "posterior: cache/model mismatch");
+  const size_t es = esize(dtype);
+  const int fdim = feature_dim(m), fm = mean_feature_dim(m);
+  // Candidates are STREAMED: chunks of `CH` queries, so that the cross-Gram workspace (npad x CH) does not grow with M
+  // (gp.py:295-305 materialises all of Kxq; at cfg 3 that is 16384 x 65536 fp32 = 4.3 GB).  Two workspaces alternate:
+  // upload + features + cross Gram of chunk i+1 run on a second stream beside the triangular product of chunk i; the
+  // results of all chunks are gathered in M-sized vectors and come back in one copy.  full_cov keeps a single pass.
+  const int64_t CH = full_cov ? 65536 : std::max<int64_t>(c->opt_post_chunk, HBO_TILE);
+  if (full_cov && M > CH) { return fail(c, HBO_ERR_UNSUPPORTED, "posterior: full_cov limited to 65536 queries"); }
+  const int64_t mc_max = std::min<int64_t>(M, CH);
+  const int nbuf = (!full_cov && M > CH) ? 2 : 1;
+  const int mpad_max = round_up(mc_max, HBO_TILE);
+  const int64_t ldq_max = padded_ld(mpad_max, dtype);
+  hipStream_t sa = c->stream, sb = nbuf == 2 ? c->stream2 : c->stream;
+  char *d_xq = nullptr, *d_mu0 = nullptr, *d_kd = nullptr, *d_K = nullptr, *d_colsq = nullptr, *d_mupart = nullptr;
+  void *d_mu = nullptr, *d_var = nullptr, *d_acq = nullptr, *d_V = nullptr, *d_Kqq = nullptr, *d_cov = nullptr;
+  char* fq_acts[HBO_MAX_MLP_LAYERS] = {nullptr};
+  size_t fq_stride[HBO_MAX_MLP_LAYERS] = {0};
+#define HIPCHK_P(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) { c->err = std::string(#call " failed: ") + hipGetErrorString(e__); return HBO_ERR_HIP; } } while (0)
+  auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+  const size_t vec_b = al((size_t)mc_max * es);
+  // the queries go up in ONE copy (M x D elements: small beside the N x CH workspace): a pageable host-to-device copy
+  // inside the chunk loop waits for the products in flight on the other stream -- it serialised the two streams and
+  // took cfg 3 from 142 to 197 ms
+  { d_xq = (char*)ws_get(c, WS_XQ, (size_t)M * m->input_dim * es); if (!d_xq) return HBO_ERR_HIP; }
+  HIPCHK_P(hipMemcpyAsync(d_xq, xq, (size_t)M * m->input_dim * es, hipMemcpyHostToDevice, sa));
+  { d_mu0 = (char*)ws_get(c, WS_MU0, vec_b * nbuf); if (!d_mu0) return HBO_ERR_HIP; }
+  { d_kd = (char*)ws_get(c, WS_KD, vec_b * nbuf); if (!d_kd) return HBO_ERR_HIP; }
+  { d_mu = ws_get(c, WS_MU, (size_t)M * es); if (!d_mu) return HBO_ERR_HIP; }
+  { d_var = ws_get(c, WS_VAR, (size_t)M * es); if (!d_var) return HBO_ERR_HIP; }
+  if (acq_out) { d_acq = ws_get(c, WS_ACQ, (size_t)M * es); if (!d_acq) return HBO_ERR_HIP; }
+  if (needs_mlp(m)) for (int l = 0; l < m->n_layers; ++l) {
+    fq_stride[l] = al((size_t)mc_max * m->features[l] * es);
+    fq_acts[l] = (char*)ws_get(c, WS_FQ0 + l, fq_stride[l] * nbuf); if (!fq_acts[l]) return HBO_ERR_HIP;
+  }
+  TaskHost* t = k ? k->t : nullptr;
+  size_t K_b = 0, colsq_b = 0;
+  if (k) {
+    K_b = al((size_t)t->npad * ldq_max * es); colsq_b = al((size_t)t->nblk * ldq_max * es);
+    { d_K = (char*)ws_get(c, WS_K, K_b * nbuf); if (!d_K) return HBO_ERR_HIP; }
+    { d_colsq = (char*)ws_get(c, WS_COLSQ, colsq_b * nbuf); if (!d_colsq) return HBO_ERR_HIP; }
+    { d_mupart = (char*)ws_get(c, WS_MUPART, colsq_b * nbuf); if (!d_mupart) return HBO_ERR_HIP; }
+    if (full_cov) { d_V = ws_get(c, WS_V, (size_t)t->npad * ldq_max * es); if (!d_V) return HBO_ERR_HIP; }
+  }
+  if (full_cov) { { d_Kqq = ws_get(c, WS_KQQ, (size_t)M * M * es); if (!d_Kqq) return HBO_ERR_HIP; } { d_cov = ws_get(c, WS_COV, (size_t)M * M * es); if (!d_cov) return HBO_ERR_HIP; } }
+  // fp32: the product runs on the bf16 matrix cores from exact three-way splits of both operands (post3.hip)
+  bool use3 = k && dtype == HBO_F32 && c->opt_post_bf16x3 && !full_cov;
+  unsigned short* d_K3 = nullptr; size_t k3_b = 0;
+  const int nkb = k ? t->npad / 16 : 0;
+  if (use3 && !k->w3_valid) {
+    // the split copy of W costs 1.5 x its bytes: when the device cannot spare them the fp32-MFMA product takes over
+    const size_t elems = (size_t)t->npad * t->npad * 3;
+    if (!k->w3 || k->w3_elems != elems) {
+      if (k->w3) hipFree(k->w3);
+      k->w3 = nullptr; k->w3_elems = 0;
+      if (hbo_malloc(c, (void**)&k->w3, elems * sizeof(unsigned short)) != hipSuccess) { (void)hipGetLastError(); k->w3 = nullptr; use3 = false; }
+      else k->w3_elems = elems;
+    }
+    if (use3) {
+      ProfScope ps(c, "split_w", 1, sa);
+      launch_split3_rows(static_cast<const float*>(t->W), t->ld, t->nblk, k->w3, nkb, sa);
+      k->w3_valid = true;
+    }
+  }
+  if (use3) {
+    k3_b = al((size_t)mpad_max * t->npad * 3 * sizeof(unsigned short));   // (mpad / 128) x nkb blocks of 3 x 128 x 16
+    d_K3 = (unsigned short*)ws_get(c, WS_K3, k3_b * nbuf);
+    if (!d_K3) { c->err.clear(); use3 = false; }
+  }
+  const bool bad = k && k->info != INT_MAX;
+  hipEvent_t ev_ready[2] = {nullptr, nullptr}, ev_free[2] = {nullptr, nullptr};
+  size_t evi = 0;
+  if (nbuf == 2) {   // the side stream starts behind whatever the main stream still holds (model upload)
+    hipEvent_t e = pool_event(c, evi++); hipEventRecord(e, sa); hipStreamWaitEvent(sb, e, 0);
+  }
+
+  int64_t chunk = 0;
+  for (int64_t q0 = 0; q0 < M; q0 += CH, ++chunk) {
+    const int b = (int)(chunk % nbuf);
+    const int64_t mc = std::min<int64_t>(CH, M - q0);
+    const int mpad = round_up(mc, HBO_TILE);
+    const int64_t ldq = padded_ld(mpad, dtype);
+    char* xq_d = d_xq + (size_t)q0 * m->input_dim * es; char* mu0_d = d_mu0 + b * vec_b; char* kd_d = d_kd + b * vec_b;
+    // ---- producer side (sb): inputs, features, prior mean / variance, cross Gram into workspace b ----
+    if (ev_free[b]) hipStreamWaitEvent(sb, ev_free[b], 0);   // workspace b was read by the products of chunk - 2
+    const void* fq_last = nullptr;
+    { ProfScope ps(c, "features", 1, sb);
+      if (needs_mlp(m)) {
+        void* acts[HBO_MAX_MLP_LAYERS];
+        for (int l = 0; l < m->n_layers; ++l) acts[l] = fq_acts[l] + b * fq_stride[l];
+        const void* in = xq_d; int fin = m->input_dim;
+        for (int l = 0; l < m->n_layers; ++l) { launch_dense_tanh(dtype, in, c->d_mlp_w[l], c->d_mlp_b[l], acts[l], mc, fin, m->features[l], sb); in = acts[l]; fin = m->features[l]; }
+        fq_last = acts[m->n_layers - 1];
+      } }
+    const void* Fq = m->kernel_uses_mlp ? fq_last : xq_d;
+    const void* Fmq = (m->mean_id == HBO_MEAN_LINEAR) ? (const void*)xq_d : (m->mean_id == HBO_MEAN_LINEAR_MLP ? fq_last : nullptr);
+    launch_mean(dtype, Fmq, mc, fm, c->d_model, mu0_d, sb);
+    launch_kdiag(dtype, Fq, mc, fdim, c->d_model, kd_d, sb);
+    void* mu_d = (char*)d_mu + (size_t)q0 * es; void* var_d = (char*)d_var + (size_t)q0 * es;
+    void* acq_d = d_acq ? (char*)d_acq + (size_t)q0 * es : nullptr;
+    if (!k) {  // prior branch (gp.py:275-282)
+      HIPCHK_P(hipMemcpyAsync(mu_d, mu0_d, (size_t)mc * es, hipMemcpyDeviceToDevice, sb));
+      if (full_cov) {
+        GramArgs g = {}; g.kernel_id = c->h_model->kernel_id; g.x1 = Fq; g.x2 = Fq; g.out = d_cov; g.n1 = mc; g.n2 = mc; g.ldo = mc; g.fdim = fdim;
+        launch_gram(dtype, g, c->d_model, dim3((unsigned)((mc + 127) / 128), (unsigned)((mc + 127) / 128), 1), sb);
+      } else {
+        HIPCHK_P(hipMemcpyAsync(var_d, kd_d, (size_t)mc * es, hipMemcpyDeviceToDevice, sb));
+      }
+      if (acq_out) {   // acquisition on the prior
+        PostArgs pa = {}; pa.Kxq = nullptr; pa.n = 0; pa.nblk = 0; pa.ldq = ldq; pa.alpha = nullptr; pa.colsq = nullptr;
+        pa.kdiag = kd_d; pa.muq = mu0_d; pa.acq_out = acq_d; pa.M = mc; pa.acq_id = acq_id; pa.param = param; pa.add_noise = add_noise; pa.scale = scale;
+        launch_post_epilogue(dtype, pa, sb);
+      }
+      if (nbuf == 2) { ev_free[b] = pool_event(c, evi++); hipEventRecord(ev_free[b], sb); }
+      continue;
+    }
+    char* K_d = d_K + b * K_b; char* colsq_d = d_colsq + b * colsq_b;
+    { ProfScope ps(c, "cross_gram", 1, sb);
+      GramArgs g = {}; g.kernel_id = c->h_model->kernel_id; g.x1 = k->h_desc.F; g.x2 = Fq; g.out = K_d; g.n1 = t->n; g.n2 = mc; g.ldo = ldq;
+      g.n1pad = t->npad; g.n2pad = mpad; g.fdim = fdim; g.symmetric = 0; g.padded = 1;
+      launch_gram(dtype, g, c->d_model, dim3(mpad / HBO_TILE, t->nblk, 1), sb); }
+    unsigned short* K3_d = use3 ? d_K3 + (size_t)b * (k3_b / sizeof(unsigned short)) : nullptr;
+    if (use3) {
+      ProfScope ps(c, "split_kxq", 1, sb);
+      launch_split3_transpose(reinterpret_cast<const float*>(K_d), ldq, t->npad, mpad, K3_d, nkb, sb);
+    }
+    if (nbuf == 2) { ev_ready[b] = pool_event(c, evi++); hipEventRecord(ev_ready[b], sb); hipStreamWaitEvent(sa, ev_ready[b], 0); }
+    // ---- consumer side (sa): V = L^-1 Kxq on MFMA (column sums of squares), then mean / variance / acquisition ----
+    if (use3) {
+      ProfScope ps(c, "post_gemm", 1, sa);
+      Post3Args a = {}; a.Wp = k->w3; a.Kp = K3_d; a.nkb = nkb;
+      a.colsq = reinterpret_cast<float*>(colsq_d); a.ldc = ldq; a.V = nullptr; a.ldv = 0; a.nblk = t->nblk;
+      launch_post3(a, mpad / HBO_TILE, sa);
+    } else {
+      ProfScope ps(c, "post_gemm", 1, sa);
+      GemmArgs a = {}; a.tasks = k->d_desc; a.mode = GEMM_POST; a.B = K_d; a.ldb = ldq; a.V = full_cov ? d_V : nullptr; a.colsq = colsq_d;
+      launch_gemm(dtype, a, dim3(mpad / HBO_TILE, t->nblk, 1), sa); }
+    { ProfScope ps(c, "post_epilogue", 1, sa);
+      PostArgs pa = {}; pa.Kxq = K_d; pa.ldq = ldq; pa.npad = t->npad; pa.n = (int)t->n; pa.nblk = t->nblk; pa.alpha = t->svec; pa.colsq = colsq_d; pa.mupart = d_mupart + b * colsq_b;
+      pa.kdiag = kd_d; pa.muq = mu0_d; pa.mu_out = mu_d; pa.var_out = var_d; pa.acq_out = acq_d; pa.M = mc;
+      pa.acq_id = acq_id; pa.param = param; pa.add_noise = add_noise; pa.scale = scale;
+      launch_post_epilogue(dtype, pa, sa); }
+    if (nbuf == 2) { ev_free[b] = pool_event(c, evi++); hipEventRecord(ev_free[b], sa); }
+    if (full_cov) {
+      GramArgs g = {}; g.kernel_id = c->h_model->kernel_id; g.x1 = Fq; g.x2 = Fq; g.out = d_Kqq; g.n1 = mc; g.n2 = mc; g.ldo = mc; g.fdim = fdim;
+      launch_gram(dtype, g, c->d_model, dim3((unsigned)((mc + 127) / 128), (unsigned)((mc + 127) / 128), 1), sa);
+      launch_fullcov(dtype, d_V, ldq, t->npad, d_Kqq, mc, d_cov, sa);
+    }
+  }
+  if (nbuf == 2) {   // join: everything the side stream produced (the prior branch runs there entirely)
+    hipEvent_t e = pool_event(c, evi++); hipEventRecord(e, sb); hipStreamWaitEvent(sa, e, 0);
+  }
+  if (mu_out) HIPCHK_P(hipMemcpyAsync(mu_out, d_mu, (size_t)M * es, hipMemcpyDeviceToHost, sa));
+  if (var_out) {
+    if (full_cov) HIPCHK_P(hipMemcpyAsync(var_out, d_cov, (size_t)M * M * es, hipMemcpyDeviceToHost, sa));
+    else HIPCHK_P(hipMemcpyAsync(var_out, d_var, (size_t)M * es, hipMemcpyDeviceToHost, sa));
+  }
+  if (acq_out) HIPCHK_P(hipMemcpyAsync(acq_out, d_acq, (size_t)M * es, hipMemcpyDeviceToHost, sa));
+  HIPCHK_P(hipStreamSynchronize(sa));
+  if (nbuf == 2) HIPCHK_P(hipStreamSynchronize(sb));
+  HIPCHK_P(hipGetLastError());
+#undef HIPCHK_P
+  prof_collect(c);
+  if (bad) {
+    if (mu_out) fill_nan(mu_out, (size_t)M, dtype);
+    if (var_out) fill_nan(var_out, full_cov ? (size_t)M * M : (size_t)M, dtype);
+    if (acq_out) fill_nan(acq_out, (size_t)M, dtype);
+    return HBO_NOT_PD;
+  }
+  return HBO_OK;
+}
+
+extern "C" int hbo_predict(hbo_ctx* c, const hbo_model* m, hbo_cache* k, const void* xq, int64_t M, int full_cov,
+                           void* mu_out, void* var_out) {
+  return posterior(c, m, k, xq, M, full_cov, mu_out, var_out, nullptr, 0, 0, 0, 1);
+}
+extern "C" int hbo_acq(hbo_ctx* c, const hbo_model* m, hbo_cache* k, const void* xq, int64_t M, int acq_id,
+                       double param, double add_noise, double scale, void* out) {
+  if (acq_id < 0 || acq_id > HBO_ACQ_UCB) return fail(c, HBO_ERR_ARG, "hbo_acq: bad acq_id");
+  if (!out) return fail(c, HBO_ERR_ARG, "hbo_acq: out is null");
+  return posterior(c, m, k, xq, M, 0, nullptr, nullptr, out, acq_id, param, add_noise, scale);
+}
+
+// ---- d acquisition / d x_query: what jaxopt's L-BFGS-B differentiates in bayesopt() (bayesopt.py:116-125) ----
+extern "C" int hbo_acq_grad(hbo_ctx* c, const hbo_model* m, hbo_cache* k, const void* xq, int64_t M, int acq_id,
+                            double param, double add_noise, double scale, void* acq_out, double* grad_out) {
+  if (!c || !xq || !acq_out || !grad_out || !m) return fail(c, HBO_ERR_ARG, "hbo_acq_grad: null argument");
+  if (acq_id < 0 || acq_id > HBO_ACQ_UCB) return fail(c, HBO_ERR_ARG, "hbo_acq_grad: bad acq_id");
+  if (M <= 0) return HBO_OK;
+  HIPCHK(c, hipSetDevice(c->device));
+  int rc = validate_model(c, m);
+  if (rc) return rc;
+  rc = upload_model(c, m);
+  if (rc) return rc;
+  const int dtype = m->dtype;
+  if (k && (k->dtype != dtype || k->D != m->input_dim)) return fail(c, HBO_ERR_ARG, "hbo_acq_grad: cache/model mismatch");
+  const size_t es = esize(dtype);
+  hipStream_t st = c->stream;
+  const int D = m->input_dim, fdim = feature_dim(m), fm = mean_feature_dim(m);
+  const bool mlp = needs_mlp(m);
+  const int L = m->n_layers, flast = mlp ? m->features[L - 1] : 0;
+  TaskHost* t = (k && k->t->n > 0) ? k->t : nullptr;
+  const int64_t CH = 1024;   // queries per pass: three [CH][npad] panels of workspace
+  const int64_t mc_max = std::min<int64_t>(M, CH);
+  int maxf = D;
+  for (int l = 0; l < L; ++l) maxf = std::max(maxf, (int)m->features[l]);
+  size_t nparam = 1;
+  { int fin0 = D; for (int l = 0; l < L; ++l) { nparam = std::max(nparam, (size_t)(fin0 + 1) * m->features[l]); fin0 = m->features[l]; } }
+  void* d_xq = ws_get(c, WS_XQ, (size_t)mc_max * D * es);
+  void* d_mu0 = ws_get(c, WS_MU0, (size_t)mc_max * es);
+  void* d_kd = ws_get(c, WS_KD, (size_t)mc_max * es);
+  void* d_acq = ws_get(c, WS_ACQ, (size_t)mc_max * es);
+  double* d_gf = (double*)ws_get(c, WS_AG_GF, (size_t)mc_max * fdim * sizeof(double));
+  double* d_dmu = (double*)ws_get(c, WS_AG_DMU, (size_t)mc_max * sizeof(double));
+  double* d_gx = (double*)ws_get(c, WS_AG_GX, (size_t)mc_max * D * sizeof(double));
+  double* d_t0 = (double*)ws_get(c, WS_AG_T0, (size_t)mc_max * maxf * sizeof(double));
+  double* d_t1 = (double*)ws_get(c, WS_AG_T1, (size_t)mc_max * maxf * sizeof(double));
+  double* d_dw = (double*)ws_get(c, WS_AG_DW, nparam * sizeof(double));   // weight-gradient sink of the shared MLP backward
+  if (!d_xq || !d_mu0 || !d_kd || !d_acq || !d_gf || !d_dmu || !d_gx || !d_t0 || !d_t1 || !d_dw) return HBO_ERR_HIP;
+  void *d_K = nullptr, *d_L = nullptr, *d_B = nullptr;
+  if (t) {
+    d_K = ws_get(c, WS_AG_K, (size_t)mc_max * t->npad * es); d_L = ws_get(c, WS_AG_L, (size_t)mc_max * t->npad * es);
+    d_B = ws_get(c, WS_AG_B, (size_t)mc_max * t->npad * es);
+    if (!d_K || !d_L || !d_B) return HBO_ERR_HIP;
+  }
+  void* fq_acts[HBO_MAX_MLP_LAYERS] = {nullptr};
+  if (mlp) for (int l = 0; l < L; ++l) { fq_acts[l] = ws_get(c, WS_FQ0 + l, (size_t)mc_max * m->features[l] * es); if (!fq_acts[l]) return HBO_ERR_HIP; }
+  const bool bad = k && k->info != INT_MAX;
+#define HIPCHK_D(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) { c->err = std::string(#call " failed: ") + hipGetErrorString(e__); return HBO_ERR_HIP; } } while (0)
+  for (int64_t q0 = 0; q0 < M; q0 += CH) {
+    const int64_t mc = std::min<int64_t>(CH, M - q0);
+    HIPCHK_D(hipMemcpyAsync(d_xq, (const char*)xq + (size_t)q0 * D * es, (size_t)mc * D * es, hipMemcpyHostToDevice, st));
+    const void* fq_last = nullptr;
+    if (mlp) { run_mlp(c, m, d_xq, mc, fq_acts); fq_last = fq_acts[L - 1]; }
+    const void* Fq = m->kernel_uses_mlp ? fq_last : d_xq;
+    const void* Fmq = (m->mean_id == HBO_MEAN_LINEAR) ? d_xq : (m->mean_id == HBO_MEAN_LINEAR_MLP ? fq_last : nullptr);
+    launch_mean(dtype, Fmq, mc, fm, c->d_model, d_mu0, st);
+    launch_kdiag(dtype, Fq, mc, fdim, c->d_model, d_kd, st);
+    if (t) {
+      HIPCHK_D(hipMemsetAsync(d_K, 0, (size_t)mc * t->npad * es, st));
+      GramArgs g = {}; g.kernel_id = c->h_model->kernel_id; g.x1 = Fq; g.x2 = k->h_desc.F; g.out = d_K; g.n1 = mc; g.n2 = t->n; g.ldo = t->npad; g.fdim = fdim;
+      launch_gram(dtype, g, c->d_model, dim3((unsigned)((t->n + 127) / 128), (unsigned)((mc + 127) / 128), 1), st);
+      launch_tri_matvec(dtype, t->W, t->ld, t->npad, d_K, t->npad, (int)mc, 0, d_L, t->npad, st);
+      launch_tri_matvec(dtype, t->W, t->ld, t->npad, d_L, t->npad, (int)mc, 1, d_B, t->npad, st);
+    }
+    AcqGradArgs a = {};
+    a.Fq = Fq; a.F = t ? k->h_desc.F : nullptr; a.fdim = fdim; a.n = t ? t->n : 0; a.npad = t ? t->npad : 0;
+    a.Kq = d_K; a.L = d_L; a.B = d_B; a.alpha = t ? t->svec : nullptr; a.kdiag = d_kd; a.muq = d_mu0;
+    a.acq_id = acq_id; a.param = param; a.add_noise = add_noise; a.scale = scale;
+    a.acq_out = d_acq; a.gfeat = d_gf; a.dmu = d_dmu; a.M = mc;
+    launch_acq_grad(dtype, a, c->d_model, st);
+    // assemble d/dx: kernel part (direct or through the MLP) + mean part (mean.py:62-79)
+    double* gmlp = nullptr;   // gradient w.r.t. the MLP output
+    if (m->kernel_uses_mlp) {
+      gmlp = d_gf;
+      if (m->mean_id == HBO_MEAN_LINEAR_MLP) launch_acq_grad_mean(d_dmu, c->d_model, mc, flast, gmlp, 1, st);
+      HIPCHK_D(hipMemsetAsync(d_gx, 0, (size_t)mc * D * sizeof(double), st));
+      if (m->mean_id == HBO_MEAN_LINEAR) launch_acq_grad_mean(d_dmu, c->d_model, mc, D, d_gx, 1, st);
+    } else {
+      HIPCHK_D(hipMemcpyAsync(d_gx, d_gf, (size_t)mc * D * sizeof(double), hipMemcpyDeviceToDevice, st));
+      if (m->mean_id == HBO_MEAN_LINEAR) launch_acq_grad_mean(d_dmu, c->d_model, mc, D, d_gx, 1, st);
+      if (m->mean_id == HBO_MEAN_LINEAR_MLP) { gmlp = d_t0; launch_acq_grad_mean(d_dmu, c->d_model, mc, flast, gmlp, 0, st); }
+    }
+    if (gmlp) {
+      double* cur = gmlp; double* other = (gmlp == d_t0) ? d_t1 : d_t0;
+      for (int l = L - 1; l >= 0; --l) {
+        const int fin = l ? m->features[l - 1] : D;
+        const void* in = l ? fq_acts[l - 1] : d_xq;
+        launch_dense_bwd(dtype, in, fq_acts[l], c->d_mlp_w[l], cur, other, d_dw, d_dw + (size_t)fin * m->features[l], mc, fin, m->features[l], st);
+        cur = other; other = (cur == d_t0) ? d_t1 : d_t0;
+      }
+      launch_add_inplace(d_gx, cur, mc * D, st);
+    }
+    HIPCHK_D(hipMemcpyAsync((char*)acq_out + (size_t)q0 * es, d_acq, (size_t)mc * es, hipMemcpyDeviceToHost, st));
+    HIPCHK_D(hipMemcpyAsync(grad_out + (size_t)q0 * D, d_gx, (size_t)mc * D * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIPCHK_D(hipStreamSynchronize(st));
+  }
+  HIPCHK_D(hipGetLastError());
+#undef HIPCHK_D
+  if (bad) {
+    fill_nan(acq_out, (size_t)M, dtype);
+    for (int64_t i = 0; i < M * D; ++i) grad_out[i] = NAN;
+    return HBO_NOT_PD;
+  }
+  return HBO_OK;
+}

@@ -90,7 +90,7 @@ __device__ __forceinline__ float fast_rsqrt(float d) { return rsqrt(d); }
 // potf2).  The inverse rides in its shadow: V starts as I and takes the same eliminations, V -= f (inv * V[j,:]); row j
 // of V is final after step j-1 and never touched again, and M = L^-1 = diag(1/L_jj) V.  Its MFMA is independent of the
 // S chain and issues while the next pivot is being prepared.
-// Four columns per step, no masks, results written as they become final (HBO_LEAF4, default).  The 4x4 pivot block
+// Four columns per step, no masks, results written as they become final.  The 4x4 pivot block
 // P = S[j..j+3][j..j+3] reaches every lane through ten readlanes and its Cholesky factor (l10 l20 l30 l21 l31 l32, four
 // inverse pivots) is computed redundantly by all lanes; rows j..j+3 of S and of V are gathered into every lane group
 // (ds_bpermute), each lane forms the four elimination vectors f_t = (s_t - sum_{u<t} l_tu f_u) / pivot_t, lane group q feeds
@@ -100,10 +100,8 @@ __device__ __forceinline__ float fast_rsqrt(float d) { return rsqrt(d); }
 // rows / columns that are already final is never read again (the tile's upper triangle holds leftovers; the final store of L
 // zeroes it, M's upper triangle is exactly zero), and the per-column scaling pass at the end is gone.  A pivot <= 0 or NaN
 // needs no branch either: v_rsq of it is NaN or inf, the Newton correction turns inf into NaN (0 * inf), NaN spreads --
-// the failing column is read off the inverse pivots afterwards.  Two columns per step with masks: 4084 cycles per leaf.
-#ifndef HBO_LEAF4
-#define HBO_LEAF4 1
-#endif
+// the failing column is read off the inverse pivots afterwards.  (The two-columns-per-step leaf with masks it replaced:
+// 4084 cycles per leaf against ~3000, profiles/r02_potrf_chain.md.)
 template <typename T>
 __device__ __forceinline__ int leaf_cholesky4(typename Mma<T>::acc_t& acc, T* dt, T* sM, T* dinv_out, T* Wg, int64_t ldw, int lane) {
   typedef typename Mma<T>::acc_t acc_t;
@@ -175,120 +173,6 @@ __device__ __forceinline__ int leaf_cholesky4(typename Mma<T>::acc_t& acc, T* dt
   return badmask ? (int)__builtin_ctzll(badmask) : -1;
 }
 
-template <typename T>
-__device__ __forceinline__ int leaf_cholesky(typename Mma<T>::acc_t& acc, typename Mma<T>::acc_t& vinv, T* dinv_out,
-                                             int lane) {
-  const int l15 = lane & 15, lq = lane >> 4;
-  int bad_col = -1;
-  T myinv = (T)1;
-#pragma unroll
-  for (int r = 0; r < 4; ++r) vinv[r] = (Mma<T>::crow(lane, r) == l15) ? (T)1 : (T)0;
-  if constexpr (sizeof(T) == 8) {
-    // fp64: two columns per step.  Rows j and j+1 (j even) sit in the same accumulator register of two neighbouring
-    // 16-lane groups, so both pivots and l10 = S[j+1][j] / sqrt(d00) come from three readlanes, the second pivot is
-    // d11 - l10^2 without waiting for an update, and f1 = (S[j+1][:] - l10 f0) / sqrt(d11') follows from the
-    // un-updated row j+1 (row j reaches its lanes by a 16-lane swap).  The two rank-1 updates become ONE MFMA with
-    // two of its four K slices in use -- algebraically the same elimination, half the MFMA round trips on the chain.
-#pragma unroll
-    for (int j = 0; j < 16; j += 2) {
-      const int pr = j >> 2, pq0 = j & 3, pq1 = pq0 + 1;   // row = lq + 4 reg
-      T d00 = readlane_t(acc[pr], j + 16 * pq0);
-      const T d10 = readlane_t(acc[pr], j + 16 * pq1);
-      const T d11 = readlane_t(acc[pr], j + 1 + 16 * pq1);
-      const T own = acc[pr];                                 // S[j][l15] (lq == pq0) / S[j+1][l15] (lq == pq1)
-      const T vown = vinv[pr];                               // V[j][l15] / V[j+1][l15]
-      const T own_x = swap16(own), vown_x = swap16(vown);
-      const T sj = (lq == pq1) ? own_x : own;                // S[j][l15] in both lane groups
-      const T vj = (lq == pq1) ? vown_x : vown;
-      if (!(d00 > (T)0)) { if (bad_col < 0) bad_col = j; d00 = (T)NAN; }
-      const T inv0 = fast_rsqrt(d00);
-      const T l10 = d10 * inv0;
-      T d11p = fma(-l10, l10, d11);
-      if (!(d11p > (T)0)) { if (bad_col < 0) bad_col = j + 1; d11p = (T)NAN; }
-      const T inv1 = fast_rsqrt(d11p);
-      dinv_out[j] = inv0; dinv_out[j + 1] = inv1;
-      if (l15 == j) myinv = inv0;
-      if (l15 == j + 1) myinv = inv1;
-      const T f0 = (l15 > j) ? sj * inv0 : (T)0;
-      const T f1 = (l15 > j + 1) ? (own - f0 * l10) * inv1 : (T)0;
-      const T a = (lq == pq0) ? f0 : (lq == pq1 ? f1 : (T)0);
-      acc = Mma<T>::mma(-a, a, acc);
-      __builtin_amdgcn_sched_barrier(0);
-      const T h0 = vj * inv0;                                // inv0 * V[j][l15]
-      const T h1 = (vown - l10 * h0) * inv1;                 // inv1 * (V[j+1][l15] - l10 h0): row j+1 after step j
-      const T b = (lq == pq0) ? h0 : (lq == pq1 ? h1 : (T)0);
-      vinv = Mma<T>::mma(-a, b, vinv);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  } else if constexpr (true) {
-    // fp32 (row = 4 lq + reg): rows j and j+1 sit in two registers of the SAME 16-lane group, so the second vector has
-    // to come from other lanes to occupy a K slice of its own: the neighbouring group gets copies of both rows (two
-    // 16-lane swaps issued before the pivot chain starts) and computes f1 / h1 itself.
-#pragma unroll
-    for (int j = 0; j < 16; j += 2) {
-      const int r0 = j & 3, pq = j >> 2, pp = pq ^ 1;       // holder group pq, partner group pp
-      T d00 = readlane_t(acc[r0], j + 16 * pq);
-      const T d10 = readlane_t(acc[r0 + 1], j + 16 * pq);
-      const T d11 = readlane_t(acc[r0 + 1], j + 1 + 16 * pq);
-      const T s0x = swap16(acc[r0]), s1x = swap16(acc[r0 + 1]);
-      const T v0x = swap16(vinv[r0]), v1x = swap16(vinv[r0 + 1]);
-      const T s0 = (lq == pp) ? s0x : acc[r0];               // S[j][l15]   in both groups
-      const T s1 = (lq == pp) ? s1x : acc[r0 + 1];           // S[j+1][l15]
-      const T v0 = (lq == pp) ? v0x : vinv[r0];
-      const T v1 = (lq == pp) ? v1x : vinv[r0 + 1];
-      if (!(d00 > (T)0)) { if (bad_col < 0) bad_col = j; d00 = (T)NAN; }
-      const T inv0 = fast_rsqrt(d00);
-      const T l10 = d10 * inv0;
-      T d11p = fmaf(-l10, l10, d11);
-      if (!(d11p > (T)0)) { if (bad_col < 0) bad_col = j + 1; d11p = (T)NAN; }
-      const T inv1 = fast_rsqrt(d11p);
-      dinv_out[j] = inv0; dinv_out[j + 1] = inv1;
-      if (l15 == j) myinv = inv0;
-      if (l15 == j + 1) myinv = inv1;
-      const T f0 = (l15 > j) ? s0 * inv0 : (T)0;
-      const T f1 = (l15 > j + 1) ? (s1 - f0 * l10) * inv1 : (T)0;
-      const T a = (lq == pq) ? f0 : (lq == pp ? f1 : (T)0);
-      acc = Mma<T>::mma(-a, a, acc);
-      __builtin_amdgcn_sched_barrier(0);
-      const T h0 = v0 * inv0;
-      const T h1 = (v1 - l10 * h0) * inv1;
-      const T b = (lq == pq) ? h0 : (lq == pp ? h1 : (T)0);
-      vinv = Mma<T>::mma(-a, b, vinv);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  } else {
-#pragma unroll
-  for (int j = 0; j < 16; ++j) {
-    // element (j,j): f64 layout row = lq + 4 reg ; f32 layout row = 4 lq + reg
-    const int pr = Mma<T>::crow(0, 0) == 0 && Mma<T>::crow(16, 0) == 1 ? (j >> 2) : (j & 3);   // reg index
-    const int pq = Mma<T>::crow(16, 0) == 1 ? (j & 3) : (j >> 2);                                // lq of the holder
-    T d = readlane_t(acc[pr], j + 16 * pq);
-    if (!(d > (T)0)) {   // not PD (or NaN): propagate NaN like jax.scipy.linalg.cholesky
-      if (bad_col < 0) bad_col = j;
-      d = (T)NAN;
-    }
-    const T inv = fast_rsqrt(d);
-    dinv_out[j] = inv;                       // every lane stores the same value: no exec-mask round trip
-    if (l15 == j) myinv = inv;
-    // f_c for c = l15 > j, from row j (lanes with lq == pq hold S[j][l15] in reg pr)
-    const T f = (lq == pq && l15 > j) ? acc[pr] * inv : (T)0;
-    acc = Mma<T>::mma(-f, f, acc);
-    // the inverse's operand is read only now: its previous MFMA has long finished, and nothing of it sits between
-    // the pivot broadcast and the S update (keeps the hazard waits of the second accumulator off the chain)
-    __builtin_amdgcn_sched_barrier(0);
-    const T h = (lq == pq) ? vinv[pr] * inv : (T)0;      // inv * V[j][l15]
-    vinv = Mma<T>::mma(-f, h, vinv);
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  }
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    acc[r] *= myinv;                                       // column l15 of L (rows >= l15 are the meaningful ones)
-    vinv[r] *= dinv_out[Mma<T>::crow(lane, r)];            // M = diag(1/L_jj) V  (dinv_out: this wave's own stores)
-  }
-  return bad_col;
-}
-
 // LDS-resident factorisation of one 128x128 diagonal block as 36 packed 16x16 lower tiles (78 KB
 // for fp64, so the workgroup fits on a CU next to a running GEMM workgroup):
 //   leaf   : wave 0 factors the symmetric diagonal tile on MFMA (leaf_cholesky),
@@ -349,21 +233,8 @@ __device__ __forceinline__ void potf2_body(const TaskDesc& t, int p, int* info_s
     acc_t acc;
 #pragma unroll
     for (int r = 0; r < 4; ++r) acc[r] = dt[Mma<T>::crow(lane, r) * TS + l15];
-#if HBO_LEAF4
     const int bad = leaf_cholesky4<T>(acc, dt, sM, sDinv + jb * 16, Wb + (int64_t)(jb * 16) * ld + jb * 16, ld, lane);
     if (bad >= 0 && lane == 0) atomicMin(info_slot, p * NB + jb * 16 + bad + 1);
-#else
-    acc_t vinv;
-    const int bad = leaf_cholesky<T>(acc, vinv, sDinv + jb * 16, lane);
-    if (bad >= 0 && lane == 0) atomicMin(info_slot, p * NB + jb * 16 + bad + 1);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = Mma<T>::crow(lane, r);
-      dt[row * TS + l15] = acc[r];
-      sM[row * TS + l15] = vinv[r];
-      gst(Wb + (int64_t)(jb * 16 + row) * ld + jb * 16 + l15, vinv[r]);   // leaf inverse (lower triangular)
-    }
-#endif
   };
   auto solve_tile = [&](int jb, int R) {   // rows of tile (R, jb): X = A M^T, in place
     T* xt = sT + tri_index(R, jb) * TILE_ELEMS;

@@ -23,13 +23,9 @@ struct hbo_ctx {
                              // look-ahead): 1 = potf2 only, 2 = trsm and the chain's column updates too
   int* d_yield = nullptr;    // per-CU table (cu_token() -> panel-chain workgroups running there)
   int* gemm_yield = nullptr; // run_potrf -> trtri_level: GemmArgs::yield_flag of the launches that co-run with the panel chain
-  int opt_trtri_gran = 0;    // panels between two launches of the inverse's computable pieces during the factorisation (0: auto)
   int opt_small_nblk = 32;   // matrices up to this many 128-blocks use 64x64 GEMM tiles in trtri / lauum
   int opt_persist_free = -1; // bulk trailing update runs as 2*(CUs - this) persistent workgroups (-1: auto, see run_potrf)
-  int opt_lauum_split = 0;     // single matrix: W11^T W11 of K^-1 = W^T W runs beside the tail of the inverse (two-launch lauum; measured
-                               // neutral: N = 8192 11.68 -> 11.78 ms -- the tail of the inverse slows by what the early part saves)
   int opt_post_chunk = 8192;   // posterior / acquisition: candidates per pass (the cross-Gram workspace is npad x this, whatever M)
-  int opt_bulk_tail = 1;       // persistent bulk update: 64-tiles for a partly filled last round (1), for the whole last round (2), never (0)
   int opt_trtri_bf16x3 = 1;    // fp32, one matrix: the products of the block-recursive inverse on the bf16 cores from level trtri3_min_s on
   int opt_trtri3_min_s = 8;
   TaskDesc trtri_host_task = {};   // host copy of the single task's descriptor (pointers, ld) for those launches; valid when .A != null
@@ -39,7 +35,6 @@ struct hbo_ctx {
   int opt_syrk_bf16x3 = 1;     // fp32 factorisations: trailing updates on the bf16 matrix cores (exact three-way split of the panels, post3.hip)
   int opt_post_bf16x3 = 1;     // fp32 posterior product on the bf16 matrix cores (three-way exact split of both operands, post3.hip); 0: fp32 MFMA
   int opt_trtri_at = 0;        // single matrix: panel count (in 64ths of the block count) after which the inverse starts beside the chain (0: 5/8)
-  int opt_trtri_small_wgs = 2; // ... and workgroups per CU of their 64-tile form
   int opt_trtri_free = 48;   // CUs the inverse products that co-run with the panel chain leave free (0: one tile per workgroup)
   int* trtri_counters = nullptr; int trtri_counter_next = 0;   // run_potrf -> trtri_level: tile counters of those launches
   int n_cus = 256;
@@ -55,8 +50,6 @@ struct hbo_ctx {
   size_t pool_bytes = 0;                       // bytes parked in pool_free
   size_t pool_cap = (size_t)48 << 30;          // lowered to a quarter of the device memory at context creation
   int opt_lookahead = 1;
-  int opt_f1_on_chain = 1;         // F1 on the panel stream (no event hops around it)
-  int opt_dynamic_tiles = 1;       // persistent bulk update draws its tiles from a counter
   int opt_overlap_trtri = 1;
   std::string err;
   ModelDev* h_model = nullptr;      // pinned: uploaded without a staging copy or a synchronisation

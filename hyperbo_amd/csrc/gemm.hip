@@ -202,29 +202,10 @@ __device__ __forceinline__ bool decode_job(const GemmArgs& g, TileJob<T>& j, con
         // always received the longest of every 8 tiles); column-major with every second group of 8 reversed: 412
         // slots, 3.38 ms; this order: 481 slots, 3.08 ms.
         int lin = bxi;
-        const int nrow = g.lphase == 1 ? (g.lsplit < nblk ? g.lsplit : nblk) : nblk;
-        if (lin >= nrow * (nrow + 1) / 2) return false;
+        if (lin >= nblk * (nblk + 1) / 2) return false;
         i = 0;
         while (lin > i) { lin -= i + 1; ++i; }
         jt = lin;
-        if (g.lphase) {
-          // two-launch form: K^-1 = W^T W = (rows < split of W)^T (...) + (rows >= split)^T (...); the first term only
-          // touches W11 = W[0:split, 0:split], which the overlapped inverse finishes while the factorisation still runs
-          const int64_t ks = (int64_t)g.lsplit * HBO_TILE;
-          const int64_t kb = (int64_t)i * TM;
-          const T* W = static_cast<const T*>(t.W);
-          int64_t k0, k1;
-          if (g.lphase == 1) { k0 = kb; k1 = ks; j.beta = 0; }
-          else if (kb < ks) { k0 = ks; k1 = (int64_t)nblk * HBO_TILE; j.beta = 1; }
-          else { k0 = kb; k1 = (int64_t)nblk * HBO_TILE; j.beta = 0; }
-          j.A = W + k0 * ld + (int64_t)i * TM;
-          j.B = W + k0 * ld + (int64_t)jt * TM;
-          j.C = static_cast<T*>(t.S) + (int64_t)i * TM * ld + (int64_t)jt * TM;
-          j.lda = j.ldb = j.ldc = ld;
-          j.ksteps = (int)((k1 - k0) / BKE);
-          j.alpha = (T)1;
-          return j.ksteps > 0;
-        }
       } else {
         // 64-tiles (small / batched matrices): same row-major order; the tile right of an even diagonal tile is
         // computed too, so that every 128x128 block on the diagonal is complete (the contraction kernel reads whole

@@ -76,9 +76,6 @@ struct GemmArgs {
   int pgx, pgy;     // persistent TRTRI: the tile grid the workgroups walk (set by launch_gemm)
   int* work_counter; // persistent SYRK: zero-initialised tile counter -> workgroups draw tiles dynamically (a faster
                      // workgroup takes more of them) instead of striding over them; null: static stride
-  int lsplit, lphase; // LAUUM in two launches (128-tiles): phase 1 = tiles i, j < lsplit summed over the rows k < lsplit*128 only
-                      // (needs W[0:lsplit, 0:lsplit], final early), phase 2 = every tile over the rest of its rows, accumulating
-                      // into the phase-1 tiles; lphase 0 = one launch over everything
   int dbg;          // HBO_GEMM_TIMING builds: 1 -> this launch records per-workgroup wall-clock stamps
   int* yield_flag;  // non-null (background launches: bulk update, overlapped inverse): per-CU table indexed by cu_token(); a
                     // workgroup sleeps at a K step while the entry of the CU it runs on is non-zero -- a panel-chain kernel

@@ -1,0 +1,308 @@
+// The objectives of the C ABI: hbo_nll / hbo_objective (hyperbo/gp_utils/objectives.py:29-210 -- NLL, EKL, Euclid, value and
+// gradient in one pass: features -> Gram -> blocked Cholesky with the augmented rows -> inverse -> K^-1 -> contraction) and its
+// task-sharded form hbo_objective_sharded (device-side reduction + one in-place all-reduce).
+#include "api_internal.h"
+
+extern "C" int hbo_nll(hbo_ctx* c, const hbo_model* m, hbo_dataset* ds, double* nll_sum, double* nll_per_task,
+                       double* grad_sum) {
+  return hbo_objective(c, m, ds, HBO_OBJ_NLL, nll_sum, nll_per_task, grad_sum);
+}
+
+// Task-sharded form (hbo_objective_sharded): the sums over this rank's tasks are formed on the device, all-reduced in place
+// over the context's RCCL communicator and copied to the host once.
+struct ShardReq { double* count; double* timing; };
+int comm_allreduce_device(hbo_ctx* c, double* d_buf, int count, hipStream_t st);   // comm.hip
+void launch_shard_reduce(const double* nll, const double* grad, const int* info, int T, int out_stride, const int* map,
+                         const double* mlp, const int* mlp_seg, int n_mlp_seg, double* out, int out_count, hipStream_t st);   // gram.hip
+
+static int objective_impl(hbo_ctx* c, const hbo_model* m_in, hbo_dataset* ds, int objective, double* nll_sum,
+                          double* nll_per_task, double* grad_sum, const ShardReq* sh) {
+  if (!c || !nll_sum || !m_in || (!ds && !sh)) return fail(c, HBO_ERR_ARG, "hbo_objective: null argument");
+  if (objective != HBO_OBJ_NLL && objective != HBO_OBJ_EKL && objective != HBO_OBJ_EUC) return fail(c, HBO_ERR_ARG, "hbo_objective: unknown objective id");
+  HIPCHK(c, hipSetDevice(c->device));
+  hbo_model mcopy = *m_in;
+  if (objective != HBO_OBJ_NLL) mcopy.eps = 0.0;   // objectives.py:63-65: cov_model = K + noise I, no jitter
+  const hbo_model* m = &mcopy;
+  const int obj = objective;
+  const bool euc = obj == OBJ_EUC;
+  int rc = validate_model(c, m);
+  if (rc) return rc;
+  if (ds && ds->ntasks > 0 && (m->dtype != ds->dtype || m->input_dim != ds->D)) return fail(c, HBO_ERR_ARG, "hbo_objective: model/dataset dtype or input_dim mismatch");
+  hbo_grad_layout lay;
+  hbo_grad_layout_of(m, &lay);
+  const bool want_grad = grad_sum != nullptr;
+  *nll_sum = 0;
+  if (want_grad) for (int i = 0; i < lay.total; ++i) grad_sum[i] = 0;
+  const int T = ds ? ds->ntasks : 0;
+  hipStream_t st = c->stream;
+  // sharded: [nll, count, grad] of the whole job, reduced on the device
+  const int red_count = 2 + (want_grad ? lay.total : 0);
+  auto finish_sharded = [&](double* d_red, hipEvent_t ev0, hipEvent_t ev1) -> int {
+    hipEvent_t ev2 = pool_event_timed(c, 2);
+    int rc = c->comm ? comm_allreduce_device(c, d_red, red_count, st) : HBO_OK;
+    if (rc) return rc;
+    HIPCHK(c, hipEventRecord(ev2, st));
+    double* stage = static_cast<double*>(pinned_stage(c, sizeof(double) * red_count));
+    if (!stage) return fail(c, HBO_ERR_HIP, "hbo_objective_sharded: pinned staging buffer");
+    HIPCHK(c, hipMemcpyAsync(stage, d_red, sizeof(double) * red_count, hipMemcpyDeviceToHost, st));
+    HIPCHK(c, hipStreamSynchronize(st));
+    *nll_sum = stage[0];
+    *sh->count = stage[1];
+    if (want_grad) for (int i = 0; i < lay.total; ++i) grad_sum[i] = stage[2 + i];
+    if (sh->timing) {
+      float ms_local = 0, ms_comm = 0;
+      hipEventElapsedTime(&ms_local, ev0, ev1); hipEventElapsedTime(&ms_comm, ev1, ev2);
+      sh->timing[0] = ms_local; sh->timing[1] = 1e3 * ms_comm;
+    }
+    return HBO_OK;
+  };
+  if (T == 0) {
+    if (!sh) return HBO_OK;
+    // a rank beyond the task count: zeros into the collective
+    HIPCHK(c, hipSetDevice(c->device));
+    double* d_red = static_cast<double*>(ws_get(c, WS_SHARD_RED, sizeof(double) * red_count));
+    if (!d_red) return HBO_ERR_HIP;
+    hipEvent_t ev0 = pool_event_timed(c, 0), ev1 = pool_event_timed(c, 1);
+    HIPCHK(c, hipEventRecord(ev0, st));
+    HIPCHK(c, hipMemsetAsync(d_red, 0, sizeof(double) * red_count, st));
+    HIPCHK(c, hipEventRecord(ev1, st));
+    return finish_sharded(d_red, ev0, ev1);
+  }
+  if (obj != OBJ_NLL) for (TaskHost* t : ds->tasks) if (!t->ydiv) return fail(c, HBO_ERR_UNSUPPORTED, "hbo_objective: divergence objectives need m + 1 <= 128 aligned columns");
+  const int dtype = ds->dtype;
+  prof_begin(c);
+  hipEvent_t ev_sh0 = nullptr;
+  if (sh) { ev_sh0 = pool_event_timed(c, 0); HIPCHK(c, hipEventRecord(ev_sh0, st)); }
+  rc = upload_model(c, m);
+  if (rc) return rc;
+
+  // workspaces + descriptors
+  ds->h_desc.resize(T);
+  for (int k = 0; k < T; ++k) {
+    TaskHost* t = ds->tasks[k];
+    rc = ensure_task_workspace(c, dtype, t, want_grad && !euc, obj == OBJ_NLL ? 1 : t->m + 1);
+    if (rc) return rc;
+    if (needs_mlp(m)) { rc = t->feat.ensure(c, m, t->n); if (rc) return rc; }
+    if (needs_mlp(m) && want_grad) {
+      int maxf = m->input_dim;
+      for (int l = 0; l < m->n_layers; ++l) maxf = std::max(maxf, (int)m->features[l]);
+      const size_t need = (size_t)t->n * maxf;
+      if (t->dF_elems < need) {
+        if (t->dF) hipFree(t->dF);
+        if (t->dtmp) hipFree(t->dtmp);
+        t->dF = t->dtmp = nullptr;
+        HIPCHK(c, hbo_malloc(c, (void**)&t->dF, need * sizeof(double)));
+        HIPCHK(c, hbo_malloc(c, (void**)&t->dtmp, need * sizeof(double)));
+        t->dF_elems = need;
+      }
+    }
+    fill_desc(ds->h_desc[k], t, m, dtype, obj);
+  }
+  if (!ds->d_desc) HIPCHK(c, hbo_malloc(c, (void**)&ds->d_desc, sizeof(TaskDesc) * T));
+  const int out_stride = (m->kernel_id == HBO_KERNEL_DOT ? 0 : m->n_lengthscale) + 6 + mean_feature_dim(m);
+  const size_t pack_bytes = sizeof(double) * T * (1 + (size_t)out_stride) + sizeof(int) * T;
+  if (ds->pack_bytes < pack_bytes) {
+    if (ds->d_pack) hipFree(ds->d_pack);
+    ds->d_pack = nullptr; ds->pack_bytes = 0;
+    HIPCHK(c, hbo_malloc(c, (void**)&ds->d_pack, pack_bytes));
+    ds->pack_bytes = pack_bytes;
+  }
+  ds->d_nll = ds->d_pack; ds->d_gradout = ds->d_pack + T; ds->d_info = reinterpret_cast<int*>(ds->d_pack + T + (size_t)T * out_stride);
+  // small transfers go through one pinned buffer: descriptors up (only when they changed), results down in one copy
+  unsigned char* stage = static_cast<unsigned char*>(pinned_stage(c, std::max(sizeof(TaskDesc) * T, pack_bytes)));
+  if (!stage) return fail(c, HBO_ERR_HIP, "hbo_objective: pinned staging buffer");
+  if (ds->h_desc_dev.size() != (size_t)T || memcmp(ds->h_desc_dev.data(), ds->h_desc.data(), sizeof(TaskDesc) * T) != 0) {
+    HIPCHK(c, hipEventSynchronize(c->ev_upload));
+    memcpy(stage, ds->h_desc.data(), sizeof(TaskDesc) * T);
+    HIPCHK(c, hipMemcpyAsync(ds->d_desc, stage, sizeof(TaskDesc) * T, hipMemcpyHostToDevice, st));
+    ds->h_desc_dev = ds->h_desc;
+  }
+  HIPCHK(c, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ds->d_info), INT_MAX, T, st));
+
+  const int max_nblk = ds->max_nblk, max_npad = max_nblk * HBO_TILE;
+  {
+    ProfScope ps(c, "features", 1);
+    if (needs_mlp(m)) for (int k = 0; k < T; ++k) run_mlp(c, m, ds->tasks[k]->X, ds->tasks[k]->n, ds->tasks[k]->feat.acts.data());
+    launch_aug_rows(dtype, ds->d_desc, T, max_npad, c->d_model, st);
+  }
+  int max_naug = 1;
+  for (int k = 0; k < T; ++k) max_naug = std::max(max_naug, ds->h_desc[k].naug);
+  TrtriProgress trtri_pg;
+  hipStream_t side = st; hipEvent_t ev_side = nullptr;
+  const bool early_trtri = want_grad && c->opt_lookahead && c->opt_overlap_trtri && max_nblk >= 4;
+  if (!euc) {
+    {
+      ProfScope ps(c, "gram", 1);
+      GramArgs g = {}; g.kernel_id = c->h_model->kernel_id; g.tasks = ds->d_desc; g.fdim = feature_dim(m); g.symmetric = 1; g.padded = 1;
+      launch_gram(dtype, g, c->d_model, dim3(max_nblk, max_nblk, T), st);
+    }
+    {
+      std::vector<int> h_nblk(T);
+      for (int k = 0; k < T; ++k) h_nblk[k] = ds->h_desc[k].nblk;
+      c->trtri_host_task = TaskDesc{};
+      if (T == 1) c->trtri_host_task = ds->h_desc[0];
+      ProfScope ps(c, "potrf", 1); run_potrf(c, dtype, ds->d_desc, T, max_nblk, ds->d_info, early_trtri ? &trtri_pg : nullptr, h_nblk.data());
+    }
+    // the small reductions (log-determinant + quadratic form now, alpha = W^T z and d nll / d mu after the inverse) run on
+    // the idle panel stream beside the inverse and K^-1 = W^T W instead of between them (0.14 ms at cfg 2)
+    side = (want_grad && obj == OBJ_NLL && c->opt_lookahead) ? c->stream2 : st;
+    if (side != st) { hipEvent_t e = pool_event(c, 2); hipEventRecord(e, st); hipStreamWaitEvent(side, e, 0); }
+    { ProfScope ps(c, "nll_reduce", 1, side); launch_nll_reduce(dtype, ds->d_desc, T, ds->d_info, ds->d_nll, side); }
+  }
+
+  const int fdim = feature_dim(m);
+  const int nacc = grad_nacc(m->kernel_id, fdim);
+  const int64_t stride_task = (int64_t)(max_nblk * (max_nblk + 1)) * nacc;   // two half-tile slots per lower tile
+  if (want_grad || euc) {   // EUC: the Frobenius norm of the value comes out of the contraction pass
+    const size_t pb = sizeof(double) * (stride_task * T + (size_t)HBO_GRAD_PRE_ROWS * nacc * T);   // per-tile partials + their pre-reduction
+    if (ds->partials_bytes < pb) { if (ds->d_partials) hipFree(ds->d_partials); HIPCHK(c, hbo_malloc(c, (void**)&ds->d_partials, pb)); ds->partials_bytes = pb; }
+    if (!euc) {
+      { ProfScope ps(c, "trtri", 1);
+        run_trtri(c, dtype, ds->d_desc, T, max_nblk, &trtri_pg); }
+      if (side != st) { hipEvent_t e = pool_event(c, 3); hipEventRecord(e, st); hipStreamWaitEvent(side, e, 0); }   // W is complete
+      { ProfScope ps(c, "wt_z", 1, side);
+        for (int b = 0; b < max_naug; ++b) launch_wt_z(dtype, ds->d_desc, T, max_nblk, b, b, max_npad, side); }
+      if (side != st) {
+        launch_dmu(dtype, ds->d_desc, T, obj, side);
+        ev_side = pool_event(c, 4); hipEventRecord(ev_side, side);
+      }
+      { ProfScope ps(c, "lauum", 1); run_lauum(c, dtype, ds->d_desc, T, max_nblk); }
+      if (ev_side) hipStreamWaitEvent(st, ev_side, 0);
+    }
+    { ProfScope ps(c, "grad_contract", 1);
+      if (!ev_side) launch_dmu(dtype, ds->d_desc, T, obj, st);
+      launch_grad_contract(dtype, ds->d_desc, T, max_nblk, c->d_model, m->kernel_id, fdim, obj, ds->d_partials, stride_task, st);
+      launch_grad_finalize(dtype, ds->d_desc, T, c->d_model, m->kernel_id, fdim, obj, ds->d_partials, stride_task, ds->d_gradout, out_stride, euc ? ds->d_nll : nullptr, st,
+                           ds->d_partials + stride_task * T, max_nblk); }
+  }
+  if (want_grad) {
+    if (needs_mlp(m)) {
+      // d nll / d features -> MLP backward (hyperbo/gp_utils/basis_functions.py:24-36), summed over tasks
+      ProfScope ps(c, "mlp_backward", 1);
+      const int L = m->n_layers, flast = m->features[L - 1];
+      size_t tot = 0; int fin0 = m->input_dim;
+      std::vector<size_t> woff(L), boff(L);
+      for (int l = 0; l < L; ++l) { woff[l] = tot; tot += (size_t)fin0 * m->features[l]; boff[l] = tot; tot += m->features[l]; fin0 = m->features[l]; }
+      if (ds->mlpgrad_elems < tot) { if (ds->d_mlpgrad) hipFree(ds->d_mlpgrad); HIPCHK(c, hbo_malloc(c, (void**)&ds->d_mlpgrad, tot * sizeof(double))); ds->mlpgrad_elems = tot; }
+      HIPCHK(c, hipMemsetAsync(ds->d_mlpgrad, 0, tot * sizeof(double), st));
+      for (int k = 0; k < T; ++k) HIPCHK(c, hipMemsetAsync(ds->tasks[k]->dF, 0, (size_t)ds->tasks[k]->n * flast * sizeof(double), st));
+      if (m->kernel_uses_mlp) {
+        launch_grad_feat(dtype, ds->d_desc, T, max_nblk, c->d_model, m->kernel_id, flast, obj, st);
+        if (euc) launch_scale_dF(ds->d_desc, T, (int64_t)max_npad, flast, st);
+      }
+      if (m->mean_id == HBO_MEAN_LINEAR_MLP) launch_grad_feat_mean(dtype, ds->d_desc, T, (int64_t)max_npad, c->d_model, flast, st);
+      for (int k = 0; k < T; ++k) {
+        TaskHost* t = ds->tasks[k];
+        double* cur = t->dF; double* other = t->dtmp;
+        for (int l = L - 1; l >= 0; --l) {
+          const int fin = l ? m->features[l - 1] : m->input_dim;
+          const void* in = l ? t->feat.acts[l - 1] : t->X;
+          launch_dense_bwd(dtype, in, t->feat.acts[l], c->d_mlp_w[l], cur, l ? other : nullptr,
+                           ds->d_mlpgrad + woff[l], ds->d_mlpgrad + boff[l], t->n, fin, m->features[l], st);
+          std::swap(cur, other);
+        }
+      }
+    }
+  }
+  if (sh) {
+    // [nll, count, grad] of this rank's tasks in the caller's gradient layout, on the device: entry j of a task's gradient block
+    // goes to map[j] (the scatter the host loop below does), the MLP gradient -- already summed over the tasks -- by segments
+    const int n_ls = m->kernel_id == HBO_KERNEL_DOT ? 0 : m->n_lengthscale;
+    const int fm = mean_feature_dim(m);
+    std::vector<int> hmap(out_stride + 3 * 2 * HBO_MAX_MLP_LAYERS, -1);
+    if (want_grad) {
+      for (int d = 0; d < n_ls; ++d) hmap[d] = lay.lengthscale < 0 ? -1 : lay.lengthscale + d;
+      hmap[n_ls] = lay.signal_variance; hmap[n_ls + 1] = lay.noise_variance; hmap[n_ls + 2] = lay.constant;
+      hmap[n_ls + 3] = lay.dot_prod_sigma; hmap[n_ls + 4] = lay.dot_prod_bias;
+      for (int d = 0; d < fm; ++d) hmap[n_ls + 5 + d] = lay.linear_kernel < 0 ? -1 : lay.linear_kernel + d;
+      hmap[n_ls + 5 + fm] = lay.linear_bias;
+    }
+    int nseg = 0;
+    if (want_grad && needs_mlp(m)) {
+      int pos = 0, fin0 = m->input_dim;
+      for (int l = 0; l < m->n_layers; ++l) {
+        const int wn = fin0 * m->features[l], bn = m->features[l];
+        int* sg = hmap.data() + out_stride + 3 * nseg;
+        sg[0] = lay.mlp_kernel[l]; sg[1] = pos; sg[2] = wn; ++nseg; pos += wn;
+        sg += 3; sg[0] = lay.mlp_bias[l]; sg[1] = pos; sg[2] = bn; ++nseg; pos += bn;
+        fin0 = m->features[l];
+      }
+    }
+    int* d_map = static_cast<int*>(ws_get(c, WS_SHARD_MAP, sizeof(int) * hmap.size()));
+    double* d_red = static_cast<double*>(ws_get(c, WS_SHARD_RED, sizeof(double) * red_count));
+    if (!d_map || !d_red) return HBO_ERR_HIP;
+    HIPCHK(c, hipEventSynchronize(c->ev_upload));
+    memcpy(stage, hmap.data(), sizeof(int) * hmap.size());
+    HIPCHK(c, hipMemcpyAsync(d_map, stage, sizeof(int) * hmap.size(), hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipEventRecord(c->ev_upload, st));
+    launch_shard_reduce(ds->d_nll, want_grad ? ds->d_gradout : nullptr, ds->d_info, T, out_stride, d_map, ds->d_mlpgrad, d_map + out_stride, nseg,
+                        d_red, red_count, st);
+    hipEvent_t ev1 = pool_event_timed(c, 1);
+    HIPCHK(c, hipEventRecord(ev1, st));
+    int rcs = finish_sharded(d_red, ev_sh0, ev1);
+    HIPCHK(c, hipGetLastError());
+    prof_collect(c);
+    if (dag_aborted(c)) return objective_impl(c, m_in, ds, objective, nll_sum, nll_per_task, grad_sum, sh);
+    if (rcs) return rcs;
+    return std::isnan(*nll_sum) ? HBO_NOT_PD : HBO_OK;
+  }
+  HIPCHK(c, hipMemcpyAsync(stage, ds->d_pack, pack_bytes, hipMemcpyDeviceToHost, st));
+  const double* h_nll = reinterpret_cast<const double*>(stage);
+  const double* h_grad = h_nll + T;
+  const int* h_info = reinterpret_cast<const int*>(h_grad + (size_t)T * out_stride);
+  std::vector<double> h_mlp;
+  if (want_grad && needs_mlp(m)) {
+    h_mlp.resize(ds->mlpgrad_elems);
+    HIPCHK(c, hipMemcpyAsync(h_mlp.data(), ds->d_mlpgrad, sizeof(double) * ds->mlpgrad_elems, hipMemcpyDeviceToHost, st));
+  }
+  HIPCHK(c, hipStreamSynchronize(st));
+  HIPCHK(c, hipGetLastError());
+  prof_collect(c);
+  // the resident tile-task schedule ran out of its wall-clock bound (it never has; a hang would be a dead GPU): the context
+  // falls back to the launch schedule for good and this evaluation is repeated on it
+  if (dag_aborted(c)) return objective_impl(c, m_in, ds, objective, nll_sum, nll_per_task, grad_sum, sh);
+
+  bool notpd = false;
+  double total = 0;
+  for (int k = 0; k < T; ++k) { total += h_nll[k]; if (h_info[k] != INT_MAX) notpd = true; if (nll_per_task) nll_per_task[k] = h_nll[k]; }
+  *nll_sum = total;
+  if (want_grad) {
+    const int n_ls = m->kernel_id == HBO_KERNEL_DOT ? 0 : m->n_lengthscale;
+    const int fm = mean_feature_dim(m);
+    for (int k = 0; k < T; ++k) {
+      const double* o = h_grad + (size_t)k * out_stride;
+      const bool bad = h_info[k] != INT_MAX;
+      auto add = [&](int off, double v) { if (off >= 0) grad_sum[off] += bad ? NAN : v; };
+      for (int d = 0; d < n_ls; ++d) add(lay.lengthscale < 0 ? -1 : lay.lengthscale + d, o[d]);
+      add(lay.signal_variance, o[n_ls]);
+      add(lay.noise_variance, o[n_ls + 1]);
+      add(lay.constant, o[n_ls + 2]);
+      add(lay.dot_prod_sigma, o[n_ls + 3]);
+      add(lay.dot_prod_bias, o[n_ls + 4]);
+      for (int d = 0; d < fm; ++d) add(lay.linear_kernel + d, o[n_ls + 5 + d]);
+      add(lay.linear_bias, o[n_ls + 5 + fm]);
+    }
+    if (needs_mlp(m)) {
+      size_t pos = 0; int fin0 = m->input_dim;
+      for (int l = 0; l < m->n_layers; ++l) {
+        const size_t wn = (size_t)fin0 * m->features[l], bn = m->features[l];
+        for (size_t i = 0; i < wn; ++i) grad_sum[lay.mlp_kernel[l] + i] = notpd ? NAN : h_mlp[pos + i];
+        pos += wn;
+        for (size_t i = 0; i < bn; ++i) grad_sum[lay.mlp_bias[l] + i] = notpd ? NAN : h_mlp[pos + i];
+        pos += bn; fin0 = m->features[l];
+      }
+    }
+  }
+  return notpd ? HBO_NOT_PD : HBO_OK;
+}
+extern "C" int hbo_objective(hbo_ctx* c, const hbo_model* m, hbo_dataset* ds, int objective, double* nll_sum,
+                             double* nll_per_task, double* grad_sum) {
+  if (!ds) return fail(c, HBO_ERR_ARG, "hbo_objective: null argument");
+  return objective_impl(c, m, ds, objective, nll_sum, nll_per_task, grad_sum, nullptr);
+}
+extern "C" int hbo_objective_sharded(hbo_ctx* c, const hbo_model* m, hbo_dataset* ds, int objective, double* value_sum,
+                                     double* count, double* grad_sum, double* timing) {
+  if (!count) return fail(c, HBO_ERR_ARG, "hbo_objective_sharded: null argument");
+  ShardReq sh{count, timing};
+  return objective_impl(c, m, ds, objective, value_sum, nullptr, grad_sum, &sh);
+}

@@ -1,0 +1,241 @@
+// Posterior and acquisition kernels on gfx950: mu = Kxq^T alpha + mean(xq), var = k(xq, xq) - column sums of V^2, fused
+// EI / PI / UCB, the full-covariance epilogue, and d acquisition / d x_query.
+//
+// Reference restated: hyperbo/gp_utils/gp.py:242-305 (predict), bo_utils/acfun.py:96-142 (acquisition),
+// bo_utils/bayesopt.py:116-125 (the gradient L-BFGS-B takes of -ac_func).
+#include "kernfun.h"
+
+namespace {
+// ---------------------------------------------------------------------------------------
+// posterior epilogue: mu = Kxq^T alpha + mean(xq); var = kdiag - sum colsq; acquisition.
+// ---------------------------------------------------------------------------------------
+
+// ---------------------------------------------------------------------------------------
+// d acquisition / d (kernel features of the query), one workgroup per query (bayesopt.py:116-125 differentiates
+// -ac_func w.r.t. a single x; batches of restarts come as M rows).  With l = W k(X,x), beta = W^T l:
+//   mu = k.alpha + m(x), var = k(x,x) - |l|^2, coef_i = a_mu alpha_i - 2 a_var beta_i,
+//   SE/Matern: g_d = sum_i coef_i dk/du_i * 2 (f_d - F_id)/ls_d^2;  dot: g = sum_i coef_i F_i/sigma^2 + a_var 2 f/sigma^2.
+// ---------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void acq_grad_kernel(AcqGradArgs a, const ModelDev* __restrict__ md) {
+  __shared__ double sred[4];
+  __shared__ double s_w[256];
+  __shared__ double s_fq[HBO_MAX_FEATURE_DIM];
+  __shared__ double s_acc[256];
+  __shared__ double s_amu, s_avar;
+  const int64_t q = blockIdx.x;
+  const int tid = threadIdx.x;
+  const int fdim = a.fdim;
+  const int kid = md->kernel_id;
+  const bool is_dot = (kid == HBO_KERNEL_DOT);
+  const T* Fq = static_cast<const T*>(a.Fq) + q * fdim;
+  const T* F = static_cast<const T*>(a.F);
+  const T* Kq = a.Kq ? static_cast<const T*>(a.Kq) + q * a.npad : nullptr;
+  const T* L = a.L ? static_cast<const T*>(a.L) + q * a.npad : nullptr;
+  const T* B = a.B ? static_cast<const T*>(a.B) + q * a.npad : nullptr;
+  const T* al = static_cast<const T*>(a.alpha);
+  for (int d = tid; d < fdim; d += 256) s_fq[d] = (double)Fq[d];
+  double ka = 0, ll = 0;
+  for (int64_t i = tid; i < a.n; i += 256) { ka += (double)Kq[i] * (double)al[i]; const double l = (double)L[i]; ll += l * l; }
+  ka = block_sum(ka, sred);
+  ll = block_sum(ll, sred);
+  if (tid == 0) {
+    const double mu = ka + (double)static_cast<const T*>(a.muq)[q];
+    const double var = (double)static_cast<const T*>(a.kdiag)[q] - ll;
+    const double v2 = (var + a.add_noise) * a.scale;
+    const double sd = sqrt(v2);
+    double val, amu, asd;
+    if (a.acq_id == HBO_ACQ_UCB) { val = mu + a.param * sd; amu = 1.0; asd = a.param; }
+    else if (a.acq_id == HBO_ACQ_PI) { val = (mu - a.param) / sd; amu = 1.0 / sd; asd = -(mu - a.param) / (sd * sd); }
+    else { const double u = (mu - a.param) / sd; val = sd * (norm_pdf(u) + u * norm_cdf(u)); amu = norm_cdf(u); asd = norm_pdf(u); }
+    s_amu = amu; s_avar = asd / (2.0 * sd) * a.scale;
+    static_cast<T*>(a.acq_out)[q] = (T)val;
+    a.dmu[q] = amu;
+  }
+  __syncthreads();
+  const double amu = s_amu, avar = s_avar;
+  // thread layout for the feature reduction: FD = pow2 >= fdim lanes per group, G groups over i
+  int FD = 1; while (FD < fdim) FD <<= 1;
+  const int G = 256 / FD, grp = tid / FD, dl = tid % FD;
+  const double sv = md->sv;
+  const double inv_sigma2 = 1.0 / (md->dot_sigma * md->dot_sigma);
+  double acc = 0;
+  for (int64_t i0 = 0; i0 < a.n; i0 += 256) {
+    const int64_t i = i0 + tid;
+    double w = 0;
+    if (i < a.n) {
+      const double coef = amu * (double)al[i] - 2.0 * avar * (double)B[i];
+      if (is_dot) w = coef * inv_sigma2;
+      else {
+        double u = 0;
+        for (int d = 0; d < fdim; ++d) { const double df = (s_fq[d] - (double)F[i * fdim + d]) * md->inv_ls[d]; u += df * df; }
+        const double k = kfun<double>(kid, u, sv, inv_sigma2, 0.0);
+        w = coef * dk_du<double>(kid, u, k, sv) * 2.0;
+      }
+    }
+    __syncthreads();
+    s_w[tid] = w;
+    __syncthreads();
+    const int lim = (int)((a.n - i0) < 256 ? (a.n - i0) : 256);
+    if (dl < fdim)
+      for (int ii = grp; ii < lim; ii += G) {
+        const double fi = (double)F[(i0 + ii) * fdim + dl];
+        acc += is_dot ? s_w[ii] * fi : s_w[ii] * (s_fq[dl] - fi);
+      }
+  }
+  __syncthreads();
+  s_acc[tid] = acc;
+  __syncthreads();
+  if (grp == 0 && dl < fdim) {
+    double s = 0;
+    for (int g = 0; g < G; ++g) s += s_acc[g * FD + dl];
+    if (is_dot) s += avar * 2.0 * s_fq[dl] * inv_sigma2;
+    else s *= md->inv_ls[dl] * md->inv_ls[dl];
+    a.gfeat[q * fdim + dl] = s;
+  }
+}
+// out[q][d] (+)= dmu[q] * lin_w[d]   (linear / linear_mlp mean, mean.py:62-79)
+__global__ void acq_grad_mean_kernel(const double* dmu, const ModelDev* __restrict__ md, int64_t M, int fm,
+                                     double* out, int accumulate) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= M * fm) return;
+  const double v = dmu[idx / fm] * md->lin_w[idx % fm];
+  out[idx] = accumulate ? out[idx] + v : v;
+}
+__global__ void add_inplace_kernel(double* dst, const double* src, int64_t count) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx < count) dst[idx] += src[idx];
+}
+
+// mupart[b][q] = sum over the 128 rows i of row block b of Kxq[i][q] * alpha[i]: the posterior mean's product
+// Kxq^T alpha (gp.py:300) split by row block, so that its parallelism is (row blocks x queries) -- one thread per
+// query walking all n rows takes ~6 ms whatever the number of queries (latency-bound), which an 8192-candidate
+// chunk paid in full
+template <typename T>
+__global__ void post_mupart_kernel(const T* __restrict__ K, int64_t ldq, int n, const T* __restrict__ al, T* mupart, int64_t M) {
+  const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int b = blockIdx.y;
+  if (q >= M) return;
+  const int i0 = b * HBO_TILE, i1 = min(i0 + HBO_TILE, n);
+  T s0 = (T)0, s1 = (T)0, s2 = (T)0, s3 = (T)0;
+  int i = i0;
+  for (; i + 3 < i1; i += 4) {
+    s0 += K[(int64_t)i * ldq + q] * al[i];
+    s1 += K[(int64_t)(i + 1) * ldq + q] * al[i + 1];
+    s2 += K[(int64_t)(i + 2) * ldq + q] * al[i + 2];
+    s3 += K[(int64_t)(i + 3) * ldq + q] * al[i + 3];
+  }
+  for (; i < i1; ++i) s0 += K[(int64_t)i * ldq + q] * al[i];
+  mupart[(int64_t)b * ldq + q] = (s0 + s1) + (s2 + s3);
+}
+
+template <typename T>
+__global__ void post_epilogue_kernel(PostArgs a) {
+  const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= a.M) return;
+  const T* K = static_cast<const T*>(a.Kxq);
+  const T* al = static_cast<const T*>(a.alpha);
+  T mu = (T)0;
+  if (a.mupart) {   // per-row-block partial sums of Kxq^T alpha (post_mupart_kernel)
+    const T* mp = static_cast<const T*>(a.mupart);
+    for (int b = 0; b < a.nblk; ++b) mu += mp[(int64_t)b * a.ldq + q];
+  } else {
+    for (int64_t i = 0; i < a.n; ++i) mu += K[i * a.ldq + q] * al[i];
+  }
+  mu += static_cast<const T*>(a.muq)[q];
+  T var = static_cast<const T*>(a.kdiag)[q];
+  const T* cs = static_cast<const T*>(a.colsq);
+  T ss = (T)0;
+  for (int b = 0; b < a.nblk; ++b) ss += cs[(int64_t)b * a.ldq + q];
+  var -= ss;
+  if (a.mu_out) static_cast<T*>(a.mu_out)[q] = mu;
+  if (a.var_out) static_cast<T*>(a.var_out)[q] = var;
+  if (a.acq_out) {
+    // GP.predict post-processing (gp.py:607-619) then acfun.py:96-142 in the model dtype
+    const T v2 = (var + (T)a.add_noise) * (T)a.scale;
+    const T sd = sqrt(v2);
+    T r;
+    if (a.acq_id == HBO_ACQ_UCB) r = mu + (T)a.param * sd;
+    else {
+      const T gamma = ((T)a.param - mu) / sd;
+      if (a.acq_id == HBO_ACQ_PI) r = -gamma;
+      else r = (T)((norm_pdf((double)gamma) - (double)gamma * (1.0 - norm_cdf((double)gamma)))) * sd;
+    }
+    static_cast<T*>(a.acq_out)[q] = r;
+  }
+}
+
+// out[a][b] = Kqq[a][b] - sum_i V[i][a] V[i][b]
+template <typename T>
+__global__ void fullcov_kernel(const T* __restrict__ V, int64_t ldq, int npad, const T* __restrict__ Kqq, int64_t M,
+                               T* out) {
+  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t a = blockIdx.y;
+  if (b >= M) return;
+  T s = (T)0;
+  for (int64_t i = 0; i < npad; ++i) s += V[i * ldq + a] * V[i * ldq + b];
+  out[a * M + b] = Kqq[a * M + b] - s;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void tri_matvec_kernel(const T* __restrict__ W, int64_t ld, int npad,
+                                                         const T* __restrict__ x, int64_t xld, int trans,
+                                                         T* out, int64_t old) {
+  const int col = blockIdx.y;
+  if (!trans) {
+    // one wave per output row
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= npad) return;
+    const int lane = threadIdx.x & 63;
+    double s = 0;
+    for (int64_t j = lane; j <= r; j += 64) s += (double)W[r * ld + j] * (double)x[(int64_t)col * xld + j];
+    s = wave_sum(s);
+    if (lane == 0) out[(int64_t)col * old + r] = (T)s;
+  } else {
+    const int64_t j = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (j >= npad) return;
+    T s = (T)0;
+    for (int64_t r = j; r < npad; ++r) s += W[r * ld + j] * x[(int64_t)col * xld + r];
+    out[(int64_t)col * old + j] = s;
+  }
+}
+
+}  // namespace
+void launch_acq_grad(int dtype, const AcqGradArgs& a, const ModelDev* md, hipStream_t st) {
+  if (a.M <= 0) return;
+  if (dtype == HBO_F64) hipLaunchKernelGGL((acq_grad_kernel<double>), dim3((unsigned)a.M), dim3(256), 0, st, a, md);
+  else hipLaunchKernelGGL((acq_grad_kernel<float>), dim3((unsigned)a.M), dim3(256), 0, st, a, md);
+}
+void launch_acq_grad_mean(const double* dmu, const ModelDev* md, int64_t M, int fm, double* out, int accumulate,
+                          hipStream_t st) {
+  if (M * fm <= 0) return;
+  hipLaunchKernelGGL(acq_grad_mean_kernel, dim3((unsigned)((M * fm + 255) / 256)), dim3(256), 0, st, dmu, md, M, fm, out, accumulate);
+}
+void launch_add_inplace(double* dst, const double* src, int64_t count, hipStream_t st) {
+  if (count <= 0) return;
+  hipLaunchKernelGGL(add_inplace_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, dst, src, count);
+}
+void launch_post_epilogue(int dtype, const PostArgs& a, hipStream_t st) {
+  if (a.M <= 0) return;
+  dim3 grid((unsigned)((a.M + 255) / 256));
+  if (a.mupart && a.Kxq && a.n > 0) {
+    dim3 g2(grid.x, (unsigned)a.nblk);
+    if (dtype == HBO_F64) hipLaunchKernelGGL((post_mupart_kernel<double>), g2, dim3(256), 0, st, static_cast<const double*>(a.Kxq), a.ldq, a.n, static_cast<const double*>(a.alpha), static_cast<double*>(a.mupart), a.M);
+    else hipLaunchKernelGGL((post_mupart_kernel<float>), g2, dim3(256), 0, st, static_cast<const float*>(a.Kxq), a.ldq, a.n, static_cast<const float*>(a.alpha), static_cast<float*>(a.mupart), a.M);
+  }
+  if (dtype == HBO_F64) hipLaunchKernelGGL((post_epilogue_kernel<double>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((post_epilogue_kernel<float>), grid, dim3(256), 0, st, a);
+}
+void launch_fullcov(int dtype, const void* V, int64_t ldq, int npad, const void* Kqq, int64_t M, void* out,
+                    hipStream_t st) {
+  if (M <= 0) return;
+  dim3 grid((unsigned)((M + 255) / 256), (unsigned)M);
+  if (dtype == HBO_F64) hipLaunchKernelGGL((fullcov_kernel<double>), grid, dim3(256), 0, st, (const double*)V, ldq, npad, (const double*)Kqq, M, (double*)out);
+  else hipLaunchKernelGGL((fullcov_kernel<float>), grid, dim3(256), 0, st, (const float*)V, ldq, npad, (const float*)Kqq, M, (float*)out);
+}
+void launch_tri_matvec(int dtype, const void* W, int64_t ld, int npad, const void* x, int64_t xld, int m,
+                       int trans, void* out, int64_t old, hipStream_t st) {
+  dim3 grid(trans ? (npad + 255) / 256 : (npad + 3) / 4, m);
+  if (dtype == HBO_F64) hipLaunchKernelGGL((tri_matvec_kernel<double>), grid, dim3(256), 0, st, (const double*)W, ld, npad, (const double*)x, xld, trans, (double*)out, old);
+  else hipLaunchKernelGGL((tri_matvec_kernel<float>), grid, dim3(256), 0, st, (const float*)W, ld, npad, (const float*)x, xld, trans, (float*)out, old);
+}

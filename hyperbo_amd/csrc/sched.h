@@ -17,5 +17,4 @@ bool run_potrf_dag(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, i
 bool dag_aborted(hbo_ctx* c);
 void trtri_advance(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, int max_nblk, int cfin, hipStream_t st, TrtriProgress& pg);
 void run_trtri(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, int max_nblk, TrtriProgress* pg = nullptr);
-void run_lauum(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, int max_nblk, int split = 0, int phase = 0, hipStream_t st = nullptr);
-int lauum_split_for(int cfin, int max_nblk);
+void run_lauum(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, int max_nblk, hipStream_t st = nullptr);

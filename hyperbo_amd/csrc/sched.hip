@@ -52,7 +52,7 @@ void run_potrf(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, int m
   // early inverse: a batch takes every piece as soon as four more panels are final (16.9 against 17.35 ms for 64 tasks
   // of ~2000 points, 3.77 against 3.92 for 8); one large matrix only at half time -- more launches on the side stream
   // take slots from the panel chain (N = 8192: 13.63 ms at 32 panels, 13.8 at 4, 14.0 at 2)
-  int tgran = c->opt_trtri_gran;
+  int tgran = 0;
   // (one large matrix, measured later with the CU yield below: a single call after 13/16 of the panels instead of half --
   //  N = 8192, call after panel 32 / 40 / 44 / 48 / 52 / 56 / 60: 12.42 / 12.37 / 12.34 / 12.25 / 12.21 / 12.30 / 12.50 ms)
   int early_at = -1;   // single-task form: the one panel count after which the side stream gets its work
@@ -76,7 +76,7 @@ void run_potrf(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, int m
   int* const chain_mark = (yield_flag && c->opt_cu_yield >= 2) ? yield_flag : nullptr;   // the chain's wide kernels mark their CUs too
   c->gemm_yield = yield_flag;
   // one tile counter per bulk launch (dynamic tile assignment of the persistent form), zeroed up front
-  int* counters = c->opt_dynamic_tiles ? (int*)ws_get(c, WS_COUNTERS, sizeof(int) * 256) : nullptr;
+  int* counters = (int*)ws_get(c, WS_COUNTERS, sizeof(int) * 256);
   int n_counter = 0;
   if (counters) hipMemsetAsync(counters, 0, sizeof(int) * 256, sm);
   c->trtri_counters = counters ? counters + 128 : nullptr;   // second half: the persistent inverse products (trtri_level)
@@ -143,14 +143,14 @@ void run_potrf(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, int m
     // F1 (next group's block columns) is on the critical path: with look-ahead it is launched on the panel stream
     // itself -- no cross-stream event hop before and after it -- once the previous bulk update, which wrote the same
     // tiles, is done (ev_f2); the main stream only learns that F1 is finished (ev_f1) to start F2 behind it.
-    hipStream_t s1 = (la && c->opt_f1_on_chain) ? sp : sm;
+    hipStream_t s1 = la ? sp : sm;
     if (la && s1 == sm) { hipEvent_t e = pool_event(c, evi++); hipEventRecord(e, sp); hipStreamWaitEvent(sm, e, 0); }
     if (g1 < max_nblk) {
       GemmArgs a = {}; a.tasks = d_tasks; a.mode = GEMM_SYRK; a.p0 = g0; a.kt = g1 - g0; a.aug = 1;
       {
         // F1 is a chain kernel when it runs on the panel stream: it marks its CUs instead of polling
-        a.yield_flag = (la && c->opt_f1_on_chain && chain_mark) ? nullptr : yield_flag;
-        a.yield_mark = (la && c->opt_f1_on_chain) ? chain_mark : nullptr;
+        a.yield_flag = (la && chain_mark) ? nullptr : yield_flag;
+        a.yield_mark = la ? chain_mark : nullptr;
         if (s1 == sp && ev_f2) hipStreamWaitEvent(sp, ev_f2, 0);
         ProfScope ps(c, "syrk_trailing", 1, s1);
         a.c_lo = g1; a.c_hi = la ? g2 : max_nblk;
@@ -196,11 +196,11 @@ void run_potrf(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, int m
             a.persistent = (ntasks == 1 && persist_free > 0 && ntiles > pblocks && m <= 96) ? pblocks : 0;
             a.work_counter = (a.persistent && counters && n_counter < 128) ? counters + n_counter++ : nullptr;
             a.n_big = 0;
-            if (a.persistent && a.work_counter && !a.small_tiles && c->opt_bulk_tail) {
+            if (a.persistent && a.work_counter && !a.small_tiles) {
               // a partly filled last round (fewer than half of the workgroups would get a 128-tile) runs on 64-tiles
+              // (the whole last round on 64-tiles, or never: measured equal or slower, profiles/r02_potrf_chain.md)
               const int64_t rem = ntiles % pblocks;
-              if (c->opt_bulk_tail == 2) a.n_big = (int)std::max<int64_t>(ntiles - pblocks, 1);
-              else if (rem > 0 && rem * 2 <= pblocks) a.n_big = (int)(ntiles - rem);
+              if (rem > 0 && rem * 2 <= pblocks) a.n_big = (int)(ntiles - rem);
             }
             launch_gemm(dtype, a, dim3(max_nblk + 1 - a.c_lo, a.c_hi - a.c_lo, ntasks), sb);
             a.persistent = 0; a.work_counter = nullptr; a.n_big = 0;
@@ -294,7 +294,7 @@ static void trtri_level(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntas
   // kernel (potf2 78 KB, trsm 87 KB of LDS, 128 VGPRs) fits beside ONE 128-tile workgroup (72 KB) or TWO 64-tile
   // workgroups (2 x 40 KB), not beside more -- with 4 x (CUs - free) 64-tile workgroups every CU held three or four of
   // them and potf2 waited 330 us for the whole launch to end (rocprofv3 kernel trace, profiles/r02_potrf_chain.md)
-  const int pblocks = (a.small_tiles ? c->opt_trtri_small_wgs : 2) * (c->n_cus - c->opt_trtri_free);
+  const int pblocks = 2 * (c->n_cus - c->opt_trtri_free);
   const int tmul = a.small_tiles ? 4 : 1;
   ProfScope ps(c, "trtri_gemm", 2, st);
   // Rows of the last group's lower half that exist in the largest task: workgroups beyond them would be dispatched
@@ -350,20 +350,11 @@ void run_trtri(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, int m
   TrtriProgress fresh;
   trtri_advance(c, dtype, d_tasks, ntasks, max_nblk, max_nblk, c->stream, pg ? *pg : fresh);
 }
-// K^-1 = W^T W on the lower tiles.  `split` > 0: the two-launch form -- `phase` 1 (the leading split x split tiles over the rows
-// below split, i.e. W11^T W11) may run as soon as W11 is final, phase 2 accumulates the rest (see GemmArgs::lsplit).
-void run_lauum(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, int max_nblk, int split, int phase, hipStream_t st) {
+// K^-1 = W^T W on the lower tiles.  (A two-launch form that started the W11^T W11 part beside the tail of the inverse was
+// built and measured neutral in round 2 -- profiles/r02_potrf_chain.md -- and is gone.)
+void run_lauum(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, int max_nblk, hipStream_t st) {
   ProfScope ps(c, "lauum", 2, st ? st : c->stream);
   GemmArgs a = {}; a.tasks = d_tasks; a.mode = GEMM_LAUUM;
   a.small_tiles = max_nblk <= c->opt_small_nblk;
-  if (split > 0 && !a.small_tiles) { a.lsplit = split; a.lphase = phase; }
-  const int rows = (a.lphase == 1) ? split : max_nblk;
-  launch_gemm(dtype, a, dim3(rows, rows, ntasks), st ? st : c->stream);
-}
-// leading block count whose inverse W[0:split, 0:split] is complete once block columns [0, cfin) of L have been walked by
-// trtri_advance: the largest power of two <= cfin that is at most half the matrix (no tree node straddles it)
-int lauum_split_for(int cfin, int max_nblk) {
-  int s = 1;
-  while (2 * s <= cfin && 4 * s <= max_nblk) s *= 2;
-  return (s >= 8 && s <= cfin) ? s : 0;
+  launch_gemm(dtype, a, dim3(max_nblk, max_nblk, ntasks), st ? st : c->stream);
 }

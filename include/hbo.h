@@ -186,35 +186,28 @@ int hbo_profile_enable(hbo_ctx* ctx, int level); /* 0 off, 1 per stage, 2 per la
 /* names: array of HBO_MAX_PROFILE_STAGES char[32]; ms: total ms; launches: count */
 int hbo_profile_get(hbo_ctx* ctx, char names[][32], double* ms, int32_t* launches, int32_t* n);
 
-/* Scheduling knobs (integers by name); the defaults are the measured best, the knobs exist for A/B runs
- * (tools/ab_opt.py).  Unknown names are an error.
- *   potrf_group    0..16 128-wide panels per trailing update, K = 128*group (0 = auto: 3 up to 96 blocks, 4 up to 255, else 8)
- *   persist_free  -1..200 CUs the persistent bulk trailing update leaves to the panel chain (-1 = auto: 48 / 32)
- *   cu_yield       0..2  background GEMM workgroups (bulk update, overlapped inverse) pause at a K step while a panel-chain
- *                        workgroup runs on their CU: 1 = potf2 only, 2 = trsm and the chain's column updates too
- *   lauum_split    0/1   single matrix: the W11^T W11 part of K^-1 = W^T W runs beside the tail of the inverse (default 0:
- *                        measured neutral)
- *   pool_cap_mb    >=0   device buffers of freed datasets / caches are parked for the next one of the same shape (GP.train()
- *                        re-creates its sub-sampled batch every step); at most this many MB stay parked (default 49152; 0 = off)
- *   post_chunk     128..65536 posterior / acquisition: query candidates per pass (cross-Gram workspace = npad x post_chunk
- *                        elements whatever M; two workspaces alternate so that the Gram build of a chunk runs beside the
- *                        triangular product of the previous one)
- *   bulk_tail      0..2  single matrix: a partly filled last round of the persistent bulk trailing update (fewer than half of
- *                        its workgroups would draw a 128-tile) runs on 64-tiles; 2 = the whole last round; 0 = never.  Default 1
- *   post_bf16x3    0/1   fp32 caches: the posterior product V = L^-1 Kxq runs on the bf16 matrix cores from exact three-way
- *                        splits of both operands (six bf16 MFMAs per fp32 product, fp32 accumulate: fp32-accurate, 1.3x the
- *                        speed of the fp32-MFMA product); costs 1.5 x the bytes of W once per cache.  Default 1; full_cov uses fp32 MFMA
- *   trtri_at       0..63 single matrix: the inverse starts beside the chain after this many 64ths of the panels (0 = auto: 5/8)
- *   trtri_small_wgs 1..4 workgroups per CU of the 64-tile form of the co-running inverse products
- *   lookahead      0/1   panel chain on its own stream, one group ahead of the bulk update
- *   f1_on_chain    0/1   next group's column update launched on the panel stream
- *   dynamic_tiles  0/1   persistent bulk update draws tiles from a counter
- *   overlap_trtri  0/1   inverse walks the block tree while the factorisation runs
- *   trtri_gran     >=0   panels between two launches of the inverse's computable pieces (0 = auto: every 4 panels
- *                        for a batch, once after 5/8 of the panels for a single matrix)
- *   trtri_free     0..200 CUs left free by the inverse products that co-run with the panel chain (persistent form,
- *                        tiles from a counter; 0 = one tile per workgroup)
- *   small_nblk     int   matrices up to this many blocks use 64x64 tiles in trtri / lauum */
+/* Options (integers by name).  Unknown names are an error.  The placement / overlap knobs of the launch schedules that the
+ * measurement tools vary live behind hbo_tune (include/hbo_tune.h); they are not part of this boundary.
+ *   potrf_group     0..16 128-wide panels per trailing update, K = 128*group (0 = auto: 3 up to 96 blocks, then 4, 8 from 256
+ *                         blocks on and for fp32 factorisations on the bf16 matrix cores)
+ *   lookahead       0/1   panel chain on its own stream one group ahead of the bulk update, inverse overlapped (default 1;
+ *                         0 = everything on one stream, in order)
+ *   small_nblk      int   matrices up to this many 128-blocks use 64x64 tiles in the inverse and in K^-1 = W^T W (default 32)
+ *   pool_cap_mb     >=0   device buffers of freed datasets / caches are parked for the next one of the same shape (GP.train()
+ *                         re-creates its sub-sampled batch every step); at most this many MB stay parked (default: a quarter
+ *                         of the device memory, at most 49152; 0 = off)
+ *   post_chunk      128..65536 posterior / acquisition: query candidates per pass (cross-Gram workspace = npad x post_chunk
+ *                         elements whatever M; two workspaces alternate so that the Gram build of a chunk runs beside the
+ *                         triangular product of the previous one)
+ *   bf16x3          0/1   fp32 only: the GEMM-shaped work -- trailing updates of the factorisation, the products of the inverse
+ *                         (above small_nblk blocks) and the posterior product V = L^-1 Kxq -- runs on the bf16 matrix cores
+ *                         from exact three-way splits of both operands (six bf16 MFMAs per fp32 product, fp32 accumulate:
+ *                         fp32-class accuracy at 1.3-1.5x the fp32-MFMA rate).  Default 1; 0 = fp32 MFMA
+ *   dag             0..2  the factorisation phase as a resident tile-task kernel: 1 = bulk updates + inverse as tasks beside the
+ *                         launched panel chain, 2 = the chain-critical updates as tasks too.  Bit-identical results; measured
+ *                         slower than the launch schedule at every size (profiles/r03_dag.md), hence default 0
+ *   dag_timeout_ms  1..60000 wall-clock bound of that kernel's waits; on expiry the call is repeated on the launch schedule and
+ *                         the context stays there (default 2000) */
 int hbo_set_option(hbo_ctx* ctx, const char* name, int64_t value);
 
 /* ---- multi-GPU: one process per GPU; sum-all-reduce of [nll, grads] over RCCL (xGMI) ------ */

@@ -1,0 +1,27 @@
+/* hbo_tune.h -- measurement hooks of libhbo.  NOT part of the drop-in boundary (include/hbo.h): nothing a caller of the
+ * hyperbo.gp_utils surface needs.  The A/B tools under tools/ and the scheduling sweep of tests/test_gpu_fuzz.py use it to
+ * vary where and when the same kernels run; no knob changes a result, and every non-default value was measured equal or worse
+ * (profiles/r01_potrf_chain.md, r02_potrf_chain.md, r03_dag.md).  Names fall through to hbo_set_option.
+ *
+ *   overlap_trtri 0/1      inverse walks the block tree while the factorisation runs
+ *   cu_yield      0..2     background GEMM workgroups pause while a panel-chain workgroup runs on their CU (1: potf2 only)
+ *   persist_free  -1..200  CUs the persistent bulk update leaves with one workgroup (-1 = auto: 32)
+ *   trtri_at      0..63    the overlapped inverse starts after this many 64ths of the panels (0 = auto: 5/8)
+ *   trtri_free    0..200   CUs the co-running inverse products leave with one workgroup
+ *   post_bf16x3 / syrk_bf16x3 / trtri_bf16x3  0/1   the three parts of option bf16x3 separately
+ *   trtri3_min_s  >=1      lowest level (in blocks) of the inverse that runs on the bf16 cores
+ *   syrk3_col / syrk3_sep / syrk3_free       fp32 trailing updates: column updates on the bf16 cores too / panels split by
+ *                          their own kernel instead of inside the panel solve / CUs the bulk update leaves with one workgroup
+ *   dag_reserve 0..4 (CUs per shader engine left to the panel kernels), dag_near64, dag_trtri, dag_spin_us, dag_idle_sleep,
+ *   dag_f1_small, dag_join, dag_dbg, dag_min_nblk, dag_max_nblk   resident tile-task schedule (csrc/dag.h) */
+#ifndef HBO_TUNE_H_
+#define HBO_TUNE_H_
+#include "hbo.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+int hbo_tune(hbo_ctx* ctx, const char* name, int64_t value);
+#ifdef __cplusplus
+}
+#endif
+#endif /* HBO_TUNE_H_ */

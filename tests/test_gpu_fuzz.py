@@ -182,25 +182,24 @@ OPTION_SETS = [
     {'lookahead': 0},
     {'overlap_trtri': 0},
     {'potrf_group': 1}, {'potrf_group': 2}, {'potrf_group': 4}, {'potrf_group': 8},
-    {'persist_free': 0}, {'persist_free': 128}, {'dynamic_tiles': 0}, {'f1_on_chain': 0},
-    {'trtri_gran': 1}, {'trtri_gran': 2}, {'trtri_gran': 5}, {'trtri_gran': 64},
+    {'persist_free': 0}, {'persist_free': 128}, {'persist_free': 64, 'small_nblk': 0}, {'persist_free': 200, 'small_nblk': 0},
     {'small_nblk': 0}, {'small_nblk': 4}, {'cu_yield': 0}, {'cu_yield': 1},
     {'lookahead': 0, 'potrf_group': 3, 'small_nblk': 0},
-    # round 2: persistent co-running inverse products, their start point, the two-launch lauum, streamed posterior
-    {'trtri_free': 0}, {'trtri_free': 120, 'small_nblk': 0}, {'trtri_small_wgs': 4}, {'trtri_small_wgs': 1, 'trtri_free': 200},
-    {'trtri_at': 12}, {'trtri_at': 60, 'small_nblk': 0}, {'lauum_split': 1, 'small_nblk': 0}, {'lauum_split': 1, 'small_nblk': 0, 'trtri_at': 48},
+    # persistent co-running inverse products and their start point, streamed posterior
+    {'trtri_free': 0}, {'trtri_free': 120, 'small_nblk': 0}, {'trtri_free': 200},
+    {'trtri_at': 12}, {'trtri_at': 60, 'small_nblk': 0}, {'trtri_at': 48, 'small_nblk': 0},
     {'post_chunk': 128},
-    # 64-tile tail of the persistent bulk update: off, whole last round, and with fewer reserved CUs (other remainders)
-    {'bulk_tail': 0}, {'bulk_tail': 2, 'small_nblk': 0}, {'bulk_tail': 1, 'persist_free': 64, 'small_nblk': 0}, {'bulk_tail': 2, 'persist_free': 200, 'small_nblk': 0},
+    # round 3: the resident tile-task schedule in both forms, with and without the inverse among the tasks, fewer reserved CUs
+    {'dag': 1}, {'dag': 2}, {'dag': 1, 'dag_trtri': 0}, {'dag': 2, 'dag_trtri': 24, 'small_nblk': 0}, {'dag': 1, 'dag_reserve': 1, 'dag_join': 0},
+    {'dag': 2, 'dag_near64': 2, 'dag_spin_us': 0}, {'dag': 2, 'dag_near64': 0, 'potrf_group': 4},
 ]
-DEFAULTS = {'lookahead': 1, 'overlap_trtri': 1, 'potrf_group': 0, 'persist_free': -1, 'dynamic_tiles': 1, 'f1_on_chain': 1,
-            'trtri_gran': 0, 'small_nblk': 32, 'cu_yield': 2, 'trtri_free': 48, 'trtri_small_wgs': 2, 'trtri_at': 0,
-            'lauum_split': 0, 'post_chunk': 8192, 'bulk_tail': 1}
+DEFAULTS = {'lookahead': 1, 'overlap_trtri': 1, 'potrf_group': 0, 'persist_free': -1, 'small_nblk': 32, 'cu_yield': 2, 'trtri_free': 48,
+            'trtri_at': 0, 'post_chunk': 8192, 'dag': 0, 'dag_trtri': 64, 'dag_reserve': 2, 'dag_join': 1, 'dag_near64': 1, 'dag_spin_us': 200}
 
 
 @pytest.mark.parametrize('opts', OPTION_SETS, ids=lambda o_: ','.join(f'{k}={v}' for k, v in o_.items()))
 def test_every_scheduling_option_gives_the_same_answer(gpu_ctx, opts):
-  """The knobs of hbo_set_option only move work between streams, launches and tile sizes: NLL, gradient and posterior of
+  """The options of hbo_set_option and the measurement hooks of hbo_tune only move work between streams, launches and tile sizes: NLL, gradient and posterior of
   a single 2900-point matrix (23 blocks: persistent bulk update, partial groups at every level of the inverse) and of a
   ragged batch must not depend on them."""
   defs, acfun, gp, kernel, mean, objectives, utils = _native()

@@ -385,17 +385,16 @@ def test_cfg2_full_size_value_and_full_gradient(gpu_ctx):
     vals.append(objectives.neg_log_marginal_likelihood(mean.constant, kernel.squared_exponential, pm, dev, utils.DEFAULT_WARP_FUNC))
   num = (vals[0] - vals[1]) / (2 * h)
   assert abs(num - fn @ direction) <= 1e-5 * abs(num) + 1e-6
-  # the 64-tile tail of the persistent bulk update (only launches of >= 600 128-tiles have one): off, default rule, whole last
-  # round, and with other numbers of reserved CUs (other remainders) -- same value and gradient
+  # the 64-tile tail of the persistent bulk update (only launches of >= 600 128-tiles have one) with other numbers of reserved CUs
+  # (other remainders of the last round) and as a plain launch -- same value and gradient
   try:
-    for opts in ({'bulk_tail': 0}, {'bulk_tail': 2}, {'bulk_tail': 1, 'persist_free': 64}, {'bulk_tail': 2, 'persist_free': 100}):
+    for opts in ({'persist_free': 0}, {'persist_free': 48}, {'persist_free': 64}, {'persist_free': 100}):
       for k_, v_ in opts.items():
         gpu_ctx.set_option(k_, v_)
       v2, g2 = objectives.nll_value_and_grad(mean.constant, kernel.squared_exponential, pn, dev, utils.DEFAULT_WARP_FUNC)
       assert abs(v2 - v) <= 1e-11 * abs(v), opts
       assert np.max(np.abs(helpers.flatten(g2) - fn)) <= 1e-9 * np.max(np.abs(fn)), opts
   finally:
-    gpu_ctx.set_option('bulk_tail', 1)
     gpu_ctx.set_option('persist_free', -1)
   dev.close()
 
@@ -638,13 +637,13 @@ def test_fp32_factorisation_on_bf16_matrix_cores_is_as_accurate_as_fp32_mfma(gpu
   err = {}
   try:
     for name, on in (('mfma', 0), ('bf16x3', 1)):
-      gpu_ctx.set_option('syrk_bf16x3', on); gpu_ctx.set_option('trtri_bf16x3', on)
+      gpu_ctx.set_option('bf16x3', on)
       chol, x = linalg.solve_linear_system(a, b)
       inv, _ = linalg.spd_inverse(a)
       assert np.isfinite(chol).all()
       err[name] = (helpers.rel_err(chol, cref), helpers.rel_err(x, xref), helpers.rel_err(inv, iref))
   finally:
-    gpu_ctx.set_option('syrk_bf16x3', 1); gpu_ctx.set_option('trtri_bf16x3', 1)
+    gpu_ctx.set_option('bf16x3', 1)
   for k in range(3):
     assert err['bf16x3'][k] <= 3.0 * err['mfma'][k] + 1e-7, err
   assert err['bf16x3'][0] < 1e-3        # kappa * eps_fp32 ~ 6e-2 bounds the solve; the factor itself stays accurate
