@@ -1,6 +1,6 @@
 """One-shot pin of the golden fixtures against the JAX REFERENCE itself (last row).
 
-Runs the inputs of every committed fixture (tests/golden/*.npz: the five make_golden.py cases and cfg 1 of
+Runs the inputs of every committed fixture (tests/golden/*.npz: the five make_golden.py cases, cfg 1 and the 64 tasks of cfg 4 of
 make_golden_configs.py) through the reference's own code -- imported from /root/reference, JAX_ENABLE_X64=1 -- and
 writes `<case>_ref.npz` next to them:
 
@@ -33,6 +33,7 @@ import numpy as np  # noqa: E402
 HERE = os.path.dirname(os.path.abspath(__file__))
 TESTS = os.path.dirname(HERE)
 sys.path.insert(0, TESTS)
+sys.path.insert(0, os.path.dirname(TESTS))   # the repo root: bench.cfg4_inputs()
 import helpers  # noqa: E402
 
 
@@ -125,6 +126,20 @@ def main(reference_root='/root/reference'):
   out = run_case(raw, {}, 'squared_exponential', 'constant', x, y, None, None, x[:8], None)
   np.savez_compressed(os.path.join(HERE, 'cfg1_se_n256_d4_ref.npz'), **out)
   written.append('cfg1_se_n256_d4')
+  # cfg 4: the 64 ragged sub-datasets of bench.cfg4_inputs(): per-task NLL, their mean and the mean gradient through the
+  # reference's own multi-task objective (objectives.py:178-195) -- the same keys as cfg4_t64_oracle.npz
+  import bench
+  data, raw4 = bench.cfg4_inputs()
+  ds4 = {k: defs.SubDataset(jnp.asarray(xx), jnp.asarray(yy)) for k, (xx, yy) in data.items()}
+  jm4 = to_jnp(raw4)
+  nll4, key2nll4 = obj.neg_log_marginal_likelihood(mean.constant, kernel.squared_exponential, defs.GPParams(model=jm4), ds4, wf,
+                                                   return_key2nll=True)
+  _, g4 = jax.value_and_grad(lambda m: obj.neg_log_marginal_likelihood(mean.constant, kernel.squared_exponential,
+                                                                       defs.GPParams(model=m), ds4, wf))(jm4)
+  np.savez_compressed(os.path.join(HERE, 'cfg4_t64_oracle_ref.npz'), sizes=np.asarray([data[k][0].shape[0] for k in sorted(data)]),
+                      nll_per_task=np.asarray([float(key2nll4[k]) for k in sorted(data)]), nll_mean=float(nll4),
+                      grad_mean_flat=helpers.flatten(jax.tree.map(to_np, g4)))
+  written.append('cfg4_t64_oracle')
   print('make_golden_from_reference: wrote *_ref.npz for', ', '.join(written), f'(jax {jax.__version__})')
   return 0
 
