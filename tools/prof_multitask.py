@@ -5,8 +5,18 @@ import bench
 from hyperbo_amd import _native as nat
 from hyperbo_amd.basics import definitions as defs
 from hyperbo_amd.gp_utils import kernel, mean, objectives, utils
-T = int(sys.argv[1]) if len(sys.argv) > 1 else 64
-data, raw = bench.cfg4_inputs(tasks=T)
+# T = number of tasks of cfg 4 (first T of the generator), or "shard8" = the heaviest LPT shard of eight of the 64 tasks
+# (what rank 0 of an 8-GPU job holds: bench.py's multitask.shard_of_8)
+if len(sys.argv) > 1 and sys.argv[1] == 'shard8':
+    from hyperbo_amd import parallel
+    data, raw = bench.cfg4_inputs()
+    full = {k: defs.SubDataset(x, y) for k, (x, y) in data.items()}
+    mine = parallel.shard_dataset(full, 0, 8)
+    data = {k: (s.x, s.y) for k, s in mine.items()}
+    T = len(data)
+else:
+    T = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+    data, raw = bench.cfg4_inputs(tasks=T)
 dev = objectives.DeviceDataset({k: defs.SubDataset(x, y) for k, (x, y) in data.items()})
 ctx = nat.default_context()
 for opt in sys.argv[2:]:
