@@ -22,7 +22,8 @@ MAX_FEATURE_DIM = 256
 MAX_PROFILE_STAGES = 32
 UNIQUE_ID_BYTES = 128
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'libhbo.so')
+# ($HBO_LIB: another build of the same library, for the A/B tools under tools/)
+_LIB_PATH = os.environ.get('HBO_LIB') or os.path.join(os.path.dirname(os.path.abspath(__file__)), 'libhbo.so')
 
 
 class HboError(RuntimeError):

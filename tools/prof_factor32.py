@@ -8,6 +8,7 @@ from hyperbo_amd.basics import definitions as defs
 from hyperbo_amd.gp_utils import gp, kernel, mean, utils
 n = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 16384
 settings = [a for a in sys.argv[1:] if '=' in a] or ['']
+plain = 'plain' in sys.argv[1:]   # no stage events: three factorisations per setting, for a rocprofv3 kernel trace
 rng = np.random.Generator(np.random.PCG64(3))
 d, f = 32, 64
 isp = lambda v: np.log(np.expm1(np.asarray(v, dtype=np.float64)))
@@ -21,6 +22,10 @@ ctx = nat.default_context()
 for st in settings:
     for kv in st.split():
         ctx.set_option(kv.split('=')[0], int(kv.split('=')[1]))
+    if plain:
+        for it in range(3):
+            g.update_model_params(g.params.model); g.setup_predictor(0)
+        continue
     out = {}
     for lvl in (1, 2):
         ctx.profile_enable(lvl)

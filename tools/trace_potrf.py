@@ -1,6 +1,7 @@
 """Timeline of the Cholesky panel chain from a rocprofv3 kernel trace (csv) of tools/prof_nll.py level 0.
 usage: python tools/trace_potrf.py <kernel_trace.csv>"""
 import csv, sys, collections
+ALL = len(sys.argv) > 2 and sys.argv[2] == 'all'
 rows = []
 with open(sys.argv[1]) as f:
     for r in csv.DictReader(f):
@@ -13,7 +14,7 @@ i0 = starts[-1]
 ev = rows[i0:]
 t0 = ev[0][0]
 def short(n):
-    for k in ('potf2', 'trsm_kernel', 'gemm_kernel', 'gram_kernel', 'nll_reduce', 'trtri', 'wtz', 'grad_contract', 'grad_finalize', 'aug_rows', 'dmu'):
+    for k in ('potf2', 'trsm_kernel', 'gemm_kernel', 'syrk3', 'split3_panel', 'split3_block', 'gram_kernel', 'nll_reduce', 'trtri', 'wtz', 'grad_contract', 'grad_finalize', 'aug_rows', 'dmu'):
         if k in n:
             return k + ('<64>' if 'Li64E' in n else ('<128>' if 'Li128E' in n else ''))
     return n[:30]
@@ -34,7 +35,7 @@ for k in tot_dur:
 # panel-by-panel
 print('panel  dt_us  potf2_us  (kernels between)')
 for j, (a, b) in enumerate(zip(potf2, potf2[1:])):
-    if j % 4 == 0 or j > 58:
+    if ALL or j % 4 == 0 or j > len(potf2) - 6:
         between = [r for r in chain if a[0] <= r[0] < b[0]]
         print('%4d %7.1f %7.1f   %s' % (j, (b[0] - a[0]) / 1e3, (a[1] - a[0]) / 1e3,
               ' '.join('%s:%.0f' % (short(r[2])[:9], (r[1] - r[0]) / 1e3) for r in between)))

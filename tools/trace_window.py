@@ -12,9 +12,11 @@ t0 = ev[0][0]
 potf2 = [r for r in ev if 'potf2' in r[2]]
 gaps = [(b[0] - a[0], i) for i, (a, b) in enumerate(zip(potf2, potf2[1:]))]
 g, i = max(gaps)
-lo = potf2[max(i - 1, 0)][0]; hi = potf2[min(i + 2, len(potf2) - 1)][1]
+if len(sys.argv) > 2: i = int(sys.argv[2]); g = gaps[i][0]   # explicit panel instead of the largest gap
+SPAN = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+lo = potf2[max(i - 1, 0)][0]; hi = potf2[min(i + SPAN, len(potf2) - 1)][1]
 def short(n):
-    m = re.search(r'(potf2|trsm_kernel|gemm_kernel|gram|wtz|nll_reduce)', n)
+    m = re.search(r'(potf2|trsm_kernel|gemm_kernel|syrk3|split3_panel|split3_block|gram|wtz|nll_reduce)', n)
     s = m.group(1) if m else n[:24]
     if 'gemm_kernel' in n:
         s += '<' + ('kk' if 'Lb1ELb1' in n else ('km' if 'Lb1ELb0' in n else 'mm')) + (',64>' if 'Li64E' in n else ',128>')
