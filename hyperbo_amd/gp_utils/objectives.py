@@ -171,12 +171,22 @@ def _apply_priors(total_nll, params, warp_func):
   return total_nll
 
 
+SVD_WARN_N = 4096   # _nll_sub_dataset_svd logs its cost from this many points on
+
+
 def _nll_sub_dataset_svd(mean_func, cov_func, params, vx, vy, warp_func):
   """objectives.py:157-176: 0.5 * sum(y^T K^-1 y + sum(log s) + n log 2 pi) with K^-1 = V^T diag(1/s) U^T from the SVD
   of the jittered Gram matrix.  Mean and Gram come from the device (hbo_mean / hbo_gram through mean_func / cov_func);
   the SVD itself is host LAPACK -- the reference's reporting path for covariances that are numerically low rank, where
-  the Cholesky variant returns NaN.  For y of shape (n, m > 1) the (m, m) + scalar broadcast of the reference is kept."""
+  the Cholesky variant returns NaN.  For y of shape (n, m > 1) the (m, m) + scalar broadcast of the reference is kept.
+
+  Cost: the n x n Gram matrix crosses PCIe (8 n^2 bytes) and the SVD is O(n^3) float64 on the host -- seconds at n = 4096,
+  minutes and > 6 GB of host memory at n = 16384, per sub-dataset (and per parameter sample under HGP.stats).  A warning is
+  logged from SVD_WARN_N points on; neg_log_marginal_likelihood(use_cholesky=True) is the device path."""
   from hyperbo_amd.basics import linalg
+  if len(vx) >= SVD_WARN_N:
+    logging.warning('SVD variant of the NLL on %d points: the %d x %d Gram matrix is copied to the host and decomposed by LAPACK '
+                    '(O(n^3) float64, %.1f GB); use_cholesky=True runs on the GPU', len(vx), len(vx), len(vx), 3 * 8e-9 * len(vx) ** 2)
   vy, cov = linalg.compute_delta_y_and_cov(mean_func, cov_func, params, vx, vy, warp_func=warp_func)
   u, s, vt = np.linalg.svd(np.asarray(cov, dtype=np.float64))
   if s[-1] <= 0:
