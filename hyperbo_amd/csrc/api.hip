@@ -98,7 +98,7 @@ extern "C" int hbo_set_option(hbo_ctx* c, const char* name, int64_t value) {
     return HBO_OK;
   }
   if (!strcmp(name, "post_chunk")) { if (value < 128 || value > 65536) return fail(c, HBO_ERR_ARG, "post_chunk in 128..65536"); c->opt_post_chunk = (int)value; return HBO_OK; }
-  if (!strcmp(name, "bf16x3")) { c->opt_post_bf16x3 = c->opt_syrk_bf16x3 = c->opt_trtri_bf16x3 = value != 0; return HBO_OK; }
+  if (!strcmp(name, "bf16x3")) { c->opt_post_bf16x3 = c->opt_syrk_bf16x3 = c->opt_trtri_bf16x3 = c->opt_lauum_bf16x3 = value != 0; return HBO_OK; }
   if (!strcmp(name, "dag")) { if (value < 0 || value > 2) return fail(c, HBO_ERR_ARG, "dag in 0..2"); c->opt_dag = (int)value; c->dag_broken = 0; return HBO_OK; }
   if (!strcmp(name, "dag_timeout_ms")) { if (value < 1 || value > 60000) return fail(c, HBO_ERR_ARG, "dag_timeout_ms in 1..60000"); c->opt_dag_timeout_ms = (int)value; return HBO_OK; }
   return fail(c, HBO_ERR_ARG, std::string("unknown option ") + name);
@@ -113,7 +113,7 @@ extern "C" int hbo_tune(hbo_ctx* c, const char* name, int64_t value) {
       {"persist_free", &hbo_ctx::opt_persist_free, -1, 200}, {"trtri_at", &hbo_ctx::opt_trtri_at, 0, 63},
       {"trtri_free", &hbo_ctx::opt_trtri_free, 0, 200},
       {"post_bf16x3", &hbo_ctx::opt_post_bf16x3, 0, 1}, {"syrk_bf16x3", &hbo_ctx::opt_syrk_bf16x3, 0, 1},
-      {"trtri_bf16x3", &hbo_ctx::opt_trtri_bf16x3, 0, 1}, {"trtri3_min_s", &hbo_ctx::opt_trtri3_min_s, 1, 1024},
+      {"trtri_bf16x3", &hbo_ctx::opt_trtri_bf16x3, 0, 1}, {"lauum_bf16x3", &hbo_ctx::opt_lauum_bf16x3, 0, 1}, {"trtri3_min_s", &hbo_ctx::opt_trtri3_min_s, 1, 1024},
       {"syrk3_col", &hbo_ctx::opt_syrk3_col, 0, 1}, {"syrk3_sep", &hbo_ctx::opt_syrk3_sep, 0, 1}, {"syrk3_free", &hbo_ctx::opt_syrk3_free, 0, 200},
       {"dag_reserve", &hbo_ctx::opt_dag_reserve, 0, 4}, {"dag_near64", &hbo_ctx::opt_dag_near64, 0, 2}, {"dag_trtri", &hbo_ctx::opt_dag_trtri, 0, 64},
       {"dag_spin_us", &hbo_ctx::opt_dag_spin_us, 0, 1000}, {"dag_idle_sleep", &hbo_ctx::opt_dag_idle_sleep, 0, 1000},

@@ -28,6 +28,7 @@ struct hbo_ctx {
   int opt_post_chunk = 8192;   // posterior / acquisition: candidates per pass (the cross-Gram workspace is npad x this, whatever M)
   int opt_trtri_bf16x3 = 1;    // fp32, one matrix: the products of the block-recursive inverse on the bf16 cores from level trtri3_min_s on
   int opt_trtri3_min_s = 8;
+  int opt_lauum_bf16x3 = 1;    // fp32, one matrix: K^-1 = W^T W on the bf16 cores too
   TaskDesc trtri_host_task = {};   // host copy of the single task's descriptor (pointers, ld) for those launches; valid when .A != null
   int opt_syrk3_col = 0;       // 1: the left-looking column updates inside a group on the bf16 cores too (needs a split per panel)
   int opt_syrk3_sep = 0;       // debug: 1 = the panels are split by a kernel of their own instead of inside the panel solve

@@ -217,6 +217,7 @@ struct Syrk3Args {
   // mode 0: the trailing update above.  Modes 1 / 2: the products of the block-recursive inverse (sched.hip:trtri_level) on one
   // level of s blocks for `ngrp` groups, operands split by split3_block / split3_block_t into Xp (A operand) and Yp (B operand):
   //   1 (TRTRI_A): S21[it, jt] =  sum_{k >= jt} L21[it, k] W11[k, jt]     A = L21 rows, B = W11^T rows, K blocks [8 jt, 8 s)
+  //   3 (LAUUM): S[i, jt] = sum_{k >= i} W[k, i]^T W[k, jt] for the lower tiles, Xp = split transpose of W (nkb = 8 nblk)
   //   2 (TRTRI_B): W21[it, jt] = -sum_{k <= it} W22[it, k] S21[k, jt]     A = W22 rows, B = S21^T rows, K blocks [0, 8 (it + 1))
   // tile index = ((grp * vt + it) * s + jt) in launch order (longest K first); per group the operand tiles are contiguous:
   // A tile it of group g at ((g * s + it) * nkb), B tile jt at ((g * s + jt) * nkb), nkb = 8 s blocks.
@@ -232,7 +233,7 @@ void launch_split3_block(const Split3Block& a, int ngrp, bool transposed, hipStr
 void launch_split3_panel(const Syrk3Args& a, int row_tiles, int ntasks, hipStream_t st);
 void launch_syrk3(const Syrk3Args& a, int ntiles, int ntasks, hipStream_t st);
 void launch_split3_rows(const float* in, int64_t ld, int row_tiles, unsigned short* out, int nkb, hipStream_t st);
-void launch_split3_transpose(const float* in, int64_t ld, int krows, int jcols, unsigned short* out, int nkb, hipStream_t st);
+void launch_split3_transpose(const float* in, int64_t ld, int krows, int jcols, unsigned short* out, int nkb, hipStream_t st, int lower_only = 0);
 void launch_post3(const Post3Args& a, int col_tiles, hipStream_t st);
 
 struct AcqGradArgs {

@@ -58,9 +58,10 @@ __global__ __launch_bounds__(256) void split3_rows_kernel(const float* __restric
 
 // in: krows x ld fp32 with k = ROW (the cross-Gram Kxq: k = training point, column j = candidate); out: panel blocks of the
 // transpose (row = j).  64 (k) x 64 (j) tiles through LDS.
-__global__ __launch_bounds__(256) void split3_transpose_kernel(const float* __restrict__ in, int64_t ld, u16* __restrict__ out, int nkb) {
+__global__ __launch_bounds__(256) void split3_transpose_kernel(const float* __restrict__ in, int64_t ld, u16* __restrict__ out, int nkb, int lower_only) {
   __shared__ float tile[64][65];
   const int k0 = blockIdx.y * 64, j0 = blockIdx.x * 64;
+  if (lower_only && k0 < j0 / HBO_TILE * HBO_TILE) return;   // `in` lower triangular by 128-blocks: nobody reads the blocks above
   const int tid = threadIdx.x;
   {
     const int c = (tid & 15) * 4, r = tid >> 4;   // 16 threads x float4 per row of 64, 16 rows per pass
@@ -325,6 +326,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     ga = xp + ((int64_t)r * g.nkb + g.kb_off) * 3 * P3_CHUNK + tid * 8;
     gb = xp + ((int64_t)c * g.nkb + g.kb_off) * 3 * P3_CHUNK + tid * 8;
     C = static_cast<float*>(t.A) + (int64_t)r * HBO_TILE * t.ld + (int64_t)c * HBO_TILE;
+  } else if (g.mode == 3) {
+    // K^-1 = W^T W, lower tiles (i, jt <= i): S[i, jt] = sum_{k >= i} W[k, i]^T W[k, jt]; both operands are row tiles of the
+    // split TRANSPOSE of W (Xp), K blocks [8 i, nkb).  Row tile i slow = K descending (longest first), jt fast: consecutive
+    // workgroups share the A operand
+    int lin = tix;
+    const int nb = t.nblk;
+    if (lin >= nb * (nb + 1) / 2) break;
+    int i = 0;
+    while (lin > i) { lin -= i + 1; ++i; }
+    const int kb0 = 8 * i;
+    nk = 8 * nb - kb0;
+    ga = g.Xp + ((int64_t)i * g.nkb + kb0) * 3 * P3_CHUNK + tid * 8;
+    gb = g.Xp + ((int64_t)lin * g.nkb + kb0) * 3 * P3_CHUNK + tid * 8;
+    C = static_cast<float*>(t.S) + (int64_t)i * HBO_TILE * t.ld + (int64_t)lin * HBO_TILE;
+    csign = 1.f; cbeta = false;
   } else {
     // tiles in launch order: the index that fixes K slowest (longest first), the rows / columns of all groups fast
     const int s = g.s, ng = g.ngrp;
@@ -469,9 +485,9 @@ void launch_split3_rows(const float* in, int64_t ld, int row_tiles, unsigned sho
   if (row_tiles <= 0) return;
   hipLaunchKernelGGL(split3_rows_kernel, dim3((nkb + 3) / 4, row_tiles), dim3(256), 0, st, in, ld, out, nkb);
 }
-void launch_split3_transpose(const float* in, int64_t ld, int krows, int jcols, unsigned short* out, int nkb, hipStream_t st) {
+void launch_split3_transpose(const float* in, int64_t ld, int krows, int jcols, unsigned short* out, int nkb, hipStream_t st, int lower_only) {
   if (krows <= 0 || jcols <= 0) return;
-  hipLaunchKernelGGL(split3_transpose_kernel, dim3(jcols / 64, krows / 64), dim3(256), 0, st, in, ld, out, nkb);
+  hipLaunchKernelGGL(split3_transpose_kernel, dim3(jcols / 64, krows / 64), dim3(256), 0, st, in, ld, out, nkb, lower_only);
 }
 void launch_post3(const Post3Args& a, int col_tiles, hipStream_t st) {
   static bool attr = false;

@@ -354,6 +354,22 @@ void run_trtri(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, int m
 // built and measured neutral in round 2 -- profiles/r02_potrf_chain.md -- and is gone.)
 void run_lauum(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, int max_nblk, hipStream_t st) {
   ProfScope ps(c, "lauum", 2, st ? st : c->stream);
+  // fp32, one matrix beyond the small sizes: on the bf16 matrix cores from ONE exact three-way split of W^T (post3.hip,
+  // syrk3_kernel mode 3) -- 6 bytes per element of the lower triangle of W as workspace
+  const TaskDesc& h = c->trtri_host_task;
+  if (dtype == HBO_F32 && c->opt_lauum_bf16x3 && ntasks == 1 && h.W && h.nblk == max_nblk && max_nblk > c->opt_small_nblk) {
+    const int nkb = 8 * max_nblk;
+    const size_t bytes = sizeof(unsigned short) * (size_t)max_nblk * nkb * 3 * (HBO_TILE * 16);
+    unsigned short* xp = static_cast<unsigned short*>(ws_get(c, WS_LAUUM3, bytes));
+    if (xp) {
+      hipStream_t s = st ? st : c->stream;
+      const int n = max_nblk * HBO_TILE;
+      launch_split3_transpose(static_cast<const float*>(h.W), h.ld, n, n, xp, nkb, s, 1);
+      Syrk3Args g = {}; g.tasks = d_tasks; g.Xp = xp; g.nkb = nkb; g.mode = 3;
+      launch_syrk3(g, max_nblk * (max_nblk + 1) / 2, 1, s);
+      return;
+    }
+  }
   GemmArgs a = {}; a.tasks = d_tasks; a.mode = GEMM_LAUUM;
   a.small_tiles = max_nblk <= c->opt_small_nblk;
   launch_gemm(dtype, a, dim3(max_nblk, max_nblk, ntasks), st ? st : c->stream);

@@ -616,7 +616,7 @@ def test_ill_conditioned_fp32_cache_explicit_inverse_vs_triangular_solve(gpu_ctx
 @pytest.mark.parametrize('n', [1500, 4600])
 def test_fp32_factorisation_on_bf16_matrix_cores_is_as_accurate_as_fp32_mfma(gpu_ctx, n):
   """The fp32 trailing updates (and, above 32 blocks, the products of the inverse) run on the bf16 matrix cores from exact
-  three-way splits of their operands (post3.hip: syrk3_kernel).  On a matrix of condition number ~1e6 the factor, the solve
+  three-way splits of their operands (post3.hip: syrk3_kernel), and so does K^-1 = W^T W.  On a matrix of condition number ~1e6 the factor, the solve
   and the inverse must stay in the accuracy class of the fp32-MFMA kernels against fp64 LAPACK (linalg.py:29-33 in the
   reference's default dtype).  Measured: well-conditioned matrices come out 3-4x CLOSER to fp64 than with fp32 MFMA (fewer
   accumulation roundings: 3.7e-6 -> 8.4e-7 at n = 4224, tools/dbg32.py); at kappa = 1e6 the three dropped cross products
@@ -647,6 +647,34 @@ def test_fp32_factorisation_on_bf16_matrix_cores_is_as_accurate_as_fp32_mfma(gpu
   for k in range(3):
     assert err['bf16x3'][k] <= 3.0 * err['mfma'][k] + 1e-7, err
   assert err['bf16x3'][0] < 1e-3        # kappa * eps_fp32 ~ 6e-2 bounds the solve; the factor itself stays accurate
+
+
+def test_fp32_objective_beyond_32_blocks_on_bf16_matrix_cores(gpu_ctx):
+  """fp32 NLL + gradient of one matrix of 36 blocks (above small_nblk: trailing updates, the upper levels of the inverse AND
+  K^-1 = W^T W -- syrk3_kernel modes 0-3 -- on the bf16 matrix cores) against the fp64 path, and against the same evaluation
+  with every product on fp32 MFMA (option bf16x3 = 0): the errors must be of the same size (objectives.py:109-210 in the
+  reference's default dtype).  Measured at N = 8192 / 16384: identical to three digits (tools/check_lauum3.py)."""
+  defs, _, _, _, kernel, mean, objectives, utils = _native()
+  rng = np.random.default_rng(36)
+  n, d = 4500, 6
+  model = helpers.make_model(rng, 'constant', False, d)
+  x, y = helpers.synthetic_task(rng, n, d)
+  v64, g64 = objectives.nll_value_and_grad(mean.constant, kernel.squared_exponential, defs.GPParams(model=model),
+                                           {0: defs.SubDataset(x, y)}, utils.DEFAULT_WARP_FUNC)
+  f64 = helpers.flatten(g64)
+  to32 = lambda t: {k: to32(v) for k, v in t.items()} if isinstance(t, dict) else np.asarray(t, dtype=np.float32)
+  ds32 = {0: defs.SubDataset(x.astype(np.float32), y.astype(np.float32))}
+  err = {}
+  try:
+    for on in (0, 1):
+      gpu_ctx.set_option('bf16x3', on)
+      v, g = objectives.nll_value_and_grad(mean.constant, kernel.squared_exponential, defs.GPParams(model=to32(model)), ds32,
+                                           utils.DEFAULT_WARP_FUNC)
+      err[on] = (abs(v - v64) / max(abs(v64), 1.0), np.max(np.abs(helpers.flatten(g) - f64)) / np.max(np.abs(f64)))
+  finally:
+    gpu_ctx.set_option('bf16x3', 1)
+  assert err[1][0] <= 2e-4 and err[1][1] <= 5e-3, err           # the full-size fp32 tolerances of this file
+  assert err[1][0] <= 3 * err[0][0] + 1e-6 and err[1][1] <= 3 * err[0][1] + 1e-6, err
 
 
 def test_cfg5_full_size_closed_form(gpu_ctx):
