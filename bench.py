@@ -87,7 +87,7 @@ def bulk_update_flops(n, group):
   """Algorithmic flops of every BULK trailing-update launch (gemm_kernel<double,true,true,128>): with
   look-ahead the update of panel group g is split into F1 (next group's block columns, 64x64 tiles,
   latency-critical) and F2 (the remaining m = nblk - g2 tile columns); F2 runs on 128x128 tiles while
-  m(m+1)/2 >= 600 (hyperbo_amd/csrc/api.hip run_potrf).  Lower triangle incl. diagonal tiles, K = 128*group."""
+  m(m+1)/2 >= 600 (hyperbo_amd/csrc/sched.hip run_potrf).  Lower triangle incl. diagonal tiles, K = 128*group."""
   nblk = (n + 127) // 128
   out = []
   for g0 in range(0, nblk, group):
@@ -240,6 +240,35 @@ def bench_cfg5(ctx):
           'potrf_tflops': round(tf, 2), 'frac': round(tf / FP64_MFMA_PEAK_TFLOPS, 4)}
 
 
+def bench_fp32_objective(ctx):
+  """The headline workload in the reference's DEFAULT dtype (float32 unless JAX_ENABLE_X64): cfg-2 shape, fp32
+  NLL + gradient, theta changing every evaluation; the large products run on the bf16 matrix cores from exact three-way
+  splits (option bf16x3).  Error against the fp64 evaluation of the same theta beside it."""
+  from hyperbo_amd.basics import definitions as defs
+  from hyperbo_amd.gp_utils import kernel, mean, objectives, utils
+  x, y, raw = cfg2_inputs()
+  to32 = lambda t: {k: to32(v) for k, v in t.items()} if isinstance(t, dict) else np.asarray(t, dtype=np.float32)
+  d32 = objectives.DeviceDataset({0: defs.SubDataset(x.astype(np.float32), y.astype(np.float32))})
+  f = lambda i: objectives.nll_value_and_grad(mean.constant, kernel.squared_exponential, defs.GPParams(model=to32(perturb(raw, i, 0))), d32,
+                                              utils.DEFAULT_WARP_FUNC)
+  f(0); f(1)
+  steps = 10
+  t0 = time.perf_counter()
+  for i in range(steps):
+    v32, g32 = f(2 + i)
+  el = time.perf_counter() - t0
+  d32.close()
+  d64 = objectives.DeviceDataset({0: defs.SubDataset(x, y)})
+  v64, g64 = objectives.nll_value_and_grad(mean.constant, kernel.squared_exponential, defs.GPParams(model=perturb(raw, 1 + steps, 0)), d64,
+                                           utils.DEFAULT_WARP_FUNC)
+  d64.close()
+  flat = lambda t: np.concatenate([np.ravel(np.asarray(t[k], dtype=np.float64)) for k in sorted(t)])
+  return {'workload': f'cfg-2 shape in fp32 (N={x.shape[0]}, D={x.shape[1]}): NLL+grad, products on the bf16 matrix cores (bf16x3)',
+          'ms_per_eval': round(el / steps * 1e3, 3), 'evals_per_s': round(steps / el, 2),
+          'nll_rel_err_vs_fp64': float(abs(v32 - v64) / abs(v64)),
+          'grad_err_over_max_vs_fp64': float(np.max(np.abs(flat(g32) - flat(g64))) / np.max(np.abs(flat(g64))))}
+
+
 def bench_train():
   """GP.train() (gp.py:53-195): Adam with a fresh sub-sampled batch every step, and L-BFGS on one resident batch -- the
   callers that turn NLL+grad evaluations into pre-training time.  64 tasks x 2000 points, batch_size 500."""
@@ -357,10 +386,14 @@ def main():
 
   ctx = nat.default_context()
   wf = utils.DEFAULT_WARP_FUNC
-  # panels per trailing update: set explicitly (libhbo's own choice for <= 96 blocks is also 3, K = 384) because the
-  # roofline's algorithmic flops per launch below are computed from it
-  potrf_group = int(os.environ.get('HBO_BENCH_POTRF_GROUP', '3'))
+  # panels per trailing update: libhbo's own choice (option 0: 3 up to 96 blocks, 4 above, 8 from 256 blocks on and for fp32
+  # on the bf16 cores -- sched.hip:run_potrf) unless $HBO_BENCH_POTRF_GROUP pins it; the roofline's algorithmic flops per
+  # launch below are computed from the value in effect for the headline's fp64 matrix.  (Until round 3 the bench pinned 3 for
+  # the whole context, which also put the cfg 3 / fp32 legs on 3 instead of their 8: factor 24.6 instead of 22.1 ms.)
+  potrf_group = int(os.environ.get('HBO_BENCH_POTRF_GROUP', '0'))
   ctx.set_option('potrf_group', potrf_group)
+  nblk_headline = (args.n + 127) // 128
+  group_in_effect = potrf_group if potrf_group > 0 else (3 if nblk_headline <= 96 else (8 if nblk_headline >= 256 else 4))
 
   def sync():
     # every libhbo entry point returns with its streams drained (hbo.h: calls are synchronous), so the device is
@@ -409,7 +442,7 @@ def main():
   ms_per_step = elapsed / args.steps * 1e3
   value = world * args.steps / elapsed
 
-  group = potrf_group
+  group = group_in_effect
   fl = bulk_update_flops(args.n, group)
   roofline = None
   if 'syrk_bulk' in prof and prof['syrk_bulk'][1] > 0 and fl:
@@ -488,7 +521,7 @@ def main():
         'torch_imported': 'torch' in sys.modules,
         'device': device_info,
         'roofline': roofline, 'roofline_small': roofline_small, 'roofline_potrf': roofline_potrf, 'cpu_baseline': cpu, 'multitask': multitask,
-        'jax_baseline': extra.get('jax'), 'train': extra.get('train'), 'bo_step': extra.get('bo_step'),
+        'jax_baseline': extra.get('jax'), 'train': extra.get('train'), 'bo_step': extra.get('bo_step'), 'fp32': extra.get('fp32'),
         'cfg3': extra.get('cfg3'), 'cfg5': extra.get('cfg5'),
     }
 
@@ -607,6 +640,7 @@ def main():
       extra['cfg5'] = bench_cfg5(ctx)
       extra['train'] = bench_train()
       extra['bo_step'] = bench_bo_step()
+      extra['fp32'] = bench_fp32_objective(ctx)
     except Exception as e:  # pylint: disable=broad-except
       extra['error'] = str(e)[:200]
 

@@ -693,7 +693,7 @@ def test_cfg5_full_size_closed_form(gpu_ctx):
   cap = np.eye(2) + U.T @ U / c
   logdet = n * np.log(c) + np.linalg.slogdet(cap)[1]
   uty = U.T @ y
-  quad = (float(y.T @ y) - float(uty.T @ np.linalg.solve(cap, uty)) / c) / c
+  quad = ((y.T @ y).item() - (uty.T @ np.linalg.solve(cap, uty)).item() / c) / c
   expect = 0.5 * quad + 0.5 * logdet + 0.5 * n * np.log(2 * np.pi)
   assert abs(v - expect) <= 1e-9 * abs(expect)
 
