@@ -71,7 +71,7 @@ class DeviceDataset:
     if items:
       tasks = (nat.Task * len(items))()
       for i, (x, y) in enumerate(zip(self._xs, self._ys)):
-        tasks[i].x, tasks[i].y = nat.ptr(x).value, nat.ptr(y).value
+        tasks[i].x, tasks[i].y = x.ctypes.data, y.ctypes.data   # (the address as an int: data_as() + cast cost 3 us per array)
         tasks[i].n, tasks[i].m = x.shape[0], y.shape[1]
       self.ctx.check(nat.lib().hbo_dataset_create(self.ctx.handle, nat.dtype_code(self.dtype), self.input_dim,
                                                   tasks, len(items), C.byref(self._h)), allow_not_pd=False)
