@@ -200,7 +200,7 @@ int hbo_profile_get(hbo_ctx* ctx, char names[][32], double* ms, int32_t* launche
  *                         elements whatever M; two workspaces alternate so that the Gram build of a chunk runs beside the
  *                         triangular product of the previous one)
  *   bf16x3          0/1   fp32 only: the GEMM-shaped work -- trailing updates of the factorisation, the products of the inverse
- *                         (above small_nblk blocks) and the posterior product V = L^-1 Kxq -- runs on the bf16 matrix cores
+ *                         and K^-1 = W^T W (above small_nblk blocks), the posterior product V = L^-1 Kxq -- runs on the bf16 matrix cores
  *                         from exact three-way splits of both operands (six bf16 MFMAs per fp32 product, fp32 accumulate:
  *                         fp32-class accuracy at 1.3-1.5x the fp32-MFMA rate).  Default 1; 0 = fp32 MFMA
  *   dag             0..2  the factorisation phase as a resident tile-task kernel: 1 = bulk updates + inverse as tasks beside the
