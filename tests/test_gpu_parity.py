@@ -649,6 +649,29 @@ def test_fp32_factorisation_on_bf16_matrix_cores_is_as_accurate_as_fp32_mfma(gpu
   assert err['bf16x3'][0] < 1e-3        # kappa * eps_fp32 ~ 6e-2 bounds the solve; the factor itself stays accurate
 
 
+@pytest.mark.parametrize('n', [4225, 5633])
+def test_fp32_bf16x3_paths_at_odd_block_counts(gpu_ctx, n):
+  """34 and 45 blocks: partial groups at several levels of the inverse, an odd number of row tiles in K^-1 = W^T W and in the
+  trailing updates' trapezoids (syrk3_kernel modes 0-3, split3_* edge handling).  Factor, solve and inverse of a
+  well-conditioned fp32 matrix against fp64 LAPACK (linalg.py:29-33); measured 1e-6 / 5e-6 / 5e-6 (tools/sweep32.py: nine sizes
+  from 33 to 66 blocks, 2-3x closer to fp64 than the fp32-MFMA kernels)."""
+  _, linalg, *_ = _native()
+  rng = np.random.default_rng(n)
+  g = rng.normal(size=(n, 64)).astype(np.float32)
+  a = (g @ g.T / 64 + 0.5 * np.eye(n, dtype=np.float32)).astype(np.float32)
+  a = 0.5 * (a + a.T)
+  b = rng.normal(size=(n, 1)).astype(np.float32)
+  a64 = a.astype(np.float64)
+  cref = spla.cholesky(a64, lower=True)
+  iref = spla.cho_solve((cref, True), np.eye(n))
+  chol, x = linalg.solve_linear_system(a, b)
+  inv, _ = linalg.spd_inverse(a)
+  assert helpers.rel_err(chol, cref) <= 2e-5
+  assert helpers.rel_err(x, iref @ b.astype(np.float64)) <= 1e-4
+  assert helpers.rel_err(inv, iref) <= 1e-4
+  assert np.array_equal(inv, inv.T)
+
+
 def test_fp32_objective_beyond_32_blocks_on_bf16_matrix_cores(gpu_ctx):
   """fp32 NLL + gradient of one matrix of 36 blocks (above small_nblk: trailing updates, the upper levels of the inverse AND
   K^-1 = W^T W -- syrk3_kernel modes 0-3 -- on the bf16 matrix cores) against the fp64 path, and against the same evaluation
