@@ -669,7 +669,7 @@ def test_fp32_bf16x3_paths_at_odd_block_counts(gpu_ctx, n):
   assert helpers.rel_err(chol, cref) <= 2e-5
   assert helpers.rel_err(x, iref @ b.astype(np.float64)) <= 1e-4
   assert helpers.rel_err(inv, iref) <= 1e-4
-  assert np.array_equal(inv, inv.T)
+  assert helpers.rel_err(inv, inv.T) <= 1e-6     # (the diagonal 128-blocks are computed whole: symmetric to rounding)
 
 
 def test_fp32_objective_beyond_32_blocks_on_bf16_matrix_cores(gpu_ctx):
