@@ -597,6 +597,7 @@ def main():
     # every rank's own shard time (device time before the collective) and the collective itself, from the events of the
     # device-resident route (hbo_objective_sharded); host sockets: wall time of the whole call
     rank_ms = imbalance = coll_us = None
+    rank_ms_source = 'device events of hbo_objective_sharded'
     if pgroup is not None:
       t_local = getattr(comm, 'last_timing', None)
       if t_local:
@@ -604,6 +605,19 @@ def main():
         rank_ms = [round(v, 3) for v in all_ms]
         imbalance = round(max(all_ms) / (sum(all_ms) / len(all_ms)), 3)
         coll_us = round(max(pgroup.allgather(float(t_local[1]))), 1)
+      else:
+        # transports without the device-resident route (host sockets, torch): each rank times its own shard without the collective
+        p1 = defs.GPParams(model=perturb(raw4, 1, 0))
+        local = lambda: objectives.nll_value_and_grad(mean.constant, kernel.squared_exponential, p1, dev4, wf)
+        local(); sync()
+        t0 = time.perf_counter()
+        for _ in range(3):
+          local()
+        sync()
+        all_ms = pgroup.allgather((time.perf_counter() - t0) / 3 * 1e3)
+        rank_ms = [round(v, 3) for v in all_ms]
+        imbalance = round(max(all_ms) / (sum(all_ms) / len(all_ms)), 3)
+        rank_ms_source = 'host wall clock of the local shard, no collective'
     comm_us = None
     if comm is not None:
       buf = np.zeros(2 + 7)
@@ -618,7 +632,8 @@ def main():
                  'evals_per_s': round(k4 / el4, 3), 'ms_per_eval': round(el4 / k4 * 1e3, 3), 'steps': k4,
                  'scaling': 'strong', 'comm': comm_kind, 'comm_us': comm_us, 'nll': float(v4[0]),
                  'nll_unperturbed': float(v_ref), 'nll_oracle_fixture': expected, 'local_tasks': len(mine),
-                 'rank_ms': rank_ms, 'imbalance': imbalance, 'allreduce_in_eval_us': coll_us}
+                 'rank_ms': rank_ms, 'rank_ms_source': rank_ms_source if rank_ms else None, 'imbalance': imbalance,
+                 'allreduce_in_eval_us': coll_us}
     if world == 1:
       # what one rank of an 8-GPU job would hold: the heaviest LPT shard of 8 (eight tasks), timed alone
       shard8 = parallel.shard_dataset(full, 0, 8)
