@@ -700,6 +700,33 @@ def test_fp32_objective_beyond_32_blocks_on_bf16_matrix_cores(gpu_ctx):
   assert err[1][0] <= 3 * err[0][0] + 1e-6 and err[1][1] <= 3 * err[0][1] + 1e-6, err
 
 
+def test_largest_single_matrix_closed_form(gpu_ctx):
+  """N = 131072 fp64: the Gram matrix (137 GB) is factorised in place on one GPU's 288 GB -- the largest single matrix the path
+  takes without tiling over devices (1024 blocks: every tile / block index at its maximum).  Same closed form as the cfg-5 test
+  below.  Measured: relative error 1.5e-15, 11.8 s for the factorisation = 63 TFLOP/s = 81 % of the fp64 MFMA peak
+  (tools/big_n.py).  Skipped on a device with less than 200 GB."""
+  import ctypes as C
+  from hyperbo_amd import _native as nat
+  defs, _, _, _, kernel, mean, objectives, utils = _native()
+  name = C.create_string_buffer(128); cus = C.c_int32(0); mem = C.c_int64(0)
+  if nat.lib().hbo_device_info(gpu_ctx.device, name, 128, C.byref(cus), C.byref(mem)) != 0 or mem.value < 200e9:
+    pytest.skip('needs a device with at least 200 GB')
+  rng = np.random.default_rng(7)
+  n = 131072
+  x = rng.uniform(-1, 1, size=(n, 1)); y = rng.normal(size=(n, 1))
+  sigma, bias, noise = 0.7, 0.3, 0.1
+  model = {'dot_prod_sigma': np.array(sigma), 'dot_prod_bias': np.array(bias), 'noise_variance': np.array(noise)}
+  v = objectives.neg_log_marginal_likelihood(mean.zero, kernel.dot_product, defs.GPParams(model=model), {0: defs.SubDataset(x, y)})
+  c = noise + 1e-6
+  U = np.hstack([x / sigma, np.full((n, 1), bias)])
+  cap = np.eye(2) + U.T @ U / c
+  logdet = n * np.log(c) + np.linalg.slogdet(cap)[1]
+  uty = U.T @ y
+  quad = ((y.T @ y).item() - (uty.T @ np.linalg.solve(cap, uty)).item() / c) / c
+  expect = 0.5 * quad + 0.5 * logdet + 0.5 * n * np.log(2 * np.pi)
+  assert abs(v - expect) <= 1e-9 * abs(expect)
+
+
 def test_cfg5_full_size_closed_form(gpu_ctx):
   """N=65536 fp64 blocked Cholesky (32 GiB Gram, HBM-bound panels).  The dot-product kernel on 1-D
   inputs gives K = x x^T / s^2 + b^2 + c I, whose log-determinant and quadratic form have closed
