@@ -72,6 +72,50 @@ extern "C" int hbo_factor(hbo_ctx* c, const hbo_model* m, const void* x, int64_t
 //   W' = [[W,0],[-(l^T W)/d, 1/d]],  z' = [z; (r* - l.z)/d],  alpha' = [alpha + w' z'_n ; z'_n/d].
 // Two triangular mat-vecs on the device, O(n) arithmetic on the host.  Returns HBO_ERR_UNSUPPORTED
 // when the padded capacity (npad) is exhausted -- the caller then re-factorises.
+namespace {
+// One new observation joins a cached factorisation (GP.update_sub_dataset(is_append=True) + setup_predictor, gp.py:426-452,540-560),
+// entirely on the device: with l = W k(X, x*) and wl = W^T l from the two triangular mat-vecs before it, ONE workgroup
+//   d = sqrt(k(x*, x*) + noise + eps - l.l)        (not positive: *fail_at = n + 1, nothing is written)
+//   row n of L = [l, d],   row n of W = [-wl / d, 1 / d]
+//   per column a of y:  z_a[n] = (y*_a - mu(x*) - l.z_a) / d,   alpha_a += W[n, :] z_a[n],   resid_a[n] = y*_a - mu(x*)
+// Sums in fp64 for both dtypes (as the host loop this replaces did).
+template <typename T>
+__global__ __launch_bounds__(1024) void append_row_kernel(T* L, T* W, int64_t ld, int64_t n, const T* l, const T* wl, const T* mu_new,
+                                                          const T* kdiag, double kadd, const T* y_new, int mc, int64_t npad, T* z,
+                                                          T* alpha, T* resid, int* fail_at) {
+  __shared__ double red[16];
+  __shared__ double bc;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  auto block_sum = [&](double v) -> double {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    __syncthreads();               // red[] / bc of the previous call are no longer read
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    if (tid == 0) { double s = 0; for (int k = 0; k < 16; ++k) s += red[k]; bc = s; }
+    __syncthreads();
+    return bc;
+  };
+  if (*fail_at) return;            // an earlier row of this call failed (uniform)
+  double s = 0;
+  for (int64_t i = tid; i < n; i += 1024) { const double v = (double)l[i]; s += v * v; }
+  const double d2 = (double)kdiag[0] + kadd - block_sum(s);
+  if (!(d2 > 0)) { if (tid == 0) *fail_at = (int)n + 1; return; }
+  const double d = sqrt(d2);
+  for (int64_t i = tid; i < n; i += 1024) { L[n * ld + i] = l[i]; W[n * ld + i] = (T)(-(double)wl[i] / d); }
+  if (tid == 0) { L[n * ld + n] = (T)d; W[n * ld + n] = (T)(1.0 / d); }
+  for (int a = 0; a < mc; ++a) {
+    T* za = z + (int64_t)a * npad; T* aa = alpha + (int64_t)a * npad;
+    double lz = 0;
+    for (int64_t i = tid; i < n; i += 1024) lz += (double)l[i] * (double)za[i];
+    lz = block_sum(lz);
+    const double r_new = (double)y_new[a] - (double)mu_new[0];
+    const double zn = (r_new - lz) / d;
+    for (int64_t i = tid; i < n; i += 1024) aa[i] = (T)((double)aa[i] + (-(double)wl[i] / d) * zn);
+    if (tid == 0) { za[n] = (T)zn; aa[n] = (T)(zn / d); resid[(int64_t)a * npad + n] = (T)r_new; }
+  }
+}
+}  // namespace
+
 extern "C" int hbo_cache_append(hbo_ctx* c, const hbo_model* m, hbo_cache* k, const void* x_new, int64_t n_new,
                                 const void* y_new) {
   if (!c || !k || !x_new || !y_new) return fail(c, HBO_ERR_ARG, "hbo_cache_append: null argument");
@@ -87,28 +131,18 @@ extern "C" int hbo_cache_append(hbo_ctx* c, const hbo_model* m, hbo_cache* k, co
   const int dtype = k->dtype; const size_t es = esize(dtype);
   hipStream_t st = c->stream;
   const int fdim = feature_dim(m), fm = mean_feature_dim(m), mc = k->m;
-  void *d_kx = nullptr, *d_l = nullptr, *d_w = nullptr, *d_mu = nullptr, *d_kd = nullptr;
-  auto cleanup = [&]() {};   // ctx-owned scratch
-#define HIPCHK_A(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) { c->err = std::string(#call " failed: ") + hipGetErrorString(e__); cleanup(); return HBO_ERR_HIP; } } while (0)
-  d_kx = ws_get(c, WS_AP_KX, (size_t)t->npad * es); d_l = ws_get(c, WS_AP_L, (size_t)t->npad * es);
-  d_w = ws_get(c, WS_AP_W, (size_t)t->npad * es); d_mu = ws_get(c, WS_AP_MU, 16); d_kd = ws_get(c, WS_AP_KD, 16);
-  if (!d_kx || !d_l || !d_w || !d_mu || !d_kd) return HBO_ERR_HIP;
-  std::vector<double> l(t->npad), w(t->npad), z((size_t)mc * t->npad), al((size_t)mc * t->npad);
-  std::vector<unsigned char> buf((size_t)t->npad * es * std::max(mc, 1));
-  auto to_host = [&](const void* dev, std::vector<double>& out, size_t count) -> hipError_t {
-    hipError_t e = hipMemcpy(buf.data(), dev, count * es, hipMemcpyDeviceToHost);
-    for (size_t i = 0; i < count; ++i) out[i] = host_elem(buf.data(), dtype, (int64_t)i);
-    return e;
-  };
-  auto to_dev = [&](void* dev, const double* src, size_t count) -> hipError_t {
-    for (size_t i = 0; i < count; ++i) { if (dtype == HBO_F64) ((double*)buf.data())[i] = src[i]; else ((float*)buf.data())[i] = (float)src[i]; }
-    return hipMemcpy(dev, buf.data(), count * es, hipMemcpyHostToDevice);
-  };
-  HIPCHK_A(to_host(k->zvec, z, (size_t)mc * t->npad));
-  HIPCHK_A(to_host(t->svec, al, (size_t)mc * t->npad));
-  int status = HBO_OK;
-  for (int64_t q = 0; q < n_new && status == HBO_OK; ++q) {
-    const int64_t n = t->n;
+#define HIPCHK_A(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) { c->err = std::string(#call " failed: ") + hipGetErrorString(e__); return HBO_ERR_HIP; } } while (0)
+  void* d_kx = ws_get(c, WS_AP_KX, (size_t)t->npad * es); void* d_l = ws_get(c, WS_AP_L, (size_t)t->npad * es);
+  void* d_w = ws_get(c, WS_AP_W, (size_t)t->npad * es); void* d_mu = ws_get(c, WS_AP_MU, 16); void* d_kd = ws_get(c, WS_AP_KD, 16);
+  // per call: the new targets (n_new x m) and the failure word
+  unsigned char* d_y = static_cast<unsigned char*>(ws_get(c, WS_AP_Y, (size_t)n_new * mc * es + 16));
+  if (!d_kx || !d_l || !d_w || !d_mu || !d_kd || !d_y) return HBO_ERR_HIP;
+  int* d_fail = reinterpret_cast<int*>(d_y + (((size_t)n_new * mc * es + 15) & ~(size_t)15));
+  HIPCHK_A(hipMemsetAsync(d_fail, 0, sizeof(int), st));
+  HIPCHK_A(hipMemcpyAsync(d_y, y_new, (size_t)n_new * mc * es, hipMemcpyHostToDevice, st));
+  const int64_t n0 = t->n;
+  for (int64_t q = 0; q < n_new; ++q) {
+    const int64_t n = n0 + q;
     // new input row -> X[n], features -> acts[.][n]
     void* xrow = (char*)t->X + (size_t)n * m->input_dim * es;
     HIPCHK_A(hipMemcpyAsync(xrow, (const char*)x_new + (size_t)q * m->input_dim * es, (size_t)m->input_dim * es, hipMemcpyHostToDevice, st));
@@ -127,49 +161,29 @@ extern "C" int hbo_cache_append(hbo_ctx* c, const hbo_model* m, hbo_cache* k, co
     HIPCHK_A(hipMemsetAsync(d_kx, 0, (size_t)t->npad * es, st));
     { GramArgs g = {}; g.kernel_id = c->h_model->kernel_id; g.x1 = k->h_desc.F; g.x2 = Fq; g.out = d_kx; g.n1 = n; g.n2 = 1; g.ldo = 1; g.fdim = fdim;
       launch_gram(dtype, g, c->d_model, dim3(1, (unsigned)((n + 127) / 128), 1), st); }
-    // l = W kx ; wl = W^T l
+    // l = W kx ; wl = W^T l ; then the new rows and the updated z, alpha in one workgroup (no host round trip)
     launch_tri_matvec(dtype, t->W, t->ld, t->npad, d_kx, t->npad, 1, 0, d_l, t->npad, st);
-    launch_wt_z(dtype, k->d_desc, 1, t->nblk, 0, 0, t->npad, st, d_l, d_w);   // W^T l (two-stage, uses S as scratch)
-    HIPCHK_A(hipStreamSynchronize(st));
-    HIPCHK_A(to_host(d_l, l, (size_t)t->npad));
-    HIPCHK_A(to_host(d_w, w, (size_t)t->npad));
-    std::vector<double> one(1);
-    HIPCHK_A(to_host(d_mu, one, 1)); const double mu_new = one[0];
-    HIPCHK_A(to_host(d_kd, one, 1)); const double kappa = one[0] + m->noise_variance + m->eps;
-    double ll = 0;
-    for (int64_t i = 0; i < n; ++i) ll += l[i] * l[i];
-    const double d2 = kappa - ll;
-    if (!(d2 > 0)) { status = HBO_NOT_PD; k->info = (int)n + 1; break; }
-    const double d = sqrt(d2);
-    for (int64_t i = 0; i < n; ++i) w[i] = -w[i] / d;      // new row of W (columns < n)
-    // write row n of L and of W (identity padding row is overwritten)
-    l[n] = d; w[n] = 1.0 / d;
-    HIPCHK_A(to_dev((char*)t->A + (size_t)n * t->ld * es, l.data(), (size_t)n + 1));
-    HIPCHK_A(to_dev((char*)t->W + (size_t)n * t->ld * es, w.data(), (size_t)n + 1));
-    for (int a = 0; a < mc; ++a) {
-      double* za = z.data() + (size_t)a * t->npad; double* aa = al.data() + (size_t)a * t->npad;
-      const double r_new = host_elem(y_new, dtype, q * mc + a) - mu_new;
-      double lz = 0;
-      for (int64_t i = 0; i < n; ++i) lz += l[i] * za[i];
-      const double zn = (r_new - lz) / d;
-      za[n] = zn;
-      for (int64_t i = 0; i < n; ++i) aa[i] += w[i] * zn;
-      aa[n] = zn / d;
-      // residual buffer (y - mu) gains the new entry
-      double rr = r_new;
-      HIPCHK_A(to_dev((char*)k->resid + ((size_t)a * t->npad + n) * es, &rr, 1));
-    }
-    t->n = n + 1;
-    k->h_desc.n = (int)t->n;
+    launch_wt_z(dtype, k->d_desc, 1, t->nblk, 0, 0, t->npad, st, d_l, d_w);   // W^T l (two-stage, uses its own scratch)
+    const double kadd = m->noise_variance + m->eps;
+    if (dtype == HBO_F64)
+      hipLaunchKernelGGL(append_row_kernel<double>, dim3(1), dim3(1024), 0, st, (double*)t->A, (double*)t->W, t->ld, n, (const double*)d_l,
+                         (const double*)d_w, (const double*)d_mu, (const double*)d_kd, kadd, (const double*)d_y + q * mc, mc, (int64_t)t->npad,
+                         (double*)k->zvec, (double*)t->svec, (double*)k->resid, d_fail);
+    else
+      hipLaunchKernelGGL(append_row_kernel<float>, dim3(1), dim3(1024), 0, st, (float*)t->A, (float*)t->W, t->ld, n, (const float*)d_l,
+                         (const float*)d_w, (const float*)d_mu, (const float*)d_kd, kadd, (const float*)d_y + q * mc, mc, (int64_t)t->npad,
+                         (float*)k->zvec, (float*)t->svec, (float*)k->resid, d_fail);
   }
-  if (status == HBO_OK || status == HBO_NOT_PD) {
-    HIPCHK_A(to_dev(k->zvec, z.data(), (size_t)mc * t->npad));
-    HIPCHK_A(to_dev(t->svec, al.data(), (size_t)mc * t->npad));
-    HIPCHK_A(hipMemcpy(k->d_desc, &k->h_desc, sizeof(TaskDesc), hipMemcpyHostToDevice));
-  }
+  int failed_at = 0;
+  HIPCHK_A(hipMemcpyAsync(&failed_at, d_fail, sizeof(int), hipMemcpyDeviceToHost, st));
+  HIPCHK_A(hipStreamSynchronize(st));
+  int status = HBO_OK;
+  if (failed_at) { status = HBO_NOT_PD; k->info = failed_at; t->n = failed_at - 1; }   // the rows before it were appended
+  else t->n = n0 + n_new;
+  k->h_desc.n = (int)t->n;
+  HIPCHK_A(hipMemcpy(k->d_desc, &k->h_desc, sizeof(TaskDesc), hipMemcpyHostToDevice));
   HIPCHK_A(hipGetLastError());
 #undef HIPCHK_A
-  cleanup();
   return status;
 }
 
@@ -229,8 +243,20 @@ static int posterior(hbo_ctx* c, const hbo_model* m, hbo_cache* k, const void* x
     if (full_cov) { d_V = ws_get(c, WS_V, (size_t)t->npad * ldq_max * es); if (!d_V) return HBO_ERR_HIP; }
   }
   if (full_cov) { { d_Kqq = ws_get(c, WS_KQQ, (size_t)M * M * es); if (!d_Kqq) return HBO_ERR_HIP; } { d_cov = ws_get(c, WS_COV, (size_t)M * M * es); if (!d_cov) return HBO_ERR_HIP; } }
+  // Few candidates (a BO step asks for tens of them): one workgroup per 128-row tile of W would walk a K range of up to N alone
+  // (N = 8192, 64 queries: 1.1 ms for 8.6 GFLOP); the K range is cut into chunks of `kchunk` blocks instead, one workgroup per
+  // (row tile, chunk), partial products to a workspace, summed and squared by a second small kernel (0.1-0.2 ms).
+  int kchunk = 0;
+  void* d_vpart = nullptr;
+  // (decided on the TOTAL number of candidates, not on the chunk: every post_chunk then gives the same bits)
+  if (k && !full_cov && t->nblk >= 8 && (int64_t)((M + HBO_TILE - 1) / HBO_TILE) * t->nblk < 2 * c->n_cus) {
+    kchunk = std::max(2, std::min(8, t->nblk / 8));   // N = 8100: 1 / 2 / 4 / 8 / 16 blocks per chunk: 0.81 / 0.48 / 0.35 / 0.35 / 0.35 ms; N = 2000: 2 / 4 / 8: 0.11 / 0.11 / 0.17
+    const int nch_max = (t->nblk + kchunk - 1) / kchunk;
+    d_vpart = ws_get(c, WS_VPART, (size_t)nch_max * t->npad * ldq_max * es);
+    if (!d_vpart) { c->err.clear(); kchunk = 0; }
+  }
   // fp32: the product runs on the bf16 matrix cores from exact three-way splits of both operands (post3.hip)
-  bool use3 = k && dtype == HBO_F32 && c->opt_post_bf16x3 && !full_cov;
+  bool use3 = k && dtype == HBO_F32 && c->opt_post_bf16x3 && !full_cov && kchunk == 0;
   unsigned short* d_K3 = nullptr; size_t k3_b = 0;
   const int nkb = k ? t->npad / 16 : 0;
   if (use3 && !k->w3_valid) {
@@ -320,7 +346,15 @@ static int posterior(hbo_ctx* c, const hbo_model* m, hbo_cache* k, const void* x
     } else {
       ProfScope ps(c, "post_gemm", 1, sa);
       GemmArgs a = {}; a.tasks = k->d_desc; a.mode = GEMM_POST; a.B = K_d; a.ldb = ldq; a.V = full_cov ? d_V : nullptr; a.colsq = colsq_d;
-      launch_gemm(dtype, a, dim3(mpad / HBO_TILE, t->nblk, 1), sa); }
+      if (kchunk > 0) {
+        int pairs = 0;
+        for (int i = 0; i < t->nblk; ++i) pairs += (i + kchunk) / kchunk;
+        a.kchunk = kchunk; a.V = d_vpart; a.colsq = nullptr;
+        launch_gemm(dtype, a, dim3(mpad / HBO_TILE, pairs, 1), sa);
+        launch_post_colsq_split(dtype, d_vpart, t->npad, ldq, mpad, t->nblk, kchunk, colsq_d, sa);
+      } else {
+        launch_gemm(dtype, a, dim3(mpad / HBO_TILE, t->nblk, 1), sa);
+      } }
     { ProfScope ps(c, "post_epilogue", 1, sa);
       PostArgs pa = {}; pa.Kxq = K_d; pa.ldq = ldq; pa.npad = t->npad; pa.n = (int)t->n; pa.nblk = t->nblk; pa.alpha = t->svec; pa.colsq = colsq_d; pa.mupart = d_mupart + b * colsq_b;
       pa.kdiag = kd_d; pa.muq = mu0_d; pa.mu_out = mu_d; pa.var_out = var_d; pa.acq_out = acq_d; pa.M = mc;

@@ -227,6 +227,28 @@ __device__ __forceinline__ bool decode_job(const GemmArgs& g, TileJob<T>& j, con
       return true;
     }
     case GEMM_POST: {
+      if (g.kchunk > 0) {
+        // split-K form: byi enumerates (row tile i, chunk ch), ch < ceil((i + 1) / kchunk)
+        int i = 0, rem = byi;
+        for (;; ++i) {
+          if (i >= nblk) return false;
+          const int nch = (i + g.kchunk) / g.kchunk;
+          if (rem < nch) break;
+          rem -= nch;
+        }
+        const int k0 = rem * g.kchunk;                       // first K block of the chunk
+        const int kb = (i + 1 - k0 < g.kchunk ? i + 1 - k0 : g.kchunk);
+        const T* W = static_cast<const T*>(t.W);
+        j.A = W + (int64_t)i * HBO_TILE * ld + (int64_t)k0 * HBO_TILE;
+        j.lda = ld;
+        j.B = static_cast<const T*>(g.B) + (int64_t)k0 * HBO_TILE * g.ldb + (int64_t)bxi * HBO_TILE;
+        j.ldb = g.ldb;
+        j.C = static_cast<T*>(g.V) + ((int64_t)rem * nblk * HBO_TILE + (int64_t)i * HBO_TILE) * g.ldb + (int64_t)bxi * HBO_TILE;
+        j.ldc = g.ldb;
+        j.ksteps = kb * HBO_TILE / BKE;
+        j.alpha = (T)1; j.beta = 0;
+        return true;
+      }
       const int i = nblk - 1 - byi;  // heavy (long K) row tiles first
       if (i < 0) return false;
       const int jq = bxi;

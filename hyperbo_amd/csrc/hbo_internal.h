@@ -90,6 +90,9 @@ struct GemmArgs {
   int64_t ldb;
   void* V;       // POST: optional V output (npad x ldb), may be null
   void* colsq;   // POST: partial column sums of squares [nblk][ldb], may be null
+  // POST with few column tiles (kchunk > 0): the K range of a row tile is cut into chunks of kchunk 128-blocks, one workgroup per
+  // (row tile, chunk); chunk ch of row tile i writes its partial product to V + (ch * npad + i * 128) * ldb (no colsq): split-K
+  int kchunk;
 };
 
 #ifdef __HIPCC__
@@ -189,6 +192,8 @@ struct PostArgs {
   int acq_id; double param, add_noise, scale;
 };
 void launch_post_epilogue(int dtype, const PostArgs& a, hipStream_t st);
+// colsq[i][col] = sum over the 128 rows of row block i of (sum_ch Vpart[ch][row][col])^2, chunks ch < ceil((i + 1) / kchunk)
+void launch_post_colsq_split(int dtype, const void* vpart, int npad, int64_t ldq, int mpad, int nblk, int kchunk, void* colsq, hipStream_t st);
 
 // ---- fp32 posterior product on the bf16 matrix cores (post3.hip) --------------------------------
 struct Post3Args {

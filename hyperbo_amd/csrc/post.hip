@@ -215,6 +215,32 @@ void launch_add_inplace(double* dst, const double* src, int64_t count, hipStream
   if (count <= 0) return;
   hipLaunchKernelGGL(add_inplace_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, dst, src, count);
 }
+namespace {
+// split-K posterior product (few candidate columns): the chunks' partial products are summed, squared and summed over the 128
+// rows of a row block -- the same [nblk][ldq] partials the one-pass product leaves for the epilogue
+template <typename T>
+__global__ __launch_bounds__(256) void post_colsq_split_kernel(const T* __restrict__ vpart, int npad, int64_t ldq, int kchunk, T* __restrict__ colsq) {
+  __shared__ double red[4][64];
+  const int i = blockIdx.y, col = blockIdx.x * 64 + (threadIdx.x & 63), rg = threadIdx.x >> 6;
+  const int nch = (i + kchunk) / kchunk;
+  double s = 0;
+  for (int r = rg * 32; r < rg * 32 + 32; ++r) {
+    const int64_t off = ((int64_t)i * HBO_TILE + r) * ldq + col;
+    double v = 0;
+    for (int ch = 0; ch < nch; ++ch) v += (double)vpart[(int64_t)ch * npad * ldq + off];
+    s += v * v;
+  }
+  red[rg][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (rg == 0) colsq[(int64_t)i * ldq + col] = (T)(red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+}  // namespace
+void launch_post_colsq_split(int dtype, const void* vpart, int npad, int64_t ldq, int mpad, int nblk, int kchunk, void* colsq, hipStream_t st) {
+  const dim3 grid(mpad / 64, nblk);
+  if (dtype == HBO_F64) hipLaunchKernelGGL(post_colsq_split_kernel<double>, grid, dim3(256), 0, st, (const double*)vpart, npad, ldq, kchunk, (double*)colsq);
+  else hipLaunchKernelGGL(post_colsq_split_kernel<float>, grid, dim3(256), 0, st, (const float*)vpart, npad, ldq, kchunk, (float*)colsq);
+}
+
 void launch_post_epilogue(int dtype, const PostArgs& a, hipStream_t st) {
   if (a.M <= 0) return;
   dim3 grid((unsigned)((a.M + 255) / 256));
