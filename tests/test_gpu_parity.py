@@ -1286,6 +1286,41 @@ def test_incremental_cache_append_matches_refactorisation(gpu_ctx, kname, mlp, m
   assert helpers.rel_err(mu, mu_o) < 1e-8
 
 
+def test_append_stops_at_a_row_that_breaks_the_factorisation(gpu_ctx):
+  """hbo_cache_append on the device: a row whose pivot is not positive (here: a NaN input, the deterministic way to get one) raises
+  the failure word; the rows before it stay appended, the call reports HBO_NOT_PD, the Python cache re-factorises and ends up
+  with the NaN cache the reference would have (gp.py:552-560: jax's Cholesky yields NaN, nothing raises).  A valid dataset
+  afterwards works again."""
+  import ctypes as C
+  from hyperbo_amd import _native as nat
+  defs, linalg, acfun, gp, kernel, mean, _, utils = _native()
+  rng = np.random.default_rng(31)
+  d = 3
+  model = helpers.make_model(rng, 'constant', False, d)
+  x, y = helpers.synthetic_task(rng, 90, d)
+  xa, ya = helpers.synthetic_task(rng, 3, d)
+  xa[1, 0] = np.nan
+  xq = rng.uniform(size=(10, d))
+  m = gp.GP({0: defs.SubDataset(x, y)}, mean.constant, kernel.squared_exponential, defs.GPParams(model=model), utils.DEFAULT_WARP_FUNC)
+  mu0, _ = m.predict(xq, 0)
+  assert np.isfinite(mu0).all()
+  cache = m.params.cache[0]
+  # the C entry point itself: stops at row 1 of 3
+  from hyperbo_amd import _model
+  bm = _model.BuiltModel(mean.constant, kernel.squared_exponential, m.params, utils.DEFAULT_WARP_FUNC, np.float64, d, eps=1e-6)
+  rc = nat.lib().hbo_cache_append(gpu_ctx.handle, bm.ref(), cache.handle.handle, nat.ptr(np.ascontiguousarray(xa)), 3, nat.ptr(np.ascontiguousarray(ya)))
+  assert rc == nat.HBO_NOT_PD
+  # through the GP object: the same rows, no exception, NaN posterior like a fresh factorisation of the same data
+  m2 = gp.GP({0: defs.SubDataset(x, y)}, mean.constant, kernel.squared_exponential, defs.GPParams(model=model), utils.DEFAULT_WARP_FUNC)
+  m2.predict(xq, 0)
+  m2.update_sub_dataset((xa, ya), 0, is_append=True)
+  mu, var = m2.predict(xq, 0)
+  assert m2.dataset[0].x.shape[0] == 93 and np.isnan(mu).all()
+  m2.update_sub_dataset((x, y), 0)
+  mu1, _ = m2.predict(xq, 0)
+  assert helpers.rel_err(mu1, mu0) < 1e-12
+
+
 # ---- multi-GPU plumbing: libhbo's RCCL binding and the self-spawning bench ------------------------------------------
 def test_rccl_single_rank_allreduce(gpu_ctx):
   """hbo_comm_* with nranks = 1 (what tools/rccl_smoke.py does): id, init, all-reduce (identity), destroy, re-init."""
