@@ -74,6 +74,7 @@ SIGNATURES = {
     'hbo_mean': (C.c_int, [_P, C.POINTER(Model), _P, C.c_int64, _P]),
     'hbo_dataset_create': (C.c_int, [_P, C.c_int, C.c_int, C.POINTER(Task), C.c_int, C.POINTER(_P)]),
     'hbo_dataset_free': (C.c_int, [_P, _P]),
+    'hbo_dataset_subsample': (C.c_int, [_P, _P, C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(_P)]),
     'hbo_nll': (C.c_int, [_P, C.POINTER(Model), _P, C.POINTER(C.c_double), C.POINTER(C.c_double),
                           C.POINTER(C.c_double)]),
     'hbo_objective': (C.c_int, [_P, C.POINTER(Model), _P, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double),

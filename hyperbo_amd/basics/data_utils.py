@@ -25,3 +25,15 @@ def sub_sample_dataset_iterator(key, dataset, batch_size):
         new_sub_dataset = SubDataset(x=new_sub_dataset.x, y=new_sub_dataset.y, aligned=i)
       sub_sampled_dataset[sub_dataset_key] = new_sub_dataset
     yield sub_sampled_dataset
+
+
+def sub_sample_index_iterator(key, dataset, batch_size):
+  """The same draws as sub_sample_dataset_iterator, as row indices: yields {sub_dataset_key: int32 indices or None (kept whole)}.
+  For batches gathered on the device from a resident copy of the dataset (objectives.DeviceBatch.subsample)."""
+  rng = key if isinstance(key, np.random.Generator) else np.random.default_rng(key)
+  while True:
+    out = {}
+    for sub_dataset_key, sub_dataset in dataset.items():
+      n = sub_dataset.x.shape[0]
+      out[sub_dataset_key] = rng.choice(n, batch_size, replace=False).astype(np.int32) if n >= batch_size else None
+    yield out

@@ -257,6 +257,83 @@ extern "C" int hbo_dataset_create(hbo_ctx* c, int dtype, int input_dim, const hb
   return HBO_OK;
 }
 
+namespace {
+struct GatherTask { const void* sx; const void* sys; const void* syd; void* dx; void* dys; void* dyd; int64_t n_src, n_dst, idx_off; int m, has_idx; };
+// row r of task blockIdx.y of the sub-sample = row idx[idx_off + r] (or r) of the resident task: inputs, column sum of y, divergence rows
+template <typename T>
+__global__ __launch_bounds__(256) void gather_rows_kernel(const GatherTask* __restrict__ tasks, const int32_t* __restrict__ idx, int D) {
+  const GatherTask t = tasks[blockIdx.y];
+  const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (r >= t.n_dst) return;
+  const int64_t s = t.has_idx ? (int64_t)idx[t.idx_off + r] : r;
+  const T* sx = static_cast<const T*>(t.sx) + s * D; T* dx = static_cast<T*>(t.dx) + r * D;
+  for (int d = 0; d < D; ++d) dx[d] = sx[d];
+  static_cast<T*>(t.dys)[r] = static_cast<const T*>(t.sys)[s];
+  if (t.syd) for (int a = 0; a <= t.m; ++a) static_cast<T*>(t.dyd)[(int64_t)a * t.n_dst + r] = static_cast<const T*>(t.syd)[(int64_t)a * t.n_src + s];
+}
+}  // namespace
+
+extern "C" int hbo_dataset_subsample(hbo_ctx* c, const hbo_dataset* src, const int64_t* counts, const int32_t* idx, hbo_dataset** out) {
+  if (!c || !src || !counts || !out) return fail(c, HBO_ERR_ARG, "hbo_dataset_subsample: null argument");
+  HIPCHK(c, hipSetDevice(c->device));
+  const int T = src->ntasks, dtype = src->dtype, D = src->D;
+  const size_t es = esize(dtype);
+  auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+  size_t total = 0; int64_t nidx = 0, max_dst = 0;
+  for (int k = 0; k < T; ++k) {
+    const TaskHost* t = src->tasks[k];
+    const int64_t nd = counts[k] < 0 ? t->n : counts[k];
+    if (nd <= 0 || nd > t->n) return fail(c, HBO_ERR_ARG, "hbo_dataset_subsample: counts[k] must be in 1..n_k (or negative: the whole task)");
+    if (counts[k] >= 0) { if (!idx) return fail(c, HBO_ERR_ARG, "hbo_dataset_subsample: idx is null"); nidx += nd; }
+    total += al((size_t)nd * D * es) + al((size_t)nd * es) + (t->ydiv ? al((size_t)(t->m + 1) * nd * es) : 0);
+    max_dst = std::max(max_dst, nd);
+  }
+  hbo_dataset* ds = new hbo_dataset();
+  ds->dtype = dtype; ds->D = D;
+  if (T == 0) { *out = ds; return HBO_OK; }
+  // descriptors + indices through the pinned staging buffer, one copy
+  const size_t desc_b = al(sizeof(GatherTask) * T), idx_b = al(sizeof(int32_t) * (size_t)std::max<int64_t>(nidx, 1));
+  HIPCHK(c, hipEventSynchronize(c->ev_upload));
+  unsigned char* stage = static_cast<unsigned char*>(pinned_stage(c, desc_b + idx_b));
+  unsigned char* d_args = static_cast<unsigned char*>(ws_get(c, WS_GATHER, desc_b + idx_b));
+  hipError_t e = (stage && d_args) ? dev_alloc(c, &ds->d_inputs, total) : hipErrorOutOfMemory;
+  if (e != hipSuccess) { hbo_dataset_free(c, ds); return fail(c, HBO_ERR_HIP, std::string("hbo_dataset_subsample: ") + hipGetErrorString(e)); }
+  GatherTask* g = reinterpret_cast<GatherTask*>(stage);
+  size_t off = 0; int64_t ioff = 0;
+  for (int k = 0; k < T; ++k) {
+    const TaskHost* s = src->tasks[k];
+    const int64_t nd = counts[k] < 0 ? s->n : counts[k];
+    TaskHost* t = new TaskHost();
+    ds->tasks.push_back(t);
+    t->owns_inputs = false;
+    t->n = nd; t->m = s->m; t->npad = round_up(nd, HBO_TILE); t->nblk = t->npad / HBO_TILE; t->ld = padded_ld(t->npad, dtype);
+    t->X = (char*)ds->d_inputs + off; off += al((size_t)nd * D * es);
+    t->ysum = (char*)ds->d_inputs + off; off += al((size_t)nd * es);
+    if (s->ydiv) { t->ydiv = (char*)ds->d_inputs + off; off += al((size_t)(s->m + 1) * nd * es); }
+    g[k] = GatherTask{s->X, s->ysum, s->ydiv, t->X, t->ysum, t->ydiv, s->n, nd, ioff, s->m, counts[k] >= 0 ? 1 : 0};
+    if (counts[k] >= 0) {
+      for (int64_t r = 0; r < nd; ++r) if (idx[ioff + r] < 0 || idx[ioff + r] >= s->n) { hbo_dataset_free(c, ds); return fail(c, HBO_ERR_ARG, "hbo_dataset_subsample: index out of range"); }
+      ioff += nd;
+    }
+    ds->max_nblk = std::max(ds->max_nblk, t->nblk);
+  }
+  if (nidx) memcpy(stage + desc_b, idx, sizeof(int32_t) * (size_t)nidx);
+  hipStream_t st = c->stream;
+  e = hipMemcpyAsync(d_args, stage, desc_b + idx_b, hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) e = hipEventRecord(c->ev_upload, st);
+  if (e == hipSuccess) {
+    const dim3 grid((unsigned)((max_dst + 255) / 256), (unsigned)T);
+    if (dtype == HBO_F64) hipLaunchKernelGGL(gather_rows_kernel<double>, grid, dim3(256), 0, st, reinterpret_cast<const GatherTask*>(d_args), reinterpret_cast<const int32_t*>(d_args + desc_b), D);
+    else hipLaunchKernelGGL(gather_rows_kernel<float>, grid, dim3(256), 0, st, reinterpret_cast<const GatherTask*>(d_args), reinterpret_cast<const int32_t*>(d_args + desc_b), D);
+    e = hipGetLastError();
+  }
+  if (e != hipSuccess) { hbo_dataset_free(c, ds); return fail(c, HBO_ERR_HIP, std::string("hbo_dataset_subsample: ") + hipGetErrorString(e)); }
+  ds->ntasks = (int)ds->tasks.size();
+  std::stable_sort(ds->tasks.begin(), ds->tasks.end(), [](TaskHost* a, TaskHost* b) { return a->n > b->n; });
+  *out = ds;
+  return HBO_OK;
+}
+
 extern "C" int hbo_cache_free(hbo_ctx* c, hbo_cache* k) {
   if (!k) return HBO_OK;
   if (c) hipSetDevice(c->device);

@@ -101,13 +101,22 @@ def infer_parameters(mean_func, cov_func, init_params, dataset, warp_func=None,
 
   if method == 'adam':
     needs_resample = any(s.x.shape[0] >= batch_size for s in dataset.values())
-    dataset_iter = data_utils.sub_sample_dataset_iterator(rng, dataset, batch_size)
+    # native objectives: the dataset stays resident in HBM and every step's batch is gathered there from freshly drawn row
+    # indices (the reference indexes device arrays too); otherwise the host iterator of data_utils.py:72-100
+    resident = obj.DeviceBatch(dataset) if (needs_resample and getattr(vg, 'accepts_device_batch', False)) else None
+    if resident is not None:
+      index_iter = data_utils.sub_sample_index_iterator(rng, dataset, batch_size)
+      dataset_iter = (resident.subsample(ix) for ix in index_iter)
+      make_device = lambda b: b
+    else:
+      dataset_iter = data_utils.sub_sample_dataset_iterator(rng, dataset, batch_size)
     x, unflatten = lbfgs_lib.tree_flatten(params.model)
     opt = _Adam(params.config['learning_rate'])
     dev = None
     current_loss = None
     # the next batch is drawn on a helper thread while the device evaluates the current one (the C call releases the GIL;
-    # only this iterator uses `rng`, so the draws keep their order): 64 tasks x 2000 points, batch 500: 2.9 -> 1.9 ms per step
+    # only this iterator uses `rng`, so the draws keep their order): 64 tasks x 2000 points, batch 500: 2.9 -> 1.9 ms per step,
+    # 1.45 with the batch gathered on the device
     pool = concurrent.futures.ThreadPoolExecutor(max_workers=1) if needs_resample else None
     pending = pool.submit(next, dataset_iter) if pool else None
     try:
@@ -135,6 +144,8 @@ def infer_parameters(mean_func, cov_func, init_params, dataset, warp_func=None,
     finally:
       if pool:
         pool.shutdown(wait=True)
+      if resident is not None:
+        resident.close()
     if dev is not None:
       final_loss, _ = loss_and_grad(unflatten(x), dev)
       if np.isfinite(final_loss):

@@ -64,6 +64,7 @@ class DeviceDataset:
       dims = [np.shape(s.x)[1] for s in dataset.values() if np.ndim(s.x) == 2]
       self.input_dim = dims[0] if dims else 1
     self.num_tasks = len(items)
+    self._sizes = {k: x.shape[0] for (k, _), x in zip(items, self._xs)}
     self._h = C.c_void_p()
     # device order: largest task first (stable) -- mirrors hbo_dataset_create
     order = sorted(range(len(items)), key=lambda i: -self._xs[i].shape[0])
@@ -75,6 +76,35 @@ class DeviceDataset:
         tasks[i].n, tasks[i].m = x.shape[0], y.shape[1]
       self.ctx.check(nat.lib().hbo_dataset_create(self.ctx.handle, nat.dtype_code(self.dtype), self.input_dim,
                                                   tasks, len(items), C.byref(self._h)), allow_not_pd=False)
+
+  def subsample(self, index_map):
+    """A new DeviceDataset holding, for every key of this one, the rows index_map[key] (int array, in that order) -- or the whole
+    sub-dataset when the key is missing / None.  Gathered on the device from the resident inputs (hbo_dataset_subsample): only
+    the indices travel.  The per-step batch of infer_parameters' Adam loop (gp.py:101-111)."""
+    new = DeviceDataset.__new__(DeviceDataset)
+    new.ctx, new.only_aligned, new.keys, new.dtype, new.input_dim = self.ctx, self.only_aligned, list(self.keys), self.dtype, self.input_dim
+    new._xs, new._ys = [], []
+    new.num_tasks = self.num_tasks
+    new._h = C.c_void_p()
+    order = self.device_order_keys
+    counts = (C.c_int64 * max(len(order), 1))()
+    parts, sizes = [], {}
+    for i, k in enumerate(order):
+      ix = index_map.get(k)
+      if ix is None:
+        counts[i] = -1; sizes[k] = self._sizes[k]
+      else:
+        ix = np.ascontiguousarray(ix, dtype=np.int32)
+        counts[i] = ix.shape[0]; sizes[k] = ix.shape[0]
+        parts.append(ix)
+    new._sizes = sizes
+    # the library keeps the tasks largest first, stable in the order it was given them: mirror it
+    new.device_order_keys = [order[i] for i in sorted(range(len(order)), key=lambda i: -sizes[order[i]])]
+    if order:
+      idx = np.concatenate(parts) if parts else np.zeros(1, dtype=np.int32)
+      self.ctx.check(nat.lib().hbo_dataset_subsample(self.ctx.handle, self._h, counts, idx.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(new._h)),
+                     allow_not_pd=False)
+    return new
 
   def close(self):
     if self._h:
@@ -142,10 +172,25 @@ class DeviceBatch:
                                            only_aligned=(selection == 'aligned'), ctx=self.ctx)
     return self._dev[selection]
 
+  def subsample(self, index_map):
+    """A batch whose selections are device-side sub-samples of this (resident) one."""
+    return _SubsampledBatch(self, index_map)
+
   def close(self):
     for d in self._dev.values():
       d.close()
     self._dev = {}
+
+
+class _SubsampledBatch(DeviceBatch):
+  def __init__(self, parent, index_map):   # pylint: disable=super-init-not-called
+    self.parent, self.index_map = parent, index_map
+    self.dataset, self.ctx, self._dev = parent.dataset, parent.ctx, {}
+
+  def get(self, selection):
+    if selection not in self._dev:
+      self._dev[selection] = self.parent.get(selection).subsample(self.index_map)
+    return self._dev[selection]
 
 
 def _as_device(dataset, exclude_aligned, ctx=None, only_aligned=False):

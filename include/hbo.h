@@ -120,6 +120,13 @@ int hbo_mean(hbo_ctx* ctx, const hbo_model* model, const void* x, int64_t n, voi
 int hbo_dataset_create(hbo_ctx* ctx, int dtype, int input_dim, const hbo_task* tasks, int n_tasks,
                        hbo_dataset** out);
 int hbo_dataset_free(hbo_ctx* ctx, hbo_dataset* ds);
+/* A random sub-sample of a resident dataset, drawn by the caller, gathered on the device: what every Adam step of
+ * infer_parameters does with sub_sample_dataset_iterator (hyperbo/gp_utils/gp.py:101-111, hyperbo/basics/data_utils.py:72-100;
+ * the reference indexes device arrays with jax.random.permutation).  Task k of `src` IN THE ORDER src HOLDS THEM (largest n first,
+ * stable in the order of hbo_dataset_create's `tasks`) keeps counts[k] rows: rows idx[off_k + r], r < counts[k], off_k = sum of the
+ * non-negative counts before k -- or all of its rows, in order, when counts[k] < 0 (no indices consumed).  Only the indices travel
+ * (4 bytes per kept row); the new dataset is independent of `src` afterwards. */
+int hbo_dataset_subsample(hbo_ctx* ctx, const hbo_dataset* src, const int64_t* counts, const int32_t* idx, hbo_dataset** out);
 /* nll_sum: sum over the tasks of this dataset of the per-task Cholesky NLL (objectives.py:144-156,
  * incl. the (m,m)+scalar broadcast quirk for m>1); the caller divides by the number of tasks
  * (objectives.py:192-195) -- a sum so that task shards on different GPUs can be all-reduced.

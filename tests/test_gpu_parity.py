@@ -1321,6 +1321,41 @@ def test_append_stops_at_a_row_that_breaks_the_factorisation(gpu_ctx):
   assert helpers.rel_err(mu1, mu0) < 1e-12
 
 
+@pytest.mark.parametrize('objective_name', ['nll', 'ekl'])
+def test_adam_batches_gathered_on_the_device_match_host_sub_sampling(gpu_ctx, objective_name):
+  """infer_parameters' Adam loop keeps the dataset resident in HBM and gathers every step's batch there from freshly drawn row
+  indices (hbo_dataset_subsample) -- the reference indexes device arrays with jax.random.permutation (data_utils.py:72-100,
+  gp.py:101-111).  Same seed, same draws: the trajectory must equal, to the bit, the one through the host iterator
+  (sub_sample_dataset_iterator + one upload per step), taken here by hiding the objective's device-batch capability.
+  Ragged tasks, one of them smaller than the batch (kept whole), aligned sub-datasets for the divergence objective."""
+  defs, _, _, gp, kernel, mean, objectives, utils = _native()
+  rng = np.random.default_rng(17)
+  d = 3
+  data = {}
+  xal = rng.uniform(size=(60, d))
+  for k, n in enumerate((90, 61, 33, 130)):
+    x, y = helpers.synthetic_task(rng, n, d)
+    data[k] = defs.SubDataset(x, y)
+  data['al'] = defs.SubDataset(xal, rng.normal(size=(60, 5)), aligned='g')
+  objective = getattr(objectives, objective_name)
+  def hidden(**kw):
+    return objective(**kw)
+  def hidden_vg(**kw):
+    return objective.value_and_grad(**kw)
+  hidden.value_and_grad = hidden_vg                      # no accepts_device_batch: host batches
+  model = helpers.make_model(rng, 'constant', False, d)
+  out = []
+  for obj_fn in (objective, hidden):
+    p = defs.GPParams(model={k: np.array(v, copy=True) for k, v in model.items()},
+                      config={'method': 'adam', 'batch_size': 40, 'max_training_step': 6, 'learning_rate': 0.05, 'objective': obj_fn})
+    losses = []
+    res = gp.infer_parameters(mean.constant, kernel.squared_exponential, p, data, utils.DEFAULT_WARP_FUNC, obj_fn, key=5,
+                              callback=lambda i, m_, l_: losses.append(l_))
+    out.append((losses, helpers.flatten(res.model)))
+  assert out[0][0] == out[1][0], (out[0][0], out[1][0])
+  assert np.array_equal(out[0][1], out[1][1])
+
+
 # ---- multi-GPU plumbing: libhbo's RCCL binding and the self-spawning bench ------------------------------------------
 def test_rccl_single_rank_allreduce(gpu_ctx):
   """hbo_comm_* with nranks = 1 (what tools/rccl_smoke.py does): id, init, all-reduce (identity), destroy, re-init."""
