@@ -174,6 +174,7 @@ extern "C" int hbo_dataset_free(hbo_ctx* c, hbo_dataset* ds) {
   //  draining its streams -- none does: every entry point synchronises before it returns)
   for (TaskHost* t : ds->tasks) free_task(c, t);
   dev_free(c, ds->d_inputs);
+  dev_free(c, ds->d_svec);
   for (void* p : {(void*)ds->d_desc, (void*)ds->d_pack, (void*)ds->d_partials, (void*)ds->d_mlpgrad}) if (p) hipFree(p);
   delete ds;
   return HBO_OK;

@@ -137,7 +137,7 @@ struct TaskHost {
   bool owns_inputs = true;   // false: X / ysum / ydiv point into the dataset's single input block
   void* X = nullptr; void* ysum = nullptr;
   void* ydiv = nullptr;   // (m+1) x n rows for the divergence objectives: (y_a - mean_a y)/sqrt(m), then -mean_a y
-  void* A = nullptr; void* W = nullptr; void* S = nullptr; void* wscr = nullptr; void* svec = nullptr; int svec_cols = 0;
+  void* A = nullptr; void* W = nullptr; void* S = nullptr; void* wscr = nullptr; void* svec = nullptr; int svec_cols = 0; bool svec_shared = false;   // svec_shared: a slice of hbo_dataset::d_svec
   double* dmu = nullptr; double* fnorm = nullptr;
   double* dF = nullptr; double* dtmp = nullptr; size_t dF_elems = 0;   // MLP backward workspaces
   FeatBuf feat;
@@ -148,6 +148,8 @@ struct hbo_dataset {
   std::vector<TaskDesc> h_desc;
   TaskDesc* d_desc = nullptr;
   void* d_inputs = nullptr;   // x, column sums of y and divergence rows of every task (one upload)
+  void* d_svec = nullptr;     // the tasks' alpha vectors in one block (one memset instead of one per task: a fresh batch of 64
+                              // tasks per Adam step paid 64 fill kernels)
   // results of one evaluation, one device block = one copy back: [value T][gradient T x out_stride][info T (int)]
   double* d_pack = nullptr; size_t pack_bytes = 0;
   int* d_info = nullptr;
@@ -162,7 +164,7 @@ struct hbo_dataset {
 static void free_task(hbo_ctx* c, TaskHost* t) {
   if (!t) return;
   if (t->owns_inputs) for (void* p : {t->X, t->ysum, t->ydiv}) dev_free(c, p);
-  for (void* p : {t->A, t->W, t->S, t->wscr, t->svec, (void*)t->dmu, (void*)t->fnorm}) dev_free(c, p);
+  for (void* p : {t->A, t->W, t->S, t->wscr, t->svec_shared ? nullptr : t->svec, (void*)t->dmu, (void*)t->fnorm}) dev_free(c, p);
   for (void* p : {(void*)t->dF, (void*)t->dtmp}) if (p) hipFree(p);
   delete t;
 }
@@ -179,7 +181,8 @@ static int ensure_task_workspace(hbo_ctx* c, int dtype, TaskHost* t, bool need_S
   if (need_S && !t->S) HIPCHK(c, dev_alloc(c, &t->S, (size_t)t->npad * ld * es));
   if (!t->wscr) HIPCHK(c, dev_alloc(c, &t->wscr, (size_t)((t->npad + 511) / 512) * ld * es));
   if (t->svec_cols < naug_cols) {
-    if (t->svec) { HIPCHK(c, hipStreamSynchronize(c->stream)); dev_free(c, t->svec); t->svec = nullptr; }
+    if (t->svec && !t->svec_shared) { HIPCHK(c, hipStreamSynchronize(c->stream)); dev_free(c, t->svec); }
+    t->svec = nullptr; t->svec_shared = false;
     HIPCHK(c, dev_alloc(c, &t->svec, (size_t)t->npad * es * naug_cols));
     HIPCHK(c, hipMemsetAsync(t->svec, 0, (size_t)t->npad * es * naug_cols, c->stream));
     t->svec_cols = naug_cols;

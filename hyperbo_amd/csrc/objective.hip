@@ -77,6 +77,24 @@ static int objective_impl(hbo_ctx* c, const hbo_model* m_in, hbo_dataset* ds, in
   if (rc) return rc;
 
   // workspaces + descriptors
+  if (!ds->d_svec && T > 1) {
+    // first evaluation of this dataset: every task's alpha vector from ONE zeroed block
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t es = esize(ds->dtype);
+    size_t tot = 0;
+    for (TaskHost* t : ds->tasks) tot += al((size_t)t->npad * es * (obj == OBJ_NLL ? 1 : t->m + 1));
+    bool fresh = true;
+    for (TaskHost* t : ds->tasks) if (t->svec) fresh = false;
+    if (fresh && dev_alloc(c, &ds->d_svec, tot) == hipSuccess) {
+      HIPCHK(c, hipMemsetAsync(ds->d_svec, 0, tot, st));
+      size_t off = 0;
+      for (TaskHost* t : ds->tasks) {
+        const int cols = obj == OBJ_NLL ? 1 : t->m + 1;
+        t->svec = (char*)ds->d_svec + off; t->svec_cols = cols; t->svec_shared = true;
+        off += al((size_t)t->npad * es * cols);
+      }
+    } else { (void)hipGetLastError(); ds->d_svec = nullptr; }
+  }
   ds->h_desc.resize(T);
   for (int k = 0; k < T; ++k) {
     TaskHost* t = ds->tasks[k];
