@@ -165,7 +165,7 @@ static void free_task(hbo_ctx* c, TaskHost* t) {
   if (!t) return;
   if (t->owns_inputs) for (void* p : {t->X, t->ysum, t->ydiv}) dev_free(c, p);
   for (void* p : {t->A, t->W, t->S, t->wscr, t->svec_shared ? nullptr : t->svec, (void*)t->dmu, (void*)t->fnorm}) dev_free(c, p);
-  for (void* p : {(void*)t->dF, (void*)t->dtmp}) if (p) hipFree(p);
+  for (void* p : {(void*)t->dF, (void*)t->dtmp}) dev_free(c, p);
   delete t;
 }
 

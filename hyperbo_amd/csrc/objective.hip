@@ -106,23 +106,25 @@ static int objective_impl(hbo_ctx* c, const hbo_model* m_in, hbo_dataset* ds, in
       for (int l = 0; l < m->n_layers; ++l) maxf = std::max(maxf, (int)m->features[l]);
       const size_t need = (size_t)t->n * maxf;
       if (t->dF_elems < need) {
-        if (t->dF) hipFree(t->dF);
-        if (t->dtmp) hipFree(t->dtmp);
+        if (t->dF) dev_free(c, t->dF);
+        if (t->dtmp) dev_free(c, t->dtmp);
         t->dF = t->dtmp = nullptr;
-        HIPCHK(c, hbo_malloc(c, (void**)&t->dF, need * sizeof(double)));
-        HIPCHK(c, hbo_malloc(c, (void**)&t->dtmp, need * sizeof(double)));
+        HIPCHK(c, dev_alloc(c, (void**)&t->dF, need * sizeof(double)));
+        HIPCHK(c, dev_alloc(c, (void**)&t->dtmp, need * sizeof(double)));
         t->dF_elems = need;
       }
     }
     fill_desc(ds->h_desc[k], t, m, dtype, obj);
   }
-  if (!ds->d_desc) HIPCHK(c, hbo_malloc(c, (void**)&ds->d_desc, sizeof(TaskDesc) * T));
+  // (per-dataset buffers come from the context's pool: a fresh batch per Adam step paid three hipMalloc + three synchronising
+  //  hipFree for its descriptors, results and gradient partials)
+  if (!ds->d_desc) HIPCHK(c, dev_alloc(c, (void**)&ds->d_desc, sizeof(TaskDesc) * T));
   const int out_stride = (m->kernel_id == HBO_KERNEL_DOT ? 0 : m->n_lengthscale) + 6 + mean_feature_dim(m);
   const size_t pack_bytes = sizeof(double) * T * (1 + (size_t)out_stride) + sizeof(int) * T;
   if (ds->pack_bytes < pack_bytes) {
-    if (ds->d_pack) hipFree(ds->d_pack);
+    if (ds->d_pack) dev_free(c, ds->d_pack);
     ds->d_pack = nullptr; ds->pack_bytes = 0;
-    HIPCHK(c, hbo_malloc(c, (void**)&ds->d_pack, pack_bytes));
+    HIPCHK(c, dev_alloc(c, (void**)&ds->d_pack, pack_bytes));
     ds->pack_bytes = pack_bytes;
   }
   ds->d_nll = ds->d_pack; ds->d_gradout = ds->d_pack + T; ds->d_info = reinterpret_cast<int*>(ds->d_pack + T + (size_t)T * out_stride);
@@ -173,7 +175,7 @@ static int objective_impl(hbo_ctx* c, const hbo_model* m_in, hbo_dataset* ds, in
   const int64_t stride_task = (int64_t)(max_nblk * (max_nblk + 1)) * nacc;   // two half-tile slots per lower tile
   if (want_grad || euc) {   // EUC: the Frobenius norm of the value comes out of the contraction pass
     const size_t pb = sizeof(double) * (stride_task * T + (size_t)HBO_GRAD_PRE_ROWS * nacc * T);   // per-tile partials + their pre-reduction
-    if (ds->partials_bytes < pb) { if (ds->d_partials) hipFree(ds->d_partials); HIPCHK(c, hbo_malloc(c, (void**)&ds->d_partials, pb)); ds->partials_bytes = pb; }
+    if (ds->partials_bytes < pb) { if (ds->d_partials) dev_free(c, ds->d_partials); HIPCHK(c, dev_alloc(c, (void**)&ds->d_partials, pb)); ds->partials_bytes = pb; }
     if (!euc) {
       { ProfScope ps(c, "trtri", 1);
         run_trtri(c, dtype, ds->d_desc, T, max_nblk, &trtri_pg); }
@@ -201,7 +203,7 @@ static int objective_impl(hbo_ctx* c, const hbo_model* m_in, hbo_dataset* ds, in
       size_t tot = 0; int fin0 = m->input_dim;
       std::vector<size_t> woff(L), boff(L);
       for (int l = 0; l < L; ++l) { woff[l] = tot; tot += (size_t)fin0 * m->features[l]; boff[l] = tot; tot += m->features[l]; fin0 = m->features[l]; }
-      if (ds->mlpgrad_elems < tot) { if (ds->d_mlpgrad) hipFree(ds->d_mlpgrad); HIPCHK(c, hbo_malloc(c, (void**)&ds->d_mlpgrad, tot * sizeof(double))); ds->mlpgrad_elems = tot; }
+      if (ds->mlpgrad_elems < tot) { if (ds->d_mlpgrad) dev_free(c, ds->d_mlpgrad); HIPCHK(c, dev_alloc(c, (void**)&ds->d_mlpgrad, tot * sizeof(double))); ds->mlpgrad_elems = tot; }
       HIPCHK(c, hipMemsetAsync(ds->d_mlpgrad, 0, tot * sizeof(double), st));
       for (int k = 0; k < T; ++k) HIPCHK(c, hipMemsetAsync(ds->tasks[k]->dF, 0, (size_t)ds->tasks[k]->n * flast * sizeof(double), st));
       if (m->kernel_uses_mlp) {

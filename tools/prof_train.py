@@ -5,7 +5,7 @@ from hyperbo_amd.basics import definitions as defs
 from hyperbo_amd.gp_utils import gp, kernel, mean, objectives, utils
 from hyperbo_amd import _native as nat
 rng = np.random.default_rng(0)
-tasks, n, d, bs = 64, 2000, 4, 500
+tasks, n, d, bs = (int(a) for a in (sys.argv[1:5] if len(sys.argv) > 4 else (64, 2000, 4, 500)))
 data = {}
 for k in range(tasks):
     x = rng.uniform(size=(n, d)); w = rng.normal(size=d)
