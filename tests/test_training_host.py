@@ -56,6 +56,27 @@ def test_sub_sample_dataset_iterator():
   np.testing.assert_allclose(b1['a'].x[:, 0] / 2, b1['a'].y[:, 0])   # rows stay paired
 
 
+
+def test_index_iterator_draws_the_same_rows_as_the_dataset_iterator():
+  """sub_sample_index_iterator (batches gathered on the device from a resident dataset) must consume the generator exactly like
+  sub_sample_dataset_iterator (data_utils.py:72-100): same seed -> the same rows in the same order, sub-datasets below the batch
+  size kept whole (no draw)."""
+  rng = np.random.default_rng(3)
+  ds = {'a': defs.SubDataset(rng.normal(size=(30, 2)), rng.normal(size=(30, 1))),
+        'small': defs.SubDataset(rng.normal(size=(5, 2)), rng.normal(size=(5, 1))),
+        7: defs.SubDataset(rng.normal(size=(12, 2)), rng.normal(size=(12, 3)), aligned='g')}
+  it_d = data_utils.sub_sample_dataset_iterator(np.random.default_rng(11), ds, 8)
+  it_i = data_utils.sub_sample_index_iterator(np.random.default_rng(11), ds, 8)
+  for _ in range(4):
+    batch, index = next(it_d), next(it_i)
+    assert list(index) == list(ds)
+    assert index['small'] is None and batch['small'].x.shape == (5, 2)
+    for k in ('a', 7):
+      assert index[k].dtype == np.int32 and index[k].shape == (8,) and len(set(index[k].tolist())) == 8
+      np.testing.assert_array_equal(batch[k].x, ds[k].x[index[k]])
+      np.testing.assert_array_equal(batch[k].y, ds[k].y[index[k]])
+
+
 def _oracle_objective(cov_name, mean_name):
   def objective(**kw):
     raise AssertionError('value path not used by the driver')
