@@ -1286,6 +1286,28 @@ def test_incremental_cache_append_matches_refactorisation(gpu_ctx, kname, mlp, m
   assert helpers.rel_err(mu, mu_o) < 1e-8
 
 
+@pytest.mark.parametrize('n,mq', [(1100, 40), (2300, 129), (2300, 700)])
+def test_posterior_at_few_candidates_split_along_k(gpu_ctx, n, mq):
+  """gp.predict (gp.py:242-305) with few candidates against a cache of >= 8 blocks: the triangular product V = L^-1 Kxq is cut
+  into K chunks (one workgroup per (row tile, chunk), partial products summed and squared by a second kernel) instead of one
+  workgroup walking a row tile's whole K range -- the BO-step shape.  9 / 18 blocks, 1 / 2 / 6 column tiles (the last one is above
+  the split threshold at 18 blocks: the one-pass product), mean and variance against the oracle; EI through the same path."""
+  defs, _, acfun, gp, kernel, mean, _, utils = _native()
+  rng = np.random.default_rng(n + mq)
+  d = 4
+  model = helpers.make_model(rng, 'constant', False, d)
+  po, pn = _pair(model)
+  x, y = helpers.synthetic_task(rng, n, d)
+  xq = rng.uniform(size=(mq, d))
+  m = gp.GP({0: defs.SubDataset(x, y)}, mean.constant, kernel.matern52, pn, utils.DEFAULT_WARP_FUNC)
+  mu, var = m.predict(xq, 0)
+  mu_o, var_o = o.predict(o.constant, o.matern52, po, x, y, xq, WFO)
+  mu_o, var_o = o.gp_predict_postprocess(po, {0: o.SubDataset(x, y)}, mu_o, var_o, WFO, False, True, True)
+  assert helpers.rel_err(mu, mu_o) < 1e-9 and helpers.rel_err(var, var_o) < 1e-9
+  ei = acfun.expected_improvement(model=m, sub_dataset_key=0, x_queries=xq)
+  assert np.isfinite(ei).all() and (ei >= 0).all()
+
+
 def test_append_stops_at_a_row_that_breaks_the_factorisation(gpu_ctx):
   """hbo_cache_append on the device: a row whose pivot is not positive (here: a NaN input, the deterministic way to get one) raises
   the failure word; the rows before it stay appended, the call reports HBO_NOT_PD, the Python cache re-factorises and ends up
