@@ -1306,6 +1306,12 @@ def test_posterior_at_few_candidates_split_along_k(gpu_ctx, n, mq):
   assert helpers.rel_err(mu, mu_o) < 1e-9 and helpers.rel_err(var, var_o) < 1e-9
   ei = acfun.expected_improvement(model=m, sub_dataset_key=0, x_queries=xq)
   assert np.isfinite(ei).all() and (ei >= 0).all()
+  # the same cache in fp32 (the reference's default dtype): few candidates take the fp32-MFMA split product, not the bf16 planes
+  to32 = lambda t: {k: to32(v) for k, v in t.items()} if isinstance(t, dict) else np.asarray(t, dtype=np.float32)
+  m32 = gp.GP({0: defs.SubDataset(x.astype(np.float32), y.astype(np.float32))}, mean.constant, kernel.matern52,
+              defs.GPParams(model=to32(model)), utils.DEFAULT_WARP_FUNC)
+  mu32, var32 = m32.predict(xq.astype(np.float32), 0)
+  assert mu32.dtype == np.float32 and helpers.rel_err(mu32, mu_o) < 5e-4 and helpers.rel_err(var32, var_o) < 5e-4
 
 
 def test_append_stops_at_a_row_that_breaks_the_factorisation(gpu_ctx):
