@@ -87,23 +87,19 @@ class DeviceDataset:
     new.num_tasks = self.num_tasks
     new._h = C.c_void_p()
     order = self.device_order_keys
-    counts = (C.c_int64 * max(len(order), 1))()
-    parts, sizes = [], {}
-    for i, k in enumerate(order):
-      ix = index_map.get(k)
-      if ix is None:
-        counts[i] = -1; sizes[k] = self._sizes[k]
-      else:
-        ix = np.ascontiguousarray(ix, dtype=np.int32)
-        counts[i] = ix.shape[0]; sizes[k] = ix.shape[0]
-        parts.append(ix)
+    ixs = [index_map.get(k) for k in order]
+    counts = np.fromiter((-1 if ix is None else len(ix) for ix in ixs), dtype=np.int64, count=len(order))
+    parts = [ix for ix in ixs if ix is not None]
+    sizes = {k: (self._sizes[k] if ix is None else len(ix)) for k, ix in zip(order, ixs)}
     new._sizes = sizes
     # the library keeps the tasks largest first, stable in the order it was given them: mirror it
-    new.device_order_keys = [order[i] for i in sorted(range(len(order)), key=lambda i: -sizes[order[i]])]
+    vals = [sizes[k] for k in order]
+    new.device_order_keys = list(order) if all(a >= b for a, b in zip(vals, vals[1:])) else \
+        [order[i] for i in sorted(range(len(order)), key=lambda i: -vals[i])]
     if order:
-      idx = np.concatenate(parts) if parts else np.zeros(1, dtype=np.int32)
-      self.ctx.check(nat.lib().hbo_dataset_subsample(self.ctx.handle, self._h, counts, idx.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(new._h)),
-                     allow_not_pd=False)
+      idx = np.ascontiguousarray(np.concatenate(parts), dtype=np.int32) if parts else np.zeros(1, dtype=np.int32)
+      self.ctx.check(nat.lib().hbo_dataset_subsample(self.ctx.handle, self._h, counts.ctypes.data_as(C.POINTER(C.c_int64)),
+                                                     idx.ctypes.data_as(C.POINTER(C.c_int32)), C.byref(new._h)), allow_not_pd=False)
     return new
 
   def close(self):
