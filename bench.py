@@ -42,6 +42,9 @@ import time
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
+# multi-process GPU work on this driver stack needs dmabuf IPC (RCCL's hipIpcGetMemHandle fails with the legacy mode); the image
+# exports it already -- set here too so that self-spawned ranks and bare shells get it before the HIP runtime loads
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
 sys.path.insert(0, ROOT)
 
 FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X datasheet; confirmed 77.1 by tools/mfma_probe.hip (64 cyc/instr)
