@@ -2,6 +2,8 @@
 MLP combination, ragged multi-task datasets with empty and multi-column members, all three objectives, posterior and
 acquisition (+gradient) -- each case against the CPU oracle on the same seeded inputs.  Complements the structured
 tests of test_gpu_parity.py; sizes keep the whole file within ~1 minute."""
+import os
+
 import numpy as np
 import pytest
 
@@ -10,6 +12,8 @@ from oracle import hyperbo_oracle as o
 
 pytestmark = pytest.mark.gpu
 WFO = o.DEFAULT_WARP_FUNC
+# $HBO_FUZZ_SEEDS widens the two seeded sweeps for a soak run (default: 24 / 16 seeds, about a minute)
+FUZZ_SEEDS = int(os.environ.get('HBO_FUZZ_SEEDS', '0'))
 SIZES = [1, 2, 63, 64, 65, 127, 128, 129, 255, 256, 257, 383, 384, 511, 512, 513, 640, 1023, 1024, 1025, 1300]
 
 
@@ -29,7 +33,7 @@ def _case(seed):
   return rng, kname, mlp, mname, d
 
 
-@pytest.mark.parametrize('seed', range(24))
+@pytest.mark.parametrize('seed', range(FUZZ_SEEDS or 24))
 def test_fuzz_objectives(gpu_ctx, seed):
   defs, _, _, kernel, mean, objectives, utils = _native()
   rng, kname, mlp, mname, d = _case(seed)
@@ -61,7 +65,7 @@ def test_fuzz_objectives(gpu_ctx, seed):
     assert np.max(np.abs(fo - fn)) <= 1e-6 * max(np.max(np.abs(fo)), 1e-6)
 
 
-@pytest.mark.parametrize('seed', range(16))
+@pytest.mark.parametrize('seed', range(FUZZ_SEEDS or 16))
 def test_fuzz_posterior_and_acquisition(gpu_ctx, seed):
   defs, acfun, gp, kernel, mean, _, utils = _native()
   rng, kname, mlp, mname, d = _case(100 + seed)
