@@ -8,7 +8,7 @@
  *   persist_free  -1..200  CUs the persistent bulk update leaves with one workgroup (-1 = auto: 32)
  *   trtri_at      0..63    the overlapped inverse starts after this many 64ths of the panels (0 = auto: 5/8)
  *   trtri_free    0..200   CUs the co-running inverse products leave with one workgroup
- *   post_bf16x3 / syrk_bf16x3 / trtri_bf16x3  0/1   the three parts of option bf16x3 separately
+ *   post_bf16x3 / syrk_bf16x3 / trtri_bf16x3 / lauum_bf16x3  0/1   the four parts of option bf16x3 separately
  *   trtri3_min_s  >=1      lowest level (in blocks) of the inverse that runs on the bf16 cores
  *   syrk3_col / syrk3_sep / syrk3_free       fp32 trailing updates: column updates on the bf16 cores too / panels split by
  *                          their own kernel instead of inside the panel solve / CUs the bulk update leaves with one workgroup
