@@ -314,6 +314,16 @@ def bench_bo_step():
       m.update_sub_dataset((x[n + i:n + i + 1], y[n + i:n + i + 1]), 0, is_append=True)
       t0 = time.perf_counter(); m.predict(xq, 0); ts.append(time.perf_counter() - t0)
     out[name] = round(1e3 * float(np.median(ts)), 3)
+    if inc:
+      # the acquisition's value and gradient at 16 restart points against the same cache (bayesopt.py:116-125: what a
+      # gradient-based maximiser of the acquisition calls in its inner loop)
+      from hyperbo_amd.bo_utils import acfun
+      f = lambda: acfun.expected_improvement.value_and_grad(model=m, sub_dataset_key=0, x_queries=xq[:16])
+      f(); f()
+      t0 = time.perf_counter()
+      for _ in range(10):
+        f()
+      out['ei_value_and_grad_16_ms'] = round((time.perf_counter() - t0) / 10 * 1e3, 3)
   return out
 
 

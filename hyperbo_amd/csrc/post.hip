@@ -177,6 +177,8 @@ __global__ void fullcov_kernel(const T* __restrict__ V, int64_t ldq, int npad, c
   out[a * M + b] = Kqq[a * M + b] - s;
 }
 
+// out[col] = W x[col] (trans = 0) or W^T x[col] (trans = 1), W lower triangular, one right-hand side per blockIdx.y: the row
+// append (one vector).
 template <typename T>
 __global__ __launch_bounds__(256) void tri_matvec_kernel(const T* __restrict__ W, int64_t ld, int npad,
                                                          const T* __restrict__ x, int64_t xld, int trans,
@@ -198,6 +200,84 @@ __global__ __launch_bounds__(256) void tri_matvec_kernel(const T* __restrict__ W
     for (int64_t r = j; r < npad; ++r) s += W[r * ld + j] * x[(int64_t)col * xld + r];
     out[(int64_t)col * old + j] = s;
   }
+}
+
+// The same products for MC right-hand sides per pass over W (the acquisition gradient asks for l = W k(X, x_q) and beta = W^T l for
+// every restart point x_q; one pass per point re-read all of W: N = 8000, 16 points: 4.3 ms).
+//   forward (W x):  a workgroup owns 16 rows, four per wave; lanes stride over j; 4 x MC accumulators per lane; fp64 sums
+//   transposed (W^T x): a workgroup owns 64 columns (lane = column: the row reads of W coalesce), the right-hand sides of 256 rows at a time
+//   are staged in LDS (read by every lane), each wave takes 64 of those rows eight at a time; the waves' partial sums meet in LDS
+template <typename T, int MC>
+__global__ __launch_bounds__(256) void tri_matmat_fwd_kernel(const T* __restrict__ W, int64_t ld, int npad, const T* __restrict__ x, int64_t xld,
+                                                             int m, T* out, int64_t old) {
+  const int c0 = blockIdx.y * MC;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t r0 = (int64_t)blockIdx.x * 16 + wave * 4;
+  if (r0 >= npad) return;
+  double s[4][MC];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int c = 0; c < MC; ++c) s[a][c] = 0;
+  const int64_t rmax = r0 + 3;
+  for (int64_t j = lane; j <= rmax; j += 64) {
+    double xv[MC];
+#pragma unroll
+    for (int c = 0; c < MC; ++c) xv[c] = c0 + c < m ? (double)x[(int64_t)(c0 + c) * xld + j] : 0.0;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      const double w = j <= r0 + a ? (double)W[(r0 + a) * ld + j] : 0.0;
+#pragma unroll
+      for (int c = 0; c < MC; ++c) s[a][c] += w * xv[c];
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int c = 0; c < MC; ++c) {
+      const double v = wave_sum(s[a][c]);
+      if (lane == 0 && c0 + c < m) out[(int64_t)(c0 + c) * old + r0 + a] = (T)v;
+    }
+}
+template <typename T, int MC>
+__global__ __launch_bounds__(256) void tri_matmat_trans_kernel(const T* __restrict__ W, int64_t ld, int npad, const T* __restrict__ x, int64_t xld,
+                                                               int m, T* out, int64_t old) {
+  __shared__ double red[4][MC][64];
+  __shared__ double xs[MC][256];          // the right-hand sides of the current 256 rows (read by every lane: LDS broadcast)
+  const int c0 = blockIdx.y * MC;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t j0 = (int64_t)blockIdx.x * 64, j = j0 + lane;
+  double s[MC];
+#pragma unroll
+  for (int c = 0; c < MC; ++c) s[c] = 0;
+  for (int64_t rc = j0 / 256 * 256; rc < npad; rc += 256) {     // npad is a multiple of 128: the last chunk may be half
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < MC; ++c) {
+      const int64_t r = rc + threadIdx.x;
+      xs[c][threadIdx.x] = (c0 + c < m && r < npad) ? (double)x[(int64_t)(c0 + c) * xld + r] : 0.0;
+    }
+    __syncthreads();
+    // each wave takes 64 rows of the chunk, eight at a time: their loads of W are in flight together
+#pragma unroll 2
+    for (int g = 0; g < 8; ++g) {
+      const int rl = wave * 64 + g * 8;
+      T w[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { const int64_t r = rc + rl + u; w[u] = (r < npad && r >= j) ? W[r * ld + j] : (T)0; }
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+#pragma unroll
+        for (int c = 0; c < MC; ++c) s[c] += (double)w[u] * xs[c][rl + u];
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < MC; ++c) red[wave][c][lane] = s[c];
+  __syncthreads();
+  if (wave == 0)
+#pragma unroll
+    for (int c = 0; c < MC; ++c)
+      if (c0 + c < m) out[(int64_t)(c0 + c) * old + j] = (T)(((red[0][c][lane] + red[1][c][lane]) + red[2][c][lane]) + red[3][c][lane]);
 }
 
 }  // namespace
@@ -261,7 +341,20 @@ void launch_fullcov(int dtype, const void* V, int64_t ldq, int npad, const void*
 }
 void launch_tri_matvec(int dtype, const void* W, int64_t ld, int npad, const void* x, int64_t xld, int m,
                        int trans, void* out, int64_t old, hipStream_t st) {
-  dim3 grid(trans ? (npad + 255) / 256 : (npad + 3) / 4, m);
-  if (dtype == HBO_F64) hipLaunchKernelGGL((tri_matvec_kernel<double>), grid, dim3(256), 0, st, (const double*)W, ld, npad, (const double*)x, xld, trans, (double*)out, old);
-  else hipLaunchKernelGGL((tri_matvec_kernel<float>), grid, dim3(256), 0, st, (const float*)W, ld, npad, (const float*)x, xld, trans, (float*)out, old);
+  if (m <= 0) return;
+  if (m == 1) {
+    dim3 grid(trans ? (npad + 255) / 256 : (npad + 3) / 4, 1);
+    if (dtype == HBO_F64) hipLaunchKernelGGL((tri_matvec_kernel<double>), grid, dim3(256), 0, st, (const double*)W, ld, npad, (const double*)x, xld, trans, (double*)out, old);
+    else hipLaunchKernelGGL((tri_matvec_kernel<float>), grid, dim3(256), 0, st, (const float*)W, ld, npad, (const float*)x, xld, trans, (float*)out, old);
+    return;
+  }
+  constexpr int MC = 8;
+  const dim3 grid(trans ? npad / 64 : (npad + 15) / 16, (m + MC - 1) / MC);
+  if (dtype == HBO_F64) {
+    if (trans) hipLaunchKernelGGL((tri_matmat_trans_kernel<double, MC>), grid, dim3(256), 0, st, (const double*)W, ld, npad, (const double*)x, xld, m, (double*)out, old);
+    else hipLaunchKernelGGL((tri_matmat_fwd_kernel<double, MC>), grid, dim3(256), 0, st, (const double*)W, ld, npad, (const double*)x, xld, m, (double*)out, old);
+  } else {
+    if (trans) hipLaunchKernelGGL((tri_matmat_trans_kernel<float, MC>), grid, dim3(256), 0, st, (const float*)W, ld, npad, (const float*)x, xld, m, (float*)out, old);
+    else hipLaunchKernelGGL((tri_matmat_fwd_kernel<float, MC>), grid, dim3(256), 0, st, (const float*)W, ld, npad, (const float*)x, xld, m, (float*)out, old);
+  }
 }
