@@ -242,7 +242,12 @@ static int posterior(hbo_ctx* c, const hbo_model* m, hbo_cache* k, const void* x
     { d_mupart = (char*)ws_get(c, WS_MUPART, colsq_b * nbuf); if (!d_mupart) return HBO_ERR_HIP; }
     if (full_cov) { d_V = ws_get(c, WS_V, (size_t)t->npad * ldq_max * es); if (!d_V) return HBO_ERR_HIP; }
   }
-  if (full_cov) { { d_Kqq = ws_get(c, WS_KQQ, (size_t)M * M * es); if (!d_Kqq) return HBO_ERR_HIP; } { d_cov = ws_get(c, WS_COV, (size_t)M * M * es); if (!d_cov) return HBO_ERR_HIP; } }
+  // full covariance: Kqq goes into an mpad x ldq buffer (the candidates' padded leading dimension) and V^T V is subtracted in
+  // place by a GEMM (gemm.hip: GEMM_VTV); with no cache (prior branch) the M x M Gram is the answer
+  if (full_cov) {
+    if (k) { d_Kqq = ws_get(c, WS_KQQ, (size_t)mpad_max * ldq_max * es); if (!d_Kqq) return HBO_ERR_HIP; }
+    { d_cov = ws_get(c, WS_COV, (size_t)M * M * es); if (!d_cov) return HBO_ERR_HIP; }
+  }
   // Few candidates (a BO step asks for tens of them): one workgroup per 128-row tile of W would walk a K range of up to N alone
   // (N = 8192, 64 queries: 1.1 ms for 8.6 GFLOP); the K range is cut into chunks of `kchunk` blocks instead, one workgroup per
   // (row tile, chunk), partial products to a workspace, summed and squared by a second small kernel (0.1-0.2 ms).
@@ -362,9 +367,12 @@ static int posterior(hbo_ctx* c, const hbo_model* m, hbo_cache* k, const void* x
       launch_post_epilogue(dtype, pa, sa); }
     if (nbuf == 2) { ev_free[b] = pool_event(c, evi++); hipEventRecord(ev_free[b], sa); }
     if (full_cov) {
-      GramArgs g = {}; g.kernel_id = c->h_model->kernel_id; g.x1 = Fq; g.x2 = Fq; g.out = d_Kqq; g.n1 = mc; g.n2 = mc; g.ldo = mc; g.fdim = fdim;
+      ProfScope ps(c, "full_cov", 1, sa);
+      GramArgs g = {}; g.kernel_id = c->h_model->kernel_id; g.x1 = Fq; g.x2 = Fq; g.out = d_Kqq; g.n1 = mc; g.n2 = mc; g.ldo = ldq; g.fdim = fdim;
       launch_gram(dtype, g, c->d_model, dim3((unsigned)((mc + 127) / 128), (unsigned)((mc + 127) / 128), 1), sa);
-      launch_fullcov(dtype, d_V, ldq, t->npad, d_Kqq, mc, d_cov, sa);
+      // (columns of V beyond the candidates are zero: Kxq is zero-padded; the padded part of the Kqq buffer is never copied out)
+      GemmArgs a = {}; a.tasks = k->d_desc; a.mode = GEMM_VTV; a.B = d_V; a.ldb = ldq; a.V = d_Kqq;
+      launch_gemm(dtype, a, dim3(mpad / HBO_TILE, mpad / HBO_TILE, 1), sa);
     }
   }
   if (nbuf == 2) {   // join: everything the side stream produced (the prior branch runs there entirely)
@@ -372,6 +380,8 @@ static int posterior(hbo_ctx* c, const hbo_model* m, hbo_cache* k, const void* x
   }
   if (mu_out) HIPCHK_P(hipMemcpyAsync(mu_out, d_mu, (size_t)M * es, hipMemcpyDeviceToHost, sa));
   if (var_out) {
+    // (dense on the device first: a pitched copy to pageable host memory goes row by row)
+    if (full_cov && k) HIPCHK_P(hipMemcpy2DAsync(d_cov, (size_t)M * es, d_Kqq, (size_t)ldq_max * es, (size_t)M * es, (size_t)M, hipMemcpyDeviceToDevice, sa));
     if (full_cov) HIPCHK_P(hipMemcpyAsync(var_out, d_cov, (size_t)M * M * es, hipMemcpyDeviceToHost, sa));
     else HIPCHK_P(hipMemcpyAsync(var_out, d_var, (size_t)M * es, hipMemcpyDeviceToHost, sa));
   }

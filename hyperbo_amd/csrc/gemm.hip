@@ -226,6 +226,17 @@ __device__ __forceinline__ bool decode_job(const GemmArgs& g, TileJob<T>& j, con
       j.alpha = (T)1; j.beta = 0;
       return true;
     }
+    case GEMM_VTV: {
+      // C[i, j] -= sum_k V[k, i-tile]^T V[k, j-tile]: V = g.B (npad x ldb, candidates contiguous), C = g.V (same leading dimension)
+      const T* Vm = static_cast<const T*>(g.B);
+      j.A = Vm + (int64_t)byi * HBO_TILE;
+      j.B = Vm + (int64_t)bxi * HBO_TILE;
+      j.C = static_cast<T*>(g.V) + (int64_t)byi * HBO_TILE * g.ldb + (int64_t)bxi * HBO_TILE;
+      j.lda = j.ldb = j.ldc = g.ldb;
+      j.ksteps = nblk * HBO_TILE / BKE;
+      j.alpha = (T)-1; j.beta = 1;
+      return true;
+    }
     case GEMM_POST: {
       if (g.kchunk > 0) {
         // split-K form: byi enumerates (row tile i, chunk ch), ch < ceil((i + 1) / kchunk)
@@ -568,6 +579,9 @@ void launch_gemm_t(const GemmArgs& a_in, dim3 grid, hipStream_t st) {
       break;
     case GEMM_POST:
       hipLaunchKernelGGL((gemm_kernel<T, true, false, 128>), grid, dim3(256), GEMM_LDS_BYTES, st, a);
+      break;
+    case GEMM_VTV:
+      hipLaunchKernelGGL((gemm_kernel<T, false, false, 128>), grid, dim3(256), GEMM_LDS_BYTES, st, a);
       break;
     case GEMM_LAUUM:
       if (a.small_tiles) {

@@ -59,6 +59,7 @@ enum GemmMode {
   GEMM_TRTRI_B = 2,  // W21 = -W22 * S21
   GEMM_LAUUM = 3,    // S = W^T W (lower tiles)
   GEMM_POST = 4,     // V = W * Kxq (column sums of squares and/or V itself)
+  GEMM_VTV = 5,      // C -= V^T V over all npad rows (full posterior covariance: C holds Kqq on entry), tiles of mpad x mpad
 };
 
 struct GemmArgs {
@@ -255,8 +256,6 @@ void launch_acq_grad(int dtype, const AcqGradArgs& a, const ModelDev* md, hipStr
 void launch_acq_grad_mean(const double* dmu, const ModelDev* md, int64_t M, int fm, double* out, int accumulate,
                           hipStream_t st);
 void launch_add_inplace(double* dst, const double* src, int64_t count, hipStream_t st);
-void launch_fullcov(int dtype, const void* V, int64_t ldq, int npad, const void* Kqq, int64_t M, void* out,
-                    hipStream_t st);
 void launch_extract_lower(int dtype, const void* A, int64_t ld, int64_t n, void* out, hipStream_t st);
 void launch_symmetrize_from_lower(int dtype, const void* S, int64_t ld, int64_t n, void* out, hipStream_t st);
 void launch_fill_spd(int dtype, const void* a_dense, int64_t n, void* A, int64_t ld, int npad, hipStream_t st);

@@ -165,17 +165,6 @@ __global__ void post_epilogue_kernel(PostArgs a) {
   }
 }
 
-// out[a][b] = Kqq[a][b] - sum_i V[i][a] V[i][b]
-template <typename T>
-__global__ void fullcov_kernel(const T* __restrict__ V, int64_t ldq, int npad, const T* __restrict__ Kqq, int64_t M,
-                               T* out) {
-  const int64_t b = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t a = blockIdx.y;
-  if (b >= M) return;
-  T s = (T)0;
-  for (int64_t i = 0; i < npad; ++i) s += V[i * ldq + a] * V[i * ldq + b];
-  out[a * M + b] = Kqq[a * M + b] - s;
-}
 
 // out[col] = W x[col] (trans = 0) or W^T x[col] (trans = 1), W lower triangular, one right-hand side per blockIdx.y: the row
 // append (one vector).
@@ -331,13 +320,6 @@ void launch_post_epilogue(int dtype, const PostArgs& a, hipStream_t st) {
   }
   if (dtype == HBO_F64) hipLaunchKernelGGL((post_epilogue_kernel<double>), grid, dim3(256), 0, st, a);
   else hipLaunchKernelGGL((post_epilogue_kernel<float>), grid, dim3(256), 0, st, a);
-}
-void launch_fullcov(int dtype, const void* V, int64_t ldq, int npad, const void* Kqq, int64_t M, void* out,
-                    hipStream_t st) {
-  if (M <= 0) return;
-  dim3 grid((unsigned)((M + 255) / 256), (unsigned)M);
-  if (dtype == HBO_F64) hipLaunchKernelGGL((fullcov_kernel<double>), grid, dim3(256), 0, st, (const double*)V, ldq, npad, (const double*)Kqq, M, (double*)out);
-  else hipLaunchKernelGGL((fullcov_kernel<float>), grid, dim3(256), 0, st, (const float*)V, ldq, npad, (const float*)Kqq, M, (float*)out);
 }
 void launch_tri_matvec(int dtype, const void* W, int64_t ld, int npad, const void* x, int64_t xld, int m,
                        int trans, void* out, int64_t old, hipStream_t st) {
