@@ -11,14 +11,15 @@ for k in range(tasks):
     x = rng.uniform(size=(n, d)); w = rng.normal(size=d)
     data[k] = defs.SubDataset(x, np.sin(2 * np.pi * x @ w)[:, None] + 0.1 * rng.normal(size=(n, 1)))
 model = lambda: {'lengthscale': np.zeros(d), 'signal_variance': np.array(0.0), 'noise_variance': np.array(-2.0), 'constant': np.array(0.0)}
-p = defs.GPParams(model=model(), config={'method': 'adam', 'batch_size': bs, 'max_training_step': 40, 'learning_rate': 0.01, 'objective': objectives.nll})
+METHOD = os.environ.get('HBO_TRAIN_METHOD', 'adam')
+p = defs.GPParams(model=model(), config={'method': METHOD, 'batch_size': bs, 'max_training_step': 40 if METHOD == 'adam' else 8, 'learning_rate': 0.01, 'objective': objectives.nll})
 g = gp.GP(data, mean.constant, kernel.squared_exponential, p, utils.DEFAULT_WARP_FUNC)
 g.train(key=1)
 g.params.model = model()
 pr = cProfile.Profile(); pr.enable()
 t0 = time.perf_counter(); g.train(key=2); el = time.perf_counter() - t0
 pr.disable()
-print('ms per step', el / 40 * 1e3)
+print('ms per step', el / (40 if METHOD == 'adam' else 8) * 1e3)
 pstats.Stats(pr).sort_stats('cumulative').print_stats(22)
 ctx = nat.default_context(); ctx.profile_enable(1)
 g.params.model = model(); g.train(key=3)
