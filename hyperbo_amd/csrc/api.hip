@@ -86,7 +86,7 @@ extern "C" int hbo_ctx_destroy(hbo_ctx* c) {
 extern "C" int hbo_set_option(hbo_ctx* c, const char* name, int64_t value) {
   if (!c || !name) return HBO_ERR_ARG;
   if (!strcmp(name, "potrf_group")) { if (value < 0 || value > 16) return fail(c, HBO_ERR_ARG, "potrf_group in 0..16 (0: auto)"); c->opt_group = (int)value; return HBO_OK; }
-  if (!strcmp(name, "lookahead")) { c->opt_lookahead = value ? 1 : 0; return HBO_OK; }
+  if (!strcmp(name, "lookahead")) { if (value < 0 || value > 2) return fail(c, HBO_ERR_ARG, "lookahead in 0..2"); c->opt_lookahead = (int)value; return HBO_OK; }
   if (!strcmp(name, "small_nblk")) { c->opt_small_nblk = (int)value; return HBO_OK; }
   if (!strcmp(name, "pool_cap_mb")) {
     if (value < 0) return fail(c, HBO_ERR_ARG, "pool_cap_mb >= 0");

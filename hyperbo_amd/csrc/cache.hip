@@ -48,7 +48,7 @@ extern "C" int hbo_factor(hbo_ctx* c, const hbo_model* m, const void* x, int64_t
     launch_gram(dtype, g, c->d_model, dim3(t->nblk, t->nblk, 1), st); }
   // the inverse W = L^-1 (kept for the posterior products) starts beside the panel chain, as in the objective path
   TrtriProgress trtri_pg;
-  const bool early_trtri = c->opt_lookahead && c->opt_overlap_trtri && t->nblk >= 4;
+  const bool early_trtri = use_lookahead(c, 1, t->nblk) && c->opt_overlap_trtri && t->nblk >= 4;
   c->trtri_host_task = k->h_desc;
   { ProfScope ps(c, "potrf", 1); run_potrf(c, dtype, k->d_desc, 1, t->nblk, k->d_info, early_trtri ? &trtri_pg : nullptr); }
   HIPCHK_K(hipMemcpy2DAsync(k->zvec, (size_t)t->npad * es, (char*)t->A + (size_t)t->npad * t->ld * es, (size_t)t->ld * es, (size_t)t->npad * es, mcols, hipMemcpyDeviceToDevice, st));

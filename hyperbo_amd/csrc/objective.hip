@@ -149,7 +149,8 @@ static int objective_impl(hbo_ctx* c, const hbo_model* m_in, hbo_dataset* ds, in
   for (int k = 0; k < T; ++k) max_naug = std::max(max_naug, ds->h_desc[k].naug);
   TrtriProgress trtri_pg;
   hipStream_t side = st; hipEvent_t ev_side = nullptr;
-  const bool early_trtri = want_grad && c->opt_lookahead && c->opt_overlap_trtri && max_nblk >= 4;
+  const bool la = use_lookahead(c, T, max_nblk);
+  const bool early_trtri = want_grad && la && c->opt_overlap_trtri && max_nblk >= 4;
   if (!euc) {
     {
       ProfScope ps(c, "gram", 1);
@@ -165,7 +166,7 @@ static int objective_impl(hbo_ctx* c, const hbo_model* m_in, hbo_dataset* ds, in
     }
     // the small reductions (log-determinant + quadratic form now, alpha = W^T z and d nll / d mu after the inverse) run on
     // the idle panel stream beside the inverse and K^-1 = W^T W instead of between them (0.14 ms at cfg 2)
-    side = (want_grad && obj == OBJ_NLL && c->opt_lookahead) ? c->stream2 : st;
+    side = (want_grad && obj == OBJ_NLL && la) ? c->stream2 : st;
     if (side != st) { hipEvent_t e = pool_event(c, 2); hipEventRecord(e, st); hipStreamWaitEvent(side, e, 0); }
     { ProfScope ps(c, "nll_reduce", 1, side); launch_nll_reduce(dtype, ds->d_desc, T, ds->d_info, ds->d_nll, side); }
   }

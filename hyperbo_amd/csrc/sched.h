@@ -6,6 +6,16 @@
 struct TrtriProgress { int diag = 0; int a[12] = {0}; int b[12] = {0}; };
 
 hipEvent_t pool_event(hbo_ctx* c, size_t i);
+// Look-ahead (panel chain, bulk update and inverse on separate streams) pays once there is something to overlap; below that the
+// events and cross-stream waits cost more than they hide.  Measured (NLL+grad, look-ahead on / off, ms): one matrix of 2 / 8 / 16 / 20 /
+// 24 blocks: 0.282 / 0.253, 0.714 / 0.682, 1.362 / 1.328, 1.724 / 1.741, 2.154 / 2.204; 64 tasks of 2 / 4 / 6 / 12 blocks: 0.344 / 0.298,
+// 0.790 / 0.761, 1.569 / 1.598, 6.89 / 7.05; 8 tasks of 4 / 8 / 12 / 16-19 blocks: 0.457 / 0.415, 0.847 / 0.827, 1.508 / 1.591, 3.34 / 3.61.
+// Option lookahead: 0 = never, 1 = this rule (default), 2 = whenever there is more than one block.
+static inline bool use_lookahead(const hbo_ctx* c, int ntasks, int max_nblk) {
+  if (!c->opt_lookahead || max_nblk <= 1) return false;
+  if (c->opt_lookahead >= 2) return true;
+  return max_nblk > 4 && (max_nblk >= 18 || (int64_t)ntasks * max_nblk >= 80);
+}
 // h_nblk (optional): block count per task, host copy -- a batch needs it for the resident tile-task schedule
 void run_potrf(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, int max_nblk, int* d_info, TrtriProgress* early = nullptr,
                const int* h_nblk = nullptr);

@@ -27,7 +27,7 @@ hipEvent_t pool_event(hbo_ctx* c, size_t i) {
 void run_potrf(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, int max_nblk, int* d_info, TrtriProgress* early,
                const int* h_nblk) {
   c->dag_ctr_last = nullptr;
-  if (c->opt_dag && !c->dag_broken && c->opt_lookahead && max_nblk >= c->opt_dag_min_nblk && max_nblk <= c->opt_dag_max_nblk &&
+  if (c->opt_dag && !c->dag_broken && use_lookahead(c, ntasks, max_nblk) && max_nblk >= c->opt_dag_min_nblk && max_nblk <= c->opt_dag_max_nblk &&
       (ntasks == 1 || h_nblk) && run_potrf_dag(c, dtype, d_tasks, ntasks, max_nblk, h_nblk, d_info, early))
     return;
   // panels per trailing update and CUs the persistent bulk update leaves to the panel chain.  Measured (NLL+grad, ms):
@@ -43,7 +43,7 @@ void run_potrf(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, int m
   const int persist_free = c->opt_persist_free >= 0 ? c->opt_persist_free : 32;
   hipStream_t sm = c->stream;
   // (a single block column has no trailing matrix to look ahead over: it stays on the caller's stream)
-  const bool la = c->opt_lookahead != 0 && max_nblk > 1;
+  const bool la = use_lookahead(c, ntasks, max_nblk);
   hipStream_t sp = la ? c->stream2 : c->stream;
   hipStream_t sb = sm;   // bulk updates share the main stream (CU-masked queues were measured slower)
   size_t evi = 0;

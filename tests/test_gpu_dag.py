@@ -26,7 +26,9 @@ def _se_model(rng, d, dtype=np.float64):
 
 @pytest.fixture
 def dag_ctx(gpu_ctx):
+  gpu_ctx.set_option('lookahead', 2)     # the resident schedule is a look-ahead schedule: keep it on at every size tested here
   yield gpu_ctx
+  gpu_ctx.set_option('lookahead', 1)
   gpu_ctx.set_option('dag', 0)
   gpu_ctx.set_option('dag_timeout_ms', 2000)
   gpu_ctx.set_option('dag_trtri', 64)
