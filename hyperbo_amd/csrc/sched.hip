@@ -37,13 +37,17 @@ void run_potrf(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, int m
   //   round 2, N = 65536: group 4 / 6 / 8 / 12 / 16: 60.2 / 60.7 / 62.0 / 62.6 / 62.0 TFLOP/s; N = 32768: 4 / 6 / 8: 56.8 / 57.2 / 57.9; N = 16384: 48.1 / 47.4 / 47.8
   //   round 3, fp32 with the updates on the bf16 cores, N = 16384 (factor, ms): group 4 / 5 / 6 / 7 / 8: 23.1 / 22.5 / 22.3 / 22.4 / 22.0
   const bool s3_large = dtype == HBO_F32 && c->opt_syrk_bf16x3 && !small_mat;
-  const int q = c->opt_group > 0 ? c->opt_group : (small_mat ? 3 : ((max_nblk >= 256 || s3_large) ? 8 : 4));
+  // (without look-ahead -- small problems, see use_lookahead -- there is no chain / bulk distinction to group for: one panel per
+  //  trailing update, the plain right-looking form: N = 512 / 1024 / 2048: 0.399 -> 0.383, 0.686 -> 0.654, 1.33 -> 1.28 ms; up to
+  //  eight tasks -- 64 tasks of 4 blocks: 0.761 with groups of three, 0.796 with one)
+  const bool la_on = use_lookahead(c, ntasks, max_nblk);
+  const int q = c->opt_group > 0 ? c->opt_group : ((!la_on && ntasks <= 8) ? 1 : (small_mat ? 3 : ((max_nblk >= 256 || s3_large) ? 8 : 4)));
   //   with the CU yield (below): N = 8192 (3, 64) 12.58, (3, 48) 12.52, (3, 32) 12.61, (3, 16) 13.24, (4, 48) 12.66
   //   round 2 (chain kernels mark their CUs, background workgroups there pause): 32 beats 48 at N = 8192 (11.73 / 11.81)
   const int persist_free = c->opt_persist_free >= 0 ? c->opt_persist_free : 32;
   hipStream_t sm = c->stream;
   // (a single block column has no trailing matrix to look ahead over: it stays on the caller's stream)
-  const bool la = use_lookahead(c, ntasks, max_nblk);
+  const bool la = la_on;
   hipStream_t sp = la ? c->stream2 : c->stream;
   hipStream_t sb = sm;   // bulk updates share the main stream (CU-masked queues were measured slower)
   size_t evi = 0;
