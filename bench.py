@@ -6,8 +6,7 @@ N > 1: one rank per GPU.  Launched by torch.distributed.run (RANK / LOCAL_RANK /
 ranks find each other through hyperbo_amd.parallel.SocketGroup on a port derived from MASTER_PORT; launched plainly
 (`python bench.py --gpus 8`, no WORLD_SIZE) this process SPAWNS the N ranks itself (HBO_DEVICE = rank) and relays rank
 0's JSON line.  Either way the data path is torch-free: rendezvous / barrier / max-over-ranks over localhost sockets,
-the [nll, count, grad] all-reduce through libhbo's own RCCL binding (hbo_comm_*, xGMI).  HBO_BENCH_COMM=torch selects
-torch.distributed's nccl backend for the all-reduce instead (explicit fallback; torch is not imported otherwise).
+the [nll, count, grad] all-reduce through libhbo's own RCCL binding (hbo_comm_*, xGMI); torch is never imported.
 
 metric (BASELINE.json): GP NLL+grad evaluations/sec at N=8192, D=16, fp64  (configs[1]).
 A "step" is one NLL+gradient evaluation of a single-task SE-ARD GP (X, y resident in HBM; only the
@@ -562,23 +561,11 @@ def main():
     comm_kind = 'none'
     if world > 1:
       # the [nll, count, grad] all-reduce: libhbo's own RCCL binding (ncclAllReduce on the context's stream, xGMI),
-      # unique id broadcast over the socket group.  HBO_BENCH_COMM=torch: torch.distributed's nccl backend instead.
-      pref = os.environ.get('HBO_BENCH_COMM', 'rccl')
+      # unique id broadcast over the socket group
       try:
-        if pref == 'torch':
-          import datetime
-          import torch
-          import torch.distributed as dist
-          os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-          os.environ.setdefault('MASTER_PORT', str(int(os.environ.get('HBO_BENCH_PORT', '29500')) + 40))
-          dist.init_process_group('nccl', rank=rank, world_size=world, timeout=datetime.timedelta(seconds=120))
-          comm = parallel.TorchDistComm(device=f'cuda:{local_rank % torch.cuda.device_count()}')
-          comm.allreduce_sum(np.zeros(4))
-          comm_kind = 'torch.distributed nccl (RCCL over xGMI)'
-        else:
-          comm = parallel.RcclComm(ctx, rank, world, pgroup.bcast_bytes)
-          comm.allreduce_sum(np.zeros(4))          # first collective builds the rings now; raises if it cannot
-          comm_kind = 'rccl (libhbo, xGMI)'
+        comm = parallel.RcclComm(ctx, rank, world, pgroup.bcast_bytes)
+        comm.allreduce_sum(np.zeros(4))          # first collective builds the rings now; raises if it cannot
+        comm_kind = 'rccl (libhbo, xGMI)'
       except Exception as e:  # pylint: disable=broad-except
         comm = None
         comm_kind = f'host sockets (RCCL communicator unavailable: {str(e)[:120]})'
@@ -619,7 +606,7 @@ def main():
         imbalance = round(max(all_ms) / (sum(all_ms) / len(all_ms)), 3)
         coll_us = round(max(pgroup.allgather(float(t_local[1]))), 1)
       else:
-        # transports without the device-resident route (host sockets, torch): each rank times its own shard without the collective
+        # transports without the device-resident route (host sockets): each rank times its own shard without the collective
         p1 = defs.GPParams(model=perturb(raw4, 1, 0))
         local = lambda: objectives.nll_value_and_grad(mean.constant, kernel.squared_exponential, p1, dev4, wf)
         local(); sync()

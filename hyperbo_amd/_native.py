@@ -90,6 +90,7 @@ SIGNATURES = {
                           C.c_double, _P]),
     'hbo_spd_solve': (C.c_int, [_P, C.c_int, _P, C.c_int64, _P, C.c_int32, _P, _P, _P,
                                 C.POINTER(C.c_double)]),
+    'hbo_chol_solve': (C.c_int, [_P, C.c_int, _P, C.c_int64, _P, C.c_int32, _P]),
     'hbo_profile_enable': (C.c_int, [_P, C.c_int]),
     'hbo_profile_get': (C.c_int, [_P, _P, C.POINTER(C.c_double), C.POINTER(C.c_int32),
                                   C.POINTER(C.c_int32)]),
@@ -165,7 +166,7 @@ class Context:
       lib().hbo_ctx_destroy(self._h)
       self._h = _P()
 
-  PUBLIC_OPTIONS = ('potrf_group', 'lookahead', 'small_nblk', 'pool_cap_mb', 'post_chunk', 'bf16x3', 'dag', 'dag_timeout_ms')
+  PUBLIC_OPTIONS = ('potrf_group', 'lookahead', 'small_nblk', 'pool_cap_mb', 'post_chunk', 'bf16x3')
 
   def set_option(self, name, value):
     """The options of include/hbo.h; any other name goes to the measurement hook hbo_tune (include/hbo_tune.h)."""

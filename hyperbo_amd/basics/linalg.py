@@ -41,14 +41,19 @@ def spd_inverse(coeff):
 
 def inverse_spdmatrix_vector_product(spd_matrix, x, cached_cholesky=None):
   """linalg.py:129-145: spd_matrix^-1 x.  With `cached_cholesky` (a lower factor as an array, what the reference's
-  GPCache.chol holds) no factorisation is repeated: two O(n^2) triangular solves on the host (the array-level entry
-  point hands host arrays in and out; the device-resident equivalent is the hbo_cache handle)."""
+  GPCache.chol holds) no factorisation is repeated: the factor goes to the device and two substitution sweeps run there
+  (hbo_chol_solve; the device-resident equivalent without the upload is the hbo_cache handle)."""
   if cached_cholesky is not None:
-    import scipy.linalg as spla
     x = np.asarray(x)
-    chol = np.asarray(cached_cholesky, dtype=np.float64)
-    out = spla.cho_solve((chol, True), np.asarray(x, dtype=np.float64).reshape(chol.shape[0], -1))
-    return out.reshape(x.shape).astype(_model.infer_dtype(spd_matrix, x))
+    dtype = _model.infer_dtype(spd_matrix, x)
+    chol = np.ascontiguousarray(np.asarray(cached_cholesky), dtype=dtype)
+    n = chol.shape[0]
+    b = np.ascontiguousarray(x, dtype=dtype).reshape(n, -1)
+    out = np.empty_like(b)
+    ctx = nat.default_context()
+    ctx.check(nat.lib().hbo_chol_solve(ctx.handle, nat.dtype_code(dtype), nat.ptr(chol), n, nat.ptr(b), b.shape[1], nat.ptr(out)),
+              allow_not_pd=False)
+    return out.reshape(x.shape)
   return solve_linear_system(spd_matrix, x)[1]
 
 

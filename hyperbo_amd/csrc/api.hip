@@ -82,7 +82,7 @@ extern "C" int hbo_ctx_destroy(hbo_ctx* c) {
   delete c;
   return HBO_OK;
 }
-// The eight options of the boundary (include/hbo.h).
+// The six options of the boundary (include/hbo.h).
 extern "C" int hbo_set_option(hbo_ctx* c, const char* name, int64_t value) {
   if (!c || !name) return HBO_ERR_ARG;
   if (!strcmp(name, "potrf_group")) { if (value < 0 || value > 16) return fail(c, HBO_ERR_ARG, "potrf_group in 0..16 (0: auto)"); c->opt_group = (int)value; return HBO_OK; }
@@ -99,8 +99,6 @@ extern "C" int hbo_set_option(hbo_ctx* c, const char* name, int64_t value) {
   }
   if (!strcmp(name, "post_chunk")) { if (value < 128 || value > 65536) return fail(c, HBO_ERR_ARG, "post_chunk in 128..65536"); c->opt_post_chunk = (int)value; return HBO_OK; }
   if (!strcmp(name, "bf16x3")) { c->opt_post_bf16x3 = c->opt_syrk_bf16x3 = c->opt_trtri_bf16x3 = c->opt_lauum_bf16x3 = value != 0; return HBO_OK; }
-  if (!strcmp(name, "dag")) { if (value < 0 || value > 2) return fail(c, HBO_ERR_ARG, "dag in 0..2"); c->opt_dag = (int)value; c->dag_broken = 0; return HBO_OK; }
-  if (!strcmp(name, "dag_timeout_ms")) { if (value < 1 || value > 60000) return fail(c, HBO_ERR_ARG, "dag_timeout_ms in 1..60000"); c->opt_dag_timeout_ms = (int)value; return HBO_OK; }
   return fail(c, HBO_ERR_ARG, std::string("unknown option ") + name);
 }
 // Measurement hooks (include/hbo_tune.h): placement and overlap knobs of the schedules, for the A/B tools under tools/ and
@@ -115,10 +113,6 @@ extern "C" int hbo_tune(hbo_ctx* c, const char* name, int64_t value) {
       {"post_bf16x3", &hbo_ctx::opt_post_bf16x3, 0, 1}, {"syrk_bf16x3", &hbo_ctx::opt_syrk_bf16x3, 0, 1},
       {"trtri_bf16x3", &hbo_ctx::opt_trtri_bf16x3, 0, 1}, {"lauum_bf16x3", &hbo_ctx::opt_lauum_bf16x3, 0, 1}, {"trtri3_min_s", &hbo_ctx::opt_trtri3_min_s, 1, 1024},
       {"syrk3_col", &hbo_ctx::opt_syrk3_col, 0, 1}, {"syrk3_sep", &hbo_ctx::opt_syrk3_sep, 0, 1}, {"syrk3_free", &hbo_ctx::opt_syrk3_free, 0, 200},
-      {"dag_reserve", &hbo_ctx::opt_dag_reserve, 0, 4}, {"dag_near64", &hbo_ctx::opt_dag_near64, 0, 2}, {"dag_trtri", &hbo_ctx::opt_dag_trtri, 0, 64},
-      {"dag_spin_us", &hbo_ctx::opt_dag_spin_us, 0, 1000}, {"dag_idle_sleep", &hbo_ctx::opt_dag_idle_sleep, 0, 1000},
-      {"dag_f1_small", &hbo_ctx::opt_dag_f1_small, 0, 1 << 30}, {"dag_join", &hbo_ctx::opt_dag_join, 0, 1}, {"dag_dbg", &hbo_ctx::opt_dag_dbg, 0, 3},
-      {"dag_max_nblk", &hbo_ctx::opt_dag_max_nblk, 1, 1 << 20}, {"dag_min_nblk", &hbo_ctx::opt_dag_min_nblk, 1, 1 << 20},
   };
   for (const Knob& k : knobs)
     if (!strcmp(name, k.name)) {
@@ -449,6 +443,39 @@ extern "C" int hbo_mean(hbo_ctx* c, const hbo_model* m, const void* x, int64_t n
 }
 
 // ---- dense SPD building block ---------------------------------------------------------------
+// x = L^-T L^-1 b with a factor the caller already holds (linalg.py:139-145, the `cached_cholesky=` branch): the factor and the
+// right-hand sides go up, two substitution sweeps run on the device (trisolve.hip), the solution comes back.
+void launch_chol_solve(int dtype, const void* L, int64_t n, void* rhs, int64_t npad, int m, hipStream_t st);   // trisolve.hip
+extern "C" int hbo_chol_solve(hbo_ctx* c, int dtype, const void* chol_lower, int64_t n, const void* b, int32_t mcols, void* x_out) {
+  if (!c || !chol_lower || !b || !x_out) return fail(c, HBO_ERR_ARG, "hbo_chol_solve: null argument");
+  if (n <= 0 || mcols <= 0) return fail(c, HBO_ERR_ARG, "hbo_chol_solve: n and m must be positive");
+  if (dtype != HBO_F32 && dtype != HBO_F64) return fail(c, HBO_ERR_ARG, "hbo_chol_solve: bad dtype");
+  HIPCHK(c, hipSetDevice(c->device));
+  const size_t es = esize(dtype);
+  hipStream_t st = c->stream;
+  const int64_t npad = round_up(n, 64);
+  void *d_l = nullptr, *d_r = nullptr;
+  auto cleanup = [&]() { for (void* p : {d_l, d_r}) if (p) hipFree(p); };
+#define HIPCHK_S(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) { c->err = std::string(#call " failed: ") + hipGetErrorString(e__); cleanup(); return HBO_ERR_HIP; } } while (0)
+  // right-hand sides as rows (m x npad, zero padding)
+  std::vector<unsigned char> rt((size_t)mcols * npad * es, 0);
+  for (int64_t i = 0; i < n; ++i)
+    for (int a = 0; a < mcols; ++a) memcpy(rt.data() + ((size_t)a * npad + i) * es, (const unsigned char*)b + ((size_t)i * mcols + a) * es, es);
+  HIPCHK_S(hbo_malloc(c, &d_l, (size_t)n * n * es));
+  HIPCHK_S(hbo_malloc(c, &d_r, rt.size()));
+  HIPCHK_S(hipMemcpyAsync(d_l, chol_lower, (size_t)n * n * es, hipMemcpyHostToDevice, st));
+  HIPCHK_S(hipMemcpyAsync(d_r, rt.data(), rt.size(), hipMemcpyHostToDevice, st));
+  launch_chol_solve(dtype, d_l, n, d_r, npad, mcols, st);
+  HIPCHK_S(hipMemcpyAsync(rt.data(), d_r, rt.size(), hipMemcpyDeviceToHost, st));
+  HIPCHK_S(hipStreamSynchronize(st));
+  HIPCHK_S(hipGetLastError());
+#undef HIPCHK_S
+  for (int64_t i = 0; i < n; ++i)
+    for (int a = 0; a < mcols; ++a) memcpy((unsigned char*)x_out + ((size_t)i * mcols + a) * es, rt.data() + ((size_t)a * npad + i) * es, es);
+  cleanup();
+  return HBO_OK;
+}
+
 extern "C" int hbo_spd_solve(hbo_ctx* c, int dtype, const void* a, int64_t n, const void* b, int32_t mcols,
                              void* chol_out, void* inv_out, void* x_out, double* logdet_half) {
   if (!c || !a) return fail(c, HBO_ERR_ARG, "hbo_spd_solve: null argument");

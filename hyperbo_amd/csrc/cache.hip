@@ -59,7 +59,6 @@ extern "C" int hbo_factor(hbo_ctx* c, const hbo_model* m, const void* x, int64_t
   HIPCHK_K(hipStreamSynchronize(st));
   HIPCHK_K(hipGetLastError());
   prof_collect(c);
-  if (dag_aborted(c)) { hbo_cache_free(c, k); return hbo_factor(c, m, x, n, y, mcols, out); }
 #undef HIPCHK_K
   *out = k;
   return k->info != INT_MAX ? HBO_NOT_PD : HBO_OK;

@@ -6,7 +6,6 @@
 //                   With IDENT=true the same code produces W_pp = L_pp^-1 (trtri base case).
 // Replaces what jax.scipy.linalg.cholesky lowers to (hyperbo/basics/linalg.py:31,134).
 #include "hbo_internal.h"
-#include "dag_sync.h"
 #include <limits.h>
 #include <string.h>
 
@@ -189,7 +188,6 @@ __device__ int hbo_dbg_trsm_panel = 36;
 #else
 #define STAMP(i) do {} while (0)
 #endif
-// (device function: also called by the persistent panel-chain kernel, chain.hip)
 template <typename T>
 __device__ __forceinline__ void potf2_body(const TaskDesc& t, int p, int* info_slot, unsigned char* smem) {
   typedef typename Mma<T>::acc_t acc_t;
@@ -358,22 +356,17 @@ __device__ __forceinline__ void potf2_body(const TaskDesc& t, int p, int* info_s
 #endif
 }
 template <typename T>
-__global__ __launch_bounds__(256) void potf2_kernel(const TaskDesc* tasks, int p, int* info, int* yield_flag, ChainSync cs) {
+__global__ __launch_bounds__(256) void potf2_kernel(const TaskDesc* tasks, int p, int* info, int* yield_flag) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __builtin_amdgcn_s_setprio(3);            // critical path: outrank co-resident GEMM waves
   const TaskDesc& t = tasks[blockIdx.x];
   if (p >= t.nblk) return;
-  // resident tile-task schedule: the diagonal tile must have received every update of the earlier panels
-  if (cs.ctr && threadIdx.x == 0 && blockIdx.x == 0) dag_stamp_min(cs.stamps, p, 5);
-  if (cs.ctr && !dag_wave_wait(cs.ctr, cs.off_mat + (int)blockIdx.x * cs.stride + cs.lay.ver(p, p), cs.need, cs.timeout_ticks)) return;
-  if (cs.ctr && threadIdx.x == 0 && blockIdx.x == 0) dag_stamp_min(cs.stamps, p, 6);
   // single matrix: count this workgroup into the yield table entry of its CU -- background GEMM workgroups that share the
   // CU pause at their next K step (potf2's small MFMAs queue behind their 64-cycle ones and its LDS traffic behind theirs:
   // 50 us beside them, 22 us alone)
   int tok = 0;
   if (yield_flag && threadIdx.x == 0) tok = yield_enter(yield_flag);
   potf2_body<T>(t, p, info + blockIdx.x, smem);
-  if (cs.ctr && threadIdx.x == 0 && blockIdx.x == 0) dag_stamp_max(cs.stamps, p, 7);
   if (yield_flag) {
     __syncthreads();
     if (threadIdx.x == 0) yield_leave(yield_flag, tok);
@@ -510,7 +503,7 @@ __device__ __forceinline__ void trsm_body(const TaskDesc& t, int p, int64_t row0
   }
 }
 template <typename T, bool IDENT>
-__global__ __launch_bounds__(256) void trsm_kernel(const TaskDesc* tasks, int p_arg, int* yield_tab, ChainSync cs, SplitOut so) {
+__global__ __launch_bounds__(256) void trsm_kernel(const TaskDesc* tasks, int p_arg, int* yield_tab, SplitOut so) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __builtin_amdgcn_s_setprio(3);                // critical path: outrank co-resident GEMM waves
   const TaskDesc& t = tasks[blockIdx.z];
@@ -539,15 +532,7 @@ __global__ __launch_bounds__(256) void trsm_kernel(const TaskDesc* tasks, int p_
   }
   int tok = 0;
   if (yield_tab && threadIdx.x == 0) tok = yield_enter(yield_tab);
-  // resident tile-task schedule: the panel tile of this row block carries all its updates / (IDENT) nothing to wait for: the
-  // launch order of the panel stream puts potf2 of the block first
-  int* const cm = cs.ctr ? cs.ctr + cs.off_mat + (int)blockIdx.z * cs.stride : nullptr;
-  const int rb = (int)(row0 / NB);
-  if (cm && !IDENT && !dag_wave_wait(cm, cs.lay.ver(rb, p), cs.need, cs.timeout_ticks)) return;
-  if (cm && !IDENT && threadIdx.x == 0 && blockIdx.z == 0) { dag_stamp_min(cs.stamps, p, 8); dag_stamp_max(cs.stamps, p, 9); }
   trsm_body<T, IDENT>(t, p, row0, smem, true, so.xp ? so.xp + (int64_t)blockIdx.z * so.task_stride : nullptr, so.nkb, so.kb_off);
-  if (cm) dag_wg_publish(cm, IDENT ? cs.lay.diag(p) : cs.lay.row(p, rb), 1);
-  if (cm && !IDENT && threadIdx.x == 0 && blockIdx.z == 0) { dag_stamp_min(cs.stamps, p, 0); dag_stamp_max(cs.stamps, p, 1); }
   if (yield_tab) {
     __syncthreads();
     if (threadIdx.x == 0) yield_leave(yield_tab, tok);
@@ -560,38 +545,37 @@ __global__ __launch_bounds__(256) void trsm_kernel(const TaskDesc* tasks, int p_
 #ifndef HBO_DEVICE_ONLY
 template <typename T>
 void set_attrs() {
-  static bool done = false;
-  if (done) return;
+  static unsigned long long seen = 0;
+  if (!hbo_first_use_on_device(seen)) return;
   hipFuncSetAttribute(reinterpret_cast<const void*>(&potf2_kernel<T>),
                       hipFuncAttributeMaxDynamicSharedMemorySize, potf2_lds_bytes<T>());
   hipFuncSetAttribute(reinterpret_cast<const void*>(&trsm_kernel<T, false>),
                       hipFuncAttributeMaxDynamicSharedMemorySize, trsm_lds_bytes<T>());
   hipFuncSetAttribute(reinterpret_cast<const void*>(&trsm_kernel<T, true>),
                       hipFuncAttributeMaxDynamicSharedMemorySize, trsm_lds_bytes<T>());
-  done = true;
 }
 
 template <typename T>
-void potf2_t(const TaskDesc* tasks, int ntasks, int p, int* info, hipStream_t st, int* yield_flag, const ChainSync& cs) {
+void potf2_t(const TaskDesc* tasks, int ntasks, int p, int* info, hipStream_t st, int* yield_flag) {
   set_attrs<T>();
   hipLaunchKernelGGL((potf2_kernel<T>), dim3(ntasks), dim3(256), potf2_lds_bytes<T>(), st, tasks, p, info,
-                     ntasks == 1 ? yield_flag : nullptr, cs);
+                     ntasks == 1 ? yield_flag : nullptr);
 }
 template <typename T>
-void trsm_t(const TaskDesc* tasks, int ntasks, int p, int max_nblk, hipStream_t st, int* yield_tab, const ChainSync& cs, const SplitOut& so) {
+void trsm_t(const TaskDesc* tasks, int ntasks, int p, int max_nblk, hipStream_t st, int* yield_tab, const SplitOut& so) {
   set_attrs<T>();
   const int nrows = (max_nblk + 1 - (p + 1)) * NB;
   if (nrows <= 0) return;
   hipLaunchKernelGGL((trsm_kernel<T, false>), dim3(nrows / 64, 1, ntasks), dim3(256), trsm_lds_bytes<T>(), st,
-                     tasks, p, ntasks == 1 ? yield_tab : nullptr, cs, so);
+                     tasks, p, ntasks == 1 ? yield_tab : nullptr, so);
 }
 template <typename T>
-void trtri_diag_t(const TaskDesc* tasks, int ntasks, int p_lo, int p_hi, hipStream_t st, const ChainSync& cs) {
+void trtri_diag_t(const TaskDesc* tasks, int ntasks, int p_lo, int p_hi, hipStream_t st) {
   set_attrs<T>();
   if (p_hi <= p_lo) return;
   SplitOut none; memset(&none, 0, sizeof none);
   hipLaunchKernelGGL((trsm_kernel<T, true>), dim3(2, p_hi - p_lo, ntasks), dim3(256), trsm_lds_bytes<T>(), st,
-                     tasks, p_lo, (int*)nullptr, cs, none);
+                     tasks, p_lo, (int*)nullptr, none);
 }
 
 #endif  // HBO_DEVICE_ONLY
@@ -606,23 +590,18 @@ extern "C" void hbo_dbg_trsm_wall(unsigned long long* host, int panel) {
 }
 extern "C" void hbo_dbg_potf2_wall(unsigned long long* host) { hipMemcpyFromSymbol(host, HIP_SYMBOL(hbo_dbg_wall), sizeof(unsigned long long) * 3 * 256); }
 #endif
-static ChainSync no_sync() { ChainSync z; memset(&z, 0, sizeof z); return z; }
-void launch_potf2(int dtype, const TaskDesc* tasks, int ntasks, int p, int* info, hipStream_t st, int* yield_flag, const ChainSync* cs) {
-  const ChainSync s = cs ? *cs : no_sync();
-  if (dtype == HBO_F64) potf2_t<double>(tasks, ntasks, p, info, st, yield_flag, s);
-  else potf2_t<float>(tasks, ntasks, p, info, st, yield_flag, s);
+void launch_potf2(int dtype, const TaskDesc* tasks, int ntasks, int p, int* info, hipStream_t st, int* yield_flag) {
+  if (dtype == HBO_F64) potf2_t<double>(tasks, ntasks, p, info, st, yield_flag);
+  else potf2_t<float>(tasks, ntasks, p, info, st, yield_flag);
 }
-void launch_trsm(int dtype, const TaskDesc* tasks, int ntasks, int p, int max_nblk, hipStream_t st, int* yield_tab, const ChainSync* cs,
-                 const SplitOut* so) {
-  const ChainSync s = cs ? *cs : no_sync();
+void launch_trsm(int dtype, const TaskDesc* tasks, int ntasks, int p, int max_nblk, hipStream_t st, int* yield_tab, const SplitOut* so) {
   SplitOut o; memset(&o, 0, sizeof o);
   if (so) o = *so;
-  if (dtype == HBO_F64) trsm_t<double>(tasks, ntasks, p, max_nblk, st, yield_tab, s, o);
-  else trsm_t<float>(tasks, ntasks, p, max_nblk, st, yield_tab, s, o);
+  if (dtype == HBO_F64) trsm_t<double>(tasks, ntasks, p, max_nblk, st, yield_tab, o);
+  else trsm_t<float>(tasks, ntasks, p, max_nblk, st, yield_tab, o);
 }
-void launch_trtri_diag(int dtype, const TaskDesc* tasks, int ntasks, int p_lo, int p_hi, hipStream_t st, const ChainSync* cs) {
-  const ChainSync s = cs ? *cs : no_sync();
-  if (dtype == HBO_F64) trtri_diag_t<double>(tasks, ntasks, p_lo, p_hi, st, s);
-  else trtri_diag_t<float>(tasks, ntasks, p_lo, p_hi, st, s);
+void launch_trtri_diag(int dtype, const TaskDesc* tasks, int ntasks, int p_lo, int p_hi, hipStream_t st) {
+  if (dtype == HBO_F64) trtri_diag_t<double>(tasks, ntasks, p_lo, p_hi, st);
+  else trtri_diag_t<float>(tasks, ntasks, p_lo, p_hi, st);
 }
 #endif  // HBO_DEVICE_ONLY

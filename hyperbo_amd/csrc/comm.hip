@@ -73,6 +73,16 @@ int comm_allreduce_device(hbo_ctx* c, double* d_buf, int count, hipStream_t st) 
   if (rc != 0) return fail(c, HBO_ERR_COMM, "ncclAllReduce failed with code " + std::to_string(rc));
   return HBO_OK;
 }
+// a rank that cannot take part in the evaluation's collective tears the communicator down: the peers' all-reduce then fails
+// instead of waiting for it for ever (objective.hip: objective_impl)
+int comm_abort(hbo_ctx* c) {
+  if (c->comm && c->rccl_lib) {
+    auto f = (fn_ncclCommDestroy)dlsym(c->rccl_lib, "ncclCommAbort");
+    if (f) f(c->comm);
+    c->comm = nullptr;
+  }
+  return HBO_OK;
+}
 extern "C" int hbo_comm_destroy(hbo_ctx* c) {
   if (!c) return HBO_OK;
   if (c->comm && c->rccl_lib) {

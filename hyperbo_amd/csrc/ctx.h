@@ -62,22 +62,6 @@ struct hbo_ctx {
   size_t mlp_w_bytes[HBO_MAX_MLP_LAYERS] = {0};
   size_t mlp_b_bytes[HBO_MAX_MLP_LAYERS] = {0};
   int opt_group = 0;         // 128-wide panels per trailing update (K = 128*group); 0: auto, see run_potrf
-  // resident tile-task schedule of the factorisation phase (dag.hip)
-  int opt_dag = 0;             // 0: the launch schedule of sched.hip; matrices of dag_min_nblk..dag_max_nblk blocks: 1 = the bulk trailing updates
-                               // and the inverse are tile tasks, the panel stream keeps its own launches; 2 = the chain-critical updates are tasks too
-  int opt_dag_min_nblk = 8, opt_dag_max_nblk = 96;
-  int opt_dag_reserve = 2;     // CUs per shader engine (32 engines) the tile workgroups leave to the panel kernels
-  int opt_dag_near64 = 1;      // chain-critical updates as 64x64 quadrants: 0 never, 1 the tiles next to the diagonal, 2 all of them
-  int opt_dag_trtri = 64;      // share (in 64ths of the block count) of the inverse's pieces that join the task lists
-  int opt_dag_spin_us = 200;   // how long a workgroup waits on the spot for a chain-critical task it has drawn
-  int opt_dag_timeout_ms = 2000;
-  int opt_dag_dbg = 0;         // DagDev::dbg_flags
-  int opt_dag_idle_sleep = 20;  // DagDev::idle_sleep
-  int opt_dag_f1_small = 600;  // dag = 1: an F1 launch with fewer 128-tiles than this runs on 64x64 tiles
-  int opt_dag_join = 1;        // dag = 1: workgroups on the panel stream's CUs join the tasks once the chain is done
-  int dag_broken = 0;          // a run hit its wall-clock bound: the context stays on the launch schedule from then on
-  double dag_flops = 0;        // algorithmic flops of the last worker launch (bench.py: roofline of the resident kernel)
-  int* dag_ctr_last = nullptr; // its counters (abort word checked after the synchronisation)
   int prof_level = 0;
   std::vector<ProfEntry> prof_pending;
   std::vector<hipEvent_t> prof_events; size_t prof_next = 0;   // event pool of the timing scopes

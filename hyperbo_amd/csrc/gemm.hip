@@ -9,7 +9,6 @@
 // Replaces, for the reference, what XLA lowers jax.scipy.linalg.cholesky / cho_solve /
 // solve_triangular to (hyperbo/basics/linalg.py:29-33,139-145; hyperbo/gp_utils/gp.py:297).
 #include "hbo_internal.h"
-#include "dag_sync.h"
 
 namespace {
 
@@ -104,7 +103,6 @@ struct TileJob {
   T alpha;
   int beta;                  // 0: C = alpha*acc ; 1: C += alpha*acc
   int* yield_flag;           // see GemmArgs::yield_flag
-  int tr, tc;                // SYRK: tile row / column in 128-units (dependency counters of the resident bulk schedule)
 };
 
 // (bx, by) = tile coordinates inside a gdx-wide grid: blockIdx of a one-tile-per-workgroup launch, or the tile a
@@ -138,7 +136,6 @@ __device__ __forceinline__ bool decode_job(const GemmArgs& g, TileJob<T>& j, con
       j.lda = j.ldb = j.ldc = ld;
       j.ksteps = g.kt * HBO_TILE / BKE;
       j.alpha = (T)-1; j.beta = 1;
-      j.tr = r / U; j.tc = c / U;
 #ifdef HBO_GEMM_DEBUG
       if (g.aug & 2) j.beta = 0;
       if (g.aug & 4) { j.C = nullptr; j.beta = 0; }
@@ -516,8 +513,6 @@ __global__ __launch_bounds__(256, TM == 64 ? 4 : 2) void gemm_kernel(GemmArgs g)
     return;
   }
   if (!decode_job<T, TM>(g, job, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x)) return;
-  if (AKC && BKC && g.dag_ctr && g.dag_need > 0 &&
-      !dag_wave_wait(g.dag_ctr, g.dag_off + (int)blockIdx.z * g.dag_stride + job.tr * g.dag_M + job.tc, g.dag_need, g.dag_timeout)) return;
   int ytok = 0;
   if (g.yield_mark && threadIdx.x == 0) ytok = yield_enter(g.yield_mark);
   gemm_tile<T, AKC, BKC, TM>(job, smem);
@@ -537,15 +532,14 @@ void launch_gemm_t(const GemmArgs& a_in, dim3 grid, hipStream_t st) {
   // the persistent forms: SYRK (any tile size), TRTRI on 128-tiles of a single matrix with a tile counter
   if (a.mode != GEMM_SYRK && !((a.mode == GEMM_TRTRI_A || a.mode == GEMM_TRTRI_B) && a.work_counter && grid.z == 1))
     a.persistent = 0;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static unsigned long long attr_seen = 0;
+  if (hbo_first_use_on_device(attr_seen)) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T, true, true, 128>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
     hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T, true, false, 128>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
     hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T, false, false, 128>),
                         hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
-    attr_set = true;
   }
   switch (a.mode) {
     case GEMM_SYRK:

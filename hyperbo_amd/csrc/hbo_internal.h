@@ -83,10 +83,6 @@ struct GemmArgs {
                     // (potf2, trsm, the chain's column updates) is running there and would otherwise share MFMA / LDS with it
   int* yield_mark;  // non-null (launches ON the panel chain): the same table; every workgroup counts itself in and out
   int grp_lo;       // TRTRI: first group (of size 2s blocks) handled by this launch
-  // resident bulk schedule (dag.hip): a SYRK launch of the panel stream waits, tile by tile, until the tile-task workgroups
-  // have applied the earlier groups' bulk updates to it: dag_ctr[dag_off + task * dag_stride + r * dag_M + c] >= dag_need
-  // (r, c in 128-units; dag_ctr null or dag_need 0: no wait)
-  int* dag_ctr; int dag_off, dag_stride, dag_M, dag_need; long long dag_timeout;
   void* B;       // POST: Kxq (npad x ldb)
   int64_t ldb;
   void* V;       // POST: optional V output (npad x ldb), may be null
@@ -125,20 +121,27 @@ __device__ __forceinline__ void yield_leave(int* tab, int tok) {
 }
 #endif
 
+// hipFuncSetAttribute is per device: a launcher sets its kernels' dynamic-LDS limit the first time it runs on EACH device of the
+// process (one bit per device ordinal; a second context on another GPU would otherwise launch with the 64 KB default and fail)
+static inline bool hbo_first_use_on_device(unsigned long long& seen) {
+  int d = 0;
+  if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 64) return true;
+  if ((seen >> d) & 1ull) return false;
+  seen |= 1ull << d;
+  return true;
+}
+
 // ---- launchers (defined in the .hip files) ---------------------------------------------
 void launch_gemm(int dtype, const GemmArgs& a, dim3 grid, hipStream_t st);
 
-// `cs` (dag.h) non-null: the kernels poll / bump the dependency counters of the resident tile-task schedule
-struct ChainSync;
 // fp32: the panel solve also writes the solved panel as three bf16 planes (the operand of the bf16x3 trailing updates, post3.hip):
 // element (row, k) of panel block column kb_off.. -> ((row / 128 * nkb + kb_off + k / 16) * 3 + plane) * 2048 + (row % 128) * 16 + k % 16
 struct SplitOut { unsigned short* xp; int64_t task_stride; int nkb, kb_off; };
-void launch_potf2(int dtype, const TaskDesc* tasks, int ntasks, int p, int* info, hipStream_t st, int* yield_flag = nullptr,
-                  const ChainSync* cs = nullptr);
+void launch_potf2(int dtype, const TaskDesc* tasks, int ntasks, int p, int* info, hipStream_t st, int* yield_flag = nullptr);
 void launch_trsm(int dtype, const TaskDesc* tasks, int ntasks, int p, int max_nblk, hipStream_t st, int* yield_tab = nullptr,
-                 const ChainSync* cs = nullptr, const SplitOut* so = nullptr);
+                 const SplitOut* so = nullptr);
 // inverses of the diagonal blocks p in [p_lo, p_hi)
-void launch_trtri_diag(int dtype, const TaskDesc* tasks, int ntasks, int p_lo, int p_hi, hipStream_t st, const ChainSync* cs = nullptr);
+void launch_trtri_diag(int dtype, const TaskDesc* tasks, int ntasks, int p_lo, int p_hi, hipStream_t st);
 
 struct GramArgs {
   const TaskDesc* tasks;   // batched symmetric mode (tasks != null): out = tasks[z].A, x = tasks[z].F

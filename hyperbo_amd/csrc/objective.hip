@@ -15,8 +15,15 @@ int comm_allreduce_device(hbo_ctx* c, double* d_buf, int count, hipStream_t st);
 void launch_shard_reduce(const double* nll, const double* grad, const int* info, int T, int out_stride, const int* map,
                          const double* mlp, const int* mlp_seg, int n_mlp_seg, double* out, int out_count, hipStream_t st);   // gram.hip
 
-static int objective_impl(hbo_ctx* c, const hbo_model* m_in, hbo_dataset* ds, int objective, double* nll_sum,
-                          double* nll_per_task, double* grad_sum, const ShardReq* sh) {
+// The sharded form never leaves its peers alone in the collective: objective_local does everything up to (not including) the
+// all-reduce and hands back the device buffer [nll, count, grad]; whatever it returns, objective_impl then takes part in the ONE
+// all-reduce of the evaluation -- with NaN in every slot after a local failure (the peers see a NaN objective, not a hang) --
+// and only if not even that buffer can be had does it abort the communicator, so that the peers' collective fails too.
+struct ShardOut { double* d_red = nullptr; hipEvent_t ev0 = nullptr, ev1 = nullptr; int red_count = 0; };
+int comm_abort(hbo_ctx* c);   // comm.hip
+
+static int objective_local(hbo_ctx* c, const hbo_model* m_in, hbo_dataset* ds, int objective, double* nll_sum,
+                           double* nll_per_task, double* grad_sum, const ShardReq* sh, ShardOut* so) {
   if (!c || !nll_sum || !m_in || (!ds && !sh)) return fail(c, HBO_ERR_ARG, "hbo_objective: null argument");
   if (objective != HBO_OBJ_NLL && objective != HBO_OBJ_EKL && objective != HBO_OBJ_EUC) return fail(c, HBO_ERR_ARG, "hbo_objective: unknown objective id");
   HIPCHK(c, hipSetDevice(c->device));
@@ -37,25 +44,7 @@ static int objective_impl(hbo_ctx* c, const hbo_model* m_in, hbo_dataset* ds, in
   hipStream_t st = c->stream;
   // sharded: [nll, count, grad] of the whole job, reduced on the device
   const int red_count = 2 + (want_grad ? lay.total : 0);
-  auto finish_sharded = [&](double* d_red, hipEvent_t ev0, hipEvent_t ev1) -> int {
-    hipEvent_t ev2 = pool_event_timed(c, 2);
-    int rc = c->comm ? comm_allreduce_device(c, d_red, red_count, st) : HBO_OK;
-    if (rc) return rc;
-    HIPCHK(c, hipEventRecord(ev2, st));
-    double* stage = static_cast<double*>(pinned_stage(c, sizeof(double) * red_count));
-    if (!stage) return fail(c, HBO_ERR_HIP, "hbo_objective_sharded: pinned staging buffer");
-    HIPCHK(c, hipMemcpyAsync(stage, d_red, sizeof(double) * red_count, hipMemcpyDeviceToHost, st));
-    HIPCHK(c, hipStreamSynchronize(st));
-    *nll_sum = stage[0];
-    *sh->count = stage[1];
-    if (want_grad) for (int i = 0; i < lay.total; ++i) grad_sum[i] = stage[2 + i];
-    if (sh->timing) {
-      float ms_local = 0, ms_comm = 0;
-      hipEventElapsedTime(&ms_local, ev0, ev1); hipEventElapsedTime(&ms_comm, ev1, ev2);
-      sh->timing[0] = ms_local; sh->timing[1] = 1e3 * ms_comm;
-    }
-    return HBO_OK;
-  };
+  if (so) so->red_count = red_count;
   if (T == 0) {
     if (!sh) return HBO_OK;
     // a rank beyond the task count: zeros into the collective
@@ -66,7 +55,8 @@ static int objective_impl(hbo_ctx* c, const hbo_model* m_in, hbo_dataset* ds, in
     HIPCHK(c, hipEventRecord(ev0, st));
     HIPCHK(c, hipMemsetAsync(d_red, 0, sizeof(double) * red_count, st));
     HIPCHK(c, hipEventRecord(ev1, st));
-    return finish_sharded(d_red, ev0, ev1);
+    so->d_red = d_red; so->ev0 = ev0; so->ev1 = ev1;
+    return HBO_OK;
   }
   if (obj != OBJ_NLL) for (TaskHost* t : ds->tasks) if (!t->ydiv) return fail(c, HBO_ERR_UNSUPPORTED, "hbo_objective: divergence objectives need m + 1 <= 128 aligned columns");
   const int dtype = ds->dtype;
@@ -135,6 +125,7 @@ static int objective_impl(hbo_ctx* c, const hbo_model* m_in, hbo_dataset* ds, in
     HIPCHK(c, hipEventSynchronize(c->ev_upload));
     memcpy(stage, ds->h_desc.data(), sizeof(TaskDesc) * T);
     HIPCHK(c, hipMemcpyAsync(ds->d_desc, stage, sizeof(TaskDesc) * T, hipMemcpyHostToDevice, st));
+    HIPCHK(c, hipEventRecord(c->ev_upload, st));   // the pinned buffer is written again further down (sharded: the scatter map)
     ds->h_desc_dev = ds->h_desc;
   }
   HIPCHK(c, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ds->d_info), INT_MAX, T, st));
@@ -158,11 +149,9 @@ static int objective_impl(hbo_ctx* c, const hbo_model* m_in, hbo_dataset* ds, in
       launch_gram(dtype, g, c->d_model, dim3(max_nblk, max_nblk, T), st);
     }
     {
-      std::vector<int> h_nblk(T);
-      for (int k = 0; k < T; ++k) h_nblk[k] = ds->h_desc[k].nblk;
       c->trtri_host_task = TaskDesc{};
       if (T == 1) c->trtri_host_task = ds->h_desc[0];
-      ProfScope ps(c, "potrf", 1); run_potrf(c, dtype, ds->d_desc, T, max_nblk, ds->d_info, early_trtri ? &trtri_pg : nullptr, h_nblk.data());
+      ProfScope ps(c, "potrf", 1); run_potrf(c, dtype, ds->d_desc, T, max_nblk, ds->d_info, early_trtri ? &trtri_pg : nullptr);
     }
     // the small reductions (log-determinant + quadratic form now, alpha = W^T z and d nll / d mu after the inverse) run on
     // the idle panel stream beside the inverse and K^-1 = W^T W instead of between them (0.14 ms at cfg 2)
@@ -260,12 +249,9 @@ static int objective_impl(hbo_ctx* c, const hbo_model* m_in, hbo_dataset* ds, in
                         d_red, red_count, st);
     hipEvent_t ev1 = pool_event_timed(c, 1);
     HIPCHK(c, hipEventRecord(ev1, st));
-    int rcs = finish_sharded(d_red, ev_sh0, ev1);
     HIPCHK(c, hipGetLastError());
-    prof_collect(c);
-    if (dag_aborted(c)) return objective_impl(c, m_in, ds, objective, nll_sum, nll_per_task, grad_sum, sh);
-    if (rcs) return rcs;
-    return std::isnan(*nll_sum) ? HBO_NOT_PD : HBO_OK;
+    so->d_red = d_red; so->ev0 = ev_sh0; so->ev1 = ev1;
+    return HBO_OK;
   }
   HIPCHK(c, hipMemcpyAsync(stage, ds->d_pack, pack_bytes, hipMemcpyDeviceToHost, st));
   const double* h_nll = reinterpret_cast<const double*>(stage);
@@ -279,9 +265,6 @@ static int objective_impl(hbo_ctx* c, const hbo_model* m_in, hbo_dataset* ds, in
   HIPCHK(c, hipStreamSynchronize(st));
   HIPCHK(c, hipGetLastError());
   prof_collect(c);
-  // the resident tile-task schedule ran out of its wall-clock bound (it never has; a hang would be a dead GPU): the context
-  // falls back to the launch schedule for good and this evaluation is repeated on it
-  if (dag_aborted(c)) return objective_impl(c, m_in, ds, objective, nll_sum, nll_per_task, grad_sum, sh);
 
   bool notpd = false;
   double total = 0;
@@ -315,6 +298,51 @@ static int objective_impl(hbo_ctx* c, const hbo_model* m_in, hbo_dataset* ds, in
     }
   }
   return notpd ? HBO_NOT_PD : HBO_OK;
+}
+static int objective_impl(hbo_ctx* c, const hbo_model* m_in, hbo_dataset* ds, int objective, double* nll_sum,
+                          double* nll_per_task, double* grad_sum, const ShardReq* sh) {
+  if (!sh) return objective_local(c, m_in, ds, objective, nll_sum, nll_per_task, grad_sum, nullptr, nullptr);
+  ShardOut so;
+  const int rc_local = objective_local(c, m_in, ds, objective, nll_sum, nll_per_task, grad_sum, sh, &so);
+  if (!c || !nll_sum || !m_in) return rc_local;   // argument errors are the same on every rank: nobody reaches the collective
+  hipStream_t st = c->stream;
+  int red_count = so.red_count;
+  if (red_count <= 0) {   // failed before the model was looked at: the layout still fixes the length the peers reduce
+    hbo_grad_layout lay;
+    if (hbo_grad_layout_of(m_in, &lay) != HBO_OK) return rc_local;
+    red_count = 2 + (grad_sum ? lay.total : 0);
+  }
+  if (rc_local != HBO_OK || !so.d_red) {
+    // local failure: NaN into every slot of the collective (0x7FF800007FF80000 is a quiet NaN)
+    (void)hipGetLastError();
+    so.d_red = static_cast<double*>(ws_get(c, WS_SHARD_RED, sizeof(double) * red_count));
+    so.ev0 = pool_event_timed(c, 0); so.ev1 = pool_event_timed(c, 1);
+    const bool ok = so.d_red && hipEventRecord(so.ev0, st) == hipSuccess &&
+                    hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(so.d_red), 0x7FF80000, 2 * (size_t)red_count, st) == hipSuccess &&
+                    hipEventRecord(so.ev1, st) == hipSuccess;
+    if (!ok) { if (c->comm) comm_abort(c); return rc_local ? rc_local : HBO_ERR_HIP; }
+  }
+  hipEvent_t ev2 = pool_event_timed(c, 2);
+  int rc = c->comm ? comm_allreduce_device(c, so.d_red, red_count, st) : HBO_OK;
+  if (rc) return rc_local ? rc_local : rc;
+  HIPCHK(c, hipEventRecord(ev2, st));
+  double* stage = static_cast<double*>(pinned_stage(c, sizeof(double) * red_count));
+  if (!stage) return fail(c, HBO_ERR_HIP, "hbo_objective_sharded: pinned staging buffer");
+  HIPCHK(c, hipEventSynchronize(c->ev_upload));
+  HIPCHK(c, hipMemcpyAsync(stage, so.d_red, sizeof(double) * red_count, hipMemcpyDeviceToHost, st));
+  HIPCHK(c, hipStreamSynchronize(st));
+  HIPCHK(c, hipGetLastError());
+  prof_collect(c);
+  *nll_sum = stage[0];
+  *sh->count = stage[1];
+  if (grad_sum) for (int i = 0; i < red_count - 2; ++i) grad_sum[i] = stage[2 + i];
+  if (sh->timing) {
+    float ms_local = 0, ms_comm = 0;
+    hipEventElapsedTime(&ms_local, so.ev0, so.ev1); hipEventElapsedTime(&ms_comm, so.ev1, ev2);
+    sh->timing[0] = ms_local; sh->timing[1] = 1e3 * ms_comm;
+  }
+  if (rc_local) return rc_local;
+  return std::isnan(*nll_sum) ? HBO_NOT_PD : HBO_OK;
 }
 extern "C" int hbo_objective(hbo_ctx* c, const hbo_model* m, hbo_dataset* ds, int objective, double* nll_sum,
                              double* nll_per_task, double* grad_sum) {

@@ -490,11 +490,9 @@ void launch_split3_transpose(const float* in, int64_t ld, int krows, int jcols, 
   hipLaunchKernelGGL(split3_transpose_kernel, dim3(jcols / 64, krows / 64), dim3(256), 0, st, in, ld, out, nkb, lower_only);
 }
 void launch_post3(const Post3Args& a, int col_tiles, hipStream_t st) {
-  static bool attr = false;
-  if (!attr) {
+  static unsigned long long seen = 0;
+  if (hbo_first_use_on_device(seen))
     hipFuncSetAttribute(reinterpret_cast<const void*>(&post3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, POST3_LDS_BYTES);
-    attr = true;
-  }
   hipLaunchKernelGGL(post3_kernel, dim3(col_tiles, a.nblk), dim3(256), POST3_LDS_BYTES, st, a);
 }
 
@@ -504,11 +502,9 @@ void launch_split3_panel(const Syrk3Args& a, int row_tiles, int ntasks, hipStrea
 }
 void launch_syrk3(const Syrk3Args& a, int ntiles, int ntasks, hipStream_t st) {
   if (ntiles <= 0) return;
-  static bool attr = false;
-  if (!attr) {
+  static unsigned long long seen = 0;
+  if (hbo_first_use_on_device(seen))
     hipFuncSetAttribute(reinterpret_cast<const void*>(&syrk3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, POST3_LDS_BYTES + 16);
-    attr = true;
-  }
   const int grid = a.persistent > 0 ? std::min(a.persistent, ntiles) : ntiles;
   hipLaunchKernelGGL(syrk3_kernel, dim3(grid, 1, ntasks), dim3(256), POST3_LDS_BYTES + 16, st, a);
 }

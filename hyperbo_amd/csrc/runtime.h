@@ -99,7 +99,7 @@ static inline hipEvent_t prof_event(hbo_ctx* c) {
 struct ProfScope {
   hbo_ctx* c; bool on; ProfEntry e; hipStream_t st;
   ProfScope(hbo_ctx* ctx, const char* name, int level, hipStream_t stream = nullptr)
-      : c(ctx), on(ctx->prof_level >= level || (ctx->prof_level < 0 && (!strcmp(name, "syrk_bulk") || !strcmp(name, "dag_worker")))),
+      : c(ctx), on(ctx->prof_level >= level || (ctx->prof_level < 0 && !strcmp(name, "syrk_bulk"))),
         st(stream ? stream : ctx->stream) {
     if (!on) return;
     e.name = name;

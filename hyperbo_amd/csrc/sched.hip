@@ -24,12 +24,7 @@ hipEvent_t pool_event(hbo_ctx* c, size_t i) {
 // launches: F1 updates only the NEXT group's block columns, F2 the rest; the next group's panel
 // work (potf2 -> trsm, the serial chain) runs on a second stream as soon as F1 is done, so F2
 // -- the bulk of the flops -- overlaps it.
-void run_potrf(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, int max_nblk, int* d_info, TrtriProgress* early,
-               const int* h_nblk) {
-  c->dag_ctr_last = nullptr;
-  if (c->opt_dag && !c->dag_broken && use_lookahead(c, ntasks, max_nblk) && max_nblk >= c->opt_dag_min_nblk && max_nblk <= c->opt_dag_max_nblk &&
-      (ntasks == 1 || h_nblk) && run_potrf_dag(c, dtype, d_tasks, ntasks, max_nblk, h_nblk, d_info, early))
-    return;
+void run_potrf(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, int max_nblk, int* d_info, TrtriProgress* early) {
   // panels per trailing update and CUs the persistent bulk update leaves to the panel chain.  Measured (NLL+grad, ms):
   //   N = 4096: (4, 32) 3.61, (3, 32) 3.54, (3, 64) 3.51;   N = 8192: (4, 32) 13.49, (3, 32) 13.34, (3, 64) 13.25,
   //   (3, 96) 13.43, (2, 64) 13.57, (5, 32) 13.61;   N = 16384: (4, 32) 78.4, (3, 32) 79.1, (3, 64) 79.5
@@ -124,7 +119,7 @@ void run_potrf(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, int m
         SplitOut so = {};
         if (use_s3) { so.xp = s3a.Xp; so.task_stride = s3a.task_stride; so.nkb = s3a.nkb; so.kb_off = (p - g0) * (HBO_TILE / 16); }
         const bool fused = use_s3 && !c->opt_syrk3_sep && c->opt_syrk3_col;
-        { ProfScope ps(c, "trsm", 2, sp); launch_trsm(dtype, d_tasks, ntasks, p, max_nblk, sp, chain_mark, nullptr, fused ? &so : nullptr); }
+        { ProfScope ps(c, "trsm", 2, sp); launch_trsm(dtype, d_tasks, ntasks, p, max_nblk, sp, chain_mark, fused ? &so : nullptr); }
         if (use_s3 && !fused && p + 1 < max_nblk && (c->opt_syrk3_col || p + 1 == g1)) {
           // the column updates inside the group stay on fp32 MFMA (64x64 tiles): ONE split of the whole group behind its last
           // solve, for the wide updates (F1, F2) -- or, with syrk3_col, one per panel for the column updates too

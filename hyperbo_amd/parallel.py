@@ -8,7 +8,6 @@ Communicators:
                    distributed by any bootstrap callable (SocketGroup.bcast_bytes below -- no torch).
   SocketComm    -- host-side sum through the SocketGroup hub (tests, and the fallback when no RCCL
                    communicator can be built, e.g. two ranks sharing one GPU).
-  TorchDistComm -- torch.distributed all_reduce (gloo on CPU for tests, nccl==RCCL on GPU); opt-in only.
   LocalComm     -- single process.
 SocketGroup is the torch-free process group of one node (rendezvous, barrier, max, byte broadcast over
 127.0.0.1): the product path needs neither torch nor an MPI launcher.
@@ -283,29 +282,6 @@ class LocalComm:
 
   def allreduce_sum(self, buf: np.ndarray) -> np.ndarray:
     return np.asarray(buf, dtype=np.float64)
-
-
-class TorchDistComm:
-  """torch.distributed is plumbing only (rendezvous + all_reduce); no tensors elsewhere."""
-
-  def __init__(self, device=None, group=None):
-    """`group`: a torch.distributed process group (e.g. one created with backend='nccl', which is RCCL on ROCm --
-    then pass the rank's `device` so that the buffer travels over xGMI); default: the default group, host tensors."""
-    import torch.distributed as dist
-    if not dist.is_initialized():
-      raise RuntimeError('torch.distributed is not initialised')
-    self._dist = dist
-    self.rank, self.world_size = dist.get_rank(), dist.get_world_size()
-    self.device = device
-    self.group = group
-
-  def allreduce_sum(self, buf: np.ndarray) -> np.ndarray:
-    import torch
-    t = torch.from_numpy(np.ascontiguousarray(buf, dtype=np.float64).copy())
-    if self.device is not None:
-      t = t.to(self.device)
-    self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM, group=self.group)
-    return t.cpu().numpy()
 
 
 class RcclComm:

@@ -184,6 +184,10 @@ int hbo_acq_grad(hbo_ctx* ctx, const hbo_model* model, hbo_cache* cache, const v
  * inv_out (nullable): full symmetric a^-1;  b/x_out (nullable): [n,m] solve a x = b. */
 int hbo_spd_solve(hbo_ctx* ctx, int dtype, const void* a, int64_t n, const void* b, int32_t m,
                   void* chol_out, void* inv_out, void* x_out, double* logdet_half);
+/* linalg.py:139-145, inverse_spdmatrix_vector_product(cached_cholesky=...): x = L^-T L^-1 b for a lower factor the caller holds
+ * as an array (chol_lower: [n,n] row-major, only the lower triangle is read; b / x_out: [n,m]).  Two substitution sweeps on the
+ * device; nothing is factorised. */
+int hbo_chol_solve(hbo_ctx* ctx, int dtype, const void* chol_lower, int64_t n, const void* b, int32_t m, void* x_out);
 
 /* ---- profiling: per-stage device time of the last hbo_nll / hbo_factor / hbo_acq call,
  *      measured with HIP events on the stream the kernels were launched on ---------------- */
@@ -210,12 +214,7 @@ int hbo_profile_get(hbo_ctx* ctx, char names[][32], double* ms, int32_t* launche
  *   bf16x3          0/1   fp32 only: the GEMM-shaped work -- trailing updates of the factorisation, the products of the inverse
  *                         and K^-1 = W^T W (above small_nblk blocks), the posterior product V = L^-1 Kxq -- runs on the bf16 matrix cores
  *                         from exact three-way splits of both operands (six bf16 MFMAs per fp32 product, fp32 accumulate:
- *                         fp32-class accuracy at 1.3-1.5x the fp32-MFMA rate).  Default 1; 0 = fp32 MFMA
- *   dag             0..2  the factorisation phase as a resident tile-task kernel: 1 = bulk updates + inverse as tasks beside the
- *                         launched panel chain, 2 = the chain-critical updates as tasks too.  Bit-identical results; measured
- *                         slower than the launch schedule at every size (profiles/r03_dag.md), hence default 0
- *   dag_timeout_ms  1..60000 wall-clock bound of that kernel's waits; on expiry the call is repeated on the launch schedule and
- *                         the context stays there (default 2000) */
+ *                         fp32-class accuracy at 1.3-1.5x the fp32-MFMA rate).  Default 1; 0 = fp32 MFMA */
 int hbo_set_option(hbo_ctx* ctx, const char* name, int64_t value);
 
 /* ---- multi-GPU: one process per GPU; sum-all-reduce of [nll, grads] over RCCL (xGMI) ------ */

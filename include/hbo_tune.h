@@ -11,9 +11,7 @@
  *   post_bf16x3 / syrk_bf16x3 / trtri_bf16x3 / lauum_bf16x3  0/1   the four parts of option bf16x3 separately
  *   trtri3_min_s  >=1      lowest level (in blocks) of the inverse that runs on the bf16 cores
  *   syrk3_col / syrk3_sep / syrk3_free       fp32 trailing updates: column updates on the bf16 cores too / panels split by
- *                          their own kernel instead of inside the panel solve / CUs the bulk update leaves with one workgroup
- *   dag_reserve 0..4 (CUs per shader engine left to the panel kernels), dag_near64, dag_trtri, dag_spin_us, dag_idle_sleep,
- *   dag_f1_small, dag_join, dag_dbg, dag_min_nblk, dag_max_nblk   resident tile-task schedule (csrc/dag.h) */
+ *                          their own kernel instead of inside the panel solve / CUs the bulk update leaves with one workgroup */
 #ifndef HBO_TUNE_H_
 #define HBO_TUNE_H_
 #include "hbo.h"

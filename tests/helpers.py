@@ -71,3 +71,25 @@ def synthetic_task(rng, n, d, m=1, dtype=np.float64):
   w = rng.normal(size=(d, m))
   y = np.sin(2 * np.pi * x @ w) + 0.1 * rng.normal(size=(n, m))
   return x.astype(dtype), y.astype(dtype)
+
+
+class TorchDistComm:
+  """Test-only communicator: torch.distributed all_reduce (gloo, world_size 2 on CPU) behind the `allreduce_sum` interface of
+  hyperbo_amd.parallel's communicators.  Lives here, not in the package: the product path is torch-free."""
+
+  def __init__(self, device=None, group=None):
+    import torch.distributed as dist
+    if not dist.is_initialized():
+      raise RuntimeError('torch.distributed is not initialised')
+    self._dist = dist
+    self.rank, self.world_size = dist.get_rank(), dist.get_world_size()
+    self.device = device
+    self.group = group
+
+  def allreduce_sum(self, buf):
+    import torch
+    t = torch.from_numpy(np.ascontiguousarray(buf, dtype=np.float64).copy())
+    if self.device is not None:
+      t = t.to(self.device)
+    self._dist.all_reduce(t, op=self._dist.ReduceOp.SUM, group=self.group)
+    return t.cpu().numpy()

@@ -165,8 +165,8 @@ def test_infer_input_dim_from_parameters_alone():
 
 
 def test_option_surface_is_small():
-  """include/hbo.h documents eight options; everything else is a measurement hook behind hbo_tune (include/hbo_tune.h)."""
+  """include/hbo.h documents six options; everything else is a measurement hook behind hbo_tune (include/hbo_tune.h)."""
   text = open(os.path.join(ROOT, 'include', 'hbo.h')).read()
   block = text[text.index('/* Options (integers by name)'):text.index('int hbo_set_option')]
   documented = re.findall(r'^ \*   ([a-z0-9_]+) ', block, flags=re.M)
-  assert sorted(documented) == sorted(nat.Context.PUBLIC_OPTIONS) and len(documented) <= 8
+  assert sorted(documented) == sorted(nat.Context.PUBLIC_OPTIONS) and len(documented) == 6

@@ -1,6 +1,6 @@
 """world_size-2 gloo test of the task-sharded objective's reduction path (CPU, no GPU):
 each rank evaluates ITS shard with the oracle standing in for the device call, the
-[nll_sum, count, grad_sum] buffer goes through parallel.TorchDistComm (gloo), and the result must
+[nll_sum, count, grad_sum] buffer goes through helpers.TorchDistComm (gloo; test-only), and the result must
 equal the single-process mean over all tasks."""
 import os
 import socket
@@ -36,7 +36,7 @@ def _worker(rank, world, port, out_dir):
   for k, s in mine.items():
     v, g = o.nll_sub_dataset_value_and_grad(o.constant, o.squared_exponential, params, s.x, s.y, o.DEFAULT_WARP_FUNC)
     nll_sum += v; grad_sum += helpers.flatten(g)
-  comm = parallel.TorchDistComm()
+  comm = helpers.TorchDistComm()
   value, grad, count = parallel.sharded_mean_nll(nll_sum, len(mine), grad_sum, comm)
   np.savez(os.path.join(out_dir, f'r{rank}.npz'), value=value, grad=grad, count=count, keys=np.array(sorted(mine)))
   dist.barrier()

@@ -193,12 +193,9 @@ OPTION_SETS = [
     {'trtri_free': 0}, {'trtri_free': 120, 'small_nblk': 0}, {'trtri_free': 200},
     {'trtri_at': 12}, {'trtri_at': 60, 'small_nblk': 0}, {'trtri_at': 48, 'small_nblk': 0},
     {'post_chunk': 128},
-    # round 3: the resident tile-task schedule in both forms, with and without the inverse among the tasks, fewer reserved CUs
-    {'dag': 1, 'lookahead': 2}, {'dag': 2, 'lookahead': 2}, {'dag': 1, 'dag_trtri': 0, 'lookahead': 2}, {'dag': 2, 'dag_trtri': 24, 'small_nblk': 0},
-    {'dag': 1, 'dag_reserve': 1, 'dag_join': 0, 'lookahead': 2}, {'dag': 2, 'dag_near64': 2, 'dag_spin_us': 0, 'lookahead': 2}, {'dag': 2, 'dag_near64': 0, 'potrf_group': 4},
 ]
 DEFAULTS = {'lookahead': 1, 'overlap_trtri': 1, 'potrf_group': 0, 'persist_free': -1, 'small_nblk': 32, 'cu_yield': 2, 'trtri_free': 48,
-            'trtri_at': 0, 'post_chunk': 8192, 'dag': 0, 'dag_trtri': 64, 'dag_reserve': 2, 'dag_join': 1, 'dag_near64': 1, 'dag_spin_us': 200}
+            'trtri_at': 0, 'post_chunk': 8192}
 
 
 @pytest.mark.parametrize('opts', OPTION_SETS, ids=lambda o_: ','.join(f'{k}={v}' for k, v in o_.items()))

@@ -148,6 +148,45 @@ def test_nll_value_and_grad_vs_oracle_fp64(gpu_ctx, kname, mlp, mname, exclude_a
     assert abs(k2[k] - k2o[k]) <= 1e-10 * abs(k2o[k])
 
 
+@pytest.mark.parametrize('kname', ['matern32', 'matern52'])
+@pytest.mark.parametrize('mlp,mname', [(False, 'constant'), (True, 'linear_mlp')])
+def test_matern_with_duplicated_training_rows(gpu_ctx, kname, mlp, mname):
+  """Duplicated training inputs put u == 0 OFF the diagonal of a Matern Gram matrix, where the reference's safe square root has
+  gradient 0 (hyperbo/basics/linalg.py:183-188; device: kernfun.h).  NLL + every gradient leaf across a ragged batch whose
+  tasks repeat rows (also across the 128-row block edge), and the acquisition value + d acq / d x at queries that sit ON
+  training points, all against the oracle."""
+  defs, _, acfun, gp, kernel, mean, objectives, utils = _native()
+  rng = np.random.default_rng(41)
+  d = 3
+  model = helpers.make_model(rng, mname, mlp, d)
+  po, pn = _pair(model)
+  def with_dups(n, ndup):
+    x, y = helpers.synthetic_task(rng, n, d)
+    src = rng.integers(0, n - ndup, size=ndup)
+    x[n - ndup:] = x[src]          # later rows repeat earlier ones (different y: the noise term keeps K PD)
+    return x, y
+  tasks = {'a': with_dups(150, 12), 'b': with_dups(40, 40 // 2), 'c': with_dups(260, 30)}
+  dso = {k: o.SubDataset(*v) for k, v in tasks.items()}
+  dsn = {k: defs.SubDataset(*v) for k, v in tasks.items()}
+  ko = getattr(o, kname + ('_mlp' if mlp else '')); kn = getattr(kernel, kname + ('_mlp' if mlp else ''))
+  vo, go = o.nll_value_and_grad(getattr(o, mname), ko, po, dso, WFO)
+  vn, gn = objectives.nll_value_and_grad(getattr(mean, mname), kn, pn, dsn, utils.DEFAULT_WARP_FUNC)
+  assert np.isfinite(vo) and abs(vn - vo) <= 1e-10 * abs(vo)
+  fo, fn = helpers.flatten(go), helpers.flatten(gn)
+  assert np.all(np.isfinite(fn)) and np.max(np.abs(fo - fn)) <= 1e-8 * np.max(np.abs(fo))
+  # acquisition at queries ON training points (two of them on a duplicated pair) and off them
+  x, y = tasks['a']
+  xq = np.concatenate([x[[0, 149, 75]], rng.uniform(size=(4, d))])
+  m = gp.GP({'t': defs.SubDataset(x, y), 'other': defs.SubDataset(*tasks['b'])}, getattr(mean, mname), kn, pn, utils.DEFAULT_WARP_FUNC)
+  noise = float(np.squeeze(o.retrieve_params(po, ['noise_variance'], WFO)[0]))
+  for acq, fn_, param in (('ei', acfun.expected_improvement, float(np.max(y))), ('ucb', acfun.ucb, 3.0)):
+    val, grad = fn_.value_and_grad(model=m, sub_dataset_key='t', x_queries=xq)
+    vo_, go_ = o.acquisition_value_and_grad(acq, getattr(o, mname), ko, po, x, y, xq, param, WFO, add_noise=noise, scale=2.0)
+    assert np.all(np.isfinite(grad))
+    np.testing.assert_allclose(val, vo_, rtol=1e-8, atol=1e-10)
+    assert np.max(np.abs(grad - go_)) <= 1e-7 * max(np.max(np.abs(go_)), 1e-3)
+
+
 def test_nll_with_priors_and_scalar_lengthscale(gpu_ctx):
   defs, _, _, _, kernel, mean, objectives, utils = _native()
   from hyperbo_amd.gp_utils import priors
@@ -908,15 +947,29 @@ def test_empty_task_shard_builds_the_same_model_and_contributes_zeros(gpu_ctx):
     assert v == 0.0 and np.all(comm.buf == 0) and helpers.flatten(g).size == helpers.flatten(gfull).size
 
 
-def test_cached_cholesky_path_of_inverse_spdmatrix_vector_product(gpu_ctx):
+@pytest.mark.parametrize('n,m', [(60, 1), (64, 2), (65, 3), (200, 1), (1000, 4)])
+def test_cached_cholesky_path_of_inverse_spdmatrix_vector_product(gpu_ctx, n, m):
+  """linalg.py:139-145 with a factor handed in as an array: two substitution sweeps on the device (hbo_chol_solve), checked
+  against the factorising path, the defining equation and host LAPACK across the 64-row block edges and several right-hand sides."""
+  import scipy.linalg as spla
   _, linalg, *_ = _native()
-  rng = np.random.default_rng(24)
-  a = rng.normal(size=(60, 60)); a = a @ a.T + 60 * np.eye(60)
-  v = rng.normal(size=(60, 1))
-  chol, x0 = linalg.solve_linear_system(a, v)
+  rng = np.random.default_rng(24 + n)
+  a = rng.normal(size=(n, n)); a = a @ a.T + n * np.eye(n)
+  v = rng.normal(size=(n, m))
+  chol = np.linalg.cholesky(a)
   x1 = linalg.inverse_spdmatrix_vector_product(a, v, cached_cholesky=chol)
-  np.testing.assert_allclose(x1, x0, rtol=1e-10)
+  assert x1.shape == v.shape and x1.dtype == np.float64
+  np.testing.assert_allclose(x1, spla.cho_solve((chol, True), v), rtol=1e-10, atol=1e-13)
   np.testing.assert_allclose(a @ x1, v, rtol=1e-9, atol=1e-10)
+  if m == 1:
+    _, x0 = linalg.solve_linear_system(a, v)
+    np.testing.assert_allclose(x1, x0, rtol=1e-9, atol=1e-12)
+  # the upper triangle of the array is never read; fp32 in -> fp32 out
+  junk = chol + np.triu(np.full((n, n), 7.0), 1)
+  np.testing.assert_array_equal(linalg.inverse_spdmatrix_vector_product(a, v, cached_cholesky=junk), x1)
+  x32 = linalg.inverse_spdmatrix_vector_product(a.astype(np.float32), v.astype(np.float32), cached_cholesky=chol.astype(np.float32))
+  assert x32.dtype == np.float32
+  np.testing.assert_allclose(x32, x1, rtol=2e-3, atol=2e-5)
 
 
 # ---- divergence objectives (objectives.py:29-106): EKL / Euclid on the device vs the oracle ------------------
