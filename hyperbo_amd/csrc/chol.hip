@@ -559,7 +559,7 @@ template <typename T>
 void potf2_t(const TaskDesc* tasks, int ntasks, int p, int* info, hipStream_t st, int* yield_flag) {
   set_attrs<T>();
   hipLaunchKernelGGL((potf2_kernel<T>), dim3(ntasks), dim3(256), potf2_lds_bytes<T>(), st, tasks, p, info,
-                     ntasks == 1 ? yield_flag : nullptr);
+                     yield_flag);
 }
 template <typename T>
 void trsm_t(const TaskDesc* tasks, int ntasks, int p, int max_nblk, hipStream_t st, int* yield_tab, const SplitOut& so) {
@@ -567,7 +567,7 @@ void trsm_t(const TaskDesc* tasks, int ntasks, int p, int max_nblk, hipStream_t 
   const int nrows = (max_nblk + 1 - (p + 1)) * NB;
   if (nrows <= 0) return;
   hipLaunchKernelGGL((trsm_kernel<T, false>), dim3(nrows / 64, 1, ntasks), dim3(256), trsm_lds_bytes<T>(), st,
-                     tasks, p, ntasks == 1 ? yield_tab : nullptr, so);
+                     tasks, p, yield_tab, so);
 }
 template <typename T>
 void trtri_diag_t(const TaskDesc* tasks, int ntasks, int p_lo, int p_hi, hipStream_t st) {

@@ -36,6 +36,11 @@ struct hbo_ctx {
   int opt_syrk_bf16x3 = 1;     // fp32 factorisations: trailing updates on the bf16 matrix cores (exact three-way split of the panels, post3.hip)
   int opt_post_bf16x3 = 1;     // fp32 posterior product on the bf16 matrix cores (three-way exact split of both operands, post3.hip); 0: fp32 MFMA
   int opt_trtri_at = 0;        // single matrix: panel count (in 64ths of the block count) after which the inverse starts beside the chain (0: 5/8)
+  int opt_sweep = 1;           // one-sweep inverse (sched.hip:sweep_advance): 0 never, 1 where measured faster (use_sweep), 2 wherever look-ahead is on
+  int opt_sweep_big = 4000;    // a sweep launch of a small / batched shape with at least this many 128-tiles (x tasks) runs on 128-tiles
+  int opt_sweep_qs = 0;        // its row-group size in 128-blocks (power of two; 0: auto)
+  int opt_batch_bg = 0;        // batches: the sweep's launches beside the panel chain are 0 plain grids, 1 persistent and slot-limited
+                               // (tiles x tasks from one counter), 2 also yielding to the chain's kernels through the per-CU table
   int opt_trtri_free = 48;   // CUs the inverse products that co-run with the panel chain leave free (0: one tile per workgroup)
   int* trtri_counters = nullptr; int trtri_counter_next = 0;   // run_potrf -> trtri_level: tile counters of those launches
   int n_cus = 256;

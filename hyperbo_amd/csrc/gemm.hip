@@ -108,9 +108,9 @@ struct TileJob {
 // (bx, by) = tile coordinates inside a gdx-wide grid: blockIdx of a one-tile-per-workgroup launch, or the tile a
 // persistent workgroup drew from the counter
 template <typename T, int TM>
-__device__ __forceinline__ bool decode_job(const GemmArgs& g, TileJob<T>& j, const int bxi, const int byi, const int gdx) {
+__device__ __forceinline__ bool decode_job(const GemmArgs& g, TileJob<T>& j, const int bxi, const int byi, const int gdx, const int task) {
   constexpr int BKE = 128 / sizeof(T);
-  const TaskDesc& t = g.tasks[blockIdx.z];
+  const TaskDesc& t = g.tasks[task];
   const int64_t ld = t.ld;
   const int nblk = t.nblk;
   j.colsq = nullptr;
@@ -123,7 +123,7 @@ __device__ __forceinline__ bool decode_job(const GemmArgs& g, TileJob<T>& j, con
       // (batches: rows rotated per (column, task) -- in a ragged batch the rows that exist are the low ones of every
       // task and workgroup i runs on XCD (i + const) mod 8)
       const int by = byi;
-      const int bx = gridDim.z > 1 ? (int)((bxi + 5 * byi + 3 * blockIdx.z) % gdx) : bxi;
+      const int bx = gridDim.z > 1 ? (int)((bxi + 5 * byi + 3 * task) % gdx) : bxi;
       const int c = g.c_lo * U + by;
       const int r = g.c_lo * U + bx;
       const int nrt = (nblk + ((g.aug & 1) ? 1 : 0)) * U;
@@ -157,7 +157,7 @@ __device__ __forceinline__ bool decode_job(const GemmArgs& g, TileJob<T>& j, con
         // runs on XCD (i + const) mod 8, so the row order is rotated per (column, task)
         jt = byi;
         const int vu = (grp == g.c_hi ? g.c_lo : s) * U;   // tile rows launched for this group (the last may be cut)
-        it = (inner + 5 * byi + 3 * (int)blockIdx.z) % vu;
+        it = (inner + 5 * byi + 3 * task) % vu;
       }
       else { it = (g.kt > 0 ? g.kt * U : su) - 1 - byi; jt = inner; }   // K = (it+1)*TM; kt = valid rows (single group)
       const int64_t o = (int64_t)grp * 2 * s * HBO_TILE;                      // element offsets from here on
@@ -221,6 +221,69 @@ __device__ __forceinline__ bool decode_job(const GemmArgs& g, TileJob<T>& j, con
       j.lda = j.ldb = j.ldc = ld;
       j.ksteps = (int)(((int64_t)nblk * HBO_TILE - k0) / BKE);
       j.alpha = (T)1; j.beta = 0;
+      return true;
+    }
+    case GEMM_SWEEP_B: {
+      // W[it, jt] = -sum_{k = b0 .. it} W[it, k] T[k, jt]: rows of the group (longest K = lowest row first), columns left of it
+      constexpr int U = HBO_TILE / TM;
+      const int b0 = g.c_lo, b1 = g.c_hi < nblk ? g.c_hi : nblk;
+      const int rows = (b1 - b0) * U;
+      if (byi >= rows || bxi >= b0 * U) return false;
+      const int it = b0 * U + rows - 1 - byi, jt = bxi;
+      const int64_t k0 = (int64_t)b0 * HBO_TILE;
+      T* W = static_cast<T*>(t.W);
+      j.A = W + (int64_t)it * TM * ld + k0;
+      j.B = static_cast<const T*>(t.S) + k0 * ld + (int64_t)jt * TM;
+      j.C = W + (int64_t)it * TM * ld + (int64_t)jt * TM;
+      j.lda = j.ldb = j.ldc = ld;
+      j.ksteps = (int)(((int64_t)(it + 1) * TM - k0) / BKE);
+      j.alpha = (T)-1; j.beta = 0;
+      return true;
+    }
+    case GEMM_SWEEP_T: {
+      // T[it, jt] (+)= sum_{k = max(jt, b0) .. b1} L[it, k] W[k, jt]: rows below the group (rotated per column and task in a
+      // batch, see SYRK), columns up to its end -- those left of the group (full K) first
+      constexpr int U = HBO_TILE / TM;
+      const int b0 = g.c_lo, b1 = g.c_hi;
+      if (b1 >= nblk) return false;                       // nothing below the front in this task
+      const int below = (nblk - b1) * U;
+      const int bx = gridDim.z > 1 || g.ptasks > 1 ? (int)((bxi + 5 * byi + 3 * task) % gdx) : bxi;
+      if (bx >= below || byi >= b1 * U) return false;
+      const int it = b1 * U + bx, jt = byi;
+      const int64_t kb = (int64_t)b0 * HBO_TILE, kj = (int64_t)jt * TM;
+      const int64_t k0 = kj > kb ? kj : kb;
+      j.A = static_cast<const T*>(t.A) + (int64_t)it * TM * ld + k0;
+      j.B = static_cast<const T*>(t.W) + k0 * ld + kj;
+      j.C = static_cast<T*>(t.S) + (int64_t)it * TM * ld + kj;
+      j.lda = j.ldb = j.ldc = ld;
+      j.ksteps = (int)(((int64_t)b1 * HBO_TILE - k0) / BKE);
+      j.alpha = (T)1; j.beta = kj >= kb ? 0 : 1;
+      return true;
+    }
+    case GEMM_SWEEP_C: {
+      // K^-1[i, jt] (+)= sum_{k = max(i, b0) .. b1} W[k, i]^T W[k, jt] over the lower tiles of the leading b1 blocks, enumerated as
+      // LAUUM does (row tile i slow; 64-tiles: the tile right of an even diagonal tile too, so that every diagonal 128-block is whole)
+      constexpr int U = HBO_TILE / TM;
+      const int b0 = g.c_lo, b1 = g.c_hi < nblk ? g.c_hi : nblk;
+      if (b1 <= b0) return false;                         // this task ended before the group
+      int i = 0, lin = bxi, jt;
+      if (U == 1) {
+        if (lin >= b1 * (b1 + 1) / 2) return false;
+        while (lin > i) { lin -= i + 1; ++i; }
+      } else {
+        if (lin >= 2 * b1 * (b1 + 1)) return false;
+        while (lin > (i | 1)) { lin -= (i | 1) + 1; ++i; }
+      }
+      jt = lin;
+      const int64_t kb = (int64_t)b0 * HBO_TILE, ki = (int64_t)i * TM;
+      const int64_t k0 = ki > kb ? ki : kb;
+      const T* W = static_cast<const T*>(t.W);
+      j.A = W + k0 * ld + ki;
+      j.B = W + k0 * ld + (int64_t)jt * TM;
+      j.C = static_cast<T*>(t.S) + ki * ld + (int64_t)jt * TM;
+      j.lda = j.ldb = j.ldc = ld;
+      j.ksteps = (int)(((int64_t)b1 * HBO_TILE - k0) / BKE);
+      j.alpha = (T)1; j.beta = ki >= kb ? 0 : 1;
       return true;
     }
     case GEMM_VTV: {
@@ -500,19 +563,23 @@ __global__ __launch_bounds__(256, TM == 64 ? 4 : 2) void gemm_kernel(GemmArgs g)
     // by a grid that is smaller than the machine.  Used for the inverse products that co-run with the panel chain:
     // the whole grid is resident at once and leaves CUs free, so the chain's kernels never wait for a tile of up to
     // 256 K steps to finish before they get a slot (potf2 took 600 us once per evaluation, tools/trace_potrf.py).
+    // Over a batch (ptasks > 1) the same counter runs over tiles x tasks, tile-major: the tiles of equal K of all tasks are
+    // neighbours, and the launch stays slot-limited whatever the number of tasks.
     __shared__ int s_tix2;
-    const int total = g.pgx * g.pgy;
+    const int nt = g.ptasks > 1 ? g.ptasks : 1;
+    const int total = g.pgx * g.pgy * nt;
     for (;;) {
       if (threadIdx.x == 0) s_tix2 = atomicAdd(g.work_counter, 1);
       __syncthreads();
       const int tix = s_tix2;
       __syncthreads();
       if (tix >= total) break;
-      if (decode_job<T, TM>(g, job, tix % g.pgx, tix / g.pgx, g.pgx)) gemm_tile<T, AKC, BKC, TM>(job, smem);
+      const int tile = tix / nt, task = g.ptasks > 1 ? tix % nt : (int)blockIdx.z;
+      if (decode_job<T, TM>(g, job, tile % g.pgx, tile / g.pgx, g.pgx, task)) gemm_tile<T, AKC, BKC, TM>(job, smem);
     }
     return;
   }
-  if (!decode_job<T, TM>(g, job, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x)) return;
+  if (!decode_job<T, TM>(g, job, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x, (int)blockIdx.z)) return;
   int ytok = 0;
   if (g.yield_mark && threadIdx.x == 0) ytok = yield_enter(g.yield_mark);
   gemm_tile<T, AKC, BKC, TM>(job, smem);
@@ -529,9 +596,11 @@ __global__ __launch_bounds__(256, TM == 64 ? 4 : 2) void gemm_kernel(GemmArgs g)
 template <typename T>
 void launch_gemm_t(const GemmArgs& a_in, dim3 grid, hipStream_t st) {
   GemmArgs a = a_in;
-  // the persistent forms: SYRK (any tile size), TRTRI on 128-tiles of a single matrix with a tile counter
-  if (a.mode != GEMM_SYRK && !((a.mode == GEMM_TRTRI_A || a.mode == GEMM_TRTRI_B) && a.work_counter && grid.z == 1))
+  // the persistent forms: SYRK (any tile size); TRTRI of a single matrix and the SWEEP modes (also over a batch) with a tile counter
+  const bool sweep_mode = a.mode == GEMM_SWEEP_B || a.mode == GEMM_SWEEP_T || a.mode == GEMM_SWEEP_C;
+  if (a.mode != GEMM_SYRK && !((a.mode == GEMM_TRTRI_A || a.mode == GEMM_TRTRI_B) && a.work_counter && grid.z == 1) && !(sweep_mode && a.work_counter))
     a.persistent = 0;
+  a.ptasks = 0;
   static unsigned long long attr_seen = 0;
   if (hbo_first_use_on_device(attr_seen)) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T, true, true, 128>),
@@ -571,6 +640,34 @@ void launch_gemm_t(const GemmArgs& a_in, dim3 grid, hipStream_t st) {
         hipLaunchKernelGGL((gemm_kernel<T, true, false, 128>), grid, dim3(256), GEMM_LDS_BYTES, st, a);
       }
       break;
+    case GEMM_SWEEP_B:
+    case GEMM_SWEEP_T:
+      // grid = tiles in 128-units (x, y) x tasks
+      if (a.persistent > 0) {
+        GemmArgs b = a; const int u = a.small_tiles ? 2 : 1;
+        b.pgx = (int)grid.x * u; b.pgy = (int)grid.y * u; b.ptasks = (int)grid.z;
+        if (a.small_tiles) hipLaunchKernelGGL((gemm_kernel<T, true, false, 64>), dim3(a.persistent, 1, 1), dim3(256), GEMM_LDS_BYTES_64, st, b);
+        else hipLaunchKernelGGL((gemm_kernel<T, true, false, 128>), dim3(a.persistent, 1, 1), dim3(256), GEMM_LDS_BYTES, st, b);
+      } else if (a.small_tiles) {
+        hipLaunchKernelGGL((gemm_kernel<T, true, false, 64>), dim3(grid.x * 2, grid.y * 2, grid.z), dim3(256), GEMM_LDS_BYTES_64, st, a);
+      } else {
+        hipLaunchKernelGGL((gemm_kernel<T, true, false, 128>), grid, dim3(256), GEMM_LDS_BYTES, st, a);
+      }
+      break;
+    case GEMM_SWEEP_C: {
+      // grid.x = leading blocks b1 of the largest task: 1-D over their lower tiles
+      const unsigned nt = a.small_tiles ? 2 * grid.x * (grid.x + 1) : grid.x * (grid.x + 1) / 2;
+      if (a.persistent > 0) {
+        GemmArgs b = a; b.pgx = (int)nt; b.pgy = 1; b.ptasks = (int)grid.z;
+        if (a.small_tiles) hipLaunchKernelGGL((gemm_kernel<T, false, false, 64>), dim3(a.persistent, 1, 1), dim3(256), GEMM_LDS_BYTES_64, st, b);
+        else hipLaunchKernelGGL((gemm_kernel<T, false, false, 128>), dim3(a.persistent, 1, 1), dim3(256), GEMM_LDS_BYTES, st, b);
+      } else if (a.small_tiles) {
+        hipLaunchKernelGGL((gemm_kernel<T, false, false, 64>), dim3(nt, 1, grid.z), dim3(256), GEMM_LDS_BYTES_64, st, a);
+      } else {
+        hipLaunchKernelGGL((gemm_kernel<T, false, false, 128>), dim3(nt, 1, grid.z), dim3(256), GEMM_LDS_BYTES, st, a);
+      }
+      break;
+    }
     case GEMM_POST:
       hipLaunchKernelGGL((gemm_kernel<T, true, false, 128>), grid, dim3(256), GEMM_LDS_BYTES, st, a);
       break;

@@ -12,6 +12,8 @@ template <typename V> __device__ __forceinline__ V gld(const V* p) { return *(co
 template <typename V> __device__ __forceinline__ void gst(V* p, V v) { *(HBO_GLOBAL V*)(p) = v; }
 
 #define HBO_TILE 128     // square tile / panel width of every blocked algorithm
+#define HBO_N_COUNTERS 4096        // tile counters of one factorisation's persistent launches: [0, HBO_N_BULK_COUNTERS) the bulk trailing
+#define HBO_N_BULK_COUNTERS 1024   // updates, the rest the inverse products that run beside the panel chain
 #define HBO_LEAF 16      // MFMA tile edge (v_mfma_*_16x16x4)
 
 // One GP sub-dataset (or one GPCache) as the kernels see it.  All matrices are row-major with
@@ -60,6 +62,11 @@ enum GemmMode {
   GEMM_LAUUM = 3,    // S = W^T W (lower tiles)
   GEMM_POST = 4,     // V = W * Kxq (column sums of squares and/or V itself)
   GEMM_VTV = 5,      // C -= V^T V over all npad rows (full posterior covariance: C holds Kqq on entry), tiles of mpad x mpad
+  // the one-sweep inverse (sched.hip:sweep_advance), row group R = blocks [c_lo, c_hi) whose block columns of L are final;
+  // S holds T (running products, rows below the front) and K^-1 (rows at and above it):
+  GEMM_SWEEP_B = 6,  // W[i,j] = -sum_{k in R, k <= i} W[i,k] T[k,j]          i in R, j < c_lo
+  GEMM_SWEEP_T = 7,  // T[i,j] (+)= sum_{k in R, k >= j} L[i,k] W[k,j]          i >= c_hi, j < c_hi   (first contribution: j in R)
+  GEMM_SWEEP_C = 8,  // K^-1[i,j] (+)= sum_{k in R, k >= i} W[k,i]^T W[k,j]     j <= i < c_hi          (first contribution: i in R)
 };
 
 struct GemmArgs {
@@ -74,7 +81,9 @@ struct GemmArgs {
   int persistent;   // >0 -> that many persistent workgroups loop over the tiles (SYRK; TRTRI on 128-tiles with a work_counter)
   int n_big;        // persistent SYRK on 128-tiles: tiles [0, n_big) of the linear order run as 128-tiles, the rest as four 64-tiles
                     // each (0 = all of them as 128-tiles): the last, partly filled round of a launch balances at a quarter of the grain
-  int pgx, pgy;     // persistent TRTRI: the tile grid the workgroups walk (set by launch_gemm)
+  int pgx, pgy;     // persistent TRTRI / SWEEP: the tile grid the workgroups walk (set by launch_gemm)
+  int ptasks;       // persistent form over a batch: tiles x tasks are drawn from ONE counter (tile-major, so that equal-K tiles of
+                    // all tasks are neighbours); 0: the task is blockIdx.z
   int* work_counter; // persistent SYRK: zero-initialised tile counter -> workgroups draw tiles dynamically (a faster
                      // workgroup takes more of them) instead of striding over them; null: static stride
   int dbg;          // HBO_GEMM_TIMING builds: 1 -> this launch records per-workgroup wall-clock stamps

@@ -139,9 +139,14 @@ static int objective_local(hbo_ctx* c, const hbo_model* m_in, hbo_dataset* ds, i
   int max_naug = 1;
   for (int k = 0; k < T; ++k) max_naug = std::max(max_naug, ds->h_desc[k].naug);
   TrtriProgress trtri_pg;
+  SweepState sweep_st;
   hipStream_t side = st; hipEvent_t ev_side = nullptr;
   const bool la = use_lookahead(c, T, max_nblk);
-  const bool early_trtri = want_grad && la && c->opt_overlap_trtri && max_nblk >= 4;
+  // the inverse and K^-1 behind the panel chain, row group by row group (sched.hip:sweep_advance) -- or the block-recursive
+  // inverse started beside the chain and K^-1 = W^T W after it
+  const bool sweep = want_grad && !euc && use_sweep(c, dtype, T, max_nblk);
+  if (sweep) sweep_st.qs = c->opt_sweep_qs > 0 ? c->opt_sweep_qs : 4;
+  const bool early_trtri = !sweep && want_grad && la && c->opt_overlap_trtri && max_nblk >= 4;
   if (!euc) {
     {
       ProfScope ps(c, "gram", 1);
@@ -151,7 +156,7 @@ static int objective_local(hbo_ctx* c, const hbo_model* m_in, hbo_dataset* ds, i
     {
       c->trtri_host_task = TaskDesc{};
       if (T == 1) c->trtri_host_task = ds->h_desc[0];
-      ProfScope ps(c, "potrf", 1); run_potrf(c, dtype, ds->d_desc, T, max_nblk, ds->d_info, early_trtri ? &trtri_pg : nullptr);
+      ProfScope ps(c, "potrf", 1); run_potrf(c, dtype, ds->d_desc, T, max_nblk, ds->d_info, early_trtri ? &trtri_pg : nullptr, sweep ? &sweep_st : nullptr);
     }
     // the small reductions (log-determinant + quadratic form now, alpha = W^T z and d nll / d mu after the inverse) run on
     // the idle panel stream beside the inverse and K^-1 = W^T W instead of between them (0.14 ms at cfg 2)
@@ -166,7 +171,20 @@ static int objective_local(hbo_ctx* c, const hbo_model* m_in, hbo_dataset* ds, i
   if (want_grad || euc) {   // EUC: the Frobenius norm of the value comes out of the contraction pass
     const size_t pb = sizeof(double) * (stride_task * T + (size_t)HBO_GRAD_PRE_ROWS * nacc * T);   // per-tile partials + their pre-reduction
     if (ds->partials_bytes < pb) { if (ds->d_partials) dev_free(c, ds->d_partials); HIPCHK(c, dev_alloc(c, (void**)&ds->d_partials, pb)); ds->partials_bytes = pb; }
-    if (!euc) {
+    if (!euc && sweep) {
+      // what the chain left: the last row group(s).  W is complete behind the last group's rows (event), K^-1 behind its update
+      hipEvent_t e = side != st ? pool_event(c, 3) : nullptr;
+      { ProfScope ps(c, "sweep_tail", 1);
+        sweep_advance(c, dtype, ds->d_desc, T, max_nblk, max_nblk, st, sweep_st, e); }
+      if (side != st) hipStreamWaitEvent(side, e, 0);
+      { ProfScope ps(c, "wt_z", 1, side);
+        for (int b = 0; b < max_naug; ++b) launch_wt_z(dtype, ds->d_desc, T, max_nblk, b, b, max_npad, side); }
+      if (side != st) {
+        launch_dmu(dtype, ds->d_desc, T, obj, side);
+        ev_side = pool_event(c, 4); hipEventRecord(ev_side, side);
+        hipStreamWaitEvent(st, ev_side, 0);
+      }
+    } else if (!euc) {
       { ProfScope ps(c, "trtri", 1);
         run_trtri(c, dtype, ds->d_desc, T, max_nblk, &trtri_pg); }
       if (side != st) { hipEvent_t e = pool_event(c, 3); hipEventRecord(e, st); hipStreamWaitEvent(side, e, 0); }   // W is complete

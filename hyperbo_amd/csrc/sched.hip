@@ -24,7 +24,8 @@ hipEvent_t pool_event(hbo_ctx* c, size_t i) {
 // launches: F1 updates only the NEXT group's block columns, F2 the rest; the next group's panel
 // work (potf2 -> trsm, the serial chain) runs on a second stream as soon as F1 is done, so F2
 // -- the bulk of the flops -- overlaps it.
-void run_potrf(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, int max_nblk, int* d_info, TrtriProgress* early) {
+void run_potrf(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, int max_nblk, int* d_info, TrtriProgress* early,
+               SweepState* sweep) {
   // panels per trailing update and CUs the persistent bulk update leaves to the panel chain.  Measured (NLL+grad, ms):
   //   N = 4096: (4, 32) 3.61, (3, 32) 3.54, (3, 64) 3.51;   N = 8192: (4, 32) 13.49, (3, 32) 13.34, (3, 64) 13.25,
   //   (3, 96) 13.43, (2, 64) 13.57, (5, 32) 13.61;   N = 16384: (4, 32) 78.4, (3, 32) 79.1, (3, 64) 79.5
@@ -70,15 +71,16 @@ void run_potrf(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, int m
   // fp32 with the trailing updates on the bf16 cores: the bulk update is 1.5x shorter and the panel chain sets the pace at
   // every size, so the chain's kernels are protected as for the small matrices
   const bool s3_wanted = dtype == HBO_F32 && c->opt_syrk_bf16x3 && max_nblk > 1;
-  int* const yield_flag = (la && ntasks == 1 && c->opt_cu_yield && (small_mat || s3_wanted)) ? c->d_yield : nullptr;
+  const bool batch_yield = la && ntasks > 1 && sweep && c->opt_batch_bg >= 2 && c->opt_cu_yield;
+  int* const yield_flag = ((la && ntasks == 1 && c->opt_cu_yield && (small_mat || s3_wanted)) || batch_yield) ? c->d_yield : nullptr;
   if (yield_flag) hipMemsetAsync(yield_flag, 0, sizeof(int) * HBO_YIELD_TAB_ENTRIES, sm);
   int* const chain_mark = (yield_flag && c->opt_cu_yield >= 2) ? yield_flag : nullptr;   // the chain's wide kernels mark their CUs too
   c->gemm_yield = yield_flag;
   // one tile counter per bulk launch (dynamic tile assignment of the persistent form), zeroed up front
-  int* counters = (int*)ws_get(c, WS_COUNTERS, sizeof(int) * 256);
+  int* counters = (int*)ws_get(c, WS_COUNTERS, sizeof(int) * HBO_N_COUNTERS);
   int n_counter = 0;
-  if (counters) hipMemsetAsync(counters, 0, sizeof(int) * 256, sm);
-  c->trtri_counters = counters ? counters + 128 : nullptr;   // second half: the persistent inverse products (trtri_level)
+  if (counters) hipMemsetAsync(counters, 0, sizeof(int) * HBO_N_COUNTERS, sm);
+  c->trtri_counters = counters ? counters + HBO_N_BULK_COUNTERS : nullptr;   // the rest: the persistent inverse products (trtri_level, sweep_advance)
   c->trtri_counter_next = 0;
   // fp32: every trailing update on the bf16 matrix cores from an exact three-way split of the group's panels (post3.hip:
   // syrk3_kernel; 1.4x the fp32-MFMA rate at fp32 accuracy).  Each panel is split right behind its solve; two buffers alternate
@@ -129,7 +131,14 @@ void run_potrf(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, int m
           launch_split3_panel(a, max_nblk + 1 - (p + 1), ntasks, sp);
         }
       }
-      if (early && ((p + 1) % tgran == 0 || p + 1 == early_at) && p + 1 < max_nblk) {
+      if (sweep && (p + 1) % sweep->qs == 0 && p + 1 < max_nblk) {
+        // block columns 0..p of L are final: the row group that ends here goes through the one-sweep inverse on the side stream
+        hipEvent_t e = pool_event(c, evi++);
+        hipEventRecord(e, sp);
+        hipStreamWaitEvent(c->stream4, e, 0);
+        ProfScope ps(c, "sweep_early", 1, c->stream4);
+        sweep_advance(c, dtype, d_tasks, ntasks, max_nblk, p + 1, c->stream4, *sweep);
+      } else if (early && ((p + 1) % tgran == 0 || p + 1 == early_at) && p + 1 < max_nblk) {
         // block columns 0..p of L are final: everything of the inverse that only needs them goes to a side stream
         // (the panel chain leaves most of the machine idle in the second half of the factorisation)
         hipEvent_t e = pool_event(c, evi++);
@@ -182,7 +191,7 @@ void run_potrf(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, int m
               // persistent, two workgroups on all but `s3_free` CUs: the panel kernels beside it always find a CU with room
               const int nt = tiles_of(g2, max_nblk);
               const int pb = 2 * (c->n_cus - c->opt_syrk3_free);
-              if (ntasks == 1 && la && c->opt_syrk3_free > 0 && nt > pb && counters && n_counter < 128) { b.persistent = pb; b.work_counter = counters + n_counter++; }
+              if (ntasks == 1 && la && c->opt_syrk3_free > 0 && nt > pb && counters && n_counter < HBO_N_BULK_COUNTERS) { b.persistent = pb; b.work_counter = counters + n_counter++; }
               b.yield_flag = yield_flag;
               launch_syrk3(b, nt, ntasks, sb);
             } else {
@@ -193,7 +202,7 @@ void run_potrf(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, int m
             const int pblocks = 2 * (c->n_cus - persist_free);
             // (for large trailing matrices the bulk update dominates and gets the whole machine)
             a.persistent = (ntasks == 1 && persist_free > 0 && ntiles > pblocks && m <= 96) ? pblocks : 0;
-            a.work_counter = (a.persistent && counters && n_counter < 128) ? counters + n_counter++ : nullptr;
+            a.work_counter = (a.persistent && counters && n_counter < HBO_N_BULK_COUNTERS) ? counters + n_counter++ : nullptr;
             a.n_big = 0;
             if (a.persistent && a.work_counter && !a.small_tiles) {
               // a partly filled last round (fewer than half of the workgroups would get a 128-tile) runs on 64-tiles
@@ -216,7 +225,7 @@ void run_potrf(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, int m
   c->gemm_yield = nullptr;
   c->trtri_counters = nullptr;
   if (la) { hipEvent_t e = pool_event(c, evi++); hipEventRecord(e, sp); hipStreamWaitEvent(sm, e, 0); }   // join
-  if (early) {   // the rest of the inverse (main stream) needs the early part
+  if (early || sweep) {   // the rest of the inverse (main stream) needs the early part
     hipEvent_t e = pool_event(c, evi++);
     hipEventRecord(e, c->stream4);
     hipStreamWaitEvent(sm, e, 0);
@@ -250,7 +259,7 @@ static bool trtri_level3(hbo_ctx* c, const TaskDesc* d_tasks, const TaskDesc& h,
   auto launch = [&](int mode) {
     g.mode = mode; g.persistent = 0; g.work_counter = nullptr;
     g.yield_flag = (st == c->stream4) ? c->gemm_yield : nullptr;
-    if (corun && ntiles > pblocks && c->trtri_counter_next < 128) { g.persistent = pblocks; g.work_counter = c->trtri_counters + c->trtri_counter_next++; }
+    if (corun && ntiles > pblocks && c->trtri_counter_next < HBO_N_COUNTERS - HBO_N_BULK_COUNTERS) { g.persistent = pblocks; g.work_counter = c->trtri_counters + c->trtri_counter_next++; }
     launch_syrk3(g, ntiles, 1, st);
   };
   ProfScope ps(c, "trtri_gemm", 2, st);
@@ -305,7 +314,7 @@ static void trtri_level(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntas
   a.c_hi = grp_hi - 1; a.c_lo = std::max(vlast, 0);   // TRTRI_A: last group and its launched tile rows
   auto persist = [&](int64_t tiles) {
     a.persistent = 0; a.work_counter = nullptr;
-    if (corun && tiles > pblocks && c->trtri_counter_next < 128) { a.persistent = pblocks; a.work_counter = c->trtri_counters + c->trtri_counter_next++; }
+    if (corun && tiles > pblocks && c->trtri_counter_next < HBO_N_COUNTERS - HBO_N_BULK_COUNTERS) { a.persistent = pblocks; a.work_counter = c->trtri_counters + c->trtri_counter_next++; }
   };
   if (do_a && xa > 0) { a.mode = GEMM_TRTRI_A; persist((int64_t)xa * s * tmul); launch_gemm(dtype, a, dim3(xa, s, ntasks), st); }
   if (do_b) {
@@ -327,14 +336,14 @@ static void trtri_level(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntas
 // cfin = max_nblk on the main stream, launches what is left (for a 64-block matrix: the B products on the right
 // spine of the tree, 1.25 of the inverse's 3.7 ms).
 void trtri_advance(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, int max_nblk, int cfin,
-                          hipStream_t st, TrtriProgress& pg) {
+                          hipStream_t st, TrtriProgress& pg, int max_s) {
   if (cfin > pg.diag) {
     ProfScope ps(c, "trtri_diag", 2, st);
     launch_trtri_diag(dtype, d_tasks, ntasks, pg.diag, cfin, st);
     pg.diag = cfin;
   }
   int li = 0;
-  for (int s = 1; s < max_nblk && li < 12; s *= 2, ++li) {
+  for (int s = 1; s < max_nblk && s <= max_s && li < 12; s *= 2, ++li) {
     // groups with a lower half: g*2s + s < max_nblk
     const int ngrp = (max_nblk - s + 2 * s - 1) / (2 * s);
     // A: left half final (cfin >= g*2s + s);  B: whole group final (cfin >= min(g*2s + 2s, max_nblk))
@@ -343,6 +352,75 @@ void trtri_advance(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, i
     na = std::min(na, ngrp); nb = std::min(nb, ngrp);
     if (na > pg.a[li]) { trtri_level(c, dtype, d_tasks, ntasks, max_nblk, s, pg.a[li], na, true, false, st); pg.a[li] = na; }
     if (nb > pg.b[li]) { trtri_level(c, dtype, d_tasks, ntasks, max_nblk, s, pg.b[li], nb, false, true, st); pg.b[li] = nb; }
+  }
+}
+// ---- the one-sweep inverse -----------------------------------------------------------------------------------------------------
+// With L = [[L11, 0], [L21, L22]] split at a row group R (q blocks): W = L^-1 = [[W11, 0], [-W22 L21 W11, W22]].  The product
+// L21 W11 is not formed when R comes up -- it would be a skinny product with K up to N on the critical path of the sweep -- but
+// accumulated: every finished group g' adds its term L[below, g'] W[g', :] to a running matrix T for ALL rows below it, a rank-q
+// update of the same shape as the Cholesky's trailing update.  When R's block columns of L are final, T[R, :] is complete and
+//   (a) W[R,R] = L[R,R]^-1        block-recursive inverse of the q x q diagonal group (trtri_advance capped at q / 2),
+//   (b) W[R, <R] = -W[R,R] T[R, <R]                                                                  GEMM_SWEEP_B, K <= q
+//   (c) T[>R, <=R] += L[>R, R] W[R, <=R]                                                              GEMM_SWEEP_T, K = q
+//   (d) K^-1[<=R, <=R] += W[R, <=R]^T W[R, <=R]                                                       GEMM_SWEEP_C, K = q
+// T and K^-1 share the S buffer: T lives below the front, K^-1 at and above it, and the rows R change roles between (b) and (d).
+// Same flops as the recursive inverse + K^-1 = W^T W (N^3/3 each); what changes is WHEN they can run: everything but the last
+// group's (a), (b), (d) sits beside the panel chain, and all of it is uniform K = 128 q work with thousands of tiles per launch.
+bool use_sweep(const hbo_ctx* c, int dtype, int ntasks, int max_nblk) {
+  if (!c->opt_sweep || !use_lookahead(c, ntasks, max_nblk) || max_nblk < 8) return false;
+  if (c->opt_sweep >= 2) return true;
+  // one matrix: the rank-512 updates of this form run at a lower rate than the long-K products of the recursive inverse and of
+  // K^-1 = W^T W, and the phase has no idle machine to give them (N = 8192: 13.4 against 11.5 ms, N = 4096: 3.01 / 2.99)
+  if (ntasks == 1) return false;
+  // fp32 beyond the small sizes: the block-recursive products and K^-1 run on the bf16 matrix cores (post3.hip), which this form does not
+  if (dtype == HBO_F32 && ntasks == 1 && max_nblk > c->opt_small_nblk && (c->opt_trtri_bf16x3 || c->opt_lauum_bf16x3)) return false;
+  return true;
+}
+void sweep_advance(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, int max_nblk, int cfin, hipStream_t st, SweepState& sw,
+                   hipEvent_t w_done) {
+  const int q = sw.qs;
+  // 64-tiles for small / batched matrices as everywhere else -- except where a launch has enough 128-tiles to fill the machine
+  // several times over: all tiles of a sweep launch have the same K, so the larger tile's better MFMA rate is not lost in a tail
+  const bool small_shape = max_nblk <= c->opt_small_nblk;
+  bool small = small_shape;
+  int U = small ? 2 : 1;
+  auto pick = [&](int64_t tiles128) { small = small_shape && tiles128 * ntasks < c->opt_sweep_big; U = small ? 2 : 1; };
+  // beside the panel chain (side stream, counters of this factorisation at hand): persistent and slot-limited, tiles (x tasks) from
+  // a counter, polling the yield table when the chain's kernels keep one -- see trtri_level
+  const bool corun = st == c->stream4 && c->trtri_counters && c->opt_trtri_free > 0 && (ntasks == 1 || c->opt_batch_bg >= 1);
+  const int pblocks = 2 * (c->n_cus - c->opt_trtri_free);
+  auto place = [&](GemmArgs& a, int64_t tiles) {
+    a.persistent = 0; a.work_counter = nullptr;
+    a.yield_flag = (st == c->stream4) ? c->gemm_yield : nullptr;
+    if (corun && tiles * ntasks > pblocks && c->trtri_counter_next < HBO_N_COUNTERS - HBO_N_BULK_COUNTERS) {
+      a.persistent = pblocks; a.work_counter = c->trtri_counters + c->trtri_counter_next++;
+    }
+  };
+  while (sw.done < max_nblk) {
+    const int b0 = sw.done, b1 = std::min(b0 + q, max_nblk);
+    if (b1 > cfin) break;
+    trtri_advance(c, dtype, d_tasks, ntasks, max_nblk, b1, st, sw.pg, q / 2);                       // (a)
+    GemmArgs a = {}; a.tasks = d_tasks; a.c_lo = b0; a.c_hi = b1;
+    if (b0 > 0) {                                                                                    // (b)
+      ProfScope ps(c, "sweep_b", 2, st);
+      pick((int64_t)b0 * (b1 - b0)); a.small_tiles = small;
+      a.mode = GEMM_SWEEP_B; place(a, (int64_t)b0 * (b1 - b0) * U * U);
+      launch_gemm(dtype, a, dim3(b0, b1 - b0, ntasks), st);
+    }
+    if (b1 == max_nblk && w_done) hipEventRecord(w_done, st);
+    if (b1 < max_nblk) {                                                                             // (c)
+      ProfScope ps(c, "sweep_t", 2, st);
+      pick((int64_t)(max_nblk - b1) * b1); a.small_tiles = small;
+      a.mode = GEMM_SWEEP_T; place(a, (int64_t)(max_nblk - b1) * b1 * U * U);
+      launch_gemm(dtype, a, dim3(max_nblk - b1, b1, ntasks), st);
+    }
+    {                                                                                                // (d)
+      ProfScope ps(c, "sweep_c", 2, st);
+      pick((int64_t)b1 * (b1 + 1) / 2); a.small_tiles = small;
+      a.mode = GEMM_SWEEP_C; place(a, small ? 2 * (int64_t)b1 * (b1 + 1) : (int64_t)b1 * (b1 + 1) / 2);
+      launch_gemm(dtype, a, dim3(b1, 1, ntasks), st);
+    }
+    sw.done = b1;
   }
 }
 void run_trtri(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, int max_nblk, TrtriProgress* pg) {
