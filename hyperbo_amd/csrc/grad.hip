@@ -80,6 +80,10 @@ __global__ __launch_bounds__(256) void grad_contract_kernel(const TaskDesc* task
         }
     }
   }
+  // (literal coefficients and no straight path for interior tiles, unlike gram_kernel: with either the kernel goes from 150 to
+  //  180-232 VGPRs and from three to two waves per SIMD, and it is bound by latency, not by instruction count -- 0.255 ms at cfg 2
+  //  against 0.28-0.29 with one or both; profiles/r04_elementwise.md)
+  const ExpLit ec;
   const T sv = (T)md->sv;
   const T inv_sigma2 = (T)(1.0 / (md->dot_sigma * md->dot_sigma));
   const T bias2 = (T)(md->dot_bias * md->dot_bias);
@@ -131,12 +135,12 @@ __global__ __launch_bounds__(256) void grad_contract_kernel(const TaskDesc* task
       T gw = (T)0;
       if (row < n && col < n) {
         const T u = acc[a][q];
-        const T k = kfun<T>(kid, u, sv, inv_sigma2, bias2);
+        const T k = kfun(kid, u, sv, inv_sigma2, bias2, ec);
         const T G0 = euc ? (k + (row == col ? noise : (T)0) - outer[q]) : (lh * kinv_row[q] - cc * outer[q]);
         const T G = G0 * wt;
         if (MULTI) a_fro += (double)(G0 * G);
         if (is_dot) { a_gk += (double)(G * u); a_g += (double)G; }
-        else { a_gk += (double)(G * k); gw = G * dk_du<T>(kid, u, k, sv); }
+        else { a_gk += (double)(G * k); gw = G * dk_du(kid, u, k, sv, ec); }
         if (row == col) a_tr += (double)G;
       }
       acc[a][q] = gw;
@@ -237,6 +241,7 @@ __global__ __launch_bounds__(256) void grad_feat_kernel(const TaskDesc* tasks, c
         }
     }
   }
+  const ExpLit ec;
   const T sv = (T)md->sv;
   const T inv_sigma2 = (T)(1.0 / (md->dot_sigma * md->dot_sigma));
   const T bias2 = (T)(md->dot_bias * md->dot_bias);
@@ -251,12 +256,12 @@ __global__ __launch_bounds__(256) void grad_feat_kernel(const TaskDesc* tasks, c
       T g = (T)0;
       if (row < n && col < n) {
         const T u = acc[a][q];
-        const T k = kfun<T>(kid, u, sv, inv_sigma2, bias2);
+        const T k = kfun(kid, u, sv, inv_sigma2, bias2, ec);
         T outer = (T)0;
         for (int b = 0; b < nvec; ++b) outer += sv_[(int64_t)b * vstride + row] * sv_[(int64_t)b * vstride + col];
         const T G = euc ? (k + (row == col ? noise : (T)0) - outer) : (lh * S[row * t.ld + col] - cc * outer);
         if (is_dot) g = G;
-        else g = G * dk_du<T>(kid, u, k, sv);
+        else g = G * dk_du(kid, u, k, sv, ec);
       }
       acc[a][q] = g;
     }

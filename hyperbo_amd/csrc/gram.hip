@@ -51,7 +51,7 @@ __global__ __launch_bounds__(256) void gram_kernel(GramArgs g, const ModelDev* _
     stage_x<T, 8>(sB, x2, n2, fdim, c0, d0, md->inv_ls, !is_dot, tid);
     __syncthreads();
     const int dlim = (fdim - d0) < DC ? (fdim - d0) : DC;
-    for (int dd = 0; dd < dlim; ++dd) {
+    auto step = [&](int dd) {
       T av[GRA], bv[8];
 #pragma unroll
       for (int a = 0; a < GRA; ++a) av[a] = sA[dd * SXS + ty + 16 * a];
@@ -68,15 +68,40 @@ __global__ __launch_bounds__(256) void gram_kernel(GramArgs g, const ModelDev* _
 #pragma unroll
           for (int q = 0; q < 8; ++q) { const T df = av[a] - bv[q]; acc[a][q] += df * df; }
       }
-    }
+    };
+    // (not unrolled: by 4 or 16 the LDS reads of all the steps are hoisted -- 232-238 VGPRs, two waves per SIMD)
+    for (int dd = 0; dd < dlim; ++dd) step(dd);
   }
 
+  const ExpCoef ec = hbo_exp_coef();
   const T sv = (T)md->sv;
   const T inv_sigma2 = (T)(1.0 / (md->dot_sigma * md->dot_sigma));
   const T bias2 = (T)(md->dot_bias * md->dot_bias);
   const T diag_add = (T)(md->noise + md->eps);
+  // Interior tiles -- all 64 x 128 elements are data and none is on the diagonal -- take a straight epilogue: the per-element
+  // "inside the data? on the diagonal?" 64-bit compares, selects and exec-mask branches of the general one were a third of the
+  // kernel's instructions (it is bound by VALU issue: ~3700 instructions per wave x 4 cycles x 16 waves per SIMD = the 100 us
+  // of the N = 8192 build), and all but ~3 % of the tiles of a large matrix are interior.
+  const bool interior = PADDED && r0 + GTR <= n1 && c0 + HBO_TILE <= n2 && !(g.symmetric && r0 < c0 + HBO_TILE && c0 < r0 + GTR);
+  if (interior) {
+    // (a scheduling barrier per row of 8 elements: left alone the scheduler interleaves all 32 exponentials: 232 VGPRs)
+#pragma unroll
+    for (int a = 0; a < GRA; ++a) {
+      __builtin_amdgcn_sched_barrier(0);
+      T* orow = out + (r0 + ty + 16 * a) * ldo + c0 + VEC * tx;
+#pragma unroll
+      for (int qb = 0; qb < 8 / VEC; ++qb) {
+        vec_t vv;
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) vv[e] = kfun(kid, acc[a][qb * VEC + e], sv, inv_sigma2, bias2, ec);
+        gst(reinterpret_cast<vec_t*>(orow + 16 * VEC * qb), vv);
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int a = 0; a < GRA; ++a) {
+    __builtin_amdgcn_sched_barrier(0);
     const int64_t row = r0 + ty + 16 * a;
     if (row >= e1) continue;
 #pragma unroll
@@ -91,7 +116,7 @@ __global__ __launch_bounds__(256) void gram_kernel(GramArgs g, const ModelDev* _
 #ifdef HBO_GRAM_NOEXP
           v = acc[a][qb * VEC + e] * sv;
 #else
-          v = kfun<T>(kid, acc[a][qb * VEC + e], sv, inv_sigma2, bias2);
+          v = kfun(kid, acc[a][qb * VEC + e], sv, inv_sigma2, bias2, ec);
 #endif
           if (g.symmetric && row == col) v += diag_add;
         } else {

@@ -57,6 +57,7 @@ __global__ __launch_bounds__(256) void acq_grad_kernel(AcqGradArgs a, const Mode
   // thread layout for the feature reduction: FD = pow2 >= fdim lanes per group, G groups over i
   int FD = 1; while (FD < fdim) FD <<= 1;
   const int G = 256 / FD, grp = tid / FD, dl = tid % FD;
+  const ExpCoef ec = hbo_exp_coef();
   const double sv = md->sv;
   const double inv_sigma2 = 1.0 / (md->dot_sigma * md->dot_sigma);
   double acc = 0;
@@ -69,8 +70,8 @@ __global__ __launch_bounds__(256) void acq_grad_kernel(AcqGradArgs a, const Mode
       else {
         double u = 0;
         for (int d = 0; d < fdim; ++d) { const double df = (s_fq[d] - (double)F[i * fdim + d]) * md->inv_ls[d]; u += df * df; }
-        const double k = kfun<double>(kid, u, sv, inv_sigma2, 0.0);
-        w = coef * dk_du<double>(kid, u, k, sv) * 2.0;
+        const double k = kfun(kid, u, sv, inv_sigma2, 0.0, ec);
+        w = coef * dk_du(kid, u, k, sv, ec) * 2.0;
       }
     }
     __syncthreads();

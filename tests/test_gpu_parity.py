@@ -98,6 +98,29 @@ def test_gram_vs_oracle(gpu_ctx, kname, mlp, dtype, tol):
   assert kn(pn, np.zeros((0, d), dtype), warp_func=utils.DEFAULT_WARP_FUNC).shape == (0, 0)
 
 
+def test_device_exp_against_numpy(gpu_ctx):
+  """The pair kernels' own fp64 exp (csrc/kernfun.h: hbo_exp) through the one place it is observable in isolation: the squared
+  exponential with unit length-scale and amplitude on 1-D inputs against the origin is exp(-x^2 / 2), and -x^2 / 2 is formed
+  identically on host and device.  <= 2 ulp over the whole range down to the underflow, exact 1 at 0, 0 beyond it, NaN stays NaN."""
+  defs, _, _, _, kernel, *_ = _native()
+  rng = np.random.default_rng(77)
+  t = np.concatenate([[0.0, 1e-300, 1e-17, 0.5 * np.log(2.0), 1.0, 700.0, 708.0, 744.0, 745.13, 746.5, 800.0, 1e6], rng.uniform(0, 40, 4000),
+                      rng.uniform(0, 745, 4000), 10.0 ** rng.uniform(-12, 2.8, 2000)])
+  x1 = np.sqrt(2.0 * t)[:, None]
+  pn = defs.GPParams(model={'lengthscale': np.array(1.0), 'signal_variance': np.array(1.0)})
+  got = kernel.squared_exponential(pn, x1, np.zeros((1, 1)), None)[:, 0]
+  arg = -0.5 * (x1[:, 0] * x1[:, 0])
+  want = np.exp(arg)
+  normal = want > 1e-290
+  ulp = np.abs(got[normal] - want[normal]) / np.spacing(want[normal])
+  assert ulp.max() <= 2.0, ulp.max()
+  assert got[0] == 1.0 and np.all(got[arg < -746.0] == 0.0)
+  np.testing.assert_allclose(got[~normal], want[~normal], rtol=1e-10, atol=1e-320)
+  xn = np.array([[np.nan], [1.0]])
+  out = kernel.squared_exponential(pn, xn, np.zeros((1, 1)), None)[:, 0]
+  assert np.isnan(out[0]) and out[1] == np.exp(-0.5)
+
+
 @pytest.mark.parametrize('mname', helpers.MEANS)
 def test_mean_vs_oracle(gpu_ctx, mname):
   defs, _, _, _, _, mean, _, utils = _native()
