@@ -46,7 +46,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
 sys.path.insert(0, ROOT)
 
-FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X datasheet; confirmed 77.1 by tools/mfma_probe.hip (64 cyc/instr)
+FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X datasheet (v_mfma_f64_16x16x4_f64: 64 cycles per SIMD); the rate sustained in THIS run is measured
+                               # by hbo_mfma_peak_probe and reported as peak_ubench / frac_of_ubench beside it
+HBM_PEAK_TBPS = 8.0            # /opt/skills/guides/MI355X_MICROARCH.md
 FP32_MFMA_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md
 BF16_MFMA_PEAK_TFLOPS = 2500.0   # dense bf16 MFMA (MI355X_MICROARCH.md)
 
@@ -203,11 +205,11 @@ def bench_cfg3(ctx):
           'factor_ms': round(tf * 1e3, 2), 'potrf_ms': round(pf['potrf'][0], 2), 'trtri_ms': round(pf['trtri'][0], 2),
           'ei_ms': round(te * 1e3, 2), 'post_gemm_ms': round(post_ms, 2), 'post_gemm_tflops': round(post_tf, 1),
           'post_gemm_path': 'bf16x3 (exact 3-way split of fp32 operands, 6 bf16 MFMAs per product, fp32 accumulate)',
-          'frac_fp32': round(post_tf / FP32_MFMA_PEAK_TFLOPS, 4),
           'frac_bf16_executed': round(6.0 * post_tf / BF16_MFMA_PEAK_TFLOPS, 4), 'ei_flops': float(n) * n * m,
+          'factor_frac_fp32': round(float(n)**3 / 3 / (pf['potrf'][0] * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
           'note': 'wall times include the host<->device copies of x_query / EI; post_gemm = V = L^-1 Kxq (algorithmic fp32 flops N^2 M); '
-                  'frac_fp32 is against the fp32 MFMA peak this path no longer uses (> 1 = beyond that roofline), '
-                  'frac_bf16_executed = 6 x algorithmic flops against the dense bf16 MFMA peak'}
+                  'frac_bf16_executed = 6 x algorithmic flops (the bf16 MFMAs the product executes) against the dense bf16 MFMA peak; '
+                  'factor_frac_fp32 = N^3/3 over the potrf stage time against the fp32 MFMA peak'}
 
 
 def bench_cfg5(ctx):
@@ -323,6 +325,42 @@ def bench_bo_step():
       for _ in range(10):
         f()
       out['ei_value_and_grad_16_ms'] = round((time.perf_counter() - t0) / 10 * 1e3, 3)
+  return out
+
+
+def bench_hgp():
+  """Acquisition on an HGP (hyperbo/bo_utils/acfun.py:72-82): S = 32 model-parameter samples of an SE-ARD GP over N = 512
+  observations, EI at 64 queries.  `batched` = hbo_acq_samples (the S factorisations as one batch, posteriors queued on the
+  device), `loop` = what the reference's structure gives: one factorisation + posterior per sample from Python."""
+  from hyperbo_amd.basics import definitions as defs
+  from hyperbo_amd.bo_utils import acfun
+  from hyperbo_amd.gp_utils import gp, kernel, mean, utils
+  rng = np.random.default_rng(7)
+  n, d, S, M = 512, 8, 32, 64
+  x = rng.uniform(size=(n, d)); w = rng.normal(size=d)
+  y = np.sin(2 * np.pi * x @ w)[:, None] + 0.1 * rng.normal(size=(n, 1))
+  xq = rng.uniform(size=(M, d))
+  samples = [{'lengthscale': inv_softplus(np.full(d, 0.5)) + 0.2 * rng.normal(size=d), 'signal_variance': inv_softplus(1.0) + 0.1 * rng.normal(),
+              'noise_variance': inv_softplus(1e-2) + 0.1 * rng.normal(), 'constant': np.array(0.1 * rng.normal())} for _ in range(S)]
+  data = {0: defs.SubDataset(x, y)}
+  hgp = gp.HGP(data, mean.constant, kernel.squared_exponential, defs.GPParams(model=samples[0], samples=samples), utils.DEFAULT_WARP_FUNC)
+  batched = lambda: acfun.expected_improvement(model=hgp, sub_dataset_key=0, x_queries=xq)
+  def loop():
+    vals = []
+    for smp in samples:
+      g = gp.GP(data, mean.constant, kernel.squared_exponential, defs.GPParams(model=smp), utils.DEFAULT_WARP_FUNC)
+      vals.append(acfun.expected_improvement(model=g, sub_dataset_key=0, x_queries=xq))
+    return np.mean(vals, axis=0)
+  a, b = batched(), loop()
+  out = {'workload': f'EI on an HGP: {S} parameter samples x N={n} observations, D={d}, {M} queries, fp64',
+         'max_abs_diff_batched_vs_loop': float(np.max(np.abs(a - b)))}
+  for name, f in (('batched_ms', batched), ('loop_ms', loop)):
+    f()
+    t0 = time.perf_counter()
+    for _ in range(5):
+      f()
+    out[name] = round((time.perf_counter() - t0) / 5 * 1e3, 3)
+  out['speedup'] = round(out['loop_ms'] / out['batched_ms'], 2)
   return out
 
 
@@ -473,13 +511,14 @@ def main():
     # HBM traffic per launch from committed rocprofv3 PMC passes of this same command (separate
     # --pmc FETCH_SIZE / WRITE_SIZE runs; FETCH_SIZE doubled per MI355X_MICROARCH.md: on gfx950 it
     # reports half the bytes of wide coalesced streaming reads).  bench.py cannot run rocprof itself.
-    pmc_path = os.path.join(ROOT, 'profiles', 'r03_pmc_hbm.json')   # re-collected for this round's build (tools/pmc_to_json.py)
-    if os.path.exists(pmc_path):
-      pmc = json.load(open(pmc_path)).get('gemm_kernel<double, true, true, 128>')
+    pmc_path = next((pth for pth in (os.path.join(ROOT, 'profiles', f) for f in ('r04_pmc_hbm.json', 'r03_pmc_hbm.json')) if os.path.exists(pth)), None)
+    if pmc_path:
+      pmc_all = json.load(open(pmc_path))
+      pmc = pmc_all.get('gemm_kernel<double, true, true, 128>')
       if pmc:
         roofline['traffic'] = int((2 * pmc['FETCH_SIZE_KB'] + pmc['WRITE_SIZE_KB']) * 1024)
         roofline['traffic_note'] = ('bytes per launch = (2*FETCH_SIZE + WRITE_SIZE)*1024 from separate rocprofv3 --pmc passes of this '
-                                    'command, profiles/r03_pmc_hbm.json (kernel unchanged since: gemm.hip tile body)')
+                                    f'command, profiles/{os.path.basename(pmc_path)}')
   roofline_small = None
   if 'syrk_col' in launch_prof and 'syrk_trailing' in launch_prof:
     sm_ms = launch_prof['syrk_col'][0] + launch_prof['syrk_trailing'][0]
@@ -502,6 +541,41 @@ def main():
                                                 'with the overlapped part of the inverse running beside it',
                       'flops': fl_potrf, 'ms': stages['potrf'], 'achieved': round(tf, 3), 'peak': FP64_MFMA_PEAK_TFLOPS,
                       'unit': 'TFLOP/s', 'frac': round(tf / FP64_MFMA_PEAK_TFLOPS, 4)}
+
+  # the whole evaluation against the fp64 MFMA roofline: N^3 algorithmic flops (potrf + inverse + K^-1) / wall time per step
+  eval_tf = float(args.n)**3 / (ms_per_step * 1e-3) / 1e12
+  roofline_eval = {'bound': 'mfma', 'what': 'whole NLL+grad evaluation: N^3 algorithmic flops (potrf N^3/3 + inverse N^3/3 + K^-1 N^3/3) over the '
+                                             'wall time per step of the timed region',
+                   'flops': float(args.n)**3, 'ms': round(ms_per_step, 4), 'achieved': round(eval_tf, 3), 'peak': FP64_MFMA_PEAK_TFLOPS,
+                   'unit': 'TFLOP/s', 'frac': round(eval_tf / FP64_MFMA_PEAK_TFLOPS, 4)}
+  def gram_traffic():
+    pth = os.path.join(ROOT, 'profiles', 'r04_pmc_hbm.json')
+    if not os.path.exists(pth):
+      return None
+    g = json.load(open(pth)).get('gram_kernel<double, true, 0>')
+    return int((2 * g['FETCH_SIZE_KB'] + g['WRITE_SIZE_KB']) * 1024) if g else None
+  # the Gram build against the HBM roofline: algorithmic bytes = the lower tiles it writes (+ X once), HIP-event time of the stage
+  roofline_gram = None
+  if 'gram' in stages and stages['gram'] > 0:
+    nblk_g = (args.n + 127) // 128
+    gram_bytes = 8.0 * (nblk_g * (nblk_g + 1) / 2 * 128 * 128 + args.n * args.d)
+    gtb = gram_bytes / (stages['gram'] * 1e-3) / 1e12
+    roofline_gram = {'bound': 'hbm', 'kernel': 'gram_kernel<double,true,0> (SE-ARD Gram, lower 128-tiles + (noise + eps) I, identity padding)',
+                     'achieved': round(gtb * 1e3, 1), 'peak': HBM_PEAK_TBPS * 1e3, 'unit': 'GB/s', 'frac': round(gtb / HBM_PEAK_TBPS, 4),
+                     'algorithmic_bytes': gram_bytes, 'ms': stages['gram'], 'traffic': gram_traffic(),
+                     'note': 'bound by VALU issue, not by HBM (profiles/r04_elementwise.md): the stores are 272 MB at this size'}
+  peak_ubench = None
+  try:
+    import ctypes as _C2
+    tfp = _C2.c_double(0.0)
+    if nat.lib().hbo_mfma_peak_probe(ctx.handle, 2.0, _C2.byref(tfp)) == 0 and tfp.value > 0:
+      peak_ubench = {'tflops': round(tfp.value, 2), 'what': 'v_mfma_f64_16x16x4_f64 back to back on every SIMD for ~2 ms, measured in this run '
+                                                            '(hbo_mfma_peak_probe)', 'datasheet': FP64_MFMA_PEAK_TFLOPS}
+      for rf in (roofline, roofline_small, roofline_potrf, roofline_eval):
+        if rf is not None:
+          rf['frac_of_ubench'] = round(rf['achieved'] / tfp.value, 4)
+  except Exception as e:  # pylint: disable=broad-except
+    peak_ubench = {'error': str(e)[:100]}
 
   extra = {}
   device_info = {}
@@ -532,7 +606,8 @@ def main():
                        'bracket spans that) -- the sum of the rows is not the evaluation time',
         'torch_imported': 'torch' in sys.modules,
         'device': device_info,
-        'roofline': roofline, 'roofline_small': roofline_small, 'roofline_potrf': roofline_potrf, 'cpu_baseline': cpu, 'multitask': multitask,
+        'roofline': roofline, 'roofline_small': roofline_small, 'roofline_potrf': roofline_potrf, 'roofline_eval': roofline_eval,
+        'roofline_gram': roofline_gram, 'peak_ubench': peak_ubench, 'cpu_baseline': cpu, 'multitask': multitask, 'hgp': extra.get('hgp'),
         'jax_baseline': extra.get('jax'), 'train': extra.get('train'), 'bo_step': extra.get('bo_step'), 'fp32': extra.get('fp32'),
         'cfg3': extra.get('cfg3'), 'cfg5': extra.get('cfg5'),
     }
@@ -656,6 +731,7 @@ def main():
       extra['train'] = bench_train()
       extra['bo_step'] = bench_bo_step()
       extra['fp32'] = bench_fp32_objective(ctx)
+      extra['hgp'] = bench_hgp()
     except Exception as e:  # pylint: disable=broad-except
       extra['error'] = str(e)[:200]
 
@@ -674,7 +750,12 @@ def main():
                      f'(oracle/cpu_baseline.py + oracle/cpu_port.c: Gram build and gradient contraction in C/OpenMP on all '
                      f'cores, LAPACK potrf/potrs/potri via SciPy/OpenBLAS)',
            'seconds': round(el, 2), 'nll_matches_gpu': bool(abs(vals[-1] - float(step_fn(args.cpu_evals - 1)[0])) <= 1e-8 * abs(vals[-1]))}
+    cpu['tflops'] = round(cpu['value'] * float(args.n)**3 / 1e12, 4)
     cpu.update(cpu_provenance())
+    caps = [t.get('num_threads') for t in cpu.get('threadpools', []) if t.get('user_api') == 'blas' and t.get('num_threads')]
+    cpu['blas_threads_cap'] = min(caps) if caps else None
+    cpu['note'] = ('a stated baseline, not a target: the potrf / potri inside it run on the BLAS thread pool above (capped below the core count by '
+                   'the OpenBLAS build), the Gram build and the contraction on all cores; the GPU / CPU ratio says nothing about kernel quality')
     if args.jax:
       try:
         import jax  # noqa: F401  pylint: disable=unused-import

@@ -88,6 +88,8 @@ SIGNATURES = {
     'hbo_predict': (C.c_int, [_P, C.POINTER(Model), _P, _P, C.c_int64, C.c_int, _P, _P]),
     'hbo_acq': (C.c_int, [_P, C.POINTER(Model), _P, _P, C.c_int64, C.c_int, C.c_double, C.c_double,
                           C.c_double, _P]),
+    'hbo_acq_samples': (C.c_int, [_P, _P, C.c_int32, _P, C.c_int64, _P, C.c_int32, _P, C.c_int64, C.c_int, C.POINTER(C.c_double),
+                                  C.POINTER(C.c_double), C.c_double, _P]),
     'hbo_spd_solve': (C.c_int, [_P, C.c_int, _P, C.c_int64, _P, C.c_int32, _P, _P, _P,
                                 C.POINTER(C.c_double)]),
     'hbo_chol_solve': (C.c_int, [_P, C.c_int, _P, C.c_int64, _P, C.c_int32, _P]),
@@ -96,6 +98,7 @@ SIGNATURES = {
                                   C.POINTER(C.c_int32)]),
     'hbo_set_option': (C.c_int, [_P, C.c_char_p, C.c_int64]),
     'hbo_tune': (C.c_int, [_P, C.c_char_p, C.c_int64]),   # include/hbo_tune.h: measurement hooks, not the boundary
+    'hbo_mfma_peak_probe': (C.c_int, [_P, C.c_double, C.POINTER(C.c_double)]),   # include/hbo_tune.h
     'hbo_comm_unique_id': (C.c_int, [_P]),
     'hbo_comm_init': (C.c_int, [_P, C.c_int, C.c_int, _P]),
     'hbo_comm_allreduce_sum': (C.c_int, [_P, C.POINTER(C.c_double), C.c_int32]),

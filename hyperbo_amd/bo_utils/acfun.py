@@ -1,7 +1,10 @@
 """Acquisition functions -- hyperbo/bo_utils/acfun.py:36-185.
 
-For a plain GP the posterior and the EI/PI/UCB epilogue run fused on the GPU (hbo_acq); the `*_sub`
-functions are the host restatement used for HGP sample averaging and as documentation of the maths.
+For a plain GP the posterior and the EI/PI/UCB epilogue run fused on the GPU (hbo_acq).  For an HGP
+(acfun.py:72-82: the mean over the model-parameter samples) all samples are factorised as ONE batch and
+their posteriors + epilogues queue up on the device (hbo_acq_samples) -- the counterpart of a `jax.vmap`
+over the draws; the `*_sub` functions are the host restatement of the maths, used for callables outside
+the registry.
 """
 import functools
 from typing import Any, Callable, Union
@@ -10,6 +13,8 @@ import numpy as np
 
 from hyperbo_amd import _model
 from hyperbo_amd import _native as nat
+from hyperbo_amd.basics import definitions as defs
+from hyperbo_amd.basics.params_utils import retrieve_params
 from hyperbo_amd.gp_utils import gp
 
 partial = functools.partial
@@ -48,14 +53,61 @@ _NATIVE_ID = {expected_improvement_sub: nat.ACQ_EI, probability_of_improvement_s
               ucb_sub: nat.ACQ_UCB}
 
 
+def hgp_sample_values(model, sub_dataset_key, x_queries, acq_id, acfun_param):
+  """(S, M, 1) acquisition values of every model-parameter sample of an HGP from ONE batched device call: the S Gram
+  matrices of the sub-dataset are built, factorised and inverted together (one ModelDev per task), the S posterior +
+  acquisition passes follow one another on the stream (hbo_acq_samples).  gp.py:666-682 / acfun.py:72-82 as a batch."""
+  samples = model.get_model_params_samples()
+  sub = model.dataset[sub_dataset_key]
+  x = np.asarray(sub.x)
+  y = np.asarray(sub.y)
+  dtype = _model.infer_dtype(x, y)
+  x = np.ascontiguousarray(x, dtype=dtype)
+  y = np.ascontiguousarray(y.reshape(x.shape[0], -1), dtype=dtype)
+  xq = np.ascontiguousarray(x_queries, dtype=dtype)
+  _, scale = model.predict_noise_and_scale(True, True)
+  # the samples' hbo_model structs are rebuilt only when a sample changed (0.05-0.1 ms of Python each: most of a call's time at
+  # S = 32, N = 512); the fingerprint sees replaced leaves and in-place edits alike
+  def leaves(t):
+    if isinstance(t, dict):
+      for k in sorted(t):
+        yield from leaves(t[k])
+    else:
+      yield t
+  finger = (np.dtype(dtype).str, id(model.warp_func), model.mean_func, model.cov_func,
+            tuple((id(v), float(np.sum(v))) for smp in samples for v in leaves(smp)))
+  cached = getattr(model, '_hbo_sample_models', None)
+  if cached is None or cached[0] != finger:
+    built, noises = [], []
+    for smp in samples:
+      ps = defs.GPParams(config=model.params.config, model=smp)
+      built.append(_model.BuiltModel(model.mean_func, model.cov_func, ps, model.warp_func, dtype, model.input_dim))
+      nv, = retrieve_params(ps, ['noise_variance'], warp_func=model.warp_func)
+      noises.append(float(np.squeeze(nv)))
+    structs = (nat.Model * len(samples))(*[b.struct for b in built])
+    cached = (finger, built, structs, noises)
+    model._hbo_sample_models = cached
+  _, built, structs, noises = cached
+  s_count = len(samples)
+  prm = (nat.C.c_double * s_count)(*([float(acfun_param)] * s_count))
+  nse = (nat.C.c_double * s_count)(*noises)
+  out = np.empty((s_count, xq.shape[0], 1), dtype=dtype)
+  ctx = nat.default_context()
+  ctx.check(nat.lib().hbo_acq_samples(ctx.handle, structs, s_count, nat.ptr(x), x.shape[0], nat.ptr(y), y.shape[1], nat.ptr(xq),
+                                      xq.shape[0], int(acq_id), prm, nse, float(scale), nat.ptr(out)))
+  return out
+
+
 def acfun_wrapper(acfun_sub, acfun_callback_default):
   """acfun.py:36-93."""
 
   def acquisition_function(*, model, sub_dataset_key, x_queries, acfun_callback=acfun_callback_default):
     x_queries = np.asarray(x_queries)
     if isinstance(model, gp.HGP):
-      predicts = model.predict(x_queries, sub_dataset_key=sub_dataset_key, full_cov=False, with_noise=True)
       acfun_param = acfun_callback(model, sub_dataset_key)
+      if acfun_sub in _NATIVE_ID and model.has_observations(sub_dataset_key) and x_queries.shape[0] > 0:
+        return np.mean(hgp_sample_values(model, sub_dataset_key, x_queries, _NATIVE_ID[acfun_sub], acfun_param), axis=0)
+      predicts = model.predict(x_queries, sub_dataset_key=sub_dataset_key, full_cov=False, with_noise=True)
       ac_vals = [acfun_sub(mu, np.sqrt(var), acfun_param) for mu, var in predicts]
       return np.mean(ac_vals, axis=0)
     acfun_param = acfun_callback(model, sub_dataset_key)

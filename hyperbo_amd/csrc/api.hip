@@ -123,6 +123,63 @@ extern "C" int hbo_tune(hbo_ctx* c, const char* name, int64_t value) {
     }
   return hbo_set_option(c, name, value);   // (the tools pass every name through one entry point)
 }
+// Sustained fp64 MFMA rate of THIS device, measured now (include/hbo_tune.h): every SIMD of every CU runs two waves of
+// back-to-back independent v_mfma_f64_16x16x4_f64 (4 accumulators per wave, no memory traffic) for ~`ms` milliseconds between two
+// HIP events.  What bench.py reports beside the 78.6 TFLOP/s datasheet figure: the denominator a kernel can actually reach at the
+// clock the chip holds under an fp64 MFMA load.  (Four accumulators per wave, the loop in assembly: see the kernel.)
+namespace {
+typedef double probe_d4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void mfma_probe_kernel(double* out, int iters) {
+  probe_d4 acc[4];
+  const double a = 1.0 + threadIdx.x * 1e-9, b = 1.0 - threadIdx.x * 1e-9;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) acc[i] = (probe_d4){0, 0, 0, 0};
+  // the whole loop is ONE assembly block: around a builtin (or a per-instruction asm) inside a C loop the register allocator parks
+  // the loop-carried accumulators in VGPRs and copies them to AGPRs and back every iteration (16 v_accvgpr moves per MFMA)
+  int n = iters;
+  asm volatile(
+      "1:\n"
+      "v_mfma_f64_16x16x4_f64 %0, %5, %6, %0\n"
+      "v_mfma_f64_16x16x4_f64 %1, %5, %6, %1\n"
+      "v_mfma_f64_16x16x4_f64 %2, %5, %6, %2\n"
+      "v_mfma_f64_16x16x4_f64 %3, %5, %6, %3\n"
+      "s_sub_u32 %4, %4, 1\n"
+      "s_cmp_lg_u32 %4, 0\n"
+      "s_cbranch_scc1 1b\n"
+      "s_nop 15\n"
+      : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+s"(n)
+      : "v"(a), "v"(b)
+      : "scc");
+  double sacc = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) sacc += acc[i][0] + acc[i][1] + acc[i][2] + acc[i][3];
+  out[(size_t)blockIdx.x * blockDim.x + threadIdx.x] = sacc;
+}
+}  // namespace
+extern "C" int hbo_mfma_peak_probe(hbo_ctx* c, double ms, double* tflops_out) {
+  if (!c || !tflops_out || !(ms > 0) || ms > 1000) return fail(c, HBO_ERR_ARG, "hbo_mfma_peak_probe: bad argument");
+  HIPCHK(c, hipSetDevice(c->device));
+  const int blocks = 2 * c->n_cus;   // two 4-wave workgroups per CU: two waves per SIMD
+  double* d_out = static_cast<double*>(ws_get(c, WS_COUNTERS + 1000, sizeof(double) * 256 * blocks));
+  if (!d_out) return HBO_ERR_HIP;
+  hipEvent_t e0 = pool_event_timed(c, 0), e1 = pool_event_timed(c, 1);
+  double best = 0;
+  int iters = 8192;
+  for (int rep = 0; rep < 3; ++rep) {   // the first pass sizes the second and third to ~ms
+    HIPCHK(c, hipEventRecord(e0, c->stream));
+    hipLaunchKernelGGL(mfma_probe_kernel, dim3(blocks), dim3(256), 0, c->stream, d_out, iters);
+    HIPCHK(c, hipEventRecord(e1, c->stream));
+    HIPCHK(c, hipEventSynchronize(e1));
+    float el = 0;
+    HIPCHK(c, hipEventElapsedTime(&el, e0, e1));
+    const double flops = (double)blocks * 4 * (double)iters * 4 * 2048.0;   // waves x MFMAs x 16*16*4*2
+    if (rep > 0) best = std::max(best, flops / (el * 1e-3) / 1e12);
+    if (rep == 0) iters = (int)std::min(4.0e6, std::max(1024.0, iters * ms / std::max((double)el, 1e-3)));
+  }
+  HIPCHK(c, hipGetLastError());
+  *tflops_out = best;
+  return HBO_OK;
+}
 extern "C" int hbo_profile_enable(hbo_ctx* c, int level) { if (!c) return HBO_ERR_ARG; c->prof_level = level; return HBO_OK; }
 extern "C" int hbo_profile_get(hbo_ctx* c, char names[][32], double* ms, int32_t* launches, int32_t* n) {
   if (!c || !n) return HBO_ERR_ARG;

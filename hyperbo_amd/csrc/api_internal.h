@@ -57,13 +57,8 @@ static double host_elem(const void* p, int dtype, int64_t i) {
   return dtype == HBO_F64 ? ((const double*)p)[i] : (double)((const float*)p)[i];
 }
 
-// fills ctx->h_model, uploads it and the MLP weights
-static int upload_model(hbo_ctx* c, const hbo_model* m) {
-  int rc = validate_model(c, m);
-  if (rc) return rc;
-  // the pinned copy may still be read by the previous upload (calls that return without waiting for the stream)
-  HIPCHK(c, hipEventSynchronize(c->ev_upload));
-  ModelDev& h = *c->h_model;
+// the device-side form of an (already warped) model
+static void fill_model_dev(ModelDev& h, const hbo_model* m) {
   memset(&h, 0, sizeof h);
   h.kernel_id = m->kernel_id; h.mean_id = m->mean_id; h.fdim = feature_dim(m);
   h.n_ls = (m->kernel_id == HBO_KERNEL_DOT) ? 0 : m->n_lengthscale;
@@ -78,6 +73,15 @@ static int upload_model(hbo_ctx* c, const hbo_model* m) {
   }
   const int fm = mean_feature_dim(m);
   for (int d = 0; d < fm; ++d) h.lin_w[d] = host_elem(m->linear_kernel, m->dtype, d);
+}
+// fills ctx->h_model, uploads it and the MLP weights
+static int upload_model(hbo_ctx* c, const hbo_model* m) {
+  int rc = validate_model(c, m);
+  if (rc) return rc;
+  // the pinned copy may still be read by the previous upload (calls that return without waiting for the stream)
+  HIPCHK(c, hipEventSynchronize(c->ev_upload));
+  ModelDev& h = *c->h_model;
+  fill_model_dev(h, m);
   HIPCHK(c, hipMemcpyAsync(c->d_model, &h, sizeof h, hipMemcpyHostToDevice, c->stream));
   HIPCHK(c, hipEventRecord(c->ev_upload, c->stream));
   if (needs_mlp(m)) {
@@ -98,11 +102,13 @@ static int upload_model(hbo_ctx* c, const hbo_model* m) {
 
 // ---- feature pipeline ----------------------------------------------------------------------
 // Computes the MLP activations of x (n x D, device) into acts[l] (allocated by the caller: n x f_l)
-static void run_mlp(hbo_ctx* c, const hbo_model* m, const void* x, int64_t n, void* const* acts) {
+// (w / b: the layers' device weights -- the context's own copy of the last uploaded model unless a caller keeps several)
+static void run_mlp(hbo_ctx* c, const hbo_model* m, const void* x, int64_t n, void* const* acts, void* const* w = nullptr, void* const* b = nullptr) {
   const void* in = x;
   int fin = m->input_dim;
+  if (!w) { w = c->d_mlp_w; b = c->d_mlp_b; }
   for (int l = 0; l < m->n_layers; ++l) {
-    launch_dense_tanh(m->dtype, in, c->d_mlp_w[l], c->d_mlp_b[l], acts[l], n, fin, m->features[l], c->stream);
+    launch_dense_tanh(m->dtype, in, w[l], b[l], acts[l], n, fin, m->features[l], c->stream);
     in = acts[l];
     fin = m->features[l];
   }

@@ -187,15 +187,24 @@ extern "C" int hbo_cache_append(hbo_ctx* c, const hbo_model* m, hbo_cache* k, co
 }
 
 // ---- posterior / acquisition ---------------------------------------------------------------
+// `ov` (hbo_acq_samples): the model and its MLP weights are already on the device at ov->md / ov->mlp_w / ov->mlp_b, the queries at
+// ov->xq_dev; the acquisition values go to ov->acq_dev and stay there -- nothing is uploaded, copied back or waited for, so that
+// the posteriors of many parameter samples queue up behind one another on the stream.
+// `lane` > 0 (single-chunk calls only): the pass runs on the context's side stream `lane` with its own set of workspaces, so that
+// the latency-bound launch chains of different samples overlap.
+struct PosteriorOverride { const ModelDev* md; void* const* mlp_w; void* const* mlp_b; const void* xq_dev; void* acq_dev; int lane; };
 static int posterior(hbo_ctx* c, const hbo_model* m, hbo_cache* k, const void* xq, int64_t M, int full_cov,
                      void* mu_out, void* var_out, void* acq_out, int acq_id, double param, double add_noise,
-                     double scale) {
+                     double scale, const PosteriorOverride* ov = nullptr) {
   if (!c || !xq) return fail(c, HBO_ERR_ARG, "posterior: null argument");
   if (M <= 0) return HBO_OK;
   HIPCHK(c, hipSetDevice(c->device));
-  prof_begin(c);
-  int rc = upload_model(c, m);
+  if (!ov) prof_begin(c);
+  int rc = ov ? validate_model(c, m) : upload_model(c, m);
   if (rc) return rc;
+  const ModelDev* const md = ov ? ov->md : c->d_model;
+  void* const* const mw = ov ? ov->mlp_w : c->d_mlp_w;
+  void* const* const mb = ov ? ov->mlp_b : c->d_mlp_b;
   const int dtype = m->dtype;
   if (k && (k->dtype != dtype || k->D != m->input_dim)) return fail(c, HBO_ERR_ARG, "posterior: cache/model mismatch");
   const size_t es = esize(dtype);
@@ -210,7 +219,9 @@ static int posterior(hbo_ctx* c, const hbo_model* m, hbo_cache* k, const void* x
   const int nbuf = (!full_cov && M > CH) ? 2 : 1;
   const int mpad_max = round_up(mc_max, HBO_TILE);
   const int64_t ldq_max = padded_ld(mpad_max, dtype);
-  hipStream_t sa = c->stream, sb = nbuf == 2 ? c->stream2 : c->stream;
+  const int lane = (ov && nbuf == 1) ? ov->lane : 0;
+  const int wso = 4096 * lane;   // workspace slots of this lane
+  hipStream_t sa = lane == 1 ? c->stream2 : (lane == 2 ? c->stream4 : c->stream), sb = nbuf == 2 ? c->stream2 : sa;
   char *d_xq = nullptr, *d_mu0 = nullptr, *d_kd = nullptr, *d_K = nullptr, *d_colsq = nullptr, *d_mupart = nullptr;
   void *d_mu = nullptr, *d_var = nullptr, *d_acq = nullptr, *d_V = nullptr, *d_Kqq = nullptr, *d_cov = nullptr;
   char* fq_acts[HBO_MAX_MLP_LAYERS] = {nullptr};
@@ -221,31 +232,35 @@ static int posterior(hbo_ctx* c, const hbo_model* m, hbo_cache* k, const void* x
   // the queries go up in ONE copy (M x D elements: small beside the N x CH workspace): a pageable host-to-device copy
   // inside the chunk loop waits for the products in flight on the other stream -- it serialised the two streams and
   // took cfg 3 from 142 to 197 ms
-  { d_xq = (char*)ws_get(c, WS_XQ, (size_t)M * m->input_dim * es); if (!d_xq) return HBO_ERR_HIP; }
-  HIPCHK_P(hipMemcpyAsync(d_xq, xq, (size_t)M * m->input_dim * es, hipMemcpyHostToDevice, sa));
-  { d_mu0 = (char*)ws_get(c, WS_MU0, vec_b * nbuf); if (!d_mu0) return HBO_ERR_HIP; }
-  { d_kd = (char*)ws_get(c, WS_KD, vec_b * nbuf); if (!d_kd) return HBO_ERR_HIP; }
-  { d_mu = ws_get(c, WS_MU, (size_t)M * es); if (!d_mu) return HBO_ERR_HIP; }
-  { d_var = ws_get(c, WS_VAR, (size_t)M * es); if (!d_var) return HBO_ERR_HIP; }
-  if (acq_out) { d_acq = ws_get(c, WS_ACQ, (size_t)M * es); if (!d_acq) return HBO_ERR_HIP; }
+  if (ov) d_xq = (char*)const_cast<void*>(ov->xq_dev);
+  else {
+    d_xq = (char*)ws_get(c, WS_XQ, (size_t)M * m->input_dim * es); if (!d_xq) return HBO_ERR_HIP;
+    HIPCHK_P(hipMemcpyAsync(d_xq, xq, (size_t)M * m->input_dim * es, hipMemcpyHostToDevice, sa));
+  }
+  { d_mu0 = (char*)ws_get(c, WS_MU0 + wso, vec_b * nbuf); if (!d_mu0) return HBO_ERR_HIP; }
+  { d_kd = (char*)ws_get(c, WS_KD + wso, vec_b * nbuf); if (!d_kd) return HBO_ERR_HIP; }
+  { d_mu = ws_get(c, WS_MU + wso, (size_t)M * es); if (!d_mu) return HBO_ERR_HIP; }
+  { d_var = ws_get(c, WS_VAR + wso, (size_t)M * es); if (!d_var) return HBO_ERR_HIP; }
+  if (ov) d_acq = ov->acq_dev;
+  else if (acq_out) { d_acq = ws_get(c, WS_ACQ + wso, (size_t)M * es); if (!d_acq) return HBO_ERR_HIP; }
   if (needs_mlp(m)) for (int l = 0; l < m->n_layers; ++l) {
     fq_stride[l] = al((size_t)mc_max * m->features[l] * es);
-    fq_acts[l] = (char*)ws_get(c, WS_FQ0 + l, fq_stride[l] * nbuf); if (!fq_acts[l]) return HBO_ERR_HIP;
+    fq_acts[l] = (char*)ws_get(c, WS_FQ0 + l + wso, fq_stride[l] * nbuf); if (!fq_acts[l]) return HBO_ERR_HIP;
   }
   TaskHost* t = k ? k->t : nullptr;
   size_t K_b = 0, colsq_b = 0;
   if (k) {
     K_b = al((size_t)t->npad * ldq_max * es); colsq_b = al((size_t)t->nblk * ldq_max * es);
-    { d_K = (char*)ws_get(c, WS_K, K_b * nbuf); if (!d_K) return HBO_ERR_HIP; }
-    { d_colsq = (char*)ws_get(c, WS_COLSQ, colsq_b * nbuf); if (!d_colsq) return HBO_ERR_HIP; }
-    { d_mupart = (char*)ws_get(c, WS_MUPART, colsq_b * nbuf); if (!d_mupart) return HBO_ERR_HIP; }
-    if (full_cov) { d_V = ws_get(c, WS_V, (size_t)t->npad * ldq_max * es); if (!d_V) return HBO_ERR_HIP; }
+    { d_K = (char*)ws_get(c, WS_K + wso, K_b * nbuf); if (!d_K) return HBO_ERR_HIP; }
+    { d_colsq = (char*)ws_get(c, WS_COLSQ + wso, colsq_b * nbuf); if (!d_colsq) return HBO_ERR_HIP; }
+    { d_mupart = (char*)ws_get(c, WS_MUPART + wso, colsq_b * nbuf); if (!d_mupart) return HBO_ERR_HIP; }
+    if (full_cov) { d_V = ws_get(c, WS_V + wso, (size_t)t->npad * ldq_max * es); if (!d_V) return HBO_ERR_HIP; }
   }
   // full covariance: Kqq goes into an mpad x ldq buffer (the candidates' padded leading dimension) and V^T V is subtracted in
   // place by a GEMM (gemm.hip: GEMM_VTV); with no cache (prior branch) the M x M Gram is the answer
   if (full_cov) {
-    if (k) { d_Kqq = ws_get(c, WS_KQQ, (size_t)mpad_max * ldq_max * es); if (!d_Kqq) return HBO_ERR_HIP; }
-    { d_cov = ws_get(c, WS_COV, (size_t)M * M * es); if (!d_cov) return HBO_ERR_HIP; }
+    if (k) { d_Kqq = ws_get(c, WS_KQQ + wso, (size_t)mpad_max * ldq_max * es); if (!d_Kqq) return HBO_ERR_HIP; }
+    { d_cov = ws_get(c, WS_COV + wso, (size_t)M * M * es); if (!d_cov) return HBO_ERR_HIP; }
   }
   // Few candidates (a BO step asks for tens of them): one workgroup per 128-row tile of W would walk a K range of up to N alone
   // (N = 8192, 64 queries: 1.1 ms for 8.6 GFLOP); the K range is cut into chunks of `kchunk` blocks instead, one workgroup per
@@ -253,10 +268,13 @@ static int posterior(hbo_ctx* c, const hbo_model* m, hbo_cache* k, const void* x
   int kchunk = 0;
   void* d_vpart = nullptr;
   // (decided on the TOTAL number of candidates, not on the chunk: every post_chunk then gives the same bits)
-  if (k && !full_cov && t->nblk >= 8 && (int64_t)((M + HBO_TILE - 1) / HBO_TILE) * t->nblk < 2 * c->n_cus) {
+  if (k && !full_cov && t->nblk >= 2 && (int64_t)((M + HBO_TILE - 1) / HBO_TILE) * t->nblk < 2 * c->n_cus) {
     kchunk = std::max(2, std::min(8, t->nblk / 8));   // N = 8100: 1 / 2 / 4 / 8 / 16 blocks per chunk: 0.81 / 0.48 / 0.35 / 0.35 / 0.35 ms; N = 2000: 2 / 4 / 8: 0.11 / 0.11 / 0.17
+    // (below 8 blocks one block per chunk: the lone 128-tile of the last row block of an N = 512 cache ran its K = 512 alone on a
+    //  CU for 75 us -- an HGP acquisition over 32 samples spent half its time there)
+    if (t->nblk < 8) kchunk = 1;
     const int nch_max = (t->nblk + kchunk - 1) / kchunk;
-    d_vpart = ws_get(c, WS_VPART, (size_t)nch_max * t->npad * ldq_max * es);
+    d_vpart = ws_get(c, WS_VPART + wso, (size_t)nch_max * t->npad * ldq_max * es);
     if (!d_vpart) { c->err.clear(); kchunk = 0; }
   }
   // fp32: the product runs on the bf16 matrix cores from exact three-way splits of both operands (post3.hip)
@@ -280,7 +298,7 @@ static int posterior(hbo_ctx* c, const hbo_model* m, hbo_cache* k, const void* x
   }
   if (use3) {
     k3_b = al((size_t)mpad_max * t->npad * 3 * sizeof(unsigned short));   // (mpad / 128) x nkb blocks of 3 x 128 x 16
-    d_K3 = (unsigned short*)ws_get(c, WS_K3, k3_b * nbuf);
+    d_K3 = (unsigned short*)ws_get(c, WS_K3 + wso, k3_b * nbuf);
     if (!d_K3) { c->err.clear(); use3 = false; }
   }
   const bool bad = k && k->info != INT_MAX;
@@ -305,24 +323,24 @@ static int posterior(hbo_ctx* c, const hbo_model* m, hbo_cache* k, const void* x
         void* acts[HBO_MAX_MLP_LAYERS];
         for (int l = 0; l < m->n_layers; ++l) acts[l] = fq_acts[l] + b * fq_stride[l];
         const void* in = xq_d; int fin = m->input_dim;
-        for (int l = 0; l < m->n_layers; ++l) { launch_dense_tanh(dtype, in, c->d_mlp_w[l], c->d_mlp_b[l], acts[l], mc, fin, m->features[l], sb); in = acts[l]; fin = m->features[l]; }
+        for (int l = 0; l < m->n_layers; ++l) { launch_dense_tanh(dtype, in, mw[l], mb[l], acts[l], mc, fin, m->features[l], sb); in = acts[l]; fin = m->features[l]; }
         fq_last = acts[m->n_layers - 1];
       } }
     const void* Fq = m->kernel_uses_mlp ? fq_last : xq_d;
     const void* Fmq = (m->mean_id == HBO_MEAN_LINEAR) ? (const void*)xq_d : (m->mean_id == HBO_MEAN_LINEAR_MLP ? fq_last : nullptr);
-    launch_mean(dtype, Fmq, mc, fm, c->d_model, mu0_d, sb);
-    launch_kdiag(dtype, Fq, mc, fdim, c->d_model, kd_d, sb);
+    launch_mean(dtype, Fmq, mc, fm, md, mu0_d, sb);
+    launch_kdiag(dtype, Fq, mc, fdim, md, kd_d, sb);
     void* mu_d = (char*)d_mu + (size_t)q0 * es; void* var_d = (char*)d_var + (size_t)q0 * es;
     void* acq_d = d_acq ? (char*)d_acq + (size_t)q0 * es : nullptr;
     if (!k) {  // prior branch (gp.py:275-282)
       HIPCHK_P(hipMemcpyAsync(mu_d, mu0_d, (size_t)mc * es, hipMemcpyDeviceToDevice, sb));
       if (full_cov) {
-        GramArgs g = {}; g.kernel_id = c->h_model->kernel_id; g.x1 = Fq; g.x2 = Fq; g.out = d_cov; g.n1 = mc; g.n2 = mc; g.ldo = mc; g.fdim = fdim;
-        launch_gram(dtype, g, c->d_model, dim3((unsigned)((mc + 127) / 128), (unsigned)((mc + 127) / 128), 1), sb);
+        GramArgs g = {}; g.kernel_id = m->kernel_id; g.x1 = Fq; g.x2 = Fq; g.out = d_cov; g.n1 = mc; g.n2 = mc; g.ldo = mc; g.fdim = fdim;
+        launch_gram(dtype, g, md, dim3((unsigned)((mc + 127) / 128), (unsigned)((mc + 127) / 128), 1), sb);
       } else {
         HIPCHK_P(hipMemcpyAsync(var_d, kd_d, (size_t)mc * es, hipMemcpyDeviceToDevice, sb));
       }
-      if (acq_out) {   // acquisition on the prior
+      if (d_acq) {   // acquisition on the prior
         PostArgs pa = {}; pa.Kxq = nullptr; pa.n = 0; pa.nblk = 0; pa.ldq = ldq; pa.alpha = nullptr; pa.colsq = nullptr;
         pa.kdiag = kd_d; pa.muq = mu0_d; pa.acq_out = acq_d; pa.M = mc; pa.acq_id = acq_id; pa.param = param; pa.add_noise = add_noise; pa.scale = scale;
         launch_post_epilogue(dtype, pa, sb);
@@ -332,9 +350,9 @@ static int posterior(hbo_ctx* c, const hbo_model* m, hbo_cache* k, const void* x
     }
     char* K_d = d_K + b * K_b; char* colsq_d = d_colsq + b * colsq_b;
     { ProfScope ps(c, "cross_gram", 1, sb);
-      GramArgs g = {}; g.kernel_id = c->h_model->kernel_id; g.x1 = k->h_desc.F; g.x2 = Fq; g.out = K_d; g.n1 = t->n; g.n2 = mc; g.ldo = ldq;
+      GramArgs g = {}; g.kernel_id = m->kernel_id; g.x1 = k->h_desc.F; g.x2 = Fq; g.out = K_d; g.n1 = t->n; g.n2 = mc; g.ldo = ldq;
       g.n1pad = t->npad; g.n2pad = mpad; g.fdim = fdim; g.symmetric = 0; g.padded = 1;
-      launch_gram(dtype, g, c->d_model, dim3(mpad / HBO_TILE, t->nblk, 1), sb); }
+      launch_gram(dtype, g, md, dim3(mpad / HBO_TILE, t->nblk, 1), sb); }
     unsigned short* K3_d = use3 ? d_K3 + (size_t)b * (k3_b / sizeof(unsigned short)) : nullptr;
     if (use3) {
       ProfScope ps(c, "split_kxq", 1, sb);
@@ -367,8 +385,8 @@ static int posterior(hbo_ctx* c, const hbo_model* m, hbo_cache* k, const void* x
     if (nbuf == 2) { ev_free[b] = pool_event(c, evi++); hipEventRecord(ev_free[b], sa); }
     if (full_cov) {
       ProfScope ps(c, "full_cov", 1, sa);
-      GramArgs g = {}; g.kernel_id = c->h_model->kernel_id; g.x1 = Fq; g.x2 = Fq; g.out = d_Kqq; g.n1 = mc; g.n2 = mc; g.ldo = ldq; g.fdim = fdim;
-      launch_gram(dtype, g, c->d_model, dim3((unsigned)((mc + 127) / 128), (unsigned)((mc + 127) / 128), 1), sa);
+      GramArgs g = {}; g.kernel_id = m->kernel_id; g.x1 = Fq; g.x2 = Fq; g.out = d_Kqq; g.n1 = mc; g.n2 = mc; g.ldo = ldq; g.fdim = fdim;
+      launch_gram(dtype, g, md, dim3((unsigned)((mc + 127) / 128), (unsigned)((mc + 127) / 128), 1), sa);
       // (columns of V beyond the candidates are zero: Kxq is zero-padded; the padded part of the Kqq buffer is never copied out)
       GemmArgs a = {}; a.tasks = k->d_desc; a.mode = GEMM_VTV; a.B = d_V; a.ldb = ldq; a.V = d_Kqq;
       launch_gemm(dtype, a, dim3(mpad / HBO_TILE, mpad / HBO_TILE, 1), sa);
@@ -377,6 +395,7 @@ static int posterior(hbo_ctx* c, const hbo_model* m, hbo_cache* k, const void* x
   if (nbuf == 2) {   // join: everything the side stream produced (the prior branch runs there entirely)
     hipEvent_t e = pool_event(c, evi++); hipEventRecord(e, sb); hipStreamWaitEvent(sa, e, 0);
   }
+  if (ov) return (k && k->info != INT_MAX) ? HBO_NOT_PD : HBO_OK;   // (the caller copies back and waits once for all samples)
   if (mu_out) HIPCHK_P(hipMemcpyAsync(mu_out, d_mu, (size_t)M * es, hipMemcpyDeviceToHost, sa));
   if (var_out) {
     // (dense on the device first: a pitched copy to pageable host memory goes row by row)
@@ -408,6 +427,147 @@ extern "C" int hbo_acq(hbo_ctx* c, const hbo_model* m, hbo_cache* k, const void*
   if (acq_id < 0 || acq_id > HBO_ACQ_UCB) return fail(c, HBO_ERR_ARG, "hbo_acq: bad acq_id");
   if (!out) return fail(c, HBO_ERR_ARG, "hbo_acq: out is null");
   return posterior(c, m, k, xq, M, 0, nullptr, nullptr, out, acq_id, param, add_noise, scale);
+}
+
+// ---- S hyper-parameter samples of one model family as ONE batch ------------------------------------------------------------
+// hyperbo/bo_utils/acfun.py:72-82 evaluates an acquisition function on an HGP by looping `predict` over the model-parameter
+// samples (gp.py:666-682: every sample re-factorises the same observations under its own hyper-parameters); with jax that loop is
+// what one would `vmap`.  Here the S Gram matrices are built and factorised as one batch of S tasks -- the kernels that depend on
+// the model read one ModelDev per task (GramArgs::model_stride, launch_aug_rows) -- the inverses and alpha = K^-1 (y - mu)
+// likewise, and the S posteriors + acquisition epilogues then queue up on the stream without a host round trip between them:
+// one upload, one copy back, one wait.  out: [S, M] acquisition values (model dtype), row s = sample s.
+extern "C" int hbo_acq_samples(hbo_ctx* c, const hbo_model* models, int32_t S, const void* x, int64_t n, const void* y, int32_t mcols,
+                               const void* xq, int64_t M, int acq_id, const double* params, const double* add_noise, double scale,
+                               void* out) {
+  if (!c || !models || !x || !y || !xq || !out || !params || !add_noise) return fail(c, HBO_ERR_ARG, "hbo_acq_samples: null argument");
+  if (S <= 0 || S > 4096) return fail(c, HBO_ERR_ARG, "hbo_acq_samples: 1 <= S <= 4096");
+  if (n <= 0 || mcols <= 0 || mcols > HBO_TILE) return fail(c, HBO_ERR_ARG, "hbo_acq_samples: need n>0 and 1<=m<=128");
+  if (acq_id < 0 || acq_id > HBO_ACQ_UCB) return fail(c, HBO_ERR_ARG, "hbo_acq_samples: bad acq_id");
+  if (M <= 0) return HBO_OK;
+  HIPCHK(c, hipSetDevice(c->device));
+  const hbo_model* m0 = &models[0];
+  for (int s = 0; s < S; ++s) {
+    const hbo_model* m = &models[s];
+    int rc = validate_model(c, m);
+    if (rc) return rc;
+    bool same = m->dtype == m0->dtype && m->kernel_id == m0->kernel_id && m->mean_id == m0->mean_id && m->input_dim == m0->input_dim &&
+                m->kernel_uses_mlp == m0->kernel_uses_mlp && m->n_lengthscale == m0->n_lengthscale && needs_mlp(m) == needs_mlp(m0);
+    if (same && needs_mlp(m0)) { same = m->n_layers == m0->n_layers; for (int l = 0; same && l < m0->n_layers; ++l) same = m->features[l] == m0->features[l]; }
+    if (!same) return fail(c, HBO_ERR_ARG, "hbo_acq_samples: the samples must share dtype, covariance, mean and MLP architecture");
+  }
+  prof_begin(c);
+  const int dtype = m0->dtype;
+  const size_t es = esize(dtype);
+  hipStream_t st = c->stream;
+  const int D = m0->input_dim;
+  const bool mlp = needs_mlp(m0);
+  const int L = mlp ? m0->n_layers : 0;
+  std::vector<hbo_cache*> ks(S, nullptr);
+  auto cleanup = [&]() { for (hbo_cache* k : ks) if (k) hbo_cache_free(c, k); };
+#define HIPCHK_S(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) { c->err = std::string(#call " failed: ") + hipGetErrorString(e__); cleanup(); return HBO_ERR_HIP; } } while (0)
+#define RCCHK_S(call) do { int rc__ = (call); if (rc__) { cleanup(); return rc__; } } while (0)
+  // ---- the S models, their MLP weights, the queries: device copies that live for the whole call
+  ModelDev* d_models = static_cast<ModelDev*>(ws_get(c, WS_SMP_MODELS, sizeof(ModelDev) * S));
+  TaskDesc* d_batch = static_cast<TaskDesc*>(ws_get(c, WS_SMP_DESC, sizeof(TaskDesc) * S));
+  int* d_infos = static_cast<int*>(ws_get(c, WS_SMP_INFO, sizeof(int) * S));
+  char* d_acq = static_cast<char*>(ws_get(c, WS_SMP_ACQ, (size_t)S * M * es));
+  char* d_xq = static_cast<char*>(ws_get(c, WS_SMP_XQ, (size_t)M * D * es));
+  if (!d_models || !d_batch || !d_infos || !d_acq || !d_xq) return HBO_ERR_HIP;
+  std::vector<ModelDev> h_models(S);
+  for (int s = 0; s < S; ++s) fill_model_dev(h_models[s], &models[s]);
+  HIPCHK_S(hipMemcpyAsync(d_models, h_models.data(), sizeof(ModelDev) * S, hipMemcpyHostToDevice, st));
+  HIPCHK_S(hipMemcpyAsync(d_xq, xq, (size_t)M * D * es, hipMemcpyHostToDevice, st));
+  std::vector<void*> w_dev((size_t)S * HBO_MAX_MLP_LAYERS, nullptr), b_dev((size_t)S * HBO_MAX_MLP_LAYERS, nullptr);
+  if (mlp) {
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    size_t per = 0; int fin = D;
+    for (int l = 0; l < L; ++l) { per += al((size_t)fin * m0->features[l] * es) + al((size_t)m0->features[l] * es); fin = m0->features[l]; }
+    char* blk = static_cast<char*>(ws_get(c, WS_SMP_MLP, per * S));
+    if (!blk) return HBO_ERR_HIP;
+    for (int s = 0; s < S; ++s) {
+      char* p = blk + per * s; fin = D;
+      for (int l = 0; l < L; ++l) {
+        const size_t wb = (size_t)fin * m0->features[l] * es, bb = (size_t)m0->features[l] * es;
+        w_dev[(size_t)s * HBO_MAX_MLP_LAYERS + l] = p; HIPCHK_S(hipMemcpyAsync(p, models[s].mlp_kernel[l], wb, hipMemcpyHostToDevice, st)); p += al(wb);
+        b_dev[(size_t)s * HBO_MAX_MLP_LAYERS + l] = p; HIPCHK_S(hipMemcpyAsync(p, models[s].mlp_bias[l], bb, hipMemcpyHostToDevice, st)); p += al(bb);
+        fin = m0->features[l];
+      }
+    }
+  }
+  // ---- S caches over the same observations (each a complete hbo_cache: everything that reads one works on them)
+  const int npad = round_up(n, HBO_TILE), nblk = npad / HBO_TILE;
+  std::vector<unsigned char> yt((size_t)n * mcols * es);
+  for (int64_t i = 0; i < n; ++i)
+    for (int a = 0; a < mcols; ++a) memcpy(yt.data() + ((size_t)a * n + i) * es, (const unsigned char*)y + ((size_t)i * mcols + a) * es, es);
+  std::vector<TaskDesc> h_batch(S);
+  for (int s = 0; s < S; ++s) {
+    hbo_cache* k = ks[s] = new hbo_cache();
+    k->dtype = dtype; k->D = D; k->m = mcols;
+    TaskHost* t = k->t = new TaskHost();
+    t->n = n; t->m = mcols; t->npad = npad; t->nblk = nblk; t->ld = padded_ld(npad, dtype);
+    HIPCHK_S(dev_alloc(c, &t->X, (size_t)npad * D * es));
+    HIPCHK_S(dev_alloc(c, &t->ysum, (size_t)n * mcols * es));
+    if (s == 0) {
+      HIPCHK_S(hipMemcpyAsync(t->X, x, (size_t)n * D * es, hipMemcpyHostToDevice, st));
+      HIPCHK_S(hipMemcpyAsync(t->ysum, yt.data(), (size_t)n * mcols * es, hipMemcpyHostToDevice, st));
+    } else {
+      HIPCHK_S(hipMemcpyAsync(t->X, ks[0]->t->X, (size_t)n * D * es, hipMemcpyDeviceToDevice, st));
+      HIPCHK_S(hipMemcpyAsync(t->ysum, ks[0]->t->ysum, (size_t)n * mcols * es, hipMemcpyDeviceToDevice, st));
+    }
+    RCCHK_S(ensure_task_workspace(c, dtype, t, true, mcols));
+    if (mlp) RCCHK_S(t->feat.ensure(c, m0, npad));
+    fill_desc(k->h_desc, t, &models[s], dtype, ROLE_FACTOR);
+    h_batch[s] = k->h_desc;
+    HIPCHK_S(hbo_malloc(c, (void**)&k->d_desc, sizeof(TaskDesc)));
+    HIPCHK_S(hbo_malloc(c, (void**)&k->d_info, sizeof(int)));
+    HIPCHK_S(hbo_malloc(c, &k->resid, (size_t)mcols * npad * es));
+    HIPCHK_S(hbo_malloc(c, &k->zvec, (size_t)mcols * npad * es));
+    HIPCHK_S(hipMemcpyAsync(k->d_desc, &k->h_desc, sizeof(TaskDesc), hipMemcpyHostToDevice, st));
+  }
+  HIPCHK_S(hipMemcpyAsync(d_batch, h_batch.data(), sizeof(TaskDesc) * S, hipMemcpyHostToDevice, st));
+  HIPCHK_S(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(d_infos), INT_MAX, S, st));
+  // ---- one batched pipeline: features (per sample: its own weights), residual rows, Gram, factorisation, inverse, alpha
+  { ProfScope ps(c, "features", 1);
+    if (mlp) for (int s = 0; s < S; ++s) run_mlp(c, m0, ks[s]->t->X, n, ks[s]->t->feat.acts.data(), &w_dev[(size_t)s * HBO_MAX_MLP_LAYERS], &b_dev[(size_t)s * HBO_MAX_MLP_LAYERS]);
+    launch_aug_rows(dtype, d_batch, S, npad, d_models, st, 1); }
+  { ProfScope ps(c, "gram", 1);
+    GramArgs g = {}; g.kernel_id = m0->kernel_id; g.tasks = d_batch; g.fdim = feature_dim(m0); g.symmetric = 1; g.padded = 1; g.model_stride = 1;
+    launch_gram(dtype, g, d_models, dim3(nblk, nblk, S), st); }
+  TrtriProgress trtri_pg;
+  const bool early_trtri = use_lookahead(c, S, nblk) && c->opt_overlap_trtri && nblk >= 4;
+  c->trtri_host_task = S == 1 ? h_batch[0] : TaskDesc{};
+  { ProfScope ps(c, "potrf", 1); run_potrf(c, dtype, d_batch, S, nblk, d_infos, early_trtri ? &trtri_pg : nullptr); }
+  { ProfScope ps(c, "trtri", 1); run_trtri(c, dtype, d_batch, S, nblk, &trtri_pg); }
+  { ProfScope ps(c, "wt_z", 1);
+    for (int a = 0; a < mcols; ++a) launch_wt_z(dtype, d_batch, S, nblk, a, a, npad, st); }
+  std::vector<int> h_infos(S, INT_MAX);
+  HIPCHK_S(hipMemcpyAsync(h_infos.data(), d_infos, sizeof(int) * S, hipMemcpyDeviceToHost, st));
+  HIPCHK_S(hipStreamSynchronize(st));   // (the samples' info words decide NaN rows below; the caller's x / y / weights have been consumed)
+  // ---- S posteriors + acquisition epilogues: three independent launch chains (main stream + the two side streams, each with its
+  //      own workspaces) -- a pass is ~7 latency-bound launches of 10-20 us, and the passes of different samples share nothing
+  const int lanes = (M <= std::max<int64_t>(c->opt_post_chunk, HBO_TILE)) ? 3 : 1;
+  hipStream_t lane_stream[3] = {st, c->stream2, c->stream4};
+  if (lanes > 1) { hipEvent_t e = pool_event(c, 0); hipEventRecord(e, st); hipStreamWaitEvent(c->stream2, e, 0); hipStreamWaitEvent(c->stream4, e, 0); }
+  bool any_bad = false;
+  for (int s = 0; s < S; ++s) {
+    ks[s]->info = h_infos[s];
+    PosteriorOverride ov = {d_models + s, mlp ? &w_dev[(size_t)s * HBO_MAX_MLP_LAYERS] : nullptr, mlp ? &b_dev[(size_t)s * HBO_MAX_MLP_LAYERS] : nullptr, d_xq,
+                            d_acq + (size_t)s * M * es, lanes > 1 ? s % lanes : 0};
+    int rc = posterior(c, &models[s], ks[s], xq, M, 0, nullptr, nullptr, out, acq_id, params[s], add_noise[s], scale, &ov);
+    if (rc == HBO_NOT_PD) any_bad = true;
+    else if (rc) { for (hipStream_t q : lane_stream) hipStreamSynchronize(q); cleanup(); return rc; }
+  }
+  for (int l = 1; l < lanes; ++l) { hipEvent_t e = pool_event(c, (size_t)l); hipEventRecord(e, lane_stream[l]); hipStreamWaitEvent(st, e, 0); }
+  HIPCHK_S(hipMemcpyAsync(out, d_acq, (size_t)S * M * es, hipMemcpyDeviceToHost, st));
+  HIPCHK_S(hipStreamSynchronize(st));
+  HIPCHK_S(hipStreamSynchronize(c->stream2));
+  HIPCHK_S(hipGetLastError());
+  prof_collect(c);
+  for (int s = 0; s < S; ++s) if (h_infos[s] != INT_MAX) fill_nan((char*)out + (size_t)s * M * es, (size_t)M, dtype);
+  cleanup();
+#undef HIPCHK_S
+#undef RCCHK_S
+  return any_bad ? HBO_NOT_PD : HBO_OK;
 }
 
 // ---- d acquisition / d x_query: what jaxopt's L-BFGS-B differentiates in bayesopt() (bayesopt.py:116-125) ----

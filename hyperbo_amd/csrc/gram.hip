@@ -24,6 +24,7 @@ __global__ __launch_bounds__(256) void gram_kernel(GramArgs g, const ModelDev* _
   const T* x1; const T* x2; T* out; int64_t n1, n2, ldo; int64_t e1, e2;  // e*: padded extents
   if (g.tasks) {
     const TaskDesc& t = g.tasks[blockIdx.z];
+    md += (int64_t)blockIdx.z * g.model_stride;
     if ((int64_t)ti * GTR >= t.npad || tj >= t.nblk) return;
     x1 = x2 = static_cast<const T*>(t.F);
     out = static_cast<T*>(t.A);
@@ -179,8 +180,9 @@ __global__ void mean_kernel(const T* __restrict__ fm, int64_t n, int fmean, cons
 
 // augmented tile-row: row b < naug holds  aug_src[b*n + j] + e_b * mu_j  (see TaskDesc); everything else zero.
 template <typename T>
-__global__ void aug_rows_kernel(const TaskDesc* tasks, const ModelDev* __restrict__ md) {
+__global__ void aug_rows_kernel(const TaskDesc* tasks, const ModelDev* __restrict__ md, int model_stride) {
   const TaskDesc& t = tasks[blockIdx.z];
+  md += (int64_t)blockIdx.z * model_stride;
   const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= t.npad) return;
   T* Ar = static_cast<T*>(t.A) + (int64_t)t.npad * t.ld + j;
@@ -361,10 +363,10 @@ void launch_mean(int dtype, const void* fm, int64_t n, int fmean, const ModelDev
   if (dtype == HBO_F64) hipLaunchKernelGGL((mean_kernel<double>), grid, dim3(256), 0, st, (const double*)fm, n, fmean, md, (double*)mu);
   else hipLaunchKernelGGL((mean_kernel<float>), grid, dim3(256), 0, st, (const float*)fm, n, fmean, md, (float*)mu);
 }
-void launch_aug_rows(int dtype, const TaskDesc* tasks, int ntasks, int max_npad, const ModelDev* md, hipStream_t st) {
+void launch_aug_rows(int dtype, const TaskDesc* tasks, int ntasks, int max_npad, const ModelDev* md, hipStream_t st, int model_stride) {
   dim3 grid((max_npad + 255) / 256, 1, ntasks);
-  if (dtype == HBO_F64) hipLaunchKernelGGL((aug_rows_kernel<double>), grid, dim3(256), 0, st, tasks, md);
-  else hipLaunchKernelGGL((aug_rows_kernel<float>), grid, dim3(256), 0, st, tasks, md);
+  if (dtype == HBO_F64) hipLaunchKernelGGL((aug_rows_kernel<double>), grid, dim3(256), 0, st, tasks, md, model_stride);
+  else hipLaunchKernelGGL((aug_rows_kernel<float>), grid, dim3(256), 0, st, tasks, md, model_stride);
 }
 void launch_nll_reduce(int dtype, const TaskDesc* tasks, int ntasks, const int* info, double* out, hipStream_t st) {
   if (dtype == HBO_F64) hipLaunchKernelGGL((nll_reduce_kernel<double>), dim3(ntasks), dim3(256), 0, st, tasks, info, out);

@@ -161,6 +161,8 @@ struct GramArgs {
   int symmetric;           // lower tiles only + (noise+eps) on the diagonal + identity padding
   int padded;              // out has a padded ld/extent (16-byte vector stores, zero fill)
   int kernel_id;           // covariance of the model behind the ModelDev pointer (selects the kernel instantiation)
+  int model_stride;        // batched mode: task z reads the model at md + z * model_stride (0: one model for the batch; 1: one
+                           // ModelDev per task -- S hyper-parameter samples of one model family factorised as one batch)
 };
 void launch_gram(int dtype, const GramArgs& a, const ModelDev* model, dim3 grid, hipStream_t st);
 void launch_kdiag(int dtype, const void* f, int64_t n, int fdim, const ModelDev* model, void* out,
@@ -169,7 +171,7 @@ void launch_dense_tanh(int dtype, const void* in, const void* w, const void* b, 
                        int fin, int fout, hipStream_t st);
 void launch_mean(int dtype, const void* fm, int64_t n, int fmean, const ModelDev* model, void* mu,
                  hipStream_t st);
-void launch_aug_rows(int dtype, const TaskDesc* tasks, int ntasks, int max_npad, const ModelDev* md, hipStream_t st);
+void launch_aug_rows(int dtype, const TaskDesc* tasks, int ntasks, int max_npad, const ModelDev* md, hipStream_t st, int model_stride = 0);
 void launch_nll_reduce(int dtype, const TaskDesc* tasks, int ntasks, const int* info, double* out,
                        hipStream_t st);
 // s = W^T z_a (z_a = augmented row a of A) -> tasks[t].svec[out_col*out_ld + j]; uses wscr as scratch

@@ -172,6 +172,16 @@ int hbo_predict(hbo_ctx* ctx, const hbo_model* model, hbo_cache* cache, const vo
 int hbo_acq(hbo_ctx* ctx, const hbo_model* model, hbo_cache* cache, const void* xq, int64_t M,
             int acq_id, double param, double add_noise, double scale, void* out);
 
+/* ---- S hyper-parameter samples of ONE model family as one batch: what acquisition functions do on an HGP
+ *      (hyperbo/bo_utils/acfun.py:72-82 loops model.predict over model.params.samples, gp.py:666-682; the jax counterpart is a
+ *      vmap over the draws).  models[s]: sample s (same dtype, covariance, mean and MLP architecture for all); x [n,D], y [n,m]
+ *      the observations every sample conditions on; the S Gram matrices are built, factorised and inverted as ONE batch, the S
+ *      posteriors + acquisition epilogues queue up on the device; out [S,M] (model dtype), row s = hbo_acq of sample s with
+ *      params[s] / add_noise[s] (the caller averages: acfun.py:82).  Rows of samples whose Gram matrix is not PD are NaN
+ *      (HBO_NOT_PD). */
+int hbo_acq_samples(hbo_ctx* ctx, const hbo_model* models, int32_t S, const void* x, int64_t n, const void* y, int32_t m,
+                    const void* xq, int64_t M, int acq_id, const double* params, const double* add_noise, double scale, void* out);
+
 /* ---- d acquisition / d x_query: the gradient jaxopt.ScipyBoundedMinimize(L-BFGS-B) takes of
  *      f(x) = -ac_func(model, key, x[None]) in bayesopt() (hyperbo/bo_utils/bayesopt.py:116-125).
  *      Queries are independent rows: out [M,1] (model dtype) as hbo_acq, grad_out [M, input_dim] doubles.

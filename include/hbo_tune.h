@@ -11,7 +11,13 @@
  *   post_bf16x3 / syrk_bf16x3 / trtri_bf16x3 / lauum_bf16x3  0/1   the four parts of option bf16x3 separately
  *   trtri3_min_s  >=1      lowest level (in blocks) of the inverse that runs on the bf16 cores
  *   syrk3_col / syrk3_sep / syrk3_free       fp32 trailing updates: column updates on the bf16 cores too / panels split by
- *                          their own kernel instead of inside the panel solve / CUs the bulk update leaves with one workgroup */
+ *                          their own kernel instead of inside the panel solve / CUs the bulk update leaves with one workgroup
+ *   sweep         0..2     one-sweep inverse (W = L^-1 and K^-1 = W^T W row group by row group behind the panel chain): 0 never,
+ *                          1 batches with look-ahead (default; profiles/r04_chain_and_sweep.md), 2 wherever look-ahead is on
+ *   sweep_qs      0..16    its row-group size in 128-blocks, a power of two (0 = auto: 4)
+ *   sweep_big     >=0      sweep launches of small / batched shapes with at least this many 128-tiles (x tasks) use 128-tiles (4000)
+ *   batch_bg      0..2     batches: the sweep's launches beside the chain as plain grids (0, default), persistent over tiles x tasks
+ *                          from one counter (1), and also polling the per-CU yield table the chain's kernels then fill (2) */
 #ifndef HBO_TUNE_H_
 #define HBO_TUNE_H_
 #include "hbo.h"
@@ -19,6 +25,9 @@
 extern "C" {
 #endif
 int hbo_tune(hbo_ctx* ctx, const char* name, int64_t value);
+/* sustained fp64 MFMA rate of the device, measured now by ~ms milliseconds of back-to-back v_mfma_f64_16x16x4_f64 on every SIMD
+ * (TFLOP/s): the roofline denominator bench.py reports beside the datasheet figure */
+int hbo_mfma_peak_probe(hbo_ctx* ctx, double ms, double* tflops_out);
 #ifdef __cplusplus
 }
 #endif

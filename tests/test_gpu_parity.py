@@ -946,6 +946,68 @@ def test_hgp_acquisition_is_mean_over_parameter_samples(gpu_ctx):
   assert np.isfinite(st[0]) and set(st[4]) == {0, 1}
 
 
+@pytest.mark.parametrize('kname,mlp,mname,n', [('squared_exponential', False, 'constant', 300), ('matern52', True, 'linear_mlp', 260),
+                                                 ('matern32', False, 'linear', 129), ('dot_product', True, 'zero', 70)])
+def test_hgp_samples_as_one_batch_match_the_loop_over_samples(gpu_ctx, kname, mlp, mname, n):
+  """hbo_acq_samples (S parameter samples factorised as one batch, one ModelDev and one set of MLP weights per task) against
+  (a) the same acquisition evaluated sample by sample on plain GPs and (b) the oracle's mean over samples (acfun.py:72-82)."""
+  defs, _, acfun, gp, kernel, mean, _, utils = _native()
+  rng = np.random.default_rng(31)
+  d = 3
+  S = 5
+  samples = [helpers.make_model(np.random.default_rng(200 + i), mname, mlp, d) for i in range(S)]
+  x, y = helpers.synthetic_task(rng, n, d)
+  x2, y2 = helpers.synthetic_task(rng, 40, d)
+  xq = rng.uniform(size=(53, d))
+  cfg = {'mlp_features': helpers.MLP_FEATURES}
+  cov_n = getattr(kernel, kname + ('_mlp' if mlp else '')); cov_o = getattr(o, kname + ('_mlp' if mlp else ''))
+  dsn = {0: defs.SubDataset(x, y), 1: defs.SubDataset(x2, y2)}
+  dso = {0: o.SubDataset(x, y), 1: o.SubDataset(x2, y2)}
+  hgp = gp.HGP(dsn, getattr(mean, mname), cov_n, defs.GPParams(model=samples[0], samples=samples, config=dict(cfg)), utils.DEFAULT_WARP_FUNC)
+  target = float(np.max(y))
+  for fn, acq_id, sub, prm in ((acfun.expected_improvement, 0, o.expected_improvement_sub, target), (acfun.ucb, 2, o.ucb_sub, 3.0)):
+    per_sample = acfun.hgp_sample_values(hgp, 0, xq, acq_id, prm)
+    assert per_sample.shape == (S, 53, 1)
+    loop, refs = [], []
+    for smp in samples:
+      plain = gp.GP(dsn, getattr(mean, mname), cov_n, defs.GPParams(model=smp, config=dict(cfg)), utils.DEFAULT_WARP_FUNC)
+      loop.append(fn(model=plain, sub_dataset_key=0, x_queries=xq))
+      po = o.GPParams(model=smp, config=dict(cfg))
+      mu, var = o.predict(getattr(o, mname), cov_o, po, x, y, xq, WFO)
+      mu, var = o.gp_predict_postprocess(po, dso, mu, var, WFO, False, True, True)
+      refs.append(sub(mu, np.sqrt(var), prm))
+    np.testing.assert_allclose(per_sample, np.asarray(loop), rtol=1e-9, atol=1e-11)
+    got = fn(model=hgp, sub_dataset_key=0, x_queries=xq)
+    assert got.shape == (53, 1) and helpers.rel_err(got, np.mean(refs, axis=0)) < 1e-7
+
+
+def test_hgp_samples_batch_fp32_and_a_sample_that_is_not_positive_definite(gpu_ctx):
+  defs, _, acfun, gp, kernel, mean, _, utils = _native()
+  rng = np.random.default_rng(32)
+  d, S = 2, 4
+  samples = [helpers.make_model(np.random.default_rng(300 + i), 'constant', False, d, dtype=np.float32) for i in range(S)]
+  x, y = helpers.synthetic_task(rng, 150, d)
+  x32, y32 = x.astype(np.float32), y.astype(np.float32)
+  xq = rng.uniform(size=(20, d)).astype(np.float32)
+  hgp = gp.HGP({0: defs.SubDataset(x32, y32)}, mean.constant, kernel.squared_exponential, defs.GPParams(model=samples[0], samples=samples), utils.DEFAULT_WARP_FUNC)
+  vals = acfun.hgp_sample_values(hgp, 0, xq, 2, 3.0)
+  assert vals.dtype == np.float32 and np.all(np.isfinite(vals))
+  for s_, smp in enumerate(samples):
+    po = o.GPParams(model={k_: np.asarray(v_, dtype=np.float64) for k_, v_ in smp.items()})
+    mu, var = o.predict(o.constant, o.squared_exponential, po, x32.astype(np.float64), y32.astype(np.float64), xq.astype(np.float64), WFO)
+    mu, var = o.gp_predict_postprocess(po, {0: o.SubDataset(x, y)}, mu, var, WFO, False, True, True)
+    assert helpers.rel_err(vals[s_], o.ucb_sub(mu, np.sqrt(var), 3.0)) < 5e-3
+  # ONE of the samples has a Gram matrix that is not positive definite (un-warped negative noise): its row is NaN, like the
+  # reference's NaN Cholesky, and the other samples of the batch are untouched
+  bad = [{'dot_prod_sigma': np.array(1.0), 'dot_prod_bias': np.array(0.1), 'noise_variance': np.array(nv)} for nv in (0.1, -1.0, 0.2)]
+  h2 = gp.HGP({0: defs.SubDataset(x, y)}, mean.zero, kernel.dot_product, defs.GPParams(model=bad[0], samples=bad), None)
+  v2 = acfun.hgp_sample_values(h2, 0, xq.astype(np.float64), 2, 3.0)
+  assert np.all(np.isfinite(v2[0])) and np.all(np.isfinite(v2[2]))
+  assert np.all(np.isnan(v2[1]))
+  single = gp.GP({0: defs.SubDataset(x, y)}, mean.zero, kernel.dot_product, defs.GPParams(model=bad[2]), None)
+  np.testing.assert_allclose(v2[2], acfun.ucb(model=single, sub_dataset_key=0, x_queries=xq.astype(np.float64)), rtol=1e-9)
+
+
 def test_empty_task_shard_builds_the_same_model_and_contributes_zeros(gpu_ctx):
   """A rank beyond the task count holds an empty shard (parallel.shard_dataset): it must build the peers' model (ARD
   lengthscale / linear mean / MLP with D > 1) and reach the all-reduce with zeros of the right layout."""

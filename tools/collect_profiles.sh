@@ -1,8 +1,8 @@
 #!/bin/bash
 # Round evidence on the GPU box: bench line, rocprofv3 kernel statistics of the bench / cfg 3 / cfg 4 legs, HBM counters.
-# usage (from the repo root, through gpurun): bash tools/collect_profiles.sh r03     -> gpurun_out/<tag>_*
+# usage (from the repo root, through gpurun): bash tools/collect_profiles.sh r04     -> gpurun_out/<tag>_*
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 OUT=$PWD/gpurun_out
 mkdir -p $OUT
 export TMPDIR=/tmp
