@@ -1586,6 +1586,37 @@ def test_sharded_objective_entry_point_reduces_on_the_device(gpu_ctx):
   assert v1 == v0 and np.array_equal(helpers.flatten(g1), helpers.flatten(g0))
 
 
+def test_sharded_objective_rank_with_a_local_failure_still_reaches_the_collective(gpu_ctx):
+  """A rank whose local part of hbo_objective_sharded fails (here: a model whose dtype does not match its shard) must not leave
+  its peers waiting in the all-reduce: it takes part with NaN in every slot, reports its own error code, and the communicator
+  stays usable for the next evaluation (advisor finding, round 3)."""
+  import ctypes as C
+  defs, _, _, _, kernel, mean, objectives, utils = _native()
+  from hyperbo_amd import _model, _native as nat, parallel
+  rng = np.random.default_rng(78)
+  d = 3
+  model = helpers.make_model(rng, 'constant', False, d)
+  p = defs.GPParams(model=model)
+  full = {i: defs.SubDataset(*helpers.synthetic_task(rng, n, d)) for i, n in enumerate([120, 70])}
+  comm = parallel.RcclComm(gpu_ctx, 0, 1, lambda b: b)
+  try:
+    dev = objectives.DeviceDataset(full)                      # fp64 shard ...
+    bm = _model.BuiltModel(mean.constant, kernel.squared_exponential, defs.GPParams(model={k: np.asarray(v, np.float32) for k, v in model.items()}),
+                           utils.DEFAULT_WARP_FUNC, np.float32, d)   # ... evaluated with an fp32 model
+    val, cnt = C.c_double(0.0), C.c_double(-1.0)
+    g = (C.c_double * bm.layout.total)()
+    rc = nat.lib().hbo_objective_sharded(gpu_ctx.handle, bm.ref(), dev._h, objectives.OBJ_NLL, C.byref(val), C.byref(cnt), g, None)
+    assert rc not in (nat.HBO_OK, nat.HBO_NOT_PD)             # the rank's own error ...
+    assert np.isnan(val.value) and np.isnan(cnt.value) and all(np.isnan(v) for v in g)   # ... and what every rank of the job now sees
+    # the communicator took exactly one collective: the next evaluation is in step again
+    v1, g1 = objectives.nll_value_and_grad(mean.constant, kernel.squared_exponential, p, dev, utils.DEFAULT_WARP_FUNC, comm=comm)
+    v0, g0 = objectives.nll_value_and_grad(mean.constant, kernel.squared_exponential, p, full, utils.DEFAULT_WARP_FUNC)
+    assert v1 == v0 and np.array_equal(helpers.flatten(g1), helpers.flatten(g0))
+    dev.close()
+  finally:
+    comm.close()
+
+
 _RCCL_2RANK = r"""
 import os, sys, json
 import numpy as np
