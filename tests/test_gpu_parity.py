@@ -997,6 +997,14 @@ def test_hgp_samples_batch_fp32_and_a_sample_that_is_not_positive_definite(gpu_c
     mu, var = o.predict(o.constant, o.squared_exponential, po, x32.astype(np.float64), y32.astype(np.float64), xq.astype(np.float64), WFO)
     mu, var = o.gp_predict_postprocess(po, {0: o.SubDataset(x, y)}, mu, var, WFO, False, True, True)
     assert helpers.rel_err(vals[s_], o.ucb_sub(mu, np.sqrt(var), 3.0)) < 5e-3
+  # more candidates than one posterior chunk: the passes run one after the other, streamed in chunks, same values
+  xq_many = rng.uniform(size=(300, d)).astype(np.float32)
+  ref_many = acfun.hgp_sample_values(hgp, 0, xq_many, 2, 3.0)
+  try:
+    gpu_ctx.set_option('post_chunk', 128)
+    np.testing.assert_array_equal(acfun.hgp_sample_values(hgp, 0, xq_many, 2, 3.0), ref_many)
+  finally:
+    gpu_ctx.set_option('post_chunk', 8192)
   # ONE of the samples has a Gram matrix that is not positive definite (un-warped negative noise): its row is NaN, like the
   # reference's NaN Cholesky, and the other samples of the batch are untouched
   bad = [{'dot_prod_sigma': np.array(1.0), 'dot_prod_bias': np.array(0.1), 'noise_variance': np.array(nv)} for nv in (0.1, -1.0, 0.2)]
@@ -1094,6 +1102,54 @@ def test_divergence_value_and_grad_vs_oracle_fp64(gpu_ctx, kind, kname, mlp, mna
     v_dist = objectives.multivariate_normal_divergence(getattr(mean, mname), kn, pn, dsn, utils.DEFAULT_WARP_FUNC,
                                                        distance=utils.euclidean_multivariate_normal)
     assert v_dist == v_only
+
+
+@pytest.mark.parametrize('qs', [0, 1, 2, 8])
+@pytest.mark.parametrize('kname,mlp,mname', [('squared_exponential', False, 'constant'), ('matern52', True, 'linear_mlp'), ('dot_product', False, 'linear'),
+                                             ('matern32', True, 'zero')])
+def test_one_sweep_inverse_across_the_registry_and_objectives(gpu_ctx, kname, mlp, mname, qs):
+  """The one-sweep inverse (sched.hip:sweep_advance -- W = L^-1 and K^-1 = W^T W row group by row group behind the panel chain;
+  default only for batches large enough for look-ahead) forced on for small ragged batches and a single matrix: NLL and EKL value
+  + every gradient leaf (incl. the MLP backward, which reads K^-1 tile by tile), fp64 against the oracle and fp32 against fp64,
+  for every row-group size -- groups cut by the end of a task, tasks shorter than one group, an empty and a one-point task."""
+  defs, _, _, _, kernel, mean, objectives, utils = _native()
+  rng = np.random.default_rng(91)
+  d = 3
+  model = helpers.make_model(rng, mname, mlp, d)
+  po, pn = _pair(model)
+  ko = getattr(o, kname + ('_mlp' if mlp else '')); kn = getattr(kernel, kname + ('_mlp' if mlp else ''))
+  sizes = (700, 130, 1, 515, 0, 1290, 1153)
+  dso = {k: o.SubDataset(*helpers.synthetic_task(rng, n, d)) if n else o.SubDataset(np.zeros((0, d)), np.zeros((0, 1))) for k, n in enumerate(sizes)}
+  dsn = {k: defs.SubDataset(v.x, v.y) for k, v in dso.items()}
+  al_o = {k: o.SubDataset(*helpers.synthetic_task(rng, n, d, m=4), aligned=k) for k, n in enumerate((900, 260, 1100))}
+  al_n = {k: defs.SubDataset(v.x, v.y, v.aligned) for k, v in al_o.items()}
+  try:
+    for k_, v_ in {'lookahead': 2, 'sweep': 2, 'sweep_qs': qs}.items():
+      gpu_ctx.set_option(k_, v_)
+    vo, go = o.nll_value_and_grad(getattr(o, mname), ko, po, dso, WFO)
+    vn, gn = objectives.nll_value_and_grad(getattr(mean, mname), kn, pn, dsn, utils.DEFAULT_WARP_FUNC)
+    assert abs(vn - vo) <= 1e-10 * abs(vo)
+    fo, fn = helpers.flatten(go), helpers.flatten(gn)
+    assert np.max(np.abs(fo - fn)) <= 1e-8 * np.max(np.abs(fo))
+    single = {0: dso[5]}
+    vo1, go1 = o.nll_value_and_grad(getattr(o, mname), ko, po, single, WFO)
+    vn1, gn1 = objectives.nll_value_and_grad(getattr(mean, mname), kn, pn, {0: dsn[5]}, utils.DEFAULT_WARP_FUNC)
+    assert abs(vn1 - vo1) <= 1e-10 * abs(vo1)
+    assert np.max(np.abs(helpers.flatten(go1) - helpers.flatten(gn1))) <= 1e-8 * np.max(np.abs(helpers.flatten(go1)))
+    ve, ge = o.divergence_value_and_grad('ekl', getattr(o, mname), ko, po, al_o, WFO)
+    vne, gne = objectives.ekl.value_and_grad(getattr(mean, mname), kn, pn, al_n, utils.DEFAULT_WARP_FUNC)
+    assert abs(vne - ve) <= 5e-9 * max(abs(ve), 1.0)
+    assert np.max(np.abs(helpers.flatten(ge) - helpers.flatten(gne))) <= 1e-8 * np.max(np.abs(helpers.flatten(ge)))
+    if qs in (0, 2):
+      to32 = lambda t: {k: to32(v) for k, v in t.items()} if isinstance(t, dict) else np.asarray(t, dtype=np.float32)
+      p32 = defs.GPParams(model=to32(model), config={'mlp_features': helpers.MLP_FEATURES})
+      ds32 = {k: defs.SubDataset(v.x.astype(np.float32), v.y.astype(np.float32)) for k, v in dsn.items()}
+      v32, g32 = objectives.nll_value_and_grad(getattr(mean, mname), kn, p32, ds32, utils.DEFAULT_WARP_FUNC)
+      assert abs(v32 - vo) <= 2e-4 * abs(vo)
+      assert np.max(np.abs(helpers.flatten(g32) - fo)) <= 5e-3 * np.max(np.abs(fo))
+  finally:
+    for k_, v_ in {'lookahead': 1, 'sweep': 1, 'sweep_qs': 0}.items():
+      gpu_ctx.set_option(k_, v_)
 
 
 def test_divergence_fp32_and_no_aligned_data(gpu_ctx):
