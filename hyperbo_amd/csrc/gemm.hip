@@ -472,6 +472,259 @@ __device__ __forceinline__ void gemm_tile(const TileJob<T>& job, unsigned char* 
   }
 }
 
+// ---- the pipelined tile core (round 4) ------------------------------------------------------------------------------------------
+// Same tile, same LDS layouts, same arithmetic (every accumulator receives its products in ascending k: bit-identical results) --
+// a different pipeline.  gemm_tile issues the LDS fragment reads of a k step right before the 16 MFMAs that consume them, stores a
+// whole slab to LDS in one run of instructions and keeps two LDS stages per operand; in its K loop a wave has stretches of 40-60
+// instructions without an MFMA, and it reaches 0.80-0.85 of the fp64 MFMA peak where a vendor kernel of the same macro tile
+// (rocBLAS dgemm, 128 x 128 x 16, 256 threads) sustains the peak (profiles/r04_gemm_pipeline.md).  What this core does instead:
+//   * the fragments of k step i + 1 are read (into a second register set) between the first MFMAs of step i;
+//   * ONE LDS stage per operand and two barriers per slab: after the last fragment read of a slab every wave passes a barrier,
+//     the next slab is written from the prefetch registers, a second barrier, then its first fragments are read -- every one of
+//     those instructions between two MFMAs of the slab's last two k steps (18 MFMAs between the barriers, 5 behind the second);
+//   * global prefetch two slabs deep: each LDS write is followed, one MFMA later, by the buffer load that refills its registers
+//     (scalar base that moves with the slab + one 32-bit offset register per load);
+//   * the order is pinned with scheduling barriers: the compiler's own order gathers the LDS and memory instructions again.
+// 36 KB of LDS instead of 72.
+template <typename T>
+__device__ __forceinline__ unsigned long long uniform_addr(const T* p) {
+  const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t tile_rsrc(unsigned long long addr) {
+  return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(addr), 0, 0x7fffffff, 0x00020000);
+}
+template <typename T, bool KC, int TM>
+__device__ __forceinline__ void stage_offsets(int64_t ld, int (&off)[TM / 32], int tid) {   // byte offsets inside one K slab
+  constexpr int VEC = 16 / sizeof(T);
+  if (KC) {
+    const int c = tid & 7, row = tid >> 3;
+#pragma unroll
+    for (int q = 0; q < TM / 32; ++q) off[q] = (int)(((int64_t)(row + 32 * q) * ld + c * VEC) * (int64_t)sizeof(T));
+  } else {
+    constexpr int CPR = TM / VEC, RPP = 256 / CPR;
+    const int c = tid % CPR, kr = tid / CPR;
+#pragma unroll
+    for (int q = 0; q < TM / 32; ++q) off[q] = (int)(((int64_t)(kr + RPP * q) * ld + c * VEC) * (int64_t)sizeof(T));
+  }
+}
+// one 16-byte piece of a slab: global -> registers, registers -> LDS
+template <typename T>
+__device__ __forceinline__ typename Mma<T>::vec_t piece_load(unsigned long long slab, int off) {
+  return __builtin_bit_cast(typename Mma<T>::vec_t, __builtin_amdgcn_raw_buffer_load_b128(tile_rsrc(slab), off, 0, 0));
+}
+template <typename T, bool KC, int TM>
+__device__ __forceinline__ void piece_store(T* s, const typename Mma<T>::vec_t& r, int q, int tid) {
+  typedef typename Mma<T>::vec_t vec_t;
+  constexpr int VEC = 16 / sizeof(T);
+  if (KC) {
+    const int c = tid & 7, row = tid >> 3;
+    if ((skc<T>() * sizeof(T)) % 16 == 0) {
+      *reinterpret_cast<vec_t*>(s + (row + 32 * q) * skc<T>() + c * VEC) = r;
+    } else {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) s[(row + 32 * q) * skc<T>() + c * VEC + e] = r[e];
+    }
+  } else {
+    constexpr int CPR = TM / VEC, RPP = 256 / CPR;
+    const int c = tid % CPR, kr = tid / CPR;
+    *reinterpret_cast<vec_t*>(s + (kr + RPP * q) * smc<TM>() + c * VEC) = r;
+  }
+}
+
+template <typename T, bool AKC, bool BKC, int TM>
+__device__ __forceinline__ void gemm_tile2(const TileJob<T>& job, unsigned char* smem) {
+  typedef typename Mma<T>::acc_t acc_t;
+  typedef typename Mma<T>::vec_t vec_t;
+  constexpr int BKE = 128 / sizeof(T);
+  constexpr int KK = BKE / 4;            // MFMA k steps per slab
+  constexpr int MI = TM / 32;
+  constexpr int WT = TM / 2;
+  static_assert(MI == 4 && KK == 4, "the interleave below is written for the fp64 128-tile: 16 MFMAs, 8 fragments, 8 pieces per k step");
+  T* sA = reinterpret_cast<T*>(smem);
+  T* sB = reinterpret_cast<T*>(smem + OPERAND_BYTES);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l15 = lane & 15, lq = lane >> 4;
+
+  acc_t acc[MI][MI];
+  if (job.beta) {
+    const T inv_alpha = (T)1 / job.alpha;
+#pragma unroll
+    for (int a = 0; a < MI; ++a)
+#pragma unroll
+      for (int b = 0; b < MI; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = wm * WT + a * 16 + Mma<T>::crow(lane, r);
+          const int col = wn * WT + b * 16 + l15;
+          acc[a][b][r] = gld(job.C + (int64_t)row * job.ldc + col) * inv_alpha;
+        }
+  } else {
+#pragma unroll
+    for (int a = 0; a < MI; ++a)
+#pragma unroll
+      for (int b = 0; b < MI; ++b) acc[a][b] = (acc_t){0, 0, 0, 0};
+  }
+
+  const int nk = job.ksteps;
+  int offa[MI], offb[MI];
+  stage_offsets<T, AKC, TM>(job.lda, offa, tid);
+  stage_offsets<T, BKC, TM>(job.ldb, offb, tid);
+  // the slab's origin moves with the (uniform) base address: no 32-bit offset ever spans more than one slab of one tile
+  unsigned long long slabA = uniform_addr(job.A), slabB = uniform_addr(job.B);
+  const unsigned long long stepA = uniform_addr(reinterpret_cast<const char*>((AKC ? (int64_t)BKE : (int64_t)BKE * job.lda) * (int64_t)sizeof(T)));
+  const unsigned long long stepB = uniform_addr(reinterpret_cast<const char*>((BKC ? (int64_t)BKE : (int64_t)BKE * job.ldb) * (int64_t)sizeof(T)));
+  vec_t ra[MI], rb[MI];
+#pragma unroll
+  for (int q = 0; q < MI; ++q) { ra[q] = piece_load<T>(slabA, offa[q]); rb[q] = piece_load<T>(slabB, offb[q]); }
+#pragma unroll
+  for (int q = 0; q < MI; ++q) { piece_store<T, AKC, TM>(sA, ra[q], q, tid); piece_store<T, BKC, TM>(sB, rb[q], q, tid); }
+  if (nk > 1) { slabA += stepA; slabB += stepB; }
+#pragma unroll
+  for (int q = 0; q < MI; ++q) { ra[q] = piece_load<T>(slabA, offa[q]); rb[q] = piece_load<T>(slabB, offb[q]); }
+  __syncthreads();
+
+  T af[2][MI], bf[2][MI];
+#define HBO_SB() __builtin_amdgcn_sched_barrier(0)
+  // fragment i of k step kk (0-3: A, 4-7: B) into register set `set`
+  auto frag = [&](int set, int kk, int i) {
+    const int k = kk * 4 + lq;
+    if (i < MI) af[set][i] = frag_read<T, AKC, TM>(sA, wm * WT + i * 16 + l15, k);
+    else bf[set][i - MI] = frag_read<T, BKC, TM>(sB, wn * WT + (i - MI) * 16 + l15, k);
+  };
+  // MFMA i of a k step, serpentine over the 4 x 4 accumulators: consecutive MFMAs share an operand register
+  auto mma = [&](int set, int i) {
+    const int a = i / MI, b = (a & 1) ? MI - 1 - i % MI : i % MI;
+    acc[a][b] = Mma<T>::mma(af[set][a], bf[set][b], acc[a][b]);
+  };
+  // a k step whose only company is the next step's fragment reads: two behind each of the first four MFMAs
+  auto step_reads = [&](int set, int nset, int nkk) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      mma(set, i);
+      if (i < 4) { HBO_SB(); frag(nset, nkk, 2 * i); frag(nset, nkk, 2 * i + 1); HBO_SB(); }
+    }
+  };
+  // piece j (0-3: A, 4-7: B) of the prefetched slab to LDS / refilled from the slab after it
+  auto piece_out = [&](int j) {
+    if (j < MI) piece_store<T, AKC, TM>(sA, ra[j], j, tid); else piece_store<T, BKC, TM>(sB, rb[j - MI], j - MI, tid);
+  };
+  auto piece_in = [&](int j) {
+    if (j < MI) ra[j] = piece_load<T>(slabA, offa[j]); else rb[j - MI] = piece_load<T>(slabB, offb[j - MI]);
+  };
+#pragma unroll
+  for (int i = 0; i < 2 * MI; ++i) frag(0, 0, i);
+
+  const int* const yslot = job.yield_flag ? job.yield_flag + cu_token() : nullptr;
+  int ypoll = 0;
+  for (int kt = 0; kt + 1 < nk; ++kt) {
+    if (yslot) {
+      // a panel-chain workgroup is running on this CU: stay off its MFMA / LDS paths until it is done (bounded wait; see gemm_tile)
+      if (ypoll != 0)
+        for (int spin = 0; spin < 256 && __hip_atomic_load(yslot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0; ++spin)
+          __builtin_amdgcn_s_sleep(16);
+      ypoll = __hip_atomic_load(yslot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // the registers hold slab kt + 1; what refills them is slab kt + 2 (the last slab again when there is none: no branch in here)
+    if (kt + 2 < nk) { slabA += stepA; slabB += stepB; }
+    step_reads(0, 1, 1);
+    step_reads(1, 0, 2);
+    // k step 2: the last fragments of the slab, the first barrier, then the first four pieces
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+      mma(0, i);
+      if (i < 4) { HBO_SB(); frag(1, 3, 2 * i); frag(1, 3, 2 * i + 1); HBO_SB(); }
+    }
+    HBO_SB(); __syncthreads(); HBO_SB();                      // every wave has read the slab's last fragments
+    mma(0, 7);
+#ifdef HBO_GEMM_PRIO
+    __builtin_amdgcn_s_setprio(3);
+#endif
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      HBO_SB(); piece_out(j); HBO_SB(); mma(0, 8 + 2 * j); HBO_SB(); piece_in(j); HBO_SB(); mma(0, 9 + 2 * j);
+    }
+    // k step 3: the other four pieces, the second barrier, the next slab's first fragments
+#pragma unroll
+    for (int j = 4; j < 8; ++j) {
+      HBO_SB(); piece_out(j); HBO_SB(); mma(1, 2 * (j - 4)); HBO_SB(); piece_in(j); HBO_SB(); mma(1, 2 * (j - 4) + 1);
+    }
+    mma(1, 8); mma(1, 9);
+#ifdef HBO_GEMM_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
+    HBO_SB(); __syncthreads(); HBO_SB();                      // the new slab is in LDS
+    mma(1, 10);
+#ifdef HBO_GEMM_PRIO
+    __builtin_amdgcn_s_setprio(3);
+#endif
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { HBO_SB(); frag(0, 0, 2 * i); frag(0, 0, 2 * i + 1); HBO_SB(); mma(1, 11 + i); }
+    mma(1, 15);
+#ifdef HBO_GEMM_PRIO
+    __builtin_amdgcn_s_setprio(0);
+#endif
+    HBO_SB();
+  }
+  // the last slab
+  step_reads(0, 1, 1);
+  step_reads(1, 0, 2);
+  step_reads(0, 1, 3);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) mma(1, i);
+#undef HBO_SB
+  if (yslot) __syncthreads();   // (uniform exit of the K loop for the LDS reuse of the epilogue below)
+
+  if (job.C) {
+#pragma unroll
+    for (int a = 0; a < MI; ++a)
+#pragma unroll
+      for (int b = 0; b < MI; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = wm * WT + a * 16 + Mma<T>::crow(lane, r);
+          const int col = wn * WT + b * 16 + l15;
+          gst(job.C + (int64_t)row * job.ldc + col, job.alpha * acc[a][b][r]);
+        }
+  }
+  if (TM == 128 && job.colsq) {
+    __syncthreads();   // every wave is done with the last slab's fragments: the LDS is free for the reduction
+    T* red = reinterpret_cast<T*>(smem);  // [4 waves][64]
+    T part[MI];
+#pragma unroll
+    for (int b = 0; b < MI; ++b) {
+      T s_ = 0;
+#pragma unroll
+      for (int a = 0; a < MI; ++a)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) s_ += acc[a][b][r] * acc[a][b][r];
+      s_ += __shfl_xor(s_, 16);
+      s_ += __shfl_xor(s_, 32);
+      part[b] = s_;
+    }
+    if (lq == 0) {
+#pragma unroll
+      for (int b = 0; b < MI; ++b) red[wave * 64 + b * 16 + l15] = part[b];
+    }
+    __syncthreads();
+    if (tid < 128) {
+      const int wn2 = tid >> 6, c = tid & 63;
+      gst(job.colsq + wn2 * 64 + c, red[(0 * 2 + wn2) * 64 + c] + red[(1 * 2 + wn2) * 64 + c]);
+    }
+  }
+}
+// which core a tile takes: the pipelined one for the fp64 128-tile (every mode), the original for the rest
+template <typename T, bool AKC, bool BKC, int TM>
+__device__ __forceinline__ void run_tile(const TileJob<T>& job, unsigned char* smem) {
+#ifndef HBO_GEMM_V1
+  if constexpr (sizeof(T) == 8 && TM == 128) gemm_tile2<T, AKC, BKC, TM>(job, smem);
+  else
+#endif
+    gemm_tile<T, AKC, BKC, TM>(job, smem);
+}
+
 // SYRK tiles by linear index (column-major over the trapezoid c in [c_lo,c_hi), r in [c,nrt)): used by
 // the persistent form of the bulk trailing update, whose grid is smaller than the machine so that
 // the panel kernels of the look-ahead (potf2 / trsm / next-column update) always find free CUs.
@@ -543,11 +796,11 @@ __global__ __launch_bounds__(256, TM == 64 ? 4 : 2) void gemm_kernel(GemmArgs g)
         job.A += (int64_t)qr * 64 * ldq;
         job.B += (int64_t)qc * 64 * ldq;
         job.C += (int64_t)qr * 64 * ldq + qc * 64;
-        gemm_tile<T, AKC, BKC, 64>(job, smem);
+        run_tile<T, AKC, BKC, 64>(job, smem);
         continue;
       }
       if (!decode_syrk_linear<T, TM>(g, tix, job)) break;
-      gemm_tile<T, AKC, BKC, TM>(job, smem);
+      run_tile<T, AKC, BKC, TM>(job, smem);
 #ifdef HBO_GEMM_TIMING
       dbg_ks += (unsigned long long)job.ksteps;
 #endif
@@ -575,14 +828,14 @@ __global__ __launch_bounds__(256, TM == 64 ? 4 : 2) void gemm_kernel(GemmArgs g)
       __syncthreads();
       if (tix >= total) break;
       const int tile = tix / nt, task = g.ptasks > 1 ? tix % nt : (int)blockIdx.z;
-      if (decode_job<T, TM>(g, job, tile % g.pgx, tile / g.pgx, g.pgx, task)) gemm_tile<T, AKC, BKC, TM>(job, smem);
+      if (decode_job<T, TM>(g, job, tile % g.pgx, tile / g.pgx, g.pgx, task)) run_tile<T, AKC, BKC, TM>(job, smem);
     }
     return;
   }
   if (!decode_job<T, TM>(g, job, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x, (int)blockIdx.z)) return;
   int ytok = 0;
   if (g.yield_mark && threadIdx.x == 0) ytok = yield_enter(g.yield_mark);
-  gemm_tile<T, AKC, BKC, TM>(job, smem);
+  run_tile<T, AKC, BKC, TM>(job, smem);
   if (g.yield_mark) {
     __syncthreads();
     if (threadIdx.x == 0) yield_leave(g.yield_mark, ytok);

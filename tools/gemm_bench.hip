@@ -56,6 +56,11 @@ int main(int argc, char** argv) {
     }
     return 0;
   }
+  { // the tile core alone: a full square of 128-tiles with one K for all (C -= V^T V, the form of rocBLAS dgemm NT n^3): no
+    // triangle, no tail beyond tiles mod slots
+    GemmArgs a = {}; a.tasks = d; a.mode = GEMM_VTV; a.B = W; a.ldb = h.ld; a.V = S;
+    timeit("square n^3 (VTV)", a, dim3(nblk, nblk, 1), 2.0 * n * n * n); }
+  if (getenv("HBO_BENCH_SQUARE_ONLY")) return 0;
   for (int dbg : {0, 2, 4})
   for (int kt : {1, 2, 4, 8}) {
     GemmArgs a = {}; a.tasks = d; a.mode = GEMM_SYRK; a.p0 = 0; a.kt = kt; a.c_lo = kt; a.c_hi = nblk; a.aug = 1 | dbg;
@@ -86,7 +91,7 @@ int main(int argc, char** argv) {
   { double tot = 0; float msum = 0;
     for (int s = 1; s < nblk; s *= 2) {
       int ng = (nblk + 2 * s - 1) / (2 * s);
-      GemmArgs a = {}; a.tasks = d; a.p0 = s;
+      GemmArgs a = {}; a.tasks = d; a.p0 = s; a.c_hi = ng - 1; a.c_lo = s;   // (the last group and its row count: full)
       for (int mode : {GEMM_TRTRI_A, GEMM_TRTRI_B}) {
         a.mode = mode;
         launch_gemm(HBO_F64, a, dim3(ng * s, s, 1), 0); CK(hipDeviceSynchronize());
