@@ -9,6 +9,7 @@
 // Replaces, for the reference, what XLA lowers jax.scipy.linalg.cholesky / cho_solve /
 // solve_triangular to (hyperbo/basics/linalg.py:29-33,139-145; hyperbo/gp_utils/gp.py:297).
 #include "hbo_internal.h"
+#include <cstdlib>
 
 namespace {
 
@@ -854,28 +855,40 @@ void launch_gemm_t(const GemmArgs& a_in, dim3 grid, hipStream_t st) {
   if (a.mode != GEMM_SYRK && !((a.mode == GEMM_TRTRI_A || a.mode == GEMM_TRTRI_B) && a.work_counter && grid.z == 1) && !(sweep_mode && a.work_counter))
     a.persistent = 0;
   a.ptasks = 0;
+  // dynamic LDS of a 128-tile workgroup: one stage per operand for the pipelined fp64 core, two for gemm_tile
+#ifdef HBO_GEMM_V1
+  int lds128 = GEMM_LDS_BYTES;
+#else
+  // (the persistent update runs its last round on 64-tiles through gemm_tile inside the 128-tile kernel: n_big)
+  int lds128 = sizeof(T) == 8 ? (2 * OPERAND_BYTES > GEMM_LDS_BYTES_64 ? 2 * OPERAND_BYTES : GEMM_LDS_BYTES_64) : GEMM_LDS_BYTES;
+#endif
+#ifdef HBO_GEMM_DEBUG
+  // HBO_GEMM_LDS=<bytes>: ask for more LDS than the kernel needs (above 80 KB: one workgroup per CU instead of two)
+  static const int dbg_lds = getenv("HBO_GEMM_LDS") ? atoi(getenv("HBO_GEMM_LDS")) : 0;
+  if (dbg_lds > lds128) lds128 = dbg_lds;
+#endif
   static unsigned long long attr_seen = 0;
   if (hbo_first_use_on_device(attr_seen)) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T, true, true, 128>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
+                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T, true, false, 128>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
+                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T, false, false, 128>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS_BYTES);
+                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
   }
   switch (a.mode) {
     case GEMM_SYRK:
       if (a.persistent > 0) {
         dim3 gp(a.persistent, 1, grid.z);
         if (a.small_tiles) hipLaunchKernelGGL((gemm_kernel<T, true, true, 64>), gp, dim3(256), GEMM_LDS_BYTES_64, st, a);
-        else hipLaunchKernelGGL((gemm_kernel<T, true, true, 128>), gp, dim3(256), GEMM_LDS_BYTES, st, a);
+        else hipLaunchKernelGGL((gemm_kernel<T, true, true, 128>), gp, dim3(256), lds128, st, a);
       } else if (a.small_tiles) {
         // 64x64 tiles: 4x the workgroups, a quarter of the per-tile latency -- for the skinny
         // updates on the critical path (next block column) and small trailing matrices
         dim3 g2(grid.x * 2, grid.y * 2, grid.z);
         hipLaunchKernelGGL((gemm_kernel<T, true, true, 64>), g2, dim3(256), GEMM_LDS_BYTES_64, st, a);
       } else {
-        hipLaunchKernelGGL((gemm_kernel<T, true, true, 128>), grid, dim3(256), GEMM_LDS_BYTES, st, a);
+        hipLaunchKernelGGL((gemm_kernel<T, true, true, 128>), grid, dim3(256), lds128, st, a);
       }
       break;
     case GEMM_TRTRI_A:
@@ -888,9 +901,9 @@ void launch_gemm_t(const GemmArgs& a_in, dim3 grid, hipStream_t st) {
         hipLaunchKernelGGL((gemm_kernel<T, true, false, 64>), g2, dim3(256), GEMM_LDS_BYTES_64, st, a);
       } else if (a.persistent > 0) {
         GemmArgs b = a; b.pgx = (int)grid.x; b.pgy = (int)grid.y;
-        hipLaunchKernelGGL((gemm_kernel<T, true, false, 128>), dim3(a.persistent, 1, 1), dim3(256), GEMM_LDS_BYTES, st, b);
+        hipLaunchKernelGGL((gemm_kernel<T, true, false, 128>), dim3(a.persistent, 1, 1), dim3(256), lds128, st, b);
       } else {
-        hipLaunchKernelGGL((gemm_kernel<T, true, false, 128>), grid, dim3(256), GEMM_LDS_BYTES, st, a);
+        hipLaunchKernelGGL((gemm_kernel<T, true, false, 128>), grid, dim3(256), lds128, st, a);
       }
       break;
     case GEMM_SWEEP_B:
@@ -900,11 +913,11 @@ void launch_gemm_t(const GemmArgs& a_in, dim3 grid, hipStream_t st) {
         GemmArgs b = a; const int u = a.small_tiles ? 2 : 1;
         b.pgx = (int)grid.x * u; b.pgy = (int)grid.y * u; b.ptasks = (int)grid.z;
         if (a.small_tiles) hipLaunchKernelGGL((gemm_kernel<T, true, false, 64>), dim3(a.persistent, 1, 1), dim3(256), GEMM_LDS_BYTES_64, st, b);
-        else hipLaunchKernelGGL((gemm_kernel<T, true, false, 128>), dim3(a.persistent, 1, 1), dim3(256), GEMM_LDS_BYTES, st, b);
+        else hipLaunchKernelGGL((gemm_kernel<T, true, false, 128>), dim3(a.persistent, 1, 1), dim3(256), lds128, st, b);
       } else if (a.small_tiles) {
         hipLaunchKernelGGL((gemm_kernel<T, true, false, 64>), dim3(grid.x * 2, grid.y * 2, grid.z), dim3(256), GEMM_LDS_BYTES_64, st, a);
       } else {
-        hipLaunchKernelGGL((gemm_kernel<T, true, false, 128>), grid, dim3(256), GEMM_LDS_BYTES, st, a);
+        hipLaunchKernelGGL((gemm_kernel<T, true, false, 128>), grid, dim3(256), lds128, st, a);
       }
       break;
     case GEMM_SWEEP_C: {
@@ -913,19 +926,19 @@ void launch_gemm_t(const GemmArgs& a_in, dim3 grid, hipStream_t st) {
       if (a.persistent > 0) {
         GemmArgs b = a; b.pgx = (int)nt; b.pgy = 1; b.ptasks = (int)grid.z;
         if (a.small_tiles) hipLaunchKernelGGL((gemm_kernel<T, false, false, 64>), dim3(a.persistent, 1, 1), dim3(256), GEMM_LDS_BYTES_64, st, b);
-        else hipLaunchKernelGGL((gemm_kernel<T, false, false, 128>), dim3(a.persistent, 1, 1), dim3(256), GEMM_LDS_BYTES, st, b);
+        else hipLaunchKernelGGL((gemm_kernel<T, false, false, 128>), dim3(a.persistent, 1, 1), dim3(256), lds128, st, b);
       } else if (a.small_tiles) {
         hipLaunchKernelGGL((gemm_kernel<T, false, false, 64>), dim3(nt, 1, grid.z), dim3(256), GEMM_LDS_BYTES_64, st, a);
       } else {
-        hipLaunchKernelGGL((gemm_kernel<T, false, false, 128>), dim3(nt, 1, grid.z), dim3(256), GEMM_LDS_BYTES, st, a);
+        hipLaunchKernelGGL((gemm_kernel<T, false, false, 128>), dim3(nt, 1, grid.z), dim3(256), lds128, st, a);
       }
       break;
     }
     case GEMM_POST:
-      hipLaunchKernelGGL((gemm_kernel<T, true, false, 128>), grid, dim3(256), GEMM_LDS_BYTES, st, a);
+      hipLaunchKernelGGL((gemm_kernel<T, true, false, 128>), grid, dim3(256), lds128, st, a);
       break;
     case GEMM_VTV:
-      hipLaunchKernelGGL((gemm_kernel<T, false, false, 128>), grid, dim3(256), GEMM_LDS_BYTES, st, a);
+      hipLaunchKernelGGL((gemm_kernel<T, false, false, 128>), grid, dim3(256), lds128, st, a);
       break;
     case GEMM_LAUUM:
       if (a.small_tiles) {
@@ -934,7 +947,7 @@ void launch_gemm_t(const GemmArgs& a_in, dim3 grid, hipStream_t st) {
       } else {
         // 1-D grid over the lower tiles (grid.x = block count of the largest task)
         dim3 g1(grid.x * (grid.x + 1) / 2, 1, grid.z);
-        hipLaunchKernelGGL((gemm_kernel<T, false, false, 128>), g1, dim3(256), GEMM_LDS_BYTES, st, a);
+        hipLaunchKernelGGL((gemm_kernel<T, false, false, 128>), g1, dim3(256), lds128, st, a);
       }
       break;
   }

@@ -60,6 +60,12 @@ int main(int argc, char** argv) {
     // triangle, no tail beyond tiles mod slots
     GemmArgs a = {}; a.tasks = d; a.mode = GEMM_VTV; a.B = W; a.ldb = h.ld; a.V = S;
     timeit("square n^3 (VTV)", a, dim3(nblk, nblk, 1), 2.0 * n * n * n); }
+  for (int kt : {2, 8}) {   // the 64-tile core: the same update on 64 x 64 tiles, no C traffic
+    GemmArgs a = {}; a.tasks = d; a.mode = GEMM_SYRK; a.p0 = 0; a.kt = kt; a.c_lo = kt; a.c_hi = nblk; a.aug = 1 | 4; a.small_tiles = 1;
+    double m = nblk - kt;
+    char nm[64]; snprintf(nm, 64, "syrk 64-tiles K=%d dbg=4", kt * 128);
+    timeit(nm, a, dim3(nblk + 1 - kt, nblk - kt, 1), m * (m + 1) / 2 * 128.0 * 128 * 2 * 128 * kt);
+  }
   if (getenv("HBO_BENCH_SQUARE_ONLY")) return 0;
   for (int dbg : {0, 2, 4})
   for (int kt : {1, 2, 4, 8}) {
