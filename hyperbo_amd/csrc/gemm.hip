@@ -866,15 +866,18 @@ void launch_gemm_t(const GemmArgs& a_in, dim3 grid, hipStream_t st) {
   // HBO_GEMM_LDS=<bytes>: ask for more LDS than the kernel needs (above 80 KB: one workgroup per CU instead of two)
   static const int dbg_lds = getenv("HBO_GEMM_LDS") ? atoi(getenv("HBO_GEMM_LDS")) : 0;
   if (dbg_lds > lds128) lds128 = dbg_lds;
+  const int attr128 = dbg_lds > GEMM_LDS_BYTES ? dbg_lds : GEMM_LDS_BYTES;
+#else
+  const int attr128 = GEMM_LDS_BYTES;
 #endif
   static unsigned long long attr_seen = 0;
   if (hbo_first_use_on_device(attr_seen)) {
     hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T, true, true, 128>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                        hipFuncAttributeMaxDynamicSharedMemorySize, attr128);
     hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T, true, false, 128>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                        hipFuncAttributeMaxDynamicSharedMemorySize, attr128);
     hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<T, false, false, 128>),
-                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+                        hipFuncAttributeMaxDynamicSharedMemorySize, attr128);
   }
   switch (a.mode) {
     case GEMM_SYRK:
