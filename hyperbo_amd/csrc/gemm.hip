@@ -716,11 +716,148 @@ __device__ __forceinline__ void gemm_tile2(const TileJob<T>& job, unsigned char*
     }
   }
 }
-// which core a tile takes: the pipelined one for the fp64 128-tile (every mode), the original for the rest
+// ---- the 64-tile core with a deep global prefetch (round 4) ------------------------------------------------------------------
+// A 64 x 64 tile has 16 MFMAs per wave and slab (0.43 us at one wave per SIMD); gemm_tile prefetches ONE slab ahead, so a lone
+// workgroup -- the column updates of the panel chain launch one or two rounds of tiles with K = 128..384 -- spends a global-load
+// latency (~2 us) per slab: 8-24 slabs in sequence.  This core keeps PF slabs in flight in a ring of register sets (16 VGPRs per
+// slab and thread), one LDS stage as in gemm_tile2 (two barriers per slab, fragment reads of the next k step beside the MFMAs of
+// the current one), and the same ascending-k arithmetic: identical results.
+#ifndef HBO_PF64
+#define HBO_PF64 2
+#endif
+#ifndef HBO_LB64
+#define HBO_LB64 4
+#endif
+template <typename T, bool AKC, bool BKC, int TM, int PF>
+__device__ __forceinline__ void gemm_tile3(const TileJob<T>& job, unsigned char* smem) {
+  typedef typename Mma<T>::acc_t acc_t;
+  typedef typename Mma<T>::vec_t vec_t;
+  constexpr int BKE = 128 / sizeof(T);
+  constexpr int KK = BKE / 4;
+  constexpr int MI = TM / 32;
+  constexpr int WT = TM / 2;
+  static_assert(MI == 2 && KK == 4, "written for the fp64 64-tile: 4 MFMAs and 4 fragments per k step, 4 pieces per slab");
+  T* sA = reinterpret_cast<T*>(smem);
+  T* sB = reinterpret_cast<T*>(smem + OPERAND_BYTES_64);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l15 = lane & 15, lq = lane >> 4;
+
+  acc_t acc[MI][MI];
+  if (job.beta) {
+    const T inv_alpha = (T)1 / job.alpha;
+#pragma unroll
+    for (int a = 0; a < MI; ++a)
+#pragma unroll
+      for (int b = 0; b < MI; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = wm * WT + a * 16 + Mma<T>::crow(lane, r);
+          const int col = wn * WT + b * 16 + l15;
+          acc[a][b][r] = gld(job.C + (int64_t)row * job.ldc + col) * inv_alpha;
+        }
+  } else {
+#pragma unroll
+    for (int a = 0; a < MI; ++a)
+#pragma unroll
+      for (int b = 0; b < MI; ++b) acc[a][b] = (acc_t){0, 0, 0, 0};
+  }
+
+  const int nk = job.ksteps;
+  int offa[MI], offb[MI];
+  stage_offsets<T, AKC, TM>(job.lda, offa, tid);
+  stage_offsets<T, BKC, TM>(job.ldb, offb, tid);
+  unsigned long long slabA = uniform_addr(job.A), slabB = uniform_addr(job.B);   // origin of the next slab to be fetched
+  const unsigned long long stepA = uniform_addr(reinterpret_cast<const char*>((AKC ? (int64_t)BKE : (int64_t)BKE * job.lda) * (int64_t)sizeof(T)));
+  const unsigned long long stepB = uniform_addr(reinterpret_cast<const char*>((BKC ? (int64_t)BKE : (int64_t)BKE * job.ldb) * (int64_t)sizeof(T)));
+  vec_t ra[PF][MI], rb[PF][MI];
+  auto fetch = [&](int set) {      // the next slab into register set `set`
+#pragma unroll
+    for (int q = 0; q < MI; ++q) { ra[set][q] = piece_load<T>(slabA, offa[q]); rb[set][q] = piece_load<T>(slabB, offb[q]); }
+    slabA += stepA; slabB += stepB;
+  };
+  auto to_lds = [&](int set) {
+#pragma unroll
+    for (int q = 0; q < MI; ++q) { piece_store<T, AKC, TM>(sA, ra[set][q], q, tid); piece_store<T, BKC, TM>(sB, rb[set][q], q, tid); }
+  };
+#pragma unroll
+  for (int u = 0; u < PF; ++u)
+    if (u < nk) fetch(u);
+  to_lds(0);
+  if (PF < nk) fetch(0);
+  __syncthreads();
+
+  T af[2][MI], bf[2][MI];
+#define HBO_SB() __builtin_amdgcn_sched_barrier(0)
+  auto frags = [&](int set, int kk) {
+    const int k = kk * 4 + lq;
+#pragma unroll
+    for (int a = 0; a < MI; ++a) af[set][a] = frag_read<T, AKC, TM>(sA, wm * WT + a * 16 + l15, k);
+#pragma unroll
+    for (int b = 0; b < MI; ++b) bf[set][b] = frag_read<T, BKC, TM>(sB, wn * WT + b * 16 + l15, k);
+  };
+  auto mma = [&](int set, int i) {
+    const int a = i / MI, b = (a & 1) ? MI - 1 - i % MI : i % MI;
+    acc[a][b] = Mma<T>::mma(af[set][a], bf[set][b], acc[a][b]);
+  };
+  auto step = [&](int set, int nset, int nkk) {   // 4 MFMAs, the next step's fragments behind the first
+    mma(set, 0); HBO_SB(); frags(nset, nkk); HBO_SB(); mma(set, 1); mma(set, 2); mma(set, 3);
+  };
+  frags(0, 0);
+
+  const int* const yslot = job.yield_flag ? job.yield_flag + cu_token() : nullptr;
+  int ypoll = 0;
+  // slab s is in LDS; slab s + 1 waits in register set (s + 1) % PF and is replaced there by slab s + 1 + PF
+  for (int s0 = 0; s0 + 1 < nk; s0 += PF) {
+#pragma unroll
+    for (int u = 0; u < PF; ++u) {
+      const int s = s0 + u;
+      if (s + 1 >= nk) break;
+      const int set = (u + 1) % PF;
+      if (yslot) {
+        if (ypoll != 0)
+          for (int spin = 0; spin < 256 && __hip_atomic_load(yslot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0; ++spin)
+            __builtin_amdgcn_s_sleep(16);
+        ypoll = __hip_atomic_load(yslot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      step(0, 1, 1);
+      step(1, 0, 2);
+      mma(0, 0); HBO_SB(); frags(1, 3); HBO_SB(); mma(0, 1);
+      HBO_SB(); __syncthreads(); HBO_SB();          // every wave has read the slab's last fragments
+      mma(0, 2); HBO_SB(); to_lds(set); HBO_SB(); mma(0, 3);
+      if (s + 1 + PF < nk) fetch(set);
+      mma(1, 0); mma(1, 1);
+      HBO_SB(); __syncthreads(); HBO_SB();          // the next slab is in LDS
+      mma(1, 2); HBO_SB(); frags(0, 0); HBO_SB(); mma(1, 3);
+    }
+  }
+  step(0, 1, 1);
+  step(1, 0, 2);
+  step(0, 1, 3);
+  mma(1, 0); mma(1, 1); mma(1, 2); mma(1, 3);
+#undef HBO_SB
+
+  if (job.C) {
+#pragma unroll
+    for (int a = 0; a < MI; ++a)
+#pragma unroll
+      for (int b = 0; b < MI; ++b)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = wm * WT + a * 16 + Mma<T>::crow(lane, r);
+          const int col = wn * WT + b * 16 + l15;
+          gst(job.C + (int64_t)row * job.ldc + col, job.alpha * acc[a][b][r]);
+        }
+  }
+}
+// which core a tile takes: the pipelined ones for fp64 (128-tile: gemm_tile2, 64-tile: gemm_tile3), the original for fp32
 template <typename T, bool AKC, bool BKC, int TM>
 __device__ __forceinline__ void run_tile(const TileJob<T>& job, unsigned char* smem) {
 #ifndef HBO_GEMM_V1
   if constexpr (sizeof(T) == 8 && TM == 128) gemm_tile2<T, AKC, BKC, TM>(job, smem);
+#ifndef HBO_GEMM_NO64
+  else if constexpr (sizeof(T) == 8 && TM == 64) gemm_tile3<T, AKC, BKC, TM, HBO_PF64>(job, smem);
+#endif
   else
 #endif
     gemm_tile<T, AKC, BKC, TM>(job, smem);
@@ -758,7 +895,7 @@ __device__ unsigned long long hbo_dbg_gemm[4 * 8192];   // per workgroup of the 
 int g_dbg_mode = -1, g_dbg_index = 0, g_dbg_seen = 0;   // host: trace the g_dbg_index-th launch of g_dbg_mode (+100: persistent)
 #endif
 template <typename T, bool AKC, bool BKC, int TM>
-__global__ __launch_bounds__(256, TM == 64 ? 4 : 2) void gemm_kernel(GemmArgs g) {
+__global__ __launch_bounds__(256, TM == 64 ? (sizeof(T) == 8 ? HBO_LB64 : 4) : 2) void gemm_kernel(GemmArgs g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   TileJob<T> job;
   job.yield_flag = g.yield_flag;
@@ -859,9 +996,12 @@ void launch_gemm_t(const GemmArgs& a_in, dim3 grid, hipStream_t st) {
 #ifdef HBO_GEMM_V1
   int lds128 = GEMM_LDS_BYTES;
 #else
-  // (the persistent update runs its last round on 64-tiles through gemm_tile inside the 128-tile kernel: n_big)
-  int lds128 = sizeof(T) == 8 ? (2 * OPERAND_BYTES > GEMM_LDS_BYTES_64 ? 2 * OPERAND_BYTES : GEMM_LDS_BYTES_64) : GEMM_LDS_BYTES;
+  int lds128 = sizeof(T) == 8 ? 2 * OPERAND_BYTES : GEMM_LDS_BYTES;
 #endif
+  // 64-tiles keep the two-stage request although gemm_tile3 uses one: measured equal or better (N = 4096: 2.76 against 2.81 ms with
+  // 20 KB, profiles/r04_gemm_pipeline.md); the persistent update runs its last round on 64-tiles inside the 128-tile kernel (n_big)
+  const int lds64 = GEMM_LDS_BYTES_64;
+  if (lds128 < lds64) lds128 = lds64;
 #ifdef HBO_GEMM_DEBUG
   // HBO_GEMM_LDS=<bytes>: ask for more LDS than the kernel needs (above 80 KB: one workgroup per CU instead of two)
   static const int dbg_lds = getenv("HBO_GEMM_LDS") ? atoi(getenv("HBO_GEMM_LDS")) : 0;
@@ -883,13 +1023,13 @@ void launch_gemm_t(const GemmArgs& a_in, dim3 grid, hipStream_t st) {
     case GEMM_SYRK:
       if (a.persistent > 0) {
         dim3 gp(a.persistent, 1, grid.z);
-        if (a.small_tiles) hipLaunchKernelGGL((gemm_kernel<T, true, true, 64>), gp, dim3(256), GEMM_LDS_BYTES_64, st, a);
+        if (a.small_tiles) hipLaunchKernelGGL((gemm_kernel<T, true, true, 64>), gp, dim3(256), lds64, st, a);
         else hipLaunchKernelGGL((gemm_kernel<T, true, true, 128>), gp, dim3(256), lds128, st, a);
       } else if (a.small_tiles) {
         // 64x64 tiles: 4x the workgroups, a quarter of the per-tile latency -- for the skinny
         // updates on the critical path (next block column) and small trailing matrices
         dim3 g2(grid.x * 2, grid.y * 2, grid.z);
-        hipLaunchKernelGGL((gemm_kernel<T, true, true, 64>), g2, dim3(256), GEMM_LDS_BYTES_64, st, a);
+        hipLaunchKernelGGL((gemm_kernel<T, true, true, 64>), g2, dim3(256), lds64, st, a);
       } else {
         hipLaunchKernelGGL((gemm_kernel<T, true, true, 128>), grid, dim3(256), lds128, st, a);
       }
@@ -898,10 +1038,10 @@ void launch_gemm_t(const GemmArgs& a_in, dim3 grid, hipStream_t st) {
     case GEMM_TRTRI_B:
       if (a.small_tiles && a.persistent > 0) {
         GemmArgs b = a; b.pgx = (int)grid.x * 2; b.pgy = (int)grid.y * 2;
-        hipLaunchKernelGGL((gemm_kernel<T, true, false, 64>), dim3(a.persistent, 1, 1), dim3(256), GEMM_LDS_BYTES_64, st, b);
+        hipLaunchKernelGGL((gemm_kernel<T, true, false, 64>), dim3(a.persistent, 1, 1), dim3(256), lds64, st, b);
       } else if (a.small_tiles) {
         dim3 g2(grid.x * 2, grid.y * 2, grid.z);
-        hipLaunchKernelGGL((gemm_kernel<T, true, false, 64>), g2, dim3(256), GEMM_LDS_BYTES_64, st, a);
+        hipLaunchKernelGGL((gemm_kernel<T, true, false, 64>), g2, dim3(256), lds64, st, a);
       } else if (a.persistent > 0) {
         GemmArgs b = a; b.pgx = (int)grid.x; b.pgy = (int)grid.y;
         hipLaunchKernelGGL((gemm_kernel<T, true, false, 128>), dim3(a.persistent, 1, 1), dim3(256), lds128, st, b);
@@ -915,10 +1055,10 @@ void launch_gemm_t(const GemmArgs& a_in, dim3 grid, hipStream_t st) {
       if (a.persistent > 0) {
         GemmArgs b = a; const int u = a.small_tiles ? 2 : 1;
         b.pgx = (int)grid.x * u; b.pgy = (int)grid.y * u; b.ptasks = (int)grid.z;
-        if (a.small_tiles) hipLaunchKernelGGL((gemm_kernel<T, true, false, 64>), dim3(a.persistent, 1, 1), dim3(256), GEMM_LDS_BYTES_64, st, b);
+        if (a.small_tiles) hipLaunchKernelGGL((gemm_kernel<T, true, false, 64>), dim3(a.persistent, 1, 1), dim3(256), lds64, st, b);
         else hipLaunchKernelGGL((gemm_kernel<T, true, false, 128>), dim3(a.persistent, 1, 1), dim3(256), lds128, st, b);
       } else if (a.small_tiles) {
-        hipLaunchKernelGGL((gemm_kernel<T, true, false, 64>), dim3(grid.x * 2, grid.y * 2, grid.z), dim3(256), GEMM_LDS_BYTES_64, st, a);
+        hipLaunchKernelGGL((gemm_kernel<T, true, false, 64>), dim3(grid.x * 2, grid.y * 2, grid.z), dim3(256), lds64, st, a);
       } else {
         hipLaunchKernelGGL((gemm_kernel<T, true, false, 128>), grid, dim3(256), lds128, st, a);
       }
@@ -928,10 +1068,10 @@ void launch_gemm_t(const GemmArgs& a_in, dim3 grid, hipStream_t st) {
       const unsigned nt = a.small_tiles ? 2 * grid.x * (grid.x + 1) : grid.x * (grid.x + 1) / 2;
       if (a.persistent > 0) {
         GemmArgs b = a; b.pgx = (int)nt; b.pgy = 1; b.ptasks = (int)grid.z;
-        if (a.small_tiles) hipLaunchKernelGGL((gemm_kernel<T, false, false, 64>), dim3(a.persistent, 1, 1), dim3(256), GEMM_LDS_BYTES_64, st, b);
+        if (a.small_tiles) hipLaunchKernelGGL((gemm_kernel<T, false, false, 64>), dim3(a.persistent, 1, 1), dim3(256), lds64, st, b);
         else hipLaunchKernelGGL((gemm_kernel<T, false, false, 128>), dim3(a.persistent, 1, 1), dim3(256), lds128, st, b);
       } else if (a.small_tiles) {
-        hipLaunchKernelGGL((gemm_kernel<T, false, false, 64>), dim3(nt, 1, grid.z), dim3(256), GEMM_LDS_BYTES_64, st, a);
+        hipLaunchKernelGGL((gemm_kernel<T, false, false, 64>), dim3(nt, 1, grid.z), dim3(256), lds64, st, a);
       } else {
         hipLaunchKernelGGL((gemm_kernel<T, false, false, 128>), dim3(nt, 1, grid.z), dim3(256), lds128, st, a);
       }
@@ -946,7 +1086,7 @@ void launch_gemm_t(const GemmArgs& a_in, dim3 grid, hipStream_t st) {
     case GEMM_LAUUM:
       if (a.small_tiles) {
         dim3 g2(2 * grid.x * (grid.x + 1), 1, grid.z);
-        hipLaunchKernelGGL((gemm_kernel<T, false, false, 64>), g2, dim3(256), GEMM_LDS_BYTES_64, st, a);
+        hipLaunchKernelGGL((gemm_kernel<T, false, false, 64>), g2, dim3(256), lds64, st, a);
       } else {
         // 1-D grid over the lower tiles (grid.x = block count of the largest task)
         dim3 g1(grid.x * (grid.x + 1) / 2, 1, grid.z);
