@@ -145,7 +145,7 @@ static int objective_local(hbo_ctx* c, const hbo_model* m_in, hbo_dataset* ds, i
   // the inverse and K^-1 behind the panel chain, row group by row group (sched.hip:sweep_advance) -- or the block-recursive
   // inverse started beside the chain and K^-1 = W^T W after it
   const bool sweep = want_grad && !euc && use_sweep(c, dtype, T, max_nblk);
-  if (sweep) sweep_st.qs = c->opt_sweep_qs > 0 ? c->opt_sweep_qs : 4;
+  if (sweep) sweep_st.qs = c->opt_sweep_qs > 0 ? c->opt_sweep_qs : sweep_group(T, max_nblk);
   const bool early_trtri = !sweep && want_grad && la && c->opt_overlap_trtri && max_nblk >= 4;
   if (!euc) {
     {

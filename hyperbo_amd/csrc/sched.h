@@ -9,6 +9,7 @@ struct TrtriProgress { int diag = 0; int a[12] = {0}; int b[12] = {0}; };
 // what is left when the factorisation ends is one group's worth of O(N^2 q) work instead of the O(N^3) tail of the block-recursive
 // inverse and of K^-1 = W^T W (which needs every row of W).
 struct SweepState { int qs = 4; int done = 0; TrtriProgress pg; };
+int sweep_group(int ntasks, int max_nblk);   // row-group size of the one-sweep inverse where use_sweep() says yes
 
 hipEvent_t pool_event(hbo_ctx* c, size_t i);
 // Look-ahead (panel chain, bulk update and inverse on separate streams) pays once there is something to overlap; below that the

@@ -369,13 +369,17 @@ void trtri_advance(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, i
 bool use_sweep(const hbo_ctx* c, int dtype, int ntasks, int max_nblk) {
   if (!c->opt_sweep || !use_lookahead(c, ntasks, max_nblk) || max_nblk < 8) return false;
   if (c->opt_sweep >= 2) return true;
-  // one matrix: the rank-512 updates of this form run at a lower rate than the long-K products of the recursive inverse and of
-  // K^-1 = W^T W, and the phase has no idle machine to give them (N = 8192: 13.4 against 11.5 ms, N = 4096: 3.01 / 2.99)
-  if (ntasks == 1) return false;
+  // one matrix: at N = 8192 the rank-q updates of this form run at a lower rate than the long-K products of the recursive inverse
+  // and of K^-1 = W^T W, and the phase has no idle machine to give them (13.4 against 11.5 ms in round 4's first measurement; with
+  // the pipelined GEMM cores 11.14 against 10.71 at q = 16).  In between it wins -- fp64, ms per NLL + gradient, recursive / sweep:
+  //   N = 2048 1.193 / 1.193, 2560 1.580 / 1.417 (q = 4), 3072 1.944 / 1.740 (4), 3584 2.261 / 2.167 (4), 4096 2.780 / 2.671 (8),
+  //   5120 4.404 / 4.179 (8), 6144 6.053 / 6.010 (8)        (profiles/r04_gemm_pipeline.md)
+  if (ntasks == 1) return dtype == HBO_F64 && max_nblk > 16 && max_nblk <= 48;
   // fp32 beyond the small sizes: the block-recursive products and K^-1 run on the bf16 matrix cores (post3.hip), which this form does not
   if (dtype == HBO_F32 && ntasks == 1 && max_nblk > c->opt_small_nblk && (c->opt_trtri_bf16x3 || c->opt_lauum_bf16x3)) return false;
   return true;
 }
+int sweep_group(int ntasks, int max_nblk) { return (ntasks == 1 && max_nblk > 28) ? 8 : 4; }
 void sweep_advance(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, int max_nblk, int cfin, hipStream_t st, SweepState& sw,
                    hipEvent_t w_done) {
   const int q = sw.qs;

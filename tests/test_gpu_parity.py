@@ -1152,6 +1152,31 @@ def test_one_sweep_inverse_across_the_registry_and_objectives(gpu_ctx, kname, ml
       gpu_ctx.set_option(k_, v_)
 
 
+@pytest.mark.parametrize('n', [2200, 3750])
+def test_one_matrix_in_the_size_range_where_the_sweep_is_the_default(gpu_ctx, n):
+  """One fp64 matrix of 17-48 blocks takes the one-sweep inverse by default (sched.hip:use_sweep; row groups of 4 blocks up to 28
+  blocks, of 8 above): against the oracle, and against the block-recursive inverse + W^T W (sweep = 0) to rounding."""
+  defs, _, _, _, kernel, mean, objectives, utils = _native()
+  rng = np.random.default_rng(n)
+  d = 3
+  model = helpers.make_model(rng, 'constant', False, d)
+  po, pn = _pair(model)
+  x, y = helpers.synthetic_task(rng, n, d)
+  vo, go = o.nll_value_and_grad(o.constant, o.squared_exponential, po, {0: o.SubDataset(x, y)}, WFO)
+  dsn = {0: defs.SubDataset(x, y)}
+  vn, gn = objectives.nll_value_and_grad(mean.constant, kernel.squared_exponential, pn, dsn, utils.DEFAULT_WARP_FUNC)
+  assert abs(vn - vo) <= 1e-10 * abs(vo)
+  fo, fn = helpers.flatten(go), helpers.flatten(gn)
+  assert np.max(np.abs(fo - fn)) <= 1e-8 * np.max(np.abs(fo))
+  try:
+    gpu_ctx.set_option('sweep', 0)
+    v0, g0 = objectives.nll_value_and_grad(mean.constant, kernel.squared_exponential, pn, dsn, utils.DEFAULT_WARP_FUNC)
+  finally:
+    gpu_ctx.set_option('sweep', 1)
+  assert v0 == vn                                    # the factorisation is the same
+  assert np.max(np.abs(helpers.flatten(g0) - fn)) <= 1e-12 * np.max(np.abs(fn))
+
+
 def test_divergence_fp32_and_no_aligned_data(gpu_ctx):
   defs, _, _, _, kernel, mean, objectives, utils = _native()
   rng = np.random.default_rng(14)
