@@ -37,6 +37,7 @@ extern "C" int hbo_ctx_create(int device, hbo_ctx** out) {
   hipError_t e = hipSetDevice(device);
   if (e == hipSuccess) e = hipStreamCreate(&c->stream);
   if (e == hipSuccess) e = hipStreamCreate(&c->stream2);
+  if (e == hipSuccess) e = hipStreamCreate(&c->stream3);
   if (e == hipSuccess) e = hipStreamCreate(&c->stream4);
   if (e == hipSuccess) e = hbo_malloc(c, (void**)&c->d_model, sizeof(ModelDev));
   if (e == hipSuccess) e = hbo_malloc(c, (void**)&c->d_yield, sizeof(int) * HBO_YIELD_TAB_ENTRIES);
@@ -77,6 +78,7 @@ extern "C" int hbo_ctx_destroy(hbo_ctx* c) {
   for (hipEvent_t ev : c->ev_pool) hipEventDestroy(ev);
   for (hipEvent_t ev : c->ev_timed) if (ev) hipEventDestroy(ev);
   if (c->stream4) hipStreamDestroy(c->stream4);
+  if (c->stream3) hipStreamDestroy(c->stream3);
   if (c->stream2) hipStreamDestroy(c->stream2);
   if (c->stream) hipStreamDestroy(c->stream);
   delete c;
@@ -109,7 +111,7 @@ extern "C" int hbo_tune(hbo_ctx* c, const char* name, int64_t value) {
   static const Knob knobs[] = {
       {"overlap_trtri", &hbo_ctx::opt_overlap_trtri, 0, 1}, {"cu_yield", &hbo_ctx::opt_cu_yield, 0, 2},
       {"persist_free", &hbo_ctx::opt_persist_free, -1, 200}, {"trtri_at", &hbo_ctx::opt_trtri_at, 0, 63},
-      {"trtri_free", &hbo_ctx::opt_trtri_free, 0, 200},
+      {"trtri_free", &hbo_ctx::opt_trtri_free, 0, 200}, {"split_f1", &hbo_ctx::opt_split_f1, 0, 2},
       {"sweep", &hbo_ctx::opt_sweep, 0, 2}, {"sweep_qs", &hbo_ctx::opt_sweep_qs, 0, 16}, {"sweep_big", &hbo_ctx::opt_sweep_big, 0, 1 << 30}, {"batch_bg", &hbo_ctx::opt_batch_bg, 0, 2},
       {"post_bf16x3", &hbo_ctx::opt_post_bf16x3, 0, 1}, {"syrk_bf16x3", &hbo_ctx::opt_syrk_bf16x3, 0, 1},
       {"trtri_bf16x3", &hbo_ctx::opt_trtri_bf16x3, 0, 1}, {"lauum_bf16x3", &hbo_ctx::opt_lauum_bf16x3, 0, 1}, {"trtri3_min_s", &hbo_ctx::opt_trtri3_min_s, 1, 1024},

@@ -18,6 +18,7 @@ struct hbo_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   hipStream_t stream2 = nullptr;   // panel stream of the look-ahead Cholesky (high priority)
+  hipStream_t stream3 = nullptr;   // the later block columns of F1 (run_potrf: split_f1), beside the next diagonal block's factorisation and solve
   hipStream_t stream4 = nullptr;   // early part of trtri, overlapped with the tail of potrf
   int opt_cu_yield = 2;      // background GEMM workgroups pause while a panel-chain workgroup runs on their CU (single matrix,
                              // look-ahead): 1 = potf2 only, 2 = trsm and the chain's column updates too
@@ -41,6 +42,8 @@ struct hbo_ctx {
   int opt_sweep_qs = 0;        // its row-group size in 128-blocks (power of two; 0: auto)
   int opt_batch_bg = 0;        // batches: the sweep's launches beside the panel chain are 0 plain grids, 1 persistent and slot-limited
                                // (tiles x tasks from one counter), 2 also yielding to the chain's kernels through the per-CU table
+  int opt_split_f1 = 1;        // panel chain: F1 updates only the next block column on the panel stream, the group's later columns on a third stream:
+                               // 0 never, 1 for batches (where it was measured faster), 2 always
   int opt_trtri_free = 48;   // CUs the inverse products that co-run with the panel chain leave free (0: one tile per workgroup)
   int* trtri_counters = nullptr; int trtri_counter_next = 0;   // run_potrf -> trtri_level: tile counters of those launches
   int n_cus = 256;

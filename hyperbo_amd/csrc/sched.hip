@@ -48,7 +48,10 @@ void run_potrf(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, int m
   hipStream_t sb = sm;   // bulk updates share the main stream (CU-masked queues were measured slower)
   size_t evi = 0;
   if (la) { hipEvent_t e = pool_event(c, evi++); hipEventRecord(e, sm); hipStreamWaitEvent(sp, e, 0); }
-  hipEvent_t ev_f1 = nullptr, ev_f2 = nullptr;
+  hipEvent_t ev_f1 = nullptr, ev_f2 = nullptr, ev_f1b = nullptr;
+  // (measured: batches gain -- 64 tasks 14.32 -> 14.12 ms, the 8-task shard 2.60 -> 2.53; one matrix does not -- N = 8192
+  //  factorisation 5.35 -> 5.41, N = 4096 2.63 -> 2.68: the two cross-stream hops cost what the shorter launch saves)
+  const bool split_f1 = use_lookahead(c, ntasks, max_nblk) && c->stream3 && (c->opt_split_f1 >= 2 || (c->opt_split_f1 == 1 && ntasks > 1));
   // early inverse: a batch takes every piece as soon as four more panels are final (16.9 against 17.35 ms for 64 tasks
   // of ~2000 points, 3.77 against 3.92 for 8); one large matrix only at half time -- more launches on the side stream
   // take slots from the panel chain (N = 8192: 13.63 ms at 32 panels, 13.8 at 4, 14.0 at 2)
@@ -110,6 +113,7 @@ void run_potrf(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, int m
         a.yield_mark = chain_mark;
         launch_syrk3(a, tiles_of(p, p + 1), ntasks, sp);
       } else if (p > g0) {  // left-looking update of block column p with the group's earlier panels
+        if (ev_f1b) { hipStreamWaitEvent(sp, ev_f1b, 0); ev_f1b = nullptr; }   // (the previous group's contribution to this column)
         ProfScope ps(c, "syrk_col", 2, sp);
         GemmArgs a = {}; a.tasks = d_tasks; a.mode = GEMM_SYRK; a.p0 = g0; a.kt = p - g0; a.c_lo = p; a.c_hi = p + 1; a.aug = 1; a.small_tiles = 1;
         a.yield_mark = chain_mark;
@@ -160,6 +164,7 @@ void run_potrf(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, int m
         a.yield_flag = (la && chain_mark) ? nullptr : yield_flag;
         a.yield_mark = la ? chain_mark : nullptr;
         if (s1 == sp && ev_f2) hipStreamWaitEvent(sp, ev_f2, 0);
+        if (ev_f1b) { hipStreamWaitEvent(sp, ev_f1b, 0); ev_f1b = nullptr; }   // (a group of one panel never waited for it)
         ProfScope ps(c, "syrk_trailing", 1, s1);
         a.c_lo = g1; a.c_hi = la ? g2 : max_nblk;
         if (use_s3) {
@@ -167,6 +172,18 @@ void run_potrf(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, int m
           b.yield_mark = a.yield_mark; b.yield_flag = a.yield_flag;
           launch_syrk3(b, tiles_of(b.c_lo, b.c_hi), ntasks, s1);
         } else {
+        if (split_f1 && s1 == sp && a.c_hi - a.c_lo > 1) {
+          // only the NEXT block column is on the critical path (potf2 and the solve of panel g1 read nothing else): the group's later
+          // columns go to a third stream and are waited for by the first column update that touches them
+          hipEvent_t e = pool_event(c, evi++);
+          hipEventRecord(e, sp); hipStreamWaitEvent(c->stream3, e, 0);
+          GemmArgs b = a; b.c_lo = a.c_lo + 1;
+          b.small_tiles = (int64_t)(max_nblk + 1 - b.c_lo) * (b.c_hi - b.c_lo) * ntasks < 600;
+          launch_gemm(dtype, b, dim3(max_nblk + 1 - b.c_lo, b.c_hi - b.c_lo, ntasks), c->stream3);
+          ev_f1b = pool_event(c, evi++);
+          hipEventRecord(ev_f1b, c->stream3);
+          a.c_hi = a.c_lo + 1;
+        }
         // few tiles (one group's block columns, or a small remainder): 64x64 tiles for latency
         a.small_tiles = (int64_t)(max_nblk + 1 - a.c_lo) * (a.c_hi - a.c_lo) * ntasks < 600;
         launch_gemm(dtype, a, dim3(max_nblk + 1 - a.c_lo, a.c_hi - a.c_lo, ntasks), s1);
@@ -224,6 +241,7 @@ void run_potrf(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, int m
   }
   c->gemm_yield = nullptr;
   c->trtri_counters = nullptr;
+  if (ev_f1b) { hipStreamWaitEvent(sp, ev_f1b, 0); ev_f1b = nullptr; }
   if (la) { hipEvent_t e = pool_event(c, evi++); hipEventRecord(e, sp); hipStreamWaitEvent(sm, e, 0); }   // join
   if (early || sweep) {   // the rest of the inverse (main stream) needs the early part
     hipEvent_t e = pool_event(c, evi++);

@@ -1,7 +1,7 @@
 /* hbo_tune.h -- measurement hooks of libhbo.  NOT part of the drop-in boundary (include/hbo.h): nothing a caller of the
  * hyperbo.gp_utils surface needs.  The A/B tools under tools/ and the scheduling sweep of tests/test_gpu_fuzz.py use it to
  * vary where and when the same kernels run; no knob changes a result, and every non-default value was measured equal or worse
- * (profiles/r01_potrf_chain.md, r02_potrf_chain.md, r03_dag.md).  Names fall through to hbo_set_option.
+ * (profiles/r01_potrf_chain.md, r02_potrf_chain.md, r03_dag.md, r04_chain_and_sweep.md, r04_gemm_pipeline.md).  Names fall through to hbo_set_option.
  *
  *   overlap_trtri 0/1      inverse walks the block tree while the factorisation runs
  *   cu_yield      0..2     background GEMM workgroups pause while a panel-chain workgroup runs on their CU (1: potf2 only)
@@ -13,8 +13,11 @@
  *   syrk3_col / syrk3_sep / syrk3_free       fp32 trailing updates: column updates on the bf16 cores too / panels split by
  *                          their own kernel instead of inside the panel solve / CUs the bulk update leaves with one workgroup
  *   sweep         0..2     one-sweep inverse (W = L^-1 and K^-1 = W^T W row group by row group behind the panel chain): 0 never,
- *                          1 batches with look-ahead (default; profiles/r04_chain_and_sweep.md), 2 wherever look-ahead is on
- *   sweep_qs      0..16    its row-group size in 128-blocks, a power of two (0 = auto: 4)
+ *                          1 where measured faster (default: batches with look-ahead, one fp64 matrix of 17-48 blocks;
+ *                          profiles/r04_chain_and_sweep.md, r04_gemm_pipeline.md), 2 wherever look-ahead is on
+ *   sweep_qs      0..16    its row-group size in 128-blocks, a power of two (0 = auto: 4; 8 for one matrix above 28 blocks)
+ *   split_f1      0..2     the update of the next group's block columns (F1): only the next column on the panel stream, the later
+ *                          ones on a third stream -- 0 never, 1 batches (default: 64 tasks 14.32 -> 14.12 ms), 2 always
  *   sweep_big     >=0      sweep launches of small / batched shapes with at least this many 128-tiles (x tasks) use 128-tiles (4000)
  *   batch_bg      0..2     batches: the sweep's launches beside the chain as plain grids (0, default), persistent over tiles x tasks
  *                          from one counter (1), and also polling the per-CU yield table the chain's kernels then fill (2) */
