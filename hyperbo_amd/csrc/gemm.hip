@@ -542,7 +542,7 @@ __device__ __forceinline__ void gemm_tile2(const TileJob<T>& job, unsigned char*
   constexpr int KK = BKE / 4;            // MFMA k steps per slab
   constexpr int MI = TM / 32;
   constexpr int WT = TM / 2;
-  static_assert(MI == 4 && KK == 4, "the interleave below is written for the fp64 128-tile: 16 MFMAs, 8 fragments, 8 pieces per k step");
+  static_assert(MI == 4 && KK >= 4 && KK % 2 == 0, "the interleave below is written for the 128-tile: 16 MFMAs and 8 fragments per k step, 8 pieces per slab");
   T* sA = reinterpret_cast<T*>(smem);
   T* sB = reinterpret_cast<T*>(smem + OPERAND_BYTES);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -630,13 +630,13 @@ __device__ __forceinline__ void gemm_tile2(const TileJob<T>& job, unsigned char*
     }
     // the registers hold slab kt + 1; what refills them is slab kt + 2 (the last slab again when there is none: no branch in here)
     if (kt + 2 < nk) { slabA += stepA; slabB += stepB; }
-    step_reads(0, 1, 1);
-    step_reads(1, 0, 2);
-    // k step 2: the last fragments of the slab, the first barrier, then the first four pieces
+#pragma unroll
+    for (int kk = 0; kk < KK - 2; ++kk) step_reads(kk & 1, (kk + 1) & 1, kk + 1);
+    // the last k step but one: the last fragments of the slab, the first barrier, then the first four pieces
 #pragma unroll
     for (int i = 0; i < 7; ++i) {
       mma(0, i);
-      if (i < 4) { HBO_SB(); frag(1, 3, 2 * i); frag(1, 3, 2 * i + 1); HBO_SB(); }
+      if (i < 4) { HBO_SB(); frag(1, KK - 1, 2 * i); frag(1, KK - 1, 2 * i + 1); HBO_SB(); }
     }
     HBO_SB(); __syncthreads(); HBO_SB();                      // every wave has read the slab's last fragments
     mma(0, 7);
@@ -647,7 +647,7 @@ __device__ __forceinline__ void gemm_tile2(const TileJob<T>& job, unsigned char*
     for (int j = 0; j < 4; ++j) {
       HBO_SB(); piece_out(j); HBO_SB(); mma(0, 8 + 2 * j); HBO_SB(); piece_in(j); HBO_SB(); mma(0, 9 + 2 * j);
     }
-    // k step 3: the other four pieces, the second barrier, the next slab's first fragments
+    // the last k step: the other four pieces, the second barrier, the next slab's first fragments
 #pragma unroll
     for (int j = 4; j < 8; ++j) {
       HBO_SB(); piece_out(j); HBO_SB(); mma(1, 2 * (j - 4)); HBO_SB(); piece_in(j); HBO_SB(); mma(1, 2 * (j - 4) + 1);
@@ -670,9 +670,8 @@ __device__ __forceinline__ void gemm_tile2(const TileJob<T>& job, unsigned char*
     HBO_SB();
   }
   // the last slab
-  step_reads(0, 1, 1);
-  step_reads(1, 0, 2);
-  step_reads(0, 1, 3);
+#pragma unroll
+  for (int kk = 0; kk < KK - 1; ++kk) step_reads(kk & 1, (kk + 1) & 1, kk + 1);
 #pragma unroll
   for (int i = 0; i < 16; ++i) mma(1, i);
 #undef HBO_SB
@@ -736,7 +735,7 @@ __device__ __forceinline__ void gemm_tile3(const TileJob<T>& job, unsigned char*
   constexpr int KK = BKE / 4;
   constexpr int MI = TM / 32;
   constexpr int WT = TM / 2;
-  static_assert(MI == 2 && KK == 4, "written for the fp64 64-tile: 4 MFMAs and 4 fragments per k step, 4 pieces per slab");
+  static_assert(MI == 2 && KK >= 4 && KK % 2 == 0, "written for the 64-tile: 4 MFMAs and 4 fragments per k step, 4 pieces per slab");
   T* sA = reinterpret_cast<T*>(smem);
   T* sB = reinterpret_cast<T*>(smem + OPERAND_BYTES_64);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -820,9 +819,9 @@ __device__ __forceinline__ void gemm_tile3(const TileJob<T>& job, unsigned char*
             __builtin_amdgcn_s_sleep(16);
         ypoll = __hip_atomic_load(yslot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
-      step(0, 1, 1);
-      step(1, 0, 2);
-      mma(0, 0); HBO_SB(); frags(1, 3); HBO_SB(); mma(0, 1);
+#pragma unroll
+      for (int kk = 0; kk < KK - 2; ++kk) step(kk & 1, (kk + 1) & 1, kk + 1);
+      mma(0, 0); HBO_SB(); frags(1, KK - 1); HBO_SB(); mma(0, 1);
       HBO_SB(); __syncthreads(); HBO_SB();          // every wave has read the slab's last fragments
       mma(0, 2); HBO_SB(); to_lds(set); HBO_SB(); mma(0, 3);
       if (s + 1 + PF < nk) fetch(set);
@@ -831,9 +830,8 @@ __device__ __forceinline__ void gemm_tile3(const TileJob<T>& job, unsigned char*
       mma(1, 2); HBO_SB(); frags(0, 0); HBO_SB(); mma(1, 3);
     }
   }
-  step(0, 1, 1);
-  step(1, 0, 2);
-  step(0, 1, 3);
+#pragma unroll
+  for (int kk = 0; kk < KK - 1; ++kk) step(kk & 1, (kk + 1) & 1, kk + 1);
   mma(1, 0); mma(1, 1); mma(1, 2); mma(1, 3);
 #undef HBO_SB
 
@@ -850,13 +848,18 @@ __device__ __forceinline__ void gemm_tile3(const TileJob<T>& job, unsigned char*
         }
   }
 }
-// which core a tile takes: the pipelined ones for fp64 (128-tile: gemm_tile2, 64-tile: gemm_tile3), the original for fp32
+// which core a tile takes: the pipelined ones (128-tile: gemm_tile2, 64-tile: gemm_tile3; fp32 has 8 k steps per slab where fp64
+// has 4, everything else is the same); gemm_tile stays for the A/B builds (-DHBO_GEMM_V1, -DHBO_GEMM_F32_V1, -DHBO_GEMM_NO64)
 template <typename T, bool AKC, bool BKC, int TM>
 __device__ __forceinline__ void run_tile(const TileJob<T>& job, unsigned char* smem) {
 #ifndef HBO_GEMM_V1
-  if constexpr (sizeof(T) == 8 && TM == 128) gemm_tile2<T, AKC, BKC, TM>(job, smem);
+#ifdef HBO_GEMM_F32_V1
+  if constexpr (sizeof(T) == 4) gemm_tile<T, AKC, BKC, TM>(job, smem);
+  else
+#endif
+  if constexpr (TM == 128) gemm_tile2<T, AKC, BKC, TM>(job, smem);
 #ifndef HBO_GEMM_NO64
-  else if constexpr (sizeof(T) == 8 && TM == 64) gemm_tile3<T, AKC, BKC, TM, HBO_PF64>(job, smem);
+  else if constexpr (TM == 64) gemm_tile3<T, AKC, BKC, TM, HBO_PF64>(job, smem);
 #endif
   else
 #endif
@@ -992,11 +995,15 @@ void launch_gemm_t(const GemmArgs& a_in, dim3 grid, hipStream_t st) {
   if (a.mode != GEMM_SYRK && !((a.mode == GEMM_TRTRI_A || a.mode == GEMM_TRTRI_B) && a.work_counter && grid.z == 1) && !(sweep_mode && a.work_counter))
     a.persistent = 0;
   a.ptasks = 0;
-  // dynamic LDS of a 128-tile workgroup: one stage per operand for the pipelined fp64 core, two for gemm_tile
+  // dynamic LDS of a 128-tile workgroup: one stage per operand for the pipelined cores, two for gemm_tile
 #ifdef HBO_GEMM_V1
   int lds128 = GEMM_LDS_BYTES;
 #else
+#ifdef HBO_GEMM_F32_V1
   int lds128 = sizeof(T) == 8 ? 2 * OPERAND_BYTES : GEMM_LDS_BYTES;
+#else
+  int lds128 = 2 * OPERAND_BYTES;
+#endif
 #endif
   // 64-tiles keep the two-stage request although gemm_tile3 uses one: measured equal or better (N = 4096: 2.76 against 2.81 ms with
   // 20 KB, profiles/r04_gemm_pipeline.md); the persistent update runs its last round on 64-tiles inside the 128-tile kernel (n_big)
