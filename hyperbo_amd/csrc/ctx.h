@@ -39,6 +39,7 @@ struct hbo_ctx {
   int opt_trtri_at = 0;        // single matrix: panel count (in 64ths of the block count) after which the inverse starts beside the chain (0: 5/8)
   int opt_sweep = 1;           // one-sweep inverse (sched.hip:sweep_advance): 0 never, 1 where measured faster (use_sweep), 2 wherever look-ahead is on
   int opt_sweep_big = 4000;    // a sweep launch of a small / batched shape with at least this many 128-tiles (x tasks) runs on 128-tiles
+  int opt_sweep_side = 1;      // one matrix on 128-tiles: the sweep's K^-1 updates (d) on a stream of their own beside its (a) (b) (c) chain
   int opt_sweep_qs = 0;        // its row-group size in 128-blocks (power of two; 0: auto)
   int opt_batch_bg = 0;        // batches: the sweep's launches beside the panel chain are 0 plain grids, 1 persistent and slot-limited
                                // (tiles x tasks from one counter), 2 also yielding to the chain's kernels through the per-CU table
@@ -48,6 +49,7 @@ struct hbo_ctx {
   int* trtri_counters = nullptr; int trtri_counter_next = 0;   // run_potrf -> trtri_level: tile counters of those launches
   int n_cus = 256;
   std::vector<hipEvent_t> ev_pool;
+  std::vector<hipEvent_t> ev_pool_sweep;   // sweep_advance's own events (its calls interleave with run_potrf's use of ev_pool)
   hipEvent_t ev_timed[3] = {nullptr, nullptr, nullptr};   // hbo_objective_sharded: start / local shard done / all-reduce done
   std::map<int, std::pair<void*, size_t>> ws;   // grow-only device scratch buffers by slot (no per-call hipMalloc/hipFree)
   // Device buffers of freed datasets / caches, kept for the next one of the same shape (dev_alloc / dev_free in api.hip):

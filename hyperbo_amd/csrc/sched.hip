@@ -398,6 +398,15 @@ bool use_sweep(const hbo_ctx* c, int dtype, int ntasks, int max_nblk) {
   return true;
 }
 int sweep_group(int ntasks, int max_nblk) { return (ntasks == 1 && max_nblk > 28) ? 8 : 4; }
+static hipEvent_t sweep_event(hbo_ctx* c, SweepState& sw) {
+  const size_t i = (size_t)sw.nev++;
+  while (c->ev_pool_sweep.size() <= i) {
+    hipEvent_t ev;
+    hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+    c->ev_pool_sweep.push_back(ev);
+  }
+  return c->ev_pool_sweep[i];
+}
 void sweep_advance(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, int max_nblk, int cfin, hipStream_t st, SweepState& sw,
                    hipEvent_t w_done) {
   const int q = sw.qs;
@@ -418,6 +427,11 @@ void sweep_advance(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, i
       a.persistent = pblocks; a.work_counter = c->trtri_counters + c->trtri_counter_next++;
     }
   };
+  // (d) has no successor but the next group's (d) and the final consumers of K^-1: on a stream of its own it runs beside the
+  // (a) -> (b) -> (c) chain of the following groups instead of holding it up.  Measured (ms, same stream / own stream): one matrix on
+  // 128-tiles N = 5120 4.26 / 4.15, 6144 6.07 / 5.71, 7168 8.39 / 7.96, 8192 11.44 / 10.97; on 64-tiles N = 2560 1.43 / 1.48,
+  // 4096 2.65 / 2.79; batches 14.11 / 14.48 (64 tasks), 2.57 / 2.74 (8): where the launches are small the extra hop costs more
+  hipStream_t sd = (c->opt_sweep_side && c->stream3 && ntasks == 1 && max_nblk > c->opt_small_nblk) ? c->stream3 : st;
   while (sw.done < max_nblk) {
     const int b0 = sw.done, b1 = std::min(b0 + q, max_nblk);
     if (b1 > cfin) break;
@@ -430,6 +444,7 @@ void sweep_advance(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, i
       launch_gemm(dtype, a, dim3(b0, b1 - b0, ntasks), st);
     }
     if (b1 == max_nblk && w_done) hipEventRecord(w_done, st);
+    if (sd != st) { hipEvent_t e = sweep_event(c, sw); hipEventRecord(e, st); hipStreamWaitEvent(sd, e, 0); }   // W[R, <=R] is final
     if (b1 < max_nblk) {                                                                             // (c)
       ProfScope ps(c, "sweep_t", 2, st);
       pick((int64_t)(max_nblk - b1) * b1); a.small_tiles = small;
@@ -437,12 +452,13 @@ void sweep_advance(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, i
       launch_gemm(dtype, a, dim3(max_nblk - b1, b1, ntasks), st);
     }
     {                                                                                                // (d)
-      ProfScope ps(c, "sweep_c", 2, st);
+      ProfScope ps(c, "sweep_c", 2, sd);
       pick((int64_t)b1 * (b1 + 1) / 2); a.small_tiles = small;
       a.mode = GEMM_SWEEP_C; place(a, small ? 2 * (int64_t)b1 * (b1 + 1) : (int64_t)b1 * (b1 + 1) / 2);
-      launch_gemm(dtype, a, dim3(b1, 1, ntasks), st);
+      launch_gemm(dtype, a, dim3(b1, 1, ntasks), sd);
     }
     sw.done = b1;
+    if (b1 == max_nblk && sd != st) { hipEvent_t e = sweep_event(c, sw); hipEventRecord(e, sd); hipStreamWaitEvent(st, e, 0); }   // K^-1 is complete
   }
 }
 void run_trtri(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, int max_nblk, TrtriProgress* pg) {
