@@ -640,9 +640,6 @@ __device__ __forceinline__ void gemm_tile2(const TileJob<T>& job, unsigned char*
     }
     HBO_SB(); __syncthreads(); HBO_SB();                      // every wave has read the slab's last fragments
     mma(0, 7);
-#ifdef HBO_GEMM_PRIO
-    __builtin_amdgcn_s_setprio(3);
-#endif
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       HBO_SB(); piece_out(j); HBO_SB(); mma(0, 8 + 2 * j); HBO_SB(); piece_in(j); HBO_SB(); mma(0, 9 + 2 * j);
@@ -653,20 +650,11 @@ __device__ __forceinline__ void gemm_tile2(const TileJob<T>& job, unsigned char*
       HBO_SB(); piece_out(j); HBO_SB(); mma(1, 2 * (j - 4)); HBO_SB(); piece_in(j); HBO_SB(); mma(1, 2 * (j - 4) + 1);
     }
     mma(1, 8); mma(1, 9);
-#ifdef HBO_GEMM_PRIO
-    __builtin_amdgcn_s_setprio(0);
-#endif
     HBO_SB(); __syncthreads(); HBO_SB();                      // the new slab is in LDS
     mma(1, 10);
-#ifdef HBO_GEMM_PRIO
-    __builtin_amdgcn_s_setprio(3);
-#endif
 #pragma unroll
     for (int i = 0; i < 4; ++i) { HBO_SB(); frag(0, 0, 2 * i); frag(0, 0, 2 * i + 1); HBO_SB(); mma(1, 11 + i); }
     mma(1, 15);
-#ifdef HBO_GEMM_PRIO
-    __builtin_amdgcn_s_setprio(0);
-#endif
     HBO_SB();
   }
   // the last slab
@@ -715,12 +703,11 @@ __device__ __forceinline__ void gemm_tile2(const TileJob<T>& job, unsigned char*
     }
   }
 }
-// ---- the 64-tile core with a deep global prefetch (round 4) ------------------------------------------------------------------
-// A 64 x 64 tile has 16 MFMAs per wave and slab (0.43 us at one wave per SIMD); gemm_tile prefetches ONE slab ahead, so a lone
-// workgroup -- the column updates of the panel chain launch one or two rounds of tiles with K = 128..384 -- spends a global-load
-// latency (~2 us) per slab: 8-24 slabs in sequence.  This core keeps PF slabs in flight in a ring of register sets (16 VGPRs per
-// slab and thread), one LDS stage as in gemm_tile2 (two barriers per slab, fragment reads of the next k step beside the MFMAs of
-// the current one), and the same ascending-k arithmetic: identical results.
+// ---- the 64-tile core (round 4) ------------------------------------------------------------------------------------------------
+// The single-stage scheme of gemm_tile2 for the 64 x 64 tile: 4 MFMAs and 4 fragment reads per wave and k step, two barriers per
+// slab, fragment reads of the next k step beside the MFMAs of the current one, and a ring of PF slabs prefetched into registers
+// (16 VGPRs per slab and thread).  PF = 2: a lone workgroup's slabs come from L2 at ~1 us each, a deeper ring buys nothing and
+// costs the fourth workgroup per CU (profiles/r04_gemm_pipeline.md, section 4).  Same ascending-k arithmetic: identical results.
 #ifndef HBO_PF64
 #define HBO_PF64 2
 #endif
