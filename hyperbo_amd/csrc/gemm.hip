@@ -979,7 +979,8 @@ void launch_gemm_t(const GemmArgs& a_in, dim3 grid, hipStream_t st) {
   GemmArgs a = a_in;
   // the persistent forms: SYRK (any tile size); TRTRI of a single matrix and the SWEEP modes (also over a batch) with a tile counter
   const bool sweep_mode = a.mode == GEMM_SWEEP_B || a.mode == GEMM_SWEEP_T || a.mode == GEMM_SWEEP_C;
-  if (a.mode != GEMM_SYRK && !((a.mode == GEMM_TRTRI_A || a.mode == GEMM_TRTRI_B) && a.work_counter && grid.z == 1) && !(sweep_mode && a.work_counter))
+  if (a.mode != GEMM_SYRK && !((a.mode == GEMM_TRTRI_A || a.mode == GEMM_TRTRI_B) && a.work_counter && grid.z == 1) && !(sweep_mode && a.work_counter) &&
+      !(a.mode == GEMM_LAUUM && a.work_counter && grid.z == 1 && !a.small_tiles))
     a.persistent = 0;
   a.ptasks = 0;
   // dynamic LDS of a 128-tile workgroup: one stage per operand for the pipelined cores, two for gemm_tile
@@ -1075,6 +1076,15 @@ void launch_gemm_t(const GemmArgs& a_in, dim3 grid, hipStream_t st) {
       hipLaunchKernelGGL((gemm_kernel<T, true, false, 128>), grid, dim3(256), lds128, st, a);
       break;
     case GEMM_VTV:
+#ifdef HBO_GEMM_DEBUG
+      {
+        // HBO_BENCH_VTV_KC=1 / 2: the same square launch through the <true,false> / <true,true> cores (operands read as k-contiguous
+        // rows of the same buffer: meaningless numbers, the loop's rate for those LDS layouts)
+        static const int kc = getenv("HBO_BENCH_VTV_KC") ? atoi(getenv("HBO_BENCH_VTV_KC")) : 0;
+        if (kc == 1) { hipLaunchKernelGGL((gemm_kernel<T, true, false, 128>), grid, dim3(256), lds128, st, a); break; }
+        if (kc == 2) { hipLaunchKernelGGL((gemm_kernel<T, true, true, 128>), grid, dim3(256), lds128, st, a); break; }
+      }
+#endif
       hipLaunchKernelGGL((gemm_kernel<T, false, false, 128>), grid, dim3(256), lds128, st, a);
       break;
     case GEMM_LAUUM:
@@ -1084,6 +1094,13 @@ void launch_gemm_t(const GemmArgs& a_in, dim3 grid, hipStream_t st) {
       } else {
         // 1-D grid over the lower tiles (grid.x = block count of the largest task)
         dim3 g1(grid.x * (grid.x + 1) / 2, 1, grid.z);
+        if (a.persistent > 0) {
+          // the same tiles in the same order, drawn from a counter by a resident grid: the hardware deals the workgroups of a
+          // plain grid to the 8 XCDs in turn and waits when the next one's XCD is full -- with tiles of 1 to 64 K blocks a tenth
+          // of the slots stood empty in the middle of the launch (in-kernel stamps: 459 of 512 busy on average)
+          GemmArgs b = a; b.pgx = (int)g1.x; b.pgy = 1;
+          hipLaunchKernelGGL((gemm_kernel<T, false, false, 128>), dim3(a.persistent, 1, 1), dim3(256), lds128, st, b);
+        } else
         hipLaunchKernelGGL((gemm_kernel<T, false, false, 128>), g1, dim3(256), lds128, st, a);
       }
       break;

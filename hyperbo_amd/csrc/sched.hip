@@ -277,7 +277,7 @@ static bool trtri_level3(hbo_ctx* c, const TaskDesc* d_tasks, const TaskDesc& h,
   auto launch = [&](int mode) {
     g.mode = mode; g.persistent = 0; g.work_counter = nullptr;
     g.yield_flag = (st == c->stream4) ? c->gemm_yield : nullptr;
-    if (corun && ntiles > pblocks && c->trtri_counter_next < HBO_N_COUNTERS - HBO_N_BULK_COUNTERS) { g.persistent = pblocks; g.work_counter = c->trtri_counters + c->trtri_counter_next++; }
+    if (corun && ntiles > pblocks && c->trtri_counter_next < HBO_N_COUNTERS - HBO_N_BULK_COUNTERS - 1) { g.persistent = pblocks; g.work_counter = c->trtri_counters + c->trtri_counter_next++; }
     launch_syrk3(g, ntiles, 1, st);
   };
   ProfScope ps(c, "trtri_gemm", 2, st);
@@ -332,7 +332,7 @@ static void trtri_level(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntas
   a.c_hi = grp_hi - 1; a.c_lo = std::max(vlast, 0);   // TRTRI_A: last group and its launched tile rows
   auto persist = [&](int64_t tiles) {
     a.persistent = 0; a.work_counter = nullptr;
-    if (corun && tiles > pblocks && c->trtri_counter_next < HBO_N_COUNTERS - HBO_N_BULK_COUNTERS) { a.persistent = pblocks; a.work_counter = c->trtri_counters + c->trtri_counter_next++; }
+    if (corun && tiles > pblocks && c->trtri_counter_next < HBO_N_COUNTERS - HBO_N_BULK_COUNTERS - 1) { a.persistent = pblocks; a.work_counter = c->trtri_counters + c->trtri_counter_next++; }
   };
   if (do_a && xa > 0) { a.mode = GEMM_TRTRI_A; persist((int64_t)xa * s * tmul); launch_gemm(dtype, a, dim3(xa, s, ntasks), st); }
   if (do_b) {
@@ -423,7 +423,7 @@ void sweep_advance(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, i
   auto place = [&](GemmArgs& a, int64_t tiles) {
     a.persistent = 0; a.work_counter = nullptr;
     a.yield_flag = (st == c->stream4) ? c->gemm_yield : nullptr;
-    if (corun && tiles * ntasks > pblocks && c->trtri_counter_next < HBO_N_COUNTERS - HBO_N_BULK_COUNTERS) {
+    if (corun && tiles * ntasks > pblocks && c->trtri_counter_next < HBO_N_COUNTERS - HBO_N_BULK_COUNTERS - 1) {
       a.persistent = pblocks; a.work_counter = c->trtri_counters + c->trtri_counter_next++;
     }
   };
@@ -487,5 +487,15 @@ void run_lauum(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, int m
   }
   GemmArgs a = {}; a.tasks = d_tasks; a.mode = GEMM_LAUUM;
   a.small_tiles = max_nblk <= c->opt_small_nblk;
-  launch_gemm(dtype, a, dim3(max_nblk, max_nblk, ntasks), st ? st : c->stream);
+  hipStream_t s = st ? st : c->stream;
+  if (ntasks == 1 && !a.small_tiles && c->opt_lauum_persist && max_nblk * (max_nblk + 1) / 2 > 4 * c->n_cus) {
+    // one large matrix: a resident grid of two workgroups per CU draws the tiles from a counter (gemm.hip: launch_gemm_t)
+    int* counters = (int*)ws_get(c, WS_COUNTERS, sizeof(int) * HBO_N_COUNTERS);
+    if (counters) {
+      a.work_counter = counters + HBO_N_COUNTERS - 1;   // the last one: never handed out by run_potrf (bulk updates / inverse products)
+      hipMemsetAsync(a.work_counter, 0, sizeof(int), s);
+      a.persistent = 2 * c->n_cus;
+    }
+  }
+  launch_gemm(dtype, a, dim3(max_nblk, max_nblk, ntasks), s);
 }
