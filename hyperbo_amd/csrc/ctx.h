@@ -45,7 +45,8 @@ struct hbo_ctx {
                                // (tiles x tasks from one counter), 2 also yielding to the chain's kernels through the per-CU table
   int opt_split_f1 = 1;        // panel chain: F1 updates only the next block column on the panel stream, the group's later columns on a third stream:
                                // 0 never, 1 for batches (where it was measured faster), 2 always
-  int opt_lauum_persist = 1;   // one large matrix: K^-1 = W^T W as a resident grid drawing its tiles from a counter (0: plain grid)
+  int opt_lauum_persist = 1;   // one large matrix: K^-1 = W^T W as a resident grid drawing its tiles from a counter (0: plain grid; 1: two workgroups
+                               // on all but 16 CUs; n > 1: on all but n CUs)
   int opt_trtri_free = 48;   // CUs the inverse products that co-run with the panel chain leave free (0: one tile per workgroup)
   int* trtri_counters = nullptr; int trtri_counter_next = 0;   // run_potrf -> trtri_level: tile counters of those launches
   int n_cus = 256;

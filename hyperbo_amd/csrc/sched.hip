@@ -494,7 +494,9 @@ void run_lauum(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, int m
     if (counters) {
       a.work_counter = counters + HBO_N_COUNTERS - 1;   // the last one: never handed out by run_potrf (bulk updates / inverse products)
       hipMemsetAsync(a.work_counter, 0, sizeof(int), s);
-      a.persistent = 2 * c->n_cus;
+      // (16 CUs stay free for alpha = W^T z and d nll / d mu, which run beside this launch on the panel stream: isolated the
+      //  launch takes the same time with 480 as with 512 workgroups)
+      a.persistent = 2 * (c->n_cus - (c->opt_lauum_persist > 1 ? c->opt_lauum_persist : 16));
     }
   }
   launch_gemm(dtype, a, dim3(max_nblk, max_nblk, ntasks), s);
