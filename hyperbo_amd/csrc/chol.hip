@@ -6,6 +6,7 @@
 //                   With IDENT=true the same code produces W_pp = L_pp^-1 (trtri base case).
 // Replaces what jax.scipy.linalg.cholesky lowers to (hyperbo/basics/linalg.py:31,134).
 #include "hbo_internal.h"
+#include <type_traits>
 #include <limits.h>
 #include <string.h>
 
@@ -188,6 +189,13 @@ __device__ int hbo_dbg_trsm_panel = 36;
 #else
 #define STAMP(i) do {} while (0)
 #endif
+// workgroup of potf2: eight waves (two per SIMD) -- wave 0 owns the leaf chain, seven share the solves and the trailing tiles
+// (with four, the first two steps of a full block ended 3600 / 2100 cycles after wave 0's leaf; chol_bench)
+#ifndef HBO_POTF2_WAVES
+#define HBO_POTF2_WAVES 8
+#endif
+constexpr int POTF2_WAVES = HBO_POTF2_WAVES;
+constexpr int POTF2_THREADS = 64 * POTF2_WAVES;
 template <typename T>
 __device__ __forceinline__ void potf2_body(const TaskDesc& t, int p, int* info_slot, unsigned char* smem) {
   typedef typename Mma<T>::acc_t acc_t;
@@ -199,7 +207,7 @@ __device__ __forceinline__ void potf2_body(const TaskDesc& t, int p, int* info_s
   T* Wb = static_cast<T*>(t.W) + (int64_t)p * NB * ld + (int64_t)p * NB;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, lq = lane >> 4;
-  const int ei = tid >> 4, ej = tid & 15;    // element of a tile owned by this thread for I/O
+  const int ei = (tid & 255) >> 4, ej = tid & 15;    // element of a tile owned by this thread for I/O
   STAMP(0);
 #ifdef HBO_POTF2_TIMING
   if (tid == 0 && blockIdx.x == 0 && p < 256) {
@@ -209,21 +217,30 @@ __device__ __forceinline__ void potf2_body(const TaskDesc& t, int p, int* info_s
   }
 #endif
 
-  // load: one element of every lower tile per thread; diagonal tiles are mirrored to full symmetry
-  {
-    T v[36];
+  // load: one element of every lower tile of this thread's share of the 36 (256-thread group `sh` takes the tiles == sh mod NSH;
+  // the share is a compile-time parameter of the loop body: a run-time test per tile serialised the 36 loads, 21 000 cycles
+  // instead of 6 000); diagonal tiles are mirrored to full symmetry
+  constexpr int NSH = POTF2_THREADS / 256;
+  const int sh = __builtin_amdgcn_readfirstlane(tid >> 8);
+  auto load_share = [&](auto share) {
+    constexpr int SH = decltype(share)::value;
+    T v[36 / NSH];
     int tile = 0;
 #pragma unroll
     for (int I = 0; I < 8; ++I)
 #pragma unroll
       for (int J = 0; J <= I; ++J, ++tile) {
+        if (tile % NSH != SH) continue;
         int r = ei, c = ej;
         if (I == J && ej > ei) { r = ej; c = ei; }
-        v[tile] = gld(Ab + (int64_t)(I * 16 + r) * ld + J * 16 + c);
+        v[tile / NSH] = gld(Ab + (int64_t)(I * 16 + r) * ld + J * 16 + c);
       }
 #pragma unroll
-    for (int k = 0; k < 36; ++k) sT[k * TILE_ELEMS + ei * TS + ej] = v[k];
-  }
+    for (int k = 0; k < 36 / NSH; ++k) sT[(k * NSH + SH) * TILE_ELEMS + ei * TS + ej] = v[k];
+  };
+  if (NSH == 1 || sh == 0) load_share(std::integral_constant<int, 0>());
+  else load_share(std::integral_constant<int, NSH - 1>());
+  static_assert(NSH == 1 || NSH == 2, "one or two 256-thread groups");
   __syncthreads();
 
   auto factor_leaf = [&](int jb) {   // wave 0 only
@@ -284,7 +301,7 @@ __device__ __forceinline__ void potf2_body(const TaskDesc& t, int p, int* info_s
   {
     const int64_t rows = (int64_t)t.n - (int64_t)p * NB;
     if (rows < NB) nleaf = rows <= 0 ? 0 : (int)((rows + 15) / 16);
-    for (int jb = nleaf + wave; jb < 8; jb += 4)
+    for (int jb = nleaf + wave; jb < 8; jb += POTF2_WAVES)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = Mma<T>::crow(lane, r);
@@ -298,7 +315,7 @@ __device__ __forceinline__ void potf2_body(const TaskDesc& t, int p, int* info_s
   for (int jb = 0; jb < nleaf; ++jb) {
     // ---- (B) rows below the leaf: X = A M^T, one 16-row tile per wave and pass (wave 0 takes tile jb+1, whose
     //      result it needs first in (C)) ------------------------------------------------------
-    for (int R = jb + 1 + wave; R < nleaf; R += 4) solve_tile(jb, R);   // (tiles of padding rows are zero)
+    for (int R = jb + 1 + wave; R < nleaf; R += POTF2_WAVES) solve_tile(jb, R);   // (tiles of padding rows are zero)
     __syncthreads();
     STAMP(3 + 3 * jb);
     if (jb == nleaf - 1) break;   // (the rows below the last data leaf are zero: (B) left them zero)
@@ -306,9 +323,13 @@ __device__ __forceinline__ void potf2_body(const TaskDesc& t, int p, int* info_s
     {
       const int m = nleaf - 1 - jb;
       const int ntiles = m * (m + 1) / 2;            // tile 0 is (jb+1, jb+1): wave 0's
-      // the leaf costs about four tile updates: while more than ~13 other tiles remain (the first two steps of a full
-      // block) wave 0 takes the last n0 of them after its leaf, so that all four waves finish together
-      const int n0 = (ntiles - 1 > 13) ? (ntiles - 1 - 13) / 4 : 0;
+      // the leaf costs about four tile updates: while the other waves have more than that each (four waves: more than ~13 other
+      // tiles, the first two steps of a full block) wave 0 takes the last n0 of them after its leaf, so that all waves finish together
+      // helper waves: all but wave 0 -- and, with eight waves, but wave 4, which shares wave 0's SIMD (the leaf chain beside a
+      // second wave's LDS round trips and MFMAs: 4900-5000 cycles instead of 4400)
+      constexpr int NH = POTF2_WAVES == 8 ? 6 : POTF2_WAVES - 1;
+      const int hw = POTF2_WAVES == 8 ? (wave < 4 ? wave : wave - 1) : wave;   // 1..NH for the helpers
+      const int n0 = (ntiles - 1 > 4 * NH + 1) ? (ntiles - 1 - (4 * NH + 1)) / POTF2_WAVES : 0;
       const int nshared = ntiles - n0;               // tiles [1, nshared) go round the waves 1..3
       auto tile_of = [&](int tix, int& I, int& J) {
         int ii = 0;
@@ -320,13 +341,13 @@ __device__ __forceinline__ void potf2_body(const TaskDesc& t, int p, int* info_s
         factor_leaf(jb + 1);
         STAMP(4 + 3 * jb);
         for (int tix = nshared; tix < ntiles; ++tix) { int I, J; tile_of(tix, I, J); update_tile(jb, I, J); }
-      } else {
+      } else if (!(POTF2_WAVES == 8 && wave == 4)) {
         // two tiles per pass: their LDS round trips and MFMAs interleave (one tile at a time ran at the latency of its
         // own load -> 4 MFMA -> store chain, ~1000 cycles per tile)
-        int tix = wave;
-        for (; tix + 3 < nshared; tix += 6) {
+        int tix = hw;
+        for (; tix + NH < nshared; tix += 2 * NH) {
           int I0, J0, I1, J1;
-          tile_of(tix, I0, J0); tile_of(tix + 3, I1, J1);
+          tile_of(tix, I0, J0); tile_of(tix + NH, I1, J1);
           update_tile2(jb, I0, J0, I1, J1);
         }
         if (tix < nshared) { int I, J; tile_of(tix, I, J); update_tile(jb, I, J); }
@@ -338,17 +359,21 @@ __device__ __forceinline__ void potf2_body(const TaskDesc& t, int p, int* info_s
   STAMP(30);
 
   // write L (lower; zeros above the diagonal inside the diagonal tiles)
-  {
+  auto store_share = [&](auto share) {
+    constexpr int SH = decltype(share)::value;
     int tile = 0;
 #pragma unroll
     for (int I = 0; I < 8; ++I)
 #pragma unroll
       for (int J = 0; J <= I; ++J, ++tile) {
+        if (tile % NSH != SH) continue;
         T v = sT[tile * TILE_ELEMS + ei * TS + ej];
         if (I == J && ej > ei) v = (T)0;
         gst(Ab + (int64_t)(I * 16 + ei) * ld + J * 16 + ej, v);
       }
-  }
+  };
+  if (NSH == 1 || sh == 0) store_share(std::integral_constant<int, 0>());
+  else store_share(std::integral_constant<int, NSH - 1>());
   STAMP(31);
   STAMP(32);
 #ifdef HBO_POTF2_TIMING
@@ -356,7 +381,7 @@ __device__ __forceinline__ void potf2_body(const TaskDesc& t, int p, int* info_s
 #endif
 }
 template <typename T>
-__global__ __launch_bounds__(256) void potf2_kernel(const TaskDesc* tasks, int p, int* info, int* yield_flag) {
+__global__ __launch_bounds__(POTF2_THREADS) void potf2_kernel(const TaskDesc* tasks, int p, int* info, int* yield_flag) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __builtin_amdgcn_s_setprio(3);            // critical path: outrank co-resident GEMM waves
   const TaskDesc& t = tasks[blockIdx.x];
@@ -558,7 +583,7 @@ void set_attrs() {
 template <typename T>
 void potf2_t(const TaskDesc* tasks, int ntasks, int p, int* info, hipStream_t st, int* yield_flag) {
   set_attrs<T>();
-  hipLaunchKernelGGL((potf2_kernel<T>), dim3(ntasks), dim3(256), potf2_lds_bytes<T>(), st, tasks, p, info,
+  hipLaunchKernelGGL((potf2_kernel<T>), dim3(ntasks), dim3(POTF2_THREADS), potf2_lds_bytes<T>(), st, tasks, p, info,
                      yield_flag);
 }
 template <typename T>
