@@ -217,37 +217,14 @@ __device__ __forceinline__ void potf2_body(const TaskDesc& t, int p, int* info_s
   }
 #endif
 
-  // load: one element of every lower tile of this thread's share of the 36 (256-thread group `sh` takes the tiles == sh mod NSH;
-  // the share is a compile-time parameter of the loop body: a run-time test per tile serialised the 36 loads, 21 000 cycles
-  // instead of 6 000); diagonal tiles are mirrored to full symmetry
-  constexpr int NSH = POTF2_THREADS / 256;
-  const int sh = __builtin_amdgcn_readfirstlane(tid >> 8);
-  auto load_share = [&](auto share) {
-    constexpr int SH = decltype(share)::value;
-    T v[36 / NSH];
-    int tile = 0;
-#pragma unroll
-    for (int I = 0; I < 8; ++I)
-#pragma unroll
-      for (int J = 0; J <= I; ++J, ++tile) {
-        if (tile % NSH != SH) continue;
-        int r = ei, c = ej;
-        if (I == J && ej > ei) { r = ej; c = ei; }
-        v[tile / NSH] = gld(Ab + (int64_t)(I * 16 + r) * ld + J * 16 + c);
-      }
-#pragma unroll
-    for (int k = 0; k < 36 / NSH; ++k) sT[(k * NSH + SH) * TILE_ELEMS + ei * TS + ej] = v[k];
-  };
-  if (NSH == 1 || sh == 0) load_share(std::integral_constant<int, 0>());
-  else load_share(std::integral_constant<int, NSH - 1>());
-  static_assert(NSH == 1 || NSH == 2, "one or two 256-thread groups");
-  __syncthreads();
-
-  auto factor_leaf = [&](int jb) {   // wave 0 only
+  auto factor_leaf = [&](int jb, const acc_t* from_regs = nullptr) {   // wave 0 only
     T* dt = sT + tri_index(jb, jb) * TILE_ELEMS;
     acc_t acc;
+    if (from_regs) acc = *from_regs;
+    else {
 #pragma unroll
-    for (int r = 0; r < 4; ++r) acc[r] = dt[Mma<T>::crow(lane, r) * TS + l15];
+      for (int r = 0; r < 4; ++r) acc[r] = dt[Mma<T>::crow(lane, r) * TS + l15];
+    }
     const int bad = leaf_cholesky4<T>(acc, dt, sM, sDinv + jb * 16, Wb + (int64_t)(jb * 16) * ld + jb * 16, ld, lane);
     if (bad >= 0 && lane == 0) atomicMin(info_slot, p * NB + jb * 16 + bad + 1);
   };
@@ -294,7 +271,6 @@ __device__ __forceinline__ void potf2_body(const TaskDesc& t, int p, int* info_s
     for (int r = 0; r < 4; ++r) { c0[Mma<T>::crow(lane, r) * TS + l15] = x0[r]; c1[Mma<T>::crow(lane, r) * TS + l15] = x1[r]; }
   };
 
-  STAMP(1);
   // leaves that hold data: the identity padding of the last block factors to itself (a matrix of 64 points has four
   // of its eight leaves empty); their leaf inverse is the identity, written here once
   int nleaf = 8;
@@ -309,7 +285,53 @@ __device__ __forceinline__ void potf2_body(const TaskDesc& t, int p, int* info_s
       }
     if (tid < NB && tid >= nleaf * 16) sDinv[tid] = (T)1;
   }
-  if (wave == 0 && nleaf > 0) factor_leaf(0);
+  // The first diagonal tile goes straight from memory into wave 0's MFMA layout (both triangles from the lower one) and is
+  // factored while the other 35 tiles are still on their way to LDS: the first leaf (4500 cycles) hides behind the load phase
+  // (7300) instead of following it.  Tile 0's place in LDS is written by the leaf only (its columns of L).
+  const bool lead_tile0 = nleaf > 0;
+  acc_t tile0 = {0, 0, 0, 0};
+  if (wave == 0 && lead_tile0) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = Mma<T>::crow(lane, r);
+      const int rr = row > l15 ? row : l15, cc = row > l15 ? l15 : row;
+      tile0[r] = gld(Ab + (int64_t)rr * ld + cc);
+    }
+  }
+  // load: one element of every lower tile of this thread's share of the 36 (256-thread group `sh` takes the tiles == sh mod NSH;
+  // the share is a compile-time parameter of the loop body: a run-time test per tile serialised the 36 loads, 21 000 cycles
+  // instead of 6 000); diagonal tiles are mirrored to full symmetry
+  constexpr int NSH = POTF2_THREADS / 256;
+  const int sh = __builtin_amdgcn_readfirstlane(tid >> 8);
+  T vload[36 / NSH];
+  auto load_issue = [&](auto share) {
+    constexpr int SH = decltype(share)::value;
+    int tile = 0;
+#pragma unroll
+    for (int I = 0; I < 8; ++I)
+#pragma unroll
+      for (int J = 0; J <= I; ++J, ++tile) {
+        if (tile % NSH != SH) continue;
+        if (tile == 0 && lead_tile0) { vload[0] = (T)0; continue; }   // (wave 0 fetched it in the MFMA layout, above)
+        int r = ei, c = ej;
+        if (I == J && ej > ei) { r = ej; c = ei; }
+        vload[tile / NSH] = gld(Ab + (int64_t)(I * 16 + r) * ld + J * 16 + c);
+      }
+  };
+  auto load_commit = [&](auto share) {
+    constexpr int SH = decltype(share)::value;
+#pragma unroll
+    for (int k = 0; k < 36 / NSH; ++k)
+      if (!(k == 0 && SH == 0 && lead_tile0)) sT[(k * NSH + SH) * TILE_ELEMS + ei * TS + ej] = vload[k];
+  };
+  static_assert(NSH == 1 || NSH == 2, "one or two 256-thread groups");
+  if (NSH == 1 || sh == 0) load_issue(std::integral_constant<int, 0>());
+  else load_issue(std::integral_constant<int, NSH - 1>());
+  // wave 0: the leaf first (its tile arrives first), then its part of the other tiles to LDS -- the others wait for the leaf anyway
+  if (wave == 0 && lead_tile0) factor_leaf(0, &tile0);
+  if (NSH == 1 || sh == 0) load_commit(std::integral_constant<int, 0>());
+  else load_commit(std::integral_constant<int, NSH - 1>());
+  STAMP(1);
   __syncthreads();
   STAMP(2);
   for (int jb = 0; jb < nleaf; ++jb) {
