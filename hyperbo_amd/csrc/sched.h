@@ -8,7 +8,14 @@ struct TrtriProgress { int diag = 0; int a[12] = {0}; int b[12] = {0}; };
 // The one-sweep inverse (sweep_advance): W = L^-1 and K^-1 = W^T W built row group by row group BEHIND the panel chain, so that
 // what is left when the factorisation ends is one group's worth of O(N^2 q) work instead of the O(N^3) tail of the block-recursive
 // inverse and of K^-1 = W^T W (which needs every row of W).
-struct SweepState { int qs = 4; int done = 0; TrtriProgress pg; int nev = 0; };   // nev: events of ev_pool_sweep used so far
+struct SweepState {
+  int qs = 4; int done = 0; TrtriProgress pg;
+  int nev = 0;                                   // events of ev_pool_sweep used so far
+  // behind the last processed group's (c) and (d), and the streams they ran on: a later call on ANOTHER stream (the tail behind the
+  // factorisation, on the main stream) waits for (c) before its (a) / (b) and for (d) only before its own (d)
+  hipEvent_t ev_c = nullptr, ev_d = nullptr;
+  hipStream_t st_c = nullptr, st_d = nullptr;
+};
 int sweep_group(int ntasks, int max_nblk);   // row-group size of the one-sweep inverse where use_sweep() says yes
 
 hipEvent_t pool_event(hbo_ctx* c, size_t i);

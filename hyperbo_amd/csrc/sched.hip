@@ -243,7 +243,8 @@ void run_potrf(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, int m
   c->trtri_counters = nullptr;
   if (ev_f1b) { hipStreamWaitEvent(sp, ev_f1b, 0); ev_f1b = nullptr; }
   if (la) { hipEvent_t e = pool_event(c, evi++); hipEventRecord(e, sp); hipStreamWaitEvent(sm, e, 0); }   // join
-  if (early || sweep) {   // the rest of the inverse (main stream) needs the early part
+  // (the sweep's tail, on the main stream, waits for exactly what it needs of the side stream's work: sweep_advance)
+  if (early && !sweep) {   // the rest of the inverse (main stream) needs the early part
     hipEvent_t e = pool_event(c, evi++);
     hipEventRecord(e, c->stream4);
     hipStreamWaitEvent(sm, e, 0);
@@ -435,6 +436,7 @@ void sweep_advance(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, i
   while (sw.done < max_nblk) {
     const int b0 = sw.done, b1 = std::min(b0 + q, max_nblk);
     if (b1 > cfin) break;
+    if (sw.ev_c && sw.st_c != st) hipStreamWaitEvent(st, sw.ev_c, 0);   // T[R, <R] is complete (and every earlier launch of that stream)
     trtri_advance(c, dtype, d_tasks, ntasks, max_nblk, b1, st, sw.pg, q / 2);                       // (a)
     GemmArgs a = {}; a.tasks = d_tasks; a.c_lo = b0; a.c_hi = b1;
     if (b0 > 0) {                                                                                    // (b)
@@ -450,12 +452,15 @@ void sweep_advance(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, i
       pick((int64_t)(max_nblk - b1) * b1); a.small_tiles = small;
       a.mode = GEMM_SWEEP_T; place(a, (int64_t)(max_nblk - b1) * b1 * U * U);
       launch_gemm(dtype, a, dim3(max_nblk - b1, b1, ntasks), st);
+      sw.ev_c = sweep_event(c, sw); hipEventRecord(sw.ev_c, st); sw.st_c = st;
     }
     {                                                                                                // (d)
       ProfScope ps(c, "sweep_c", 2, sd);
       pick((int64_t)b1 * (b1 + 1) / 2); a.small_tiles = small;
       a.mode = GEMM_SWEEP_C; place(a, small ? 2 * (int64_t)b1 * (b1 + 1) : (int64_t)b1 * (b1 + 1) / 2);
+      if (sw.ev_d && sw.st_d != sd) hipStreamWaitEvent(sd, sw.ev_d, 0);   // the previous group's update of the same K^-1 tiles
       launch_gemm(dtype, a, dim3(b1, 1, ntasks), sd);
+      if (b1 < max_nblk) { sw.ev_d = sweep_event(c, sw); hipEventRecord(sw.ev_d, sd); sw.st_d = sd; }
     }
     sw.done = b1;
     if (b1 == max_nblk && sd != st) { hipEvent_t e = sweep_event(c, sw); hipEventRecord(e, sd); hipStreamWaitEvent(st, e, 0); }   // K^-1 is complete
