@@ -278,7 +278,7 @@ static bool trtri_level3(hbo_ctx* c, const TaskDesc* d_tasks, const TaskDesc& h,
   auto launch = [&](int mode) {
     g.mode = mode; g.persistent = 0; g.work_counter = nullptr;
     g.yield_flag = (st == c->stream4) ? c->gemm_yield : nullptr;
-    if (corun && ntiles > pblocks && c->trtri_counter_next < HBO_N_COUNTERS - HBO_N_BULK_COUNTERS - 1) { g.persistent = pblocks; g.work_counter = c->trtri_counters + c->trtri_counter_next++; }
+    if (corun && ntiles > pblocks && c->trtri_counter_next < HBO_N_COUNTERS - HBO_N_BULK_COUNTERS - 3) { g.persistent = pblocks; g.work_counter = c->trtri_counters + c->trtri_counter_next++; }
     launch_syrk3(g, ntiles, 1, st);
   };
   ProfScope ps(c, "trtri_gemm", 2, st);
@@ -331,9 +331,20 @@ static void trtri_level(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntas
   if (vlast <= 0 && ngroups == 1) return;
   const int xa = (ngroups - 1) * s + std::max(vlast, 0);
   a.c_hi = grp_hi - 1; a.c_lo = std::max(vlast, 0);   // TRTRI_A: last group and its launched tile rows
+  int post_slot = 0;
   auto persist = [&](int64_t tiles) {
     a.persistent = 0; a.work_counter = nullptr;
-    if (corun && tiles > pblocks && c->trtri_counter_next < HBO_N_COUNTERS - HBO_N_BULK_COUNTERS - 1) { a.persistent = pblocks; a.work_counter = c->trtri_counters + c->trtri_counter_next++; }
+    if (corun && tiles > pblocks && c->trtri_counter_next < HBO_N_COUNTERS - HBO_N_BULK_COUNTERS - 3) { a.persistent = pblocks; a.work_counter = c->trtri_counters + c->trtri_counter_next++; }
+    else if (!corun && ntasks == 1 && !a.small_tiles && c->opt_lauum_persist && tiles >= 4 * c->n_cus) {
+      // behind the factorisation, one large matrix: the big levels as a resident grid drawing tiles from a counter, like K^-1 = W^T W
+      // (run_lauum); the counters below the very last one are kept for this
+      int* counters = (int*)ws_get(c, WS_COUNTERS, sizeof(int) * HBO_N_COUNTERS);
+      if (counters && post_slot < 2) {
+        a.work_counter = counters + HBO_N_COUNTERS - 2 - post_slot++;
+        hipMemsetAsync(a.work_counter, 0, sizeof(int), st);
+        a.persistent = 2 * c->n_cus;
+      }
+    }
   };
   if (do_a && xa > 0) { a.mode = GEMM_TRTRI_A; persist((int64_t)xa * s * tmul); launch_gemm(dtype, a, dim3(xa, s, ntasks), st); }
   if (do_b) {
@@ -424,7 +435,7 @@ void sweep_advance(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, i
   auto place = [&](GemmArgs& a, int64_t tiles) {
     a.persistent = 0; a.work_counter = nullptr;
     a.yield_flag = (st == c->stream4) ? c->gemm_yield : nullptr;
-    if (corun && tiles * ntasks > pblocks && c->trtri_counter_next < HBO_N_COUNTERS - HBO_N_BULK_COUNTERS - 1) {
+    if (corun && tiles * ntasks > pblocks && c->trtri_counter_next < HBO_N_COUNTERS - HBO_N_BULK_COUNTERS - 3) {
       a.persistent = pblocks; a.work_counter = c->trtri_counters + c->trtri_counter_next++;
     }
   };

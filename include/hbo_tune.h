@@ -17,7 +17,8 @@
  *                          profiles/r04_chain_and_sweep.md, r04_gemm_pipeline.md), 2 wherever look-ahead is on
  *   sweep_qs      0..16    its row-group size in 128-blocks, a power of two (0 = auto: 4; 8 for one matrix above 28 blocks)
  *   sweep_side    0/1      one matrix on 128-tiles: the sweep's K^-1 updates on a stream of their own (default 1: N = 6144 6.07 -> 5.71 ms)
- *   lauum_persist 0/1      one large matrix: K^-1 = W^T W as a resident grid drawing its tiles from a counter (default 1; isolated 2.70 -> 2.62 ms)
+ *   lauum_persist 0..128   one large matrix: K^-1 = W^T W and the big levels of the inverse behind the factorisation as resident grids drawing
+ *                          their tiles from a counter (default 1; N = 8192 10.64 -> 10.51 ms; n > 1: K^-1 leaves n CUs free instead of 16)
  *   split_f1      0..2     the update of the next group's block columns (F1): only the next column on the panel stream, the later
  *                          ones on a third stream -- 0 never, 1 batches (default: 64 tasks 14.32 -> 14.12 ms), 2 always
  *   sweep_big     >=0      sweep launches of small / batched shapes with at least this many 128-tiles (x tasks) use 128-tiles (4000)
