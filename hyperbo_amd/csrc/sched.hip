@@ -279,6 +279,14 @@ static bool trtri_level3(hbo_ctx* c, const TaskDesc* d_tasks, const TaskDesc& h,
     g.mode = mode; g.persistent = 0; g.work_counter = nullptr;
     g.yield_flag = (st == c->stream4) ? c->gemm_yield : nullptr;
     if (corun && ntiles > pblocks && c->trtri_counter_next < HBO_N_COUNTERS - HBO_N_BULK_COUNTERS - 3) { g.persistent = pblocks; g.work_counter = c->trtri_counters + c->trtri_counter_next++; }
+    else if (!corun && c->opt_lauum_persist && ntiles >= 4 * c->n_cus) {   // behind the factorisation: as trtri_level's big levels
+      int* counters = (int*)ws_get(c, WS_COUNTERS, sizeof(int) * HBO_N_COUNTERS);
+      if (counters) {
+        g.work_counter = counters + HBO_N_COUNTERS - 2 - (mode == 2 ? 1 : 0);
+        hipMemsetAsync(g.work_counter, 0, sizeof(int), st);
+        g.persistent = 2 * c->n_cus;
+      }
+    }
     launch_syrk3(g, ntiles, 1, st);
   };
   ProfScope ps(c, "trtri_gemm", 2, st);
@@ -497,7 +505,14 @@ void run_lauum(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, int m
       const int n = max_nblk * HBO_TILE;
       launch_split3_transpose(static_cast<const float*>(h.W), h.ld, n, n, xp, nkb, s, 1);
       Syrk3Args g = {}; g.tasks = d_tasks; g.Xp = xp; g.nkb = nkb; g.mode = 3;
-      launch_syrk3(g, max_nblk * (max_nblk + 1) / 2, 1, s);
+      const int nt = max_nblk * (max_nblk + 1) / 2;
+      int* counters = c->opt_lauum_persist && nt > 4 * c->n_cus ? (int*)ws_get(c, WS_COUNTERS, sizeof(int) * HBO_N_COUNTERS) : nullptr;
+      if (counters) {   // a resident grid drawing the tiles from a counter, as the fp64 form below
+        g.work_counter = counters + HBO_N_COUNTERS - 1;
+        hipMemsetAsync(g.work_counter, 0, sizeof(int), s);
+        g.persistent = 2 * (c->n_cus - (c->opt_lauum_persist > 1 ? c->opt_lauum_persist : 16));
+      }
+      launch_syrk3(g, nt, 1, s);
       return;
     }
   }
