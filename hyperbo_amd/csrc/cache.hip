@@ -364,6 +364,10 @@ static int posterior(hbo_ctx* c, const hbo_model* m, hbo_cache* k, const void* x
       ProfScope ps(c, "post_gemm", 1, sa);
       Post3Args a = {}; a.Wp = k->w3; a.Kp = K3_d; a.nkb = nkb;
       a.colsq = reinterpret_cast<float*>(colsq_d); a.ldc = ldq; a.V = nullptr; a.ldv = 0; a.nblk = t->nblk;
+      if (c->opt_lauum_persist && !ov) {   // (a resident grid with a tile counter for the large products; one counter per chunk in flight)
+        int* counters = (int*)ws_get(c, WS_COUNTERS, sizeof(int) * HBO_N_COUNTERS);
+        if (counters) { a.work_counter = counters + HBO_N_COUNTERS - 8 + (b & 1); hipMemsetAsync(a.work_counter, 0, sizeof(int), sa); }
+      }
       launch_post3(a, mpad / HBO_TILE, sa);
     } else {
       ProfScope ps(c, "post_gemm", 1, sa);

@@ -218,6 +218,8 @@ struct Post3Args {
   float* colsq; int64_t ldc;  // [nblk][ldc] per-row-block column sums of V^2 (may be null)
   float* V; int64_t ldv;      // optional V output (npad x ldv)
   int nblk;
+  int col_tiles;              // (set by launch_post3)
+  int* work_counter;          // non-null: a resident grid draws the (row tile, column tile) pairs from this zeroed counter, long rows first
 };
 // fp32 trailing updates of the blocked Cholesky on the bf16 matrix cores (post3.hip: split3_panel_kernel, syrk3_kernel)
 struct Syrk3Args {

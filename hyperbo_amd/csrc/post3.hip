@@ -101,9 +101,20 @@ constexpr int POST3_LDS_BYTES = 2 * 2 * 3 * P3_ARR;
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void post3_kernel(Post3Args g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int i = g.nblk - 1 - (int)blockIdx.y;   // long rows first
-  const int jq = blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // one tile per workgroup, or (work_counter) a resident grid drawing the tiles in the same order -- long rows first -- from a
+  // counter: the hardware deals a plain grid's workgroups to the 8 XCDs in turn and waits when the next one's XCD is full
+  __shared__ int s_tile;
+  for (int tile = (int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x;;) {
+  if (g.work_counter) {
+    if (tid == 0) s_tile = atomicAdd(g.work_counter, 1);
+    __syncthreads();
+    tile = s_tile;
+    __syncthreads();
+    if (tile >= g.col_tiles * g.nblk) break;
+  }
+  const int i = g.nblk - 1 - tile / g.col_tiles;   // long rows first
+  const int jq = tile % g.col_tiles;
   const int wm = wave >> 1, wn = wave & 1;
   const int l32 = lane & 31, lh = lane >> 5;
   auto arr = [&](int st, int op, int p) { return smem + (size_t)((st * 2 + op) * 3 + p) * P3_ARR; };
@@ -199,6 +210,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       const int wn2 = tid >> 6, c = tid & 63;
       g.colsq[(int64_t)i * g.ldc + (int64_t)jq * HBO_TILE + tid] = red[(0 * 2 + wn2) * 64 + c] + red[(1 * 2 + wn2) * 64 + c];
     }
+  }
+  if (!g.work_counter) break;
+  __syncthreads();   // (the staging buffers and `red` are reused by the next tile)
   }
 }
 
@@ -489,10 +503,18 @@ void launch_split3_transpose(const float* in, int64_t ld, int krows, int jcols, 
   if (krows <= 0 || jcols <= 0) return;
   hipLaunchKernelGGL(split3_transpose_kernel, dim3(jcols / 64, krows / 64), dim3(256), 0, st, in, ld, out, nkb, lower_only);
 }
-void launch_post3(const Post3Args& a, int col_tiles, hipStream_t st) {
+void launch_post3(const Post3Args& a_in, int col_tiles, hipStream_t st) {
   static unsigned long long seen = 0;
   if (hbo_first_use_on_device(seen))
     hipFuncSetAttribute(reinterpret_cast<const void*>(&post3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, POST3_LDS_BYTES);
+  Post3Args a = a_in; a.col_tiles = col_tiles;
+  if (a.work_counter) {
+    int dev = 0, cus = 256;
+    hipGetDevice(&dev); hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const int resident = 2 * cus;   // two workgroups per CU (amdgpu_waves_per_eu(2, 2))
+    if (col_tiles * a.nblk > 2 * resident) { hipLaunchKernelGGL(post3_kernel, dim3(resident, 1), dim3(256), POST3_LDS_BYTES, st, a); return; }
+    a.work_counter = nullptr;
+  }
   hipLaunchKernelGGL(post3_kernel, dim3(col_tiles, a.nblk), dim3(256), POST3_LDS_BYTES, st, a);
 }
 

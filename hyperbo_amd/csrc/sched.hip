@@ -278,7 +278,7 @@ static bool trtri_level3(hbo_ctx* c, const TaskDesc* d_tasks, const TaskDesc& h,
   auto launch = [&](int mode) {
     g.mode = mode; g.persistent = 0; g.work_counter = nullptr;
     g.yield_flag = (st == c->stream4) ? c->gemm_yield : nullptr;
-    if (corun && ntiles > pblocks && c->trtri_counter_next < HBO_N_COUNTERS - HBO_N_BULK_COUNTERS - 3) { g.persistent = pblocks; g.work_counter = c->trtri_counters + c->trtri_counter_next++; }
+    if (corun && ntiles > pblocks && c->trtri_counter_next < HBO_N_COUNTERS - HBO_N_BULK_COUNTERS - 8) { g.persistent = pblocks; g.work_counter = c->trtri_counters + c->trtri_counter_next++; }
     else if (!corun && c->opt_lauum_persist && ntiles >= 4 * c->n_cus) {   // behind the factorisation: as trtri_level's big levels
       int* counters = (int*)ws_get(c, WS_COUNTERS, sizeof(int) * HBO_N_COUNTERS);
       if (counters) {
@@ -342,7 +342,7 @@ static void trtri_level(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntas
   int post_slot = 0;
   auto persist = [&](int64_t tiles) {
     a.persistent = 0; a.work_counter = nullptr;
-    if (corun && tiles > pblocks && c->trtri_counter_next < HBO_N_COUNTERS - HBO_N_BULK_COUNTERS - 3) { a.persistent = pblocks; a.work_counter = c->trtri_counters + c->trtri_counter_next++; }
+    if (corun && tiles > pblocks && c->trtri_counter_next < HBO_N_COUNTERS - HBO_N_BULK_COUNTERS - 8) { a.persistent = pblocks; a.work_counter = c->trtri_counters + c->trtri_counter_next++; }
     else if (!corun && ntasks == 1 && !a.small_tiles && c->opt_lauum_persist && tiles >= 4 * c->n_cus) {
       // behind the factorisation, one large matrix: the big levels as a resident grid drawing tiles from a counter, like K^-1 = W^T W
       // (run_lauum); the counters below the very last one are kept for this
@@ -443,7 +443,7 @@ void sweep_advance(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, i
   auto place = [&](GemmArgs& a, int64_t tiles) {
     a.persistent = 0; a.work_counter = nullptr;
     a.yield_flag = (st == c->stream4) ? c->gemm_yield : nullptr;
-    if (corun && tiles * ntasks > pblocks && c->trtri_counter_next < HBO_N_COUNTERS - HBO_N_BULK_COUNTERS - 3) {
+    if (corun && tiles * ntasks > pblocks && c->trtri_counter_next < HBO_N_COUNTERS - HBO_N_BULK_COUNTERS - 8) {
       a.persistent = pblocks; a.work_counter = c->trtri_counters + c->trtri_counter_next++;
     }
   };
