@@ -219,6 +219,8 @@ void run_potrf(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, int m
             const int pblocks = 2 * (c->n_cus - persist_free);
             // (for large trailing matrices the bulk update dominates and gets the whole machine)
             a.persistent = (ntasks == 1 && persist_free > 0 && ntiles > pblocks && m <= 96) ? pblocks : 0;
+            // (beyond that the whole machine, but still as a resident grid drawing tiles from the counter: see launch_gemm_t, LAUUM)
+            if (!a.persistent && ntasks == 1 && persist_free > 0 && m > 96 && c->opt_lauum_persist && !a.small_tiles) a.persistent = 2 * c->n_cus;
             a.work_counter = (a.persistent && counters && n_counter < HBO_N_BULK_COUNTERS) ? counters + n_counter++ : nullptr;
             a.n_big = 0;
             if (a.persistent && a.work_counter && !a.small_tiles) {
