@@ -379,6 +379,14 @@ static int posterior(hbo_ctx* c, const hbo_model* m, hbo_cache* k, const void* x
         launch_gemm(dtype, a, dim3(mpad / HBO_TILE, pairs, 1), sa);
         launch_post_colsq_split(dtype, d_vpart, t->npad, ldq, mpad, t->nblk, kchunk, colsq_d, sa);
       } else {
+        const int64_t tiles = (int64_t)(mpad / HBO_TILE) * t->nblk;
+        if (c->opt_lauum_persist && !ov && tiles > 4 * c->n_cus) {   // (as the bf16 form above)
+          int* counters = (int*)ws_get(c, WS_COUNTERS, sizeof(int) * HBO_N_COUNTERS);
+          if (counters) {
+            a.work_counter = counters + HBO_N_COUNTERS - 8 + (b & 1); hipMemsetAsync(a.work_counter, 0, sizeof(int), sa);
+            a.persistent = 2 * c->n_cus;
+          }
+        }
         launch_gemm(dtype, a, dim3(mpad / HBO_TILE, t->nblk, 1), sa);
       } }
     { ProfScope ps(c, "post_epilogue", 1, sa);

@@ -980,7 +980,7 @@ void launch_gemm_t(const GemmArgs& a_in, dim3 grid, hipStream_t st) {
   // the persistent forms: SYRK (any tile size); TRTRI of a single matrix and the SWEEP modes (also over a batch) with a tile counter
   const bool sweep_mode = a.mode == GEMM_SWEEP_B || a.mode == GEMM_SWEEP_T || a.mode == GEMM_SWEEP_C;
   if (a.mode != GEMM_SYRK && !((a.mode == GEMM_TRTRI_A || a.mode == GEMM_TRTRI_B) && a.work_counter && grid.z == 1) && !(sweep_mode && a.work_counter) &&
-      !(a.mode == GEMM_LAUUM && a.work_counter && grid.z == 1 && !a.small_tiles))
+      !(a.mode == GEMM_LAUUM && a.work_counter && grid.z == 1 && !a.small_tiles) && !(a.mode == GEMM_POST && a.work_counter && grid.z == 1))
     a.persistent = 0;
   a.ptasks = 0;
   // dynamic LDS of a 128-tile workgroup: one stage per operand for the pipelined cores, two for gemm_tile
@@ -1073,6 +1073,10 @@ void launch_gemm_t(const GemmArgs& a_in, dim3 grid, hipStream_t st) {
       break;
     }
     case GEMM_POST:
+      if (a.persistent > 0) {   // (row tile, column tile) pairs drawn from a counter, long rows first -- see LAUUM
+        GemmArgs b = a; b.pgx = (int)grid.x; b.pgy = (int)grid.y;
+        hipLaunchKernelGGL((gemm_kernel<T, true, false, 128>), dim3(a.persistent, 1, 1), dim3(256), lds128, st, b);
+      } else
       hipLaunchKernelGGL((gemm_kernel<T, true, false, 128>), grid, dim3(256), lds128, st, a);
       break;
     case GEMM_VTV:
