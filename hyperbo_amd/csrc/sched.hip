@@ -18,6 +18,11 @@ hipEvent_t pool_event(hbo_ctx* c, size_t i) {
 }
 
 
+// Batches: the sweep's launches beside the panel chain as plain grids (0), persistent and slot-limited over tiles x tasks from one
+// counter (1), also polling the chain's yield table (2).  Auto: persistent up to 8 tasks -- measured with the pipelined cores, ms per
+// NLL + gradient, plain / persistent: 4 tasks 1.781 / 1.747, 8 tasks 2.521 / 2.442, 16 tasks 4.200 / 4.223, 32 tasks 7.520 / 7.603,
+// 64 tasks 14.13 / 14.31
+static int batch_bg(const hbo_ctx* c, int ntasks) { return c->opt_batch_bg >= 0 ? c->opt_batch_bg : (ntasks <= 8 ? 1 : 0); }
 // Right-looking blocked Cholesky with look-ahead.  Panels are 128 wide; `group` consecutive panels
 // are factored left-looking (the later ones first receive the group's earlier panels: syrk_col),
 // then one trailing update with K = 128*group is applied.  The trailing update is split in two
@@ -74,7 +79,7 @@ void run_potrf(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, int m
   // fp32 with the trailing updates on the bf16 cores: the bulk update is 1.5x shorter and the panel chain sets the pace at
   // every size, so the chain's kernels are protected as for the small matrices
   const bool s3_wanted = dtype == HBO_F32 && c->opt_syrk_bf16x3 && max_nblk > 1;
-  const bool batch_yield = la && ntasks > 1 && sweep && c->opt_batch_bg >= 2 && c->opt_cu_yield;
+  const bool batch_yield = la && ntasks > 1 && sweep && batch_bg(c, ntasks) >= 2 && c->opt_cu_yield;
   int* const yield_flag = ((la && ntasks == 1 && c->opt_cu_yield && (small_mat || s3_wanted)) || batch_yield) ? c->d_yield : nullptr;
   if (yield_flag) hipMemsetAsync(yield_flag, 0, sizeof(int) * HBO_YIELD_TAB_ENTRIES, sm);
   int* const chain_mark = (yield_flag && c->opt_cu_yield >= 2) ? yield_flag : nullptr;   // the chain's wide kernels mark their CUs too
@@ -440,7 +445,7 @@ void sweep_advance(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, i
   auto pick = [&](int64_t tiles128) { small = small_shape && tiles128 * ntasks < c->opt_sweep_big; U = small ? 2 : 1; };
   // beside the panel chain (side stream, counters of this factorisation at hand): persistent and slot-limited, tiles (x tasks) from
   // a counter, polling the yield table when the chain's kernels keep one -- see trtri_level
-  const bool corun = st == c->stream4 && c->trtri_counters && c->opt_trtri_free > 0 && (ntasks == 1 || c->opt_batch_bg >= 1);
+  const bool corun = st == c->stream4 && c->trtri_counters && c->opt_trtri_free > 0 && (ntasks == 1 || batch_bg(c, ntasks) >= 1);
   const int pblocks = 2 * (c->n_cus - c->opt_trtri_free);
   auto place = [&](GemmArgs& a, int64_t tiles) {
     a.persistent = 0; a.work_counter = nullptr;

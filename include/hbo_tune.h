@@ -22,8 +22,9 @@
  *   split_f1      0..2     the update of the next group's block columns (F1): only the next column on the panel stream, the later
  *                          ones on a third stream -- 0 never, 1 batches (default: 64 tasks 14.32 -> 14.12 ms), 2 always
  *   sweep_big     >=0      sweep launches of small / batched shapes with at least this many 128-tiles (x tasks) use 128-tiles (4000)
- *   batch_bg      0..2     batches: the sweep's launches beside the chain as plain grids (0, default), persistent over tiles x tasks
- *                          from one counter (1), and also polling the per-CU yield table the chain's kernels then fill (2) */
+ *   batch_bg      -1..2    batches: the sweep's launches beside the chain as plain grids (0), persistent over tiles x tasks
+ *                          from one counter (1), and also polling the per-CU yield table the chain's kernels then fill (2);
+ *                          -1 (default): 1 up to 8 tasks, 0 above (8 tasks 2.52 -> 2.44 ms, 64 tasks 14.13 / 14.31) */
 #ifndef HBO_TUNE_H_
 #define HBO_TUNE_H_
 #include "hbo.h"
