@@ -24,7 +24,7 @@ struct hbo_ctx {
                              // look-ahead): 1 = potf2 only, 2 = trsm and the chain's column updates too
   int* d_yield = nullptr;    // per-CU table (cu_token() -> panel-chain workgroups running there)
   int* gemm_yield = nullptr; // run_potrf -> trtri_level: GemmArgs::yield_flag of the launches that co-run with the panel chain
-  int opt_small_nblk = 32;   // matrices up to this many 128-blocks use 64x64 GEMM tiles in trtri / lauum
+  int opt_small_nblk = -1;   // matrices up to this many 128-blocks use 64x64 GEMM tiles in trtri / lauum / the sweep (-1: auto, sched.hip: small_limit)
   int opt_persist_free = -1; // bulk trailing update runs as 2*(CUs - this) persistent workgroups (-1: auto, see run_potrf)
   int opt_post_chunk = 8192;   // posterior / acquisition: candidates per pass (the cross-Gram workspace is npad x this, whatever M)
   int opt_trtri_bf16x3 = 1;    // fp32, one matrix: the products of the block-recursive inverse on the bf16 cores from level trtri3_min_s on

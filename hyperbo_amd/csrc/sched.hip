@@ -18,6 +18,10 @@ hipEvent_t pool_event(hbo_ctx* c, size_t i) {
 }
 
 
+// Matrices of up to this many 128-blocks take 64 x 64 GEMM tiles in the inverse, K^-1 = W^T W and the sweep (option small_nblk; auto:
+// fp64 40 -- measured with the pipelined cores, 32 / 40: N = 4608 3.31 / 3.19 ms, 5120 4.02 / 3.82, 6144 (48 blocks) 5.71 / 5.69 at 48 --
+// fp32 32, where the larger matrices' products move to the bf16 cores instead)
+static int small_limit(const hbo_ctx* c, int dtype) { return c->opt_small_nblk >= 0 ? c->opt_small_nblk : (dtype == HBO_F64 ? 40 : 32); }
 // Batches: the sweep's launches beside the panel chain as plain grids (0), persistent and slot-limited over tiles x tasks from one
 // counter (1), also polling the chain's yield table (2).  Auto: persistent up to 8 tasks -- measured with the pipelined cores, ms per
 // NLL + gradient, plain / persistent: 4 tasks 1.781 / 1.747, 8 tasks 2.521 / 2.442, 16 tasks 4.200 / 4.223, 32 tasks 7.520 / 7.603,
@@ -321,13 +325,13 @@ static void trtri_level(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntas
   const TaskDesc& h_task0 = c->trtri_host_task;
   const int ngroups = grp_hi - grp_lo;
   if (ngroups <= 0) return;
-  if (dtype == HBO_F32 && c->opt_trtri_bf16x3 && ntasks == 1 && h_task0.A && s >= c->opt_trtri3_min_s && max_nblk > c->opt_small_nblk &&
+  if (dtype == HBO_F32 && c->opt_trtri_bf16x3 && ntasks == 1 && h_task0.A && s >= c->opt_trtri3_min_s && max_nblk > small_limit(c, dtype) &&
       trtri_level3(c, d_tasks, h_task0, max_nblk, s, grp_lo, grp_hi, do_a, do_b, st))
     return;
   GemmArgs a = {}; a.tasks = d_tasks; a.p0 = s; a.grp_lo = grp_lo;
   // few or short tiles (small levels, small / batched matrices): 64x64 tiles -- a lone 128-tile runs
   // its K loop latency-bound, four 64-tiles expose 4x the parallelism for the same flops
-  a.small_tiles = (max_nblk <= c->opt_small_nblk) || ((int64_t)ngroups * s * s * ntasks < 600);
+  a.small_tiles = (max_nblk <= small_limit(c, dtype)) || ((int64_t)ngroups * s * s * ntasks < 600);
   a.yield_flag = (st == c->stream4) ? c->gemm_yield : nullptr;
   // products that co-run with the panel chain (single matrix, side stream): persistent, 2 workgroups on all but
   // `trtri_free` CUs, tiles from a counter -- see gemm_kernel
@@ -421,7 +425,7 @@ bool use_sweep(const hbo_ctx* c, int dtype, int ntasks, int max_nblk) {
   //   5120 4.404 / 4.179 (8), 6144 6.053 / 6.010 (8)        (profiles/r04_gemm_pipeline.md)
   if (ntasks == 1) return dtype == HBO_F64 && max_nblk > 16 && max_nblk <= 48;
   // fp32 beyond the small sizes: the block-recursive products and K^-1 run on the bf16 matrix cores (post3.hip), which this form does not
-  if (dtype == HBO_F32 && ntasks == 1 && max_nblk > c->opt_small_nblk && (c->opt_trtri_bf16x3 || c->opt_lauum_bf16x3)) return false;
+  if (dtype == HBO_F32 && ntasks == 1 && max_nblk > small_limit(c, dtype) && (c->opt_trtri_bf16x3 || c->opt_lauum_bf16x3)) return false;
   return true;
 }
 int sweep_group(int ntasks, int max_nblk) { return (ntasks == 1 && max_nblk > 28) ? 8 : 4; }
@@ -439,7 +443,7 @@ void sweep_advance(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, i
   const int q = sw.qs;
   // 64-tiles for small / batched matrices as everywhere else -- except where a launch has enough 128-tiles to fill the machine
   // several times over: all tiles of a sweep launch have the same K, so the larger tile's better MFMA rate is not lost in a tail
-  const bool small_shape = max_nblk <= c->opt_small_nblk;
+  const bool small_shape = max_nblk <= small_limit(c, dtype);
   bool small = small_shape;
   int U = small ? 2 : 1;
   auto pick = [&](int64_t tiles128) { small = small_shape && tiles128 * ntasks < c->opt_sweep_big; U = small ? 2 : 1; };
@@ -458,7 +462,7 @@ void sweep_advance(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, i
   // (a) -> (b) -> (c) chain of the following groups instead of holding it up.  Measured (ms, same stream / own stream): one matrix on
   // 128-tiles N = 5120 4.26 / 4.15, 6144 6.07 / 5.71, 7168 8.39 / 7.96, 8192 11.44 / 10.97; on 64-tiles N = 2560 1.43 / 1.48,
   // 4096 2.65 / 2.79; batches 14.11 / 14.48 (64 tasks), 2.57 / 2.74 (8): where the launches are small the extra hop costs more
-  hipStream_t sd = (c->opt_sweep_side && c->stream3 && ntasks == 1 && max_nblk > c->opt_small_nblk) ? c->stream3 : st;
+  hipStream_t sd = (c->opt_sweep_side && c->stream3 && ntasks == 1 && max_nblk > small_limit(c, dtype)) ? c->stream3 : st;
   while (sw.done < max_nblk) {
     const int b0 = sw.done, b1 = std::min(b0 + q, max_nblk);
     if (b1 > cfin) break;
@@ -503,7 +507,7 @@ void run_lauum(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, int m
   // fp32, one matrix beyond the small sizes: on the bf16 matrix cores from ONE exact three-way split of W^T (post3.hip,
   // syrk3_kernel mode 3) -- 6 bytes per element of the lower triangle of W as workspace
   const TaskDesc& h = c->trtri_host_task;
-  if (dtype == HBO_F32 && c->opt_lauum_bf16x3 && ntasks == 1 && h.W && h.nblk == max_nblk && max_nblk > c->opt_small_nblk) {
+  if (dtype == HBO_F32 && c->opt_lauum_bf16x3 && ntasks == 1 && h.W && h.nblk == max_nblk && max_nblk > small_limit(c, dtype)) {
     const int nkb = 8 * max_nblk;
     const size_t bytes = sizeof(unsigned short) * (size_t)max_nblk * nkb * 3 * (HBO_TILE * 16);
     unsigned short* xp = static_cast<unsigned short*>(ws_get(c, WS_LAUUM3, bytes));
@@ -524,7 +528,7 @@ void run_lauum(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, int m
     }
   }
   GemmArgs a = {}; a.tasks = d_tasks; a.mode = GEMM_LAUUM;
-  a.small_tiles = max_nblk <= c->opt_small_nblk;
+  a.small_tiles = max_nblk <= small_limit(c, dtype);
   hipStream_t s = st ? st : c->stream;
   if (ntasks == 1 && !a.small_tiles && c->opt_lauum_persist && max_nblk * (max_nblk + 1) / 2 > 4 * c->n_cus) {
     // one large matrix: a resident grid of two workgroups per CU draws the tiles from a counter (gemm.hip: launch_gemm_t)

@@ -214,7 +214,8 @@ int hbo_profile_get(hbo_ctx* ctx, char names[][32], double* ms, int32_t* launche
  *   lookahead       0..2  panel chain on its own stream one group ahead of the bulk update, inverse overlapped.  1 (default): where
  *                         it pays -- more than 4 blocks and (>= 18 blocks or tasks x blocks >= 80); below that everything runs
  *                         on one stream in order (5-13 % faster there).  0 = never, 2 = whenever there is more than one block
- *   small_nblk      int   matrices up to this many 128-blocks use 64x64 tiles in the inverse and in K^-1 = W^T W (default 32)
+ *   small_nblk      int   matrices up to this many 128-blocks use 64x64 tiles in the inverse and in K^-1 = W^T W (default -1: auto --
+ *                         40 blocks in fp64, 32 in fp32)
  *   pool_cap_mb     >=0   device buffers of freed datasets / caches are parked for the next one of the same shape (GP.train()
  *                         re-creates its sub-sampled batch every step); at most this many MB stay parked (default: a quarter
  *                         of the device memory, at most 49152; 0 = off)

@@ -199,7 +199,7 @@ OPTION_SETS = [
     # F1 split over two streams: never / always (default: batches)
     {'batch_bg': 0, 'lookahead': 2}, {'lauum_persist': 0, 'small_nblk': 0}, {'small_nblk': 2, 'sweep': 0}, {'sweep': 2, 'small_nblk': 0, 'sweep_side': 0}, {'sweep': 2, 'small_nblk': 4, 'sweep_qs': 2}, {'split_f1': 0, 'lookahead': 2}, {'split_f1': 2}, {'split_f1': 2, 'lookahead': 2, 'potrf_group': 1}, {'split_f1': 2, 'sweep': 0, 'potrf_group': 2},
 ]
-DEFAULTS = {'lookahead': 1, 'overlap_trtri': 1, 'potrf_group': 0, 'persist_free': -1, 'small_nblk': 32, 'cu_yield': 2, 'trtri_free': 48,
+DEFAULTS = {'lookahead': 1, 'overlap_trtri': 1, 'potrf_group': 0, 'persist_free': -1, 'small_nblk': -1, 'cu_yield': 2, 'trtri_free': 48,
             'trtri_at': 0, 'post_chunk': 8192, 'sweep': 1, 'sweep_qs': 0, 'sweep_big': 4000, 'batch_bg': -1, 'split_f1': 1, 'sweep_side': 1, 'lauum_persist': 1}
 
 

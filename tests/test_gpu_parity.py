@@ -1152,10 +1152,10 @@ def test_one_sweep_inverse_across_the_registry_and_objectives(gpu_ctx, kname, ml
       gpu_ctx.set_option(k_, v_)
 
 
-@pytest.mark.parametrize('n', [2200, 3750, 4300])
+@pytest.mark.parametrize('n', [2200, 3750, 5300])
 def test_one_matrix_in_the_size_range_where_the_sweep_is_the_default(gpu_ctx, n):
   """One fp64 matrix of 17-48 blocks takes the one-sweep inverse by default (sched.hip:use_sweep; row groups of 4 blocks up to 28
-  blocks, of 8 above; above 32 blocks on 128-tiles with the K^-1 updates on a stream of their own): against the oracle, and against
+  blocks, of 8 above; above 40 blocks on 128-tiles with the K^-1 updates on a stream of their own): against the oracle, and against
   the block-recursive inverse + W^T W (sweep = 0) to rounding."""
   defs, _, _, _, kernel, mean, objectives, utils = _native()
   rng = np.random.default_rng(n)
