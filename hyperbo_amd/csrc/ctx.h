@@ -40,6 +40,7 @@ struct hbo_ctx {
   int opt_sweep = 1;           // one-sweep inverse (sched.hip:sweep_advance): 0 never, 1 where measured faster (use_sweep), 2 wherever look-ahead is on
   int opt_sweep_big = 4000;    // a sweep launch of a small / batched shape with at least this many 128-tiles (x tasks) runs on 128-tiles
   int opt_sweep_side = 1;      // one matrix on 128-tiles: the sweep's K^-1 updates (d) on a stream of their own beside its (a) (b) (c) chain
+  int opt_sweep_free = 24;     // CUs the sweep's persistent launches beside the chain leave with one workgroup (at most trtri_free)
   int opt_sweep_qs = 0;        // its row-group size in 128-blocks (power of two; 0: auto)
   int opt_batch_bg = -1;       // batches: the sweep's launches beside the panel chain are 0 plain grids, 1 persistent and slot-limited (-1: auto = 1 up to 8 tasks),
                                // (tiles x tasks from one counter), 2 also yielding to the chain's kernels through the per-CU table

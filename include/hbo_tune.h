@@ -16,6 +16,7 @@
  *                          1 where measured faster (default: batches with look-ahead, one fp64 matrix of 17-48 blocks;
  *                          profiles/r04_chain_and_sweep.md, r04_gemm_pipeline.md), 2 wherever look-ahead is on
  *   sweep_qs      0..16    its row-group size in 128-blocks, a power of two (0 = auto: 4; 8 for one matrix above 28 blocks)
+ *   sweep_free    1..200   CUs the sweep's persistent launches beside the chain leave with one workgroup (24; at most trtri_free)
  *   sweep_side    0/1      one matrix on 128-tiles: the sweep's K^-1 updates on a stream of their own (default 1: N = 6144 6.07 -> 5.71 ms)
  *   lauum_persist 0..128   one large matrix: K^-1 = W^T W and the big levels of the inverse behind the factorisation as resident grids drawing
  *                          their tiles from a counter (default 1; N = 8192 10.64 -> 10.51 ms; n > 1: K^-1 leaves n CUs free instead of 16)
