@@ -5,6 +5,7 @@
 #include "ctx.h"
 
 #include <dlfcn.h>
+#include <stdlib.h>
 #include <string.h>
 
 // ---- RCCL (loaded lazily; libhbo itself does not link against it) ----------------------------
@@ -16,6 +17,11 @@ typedef const char* (*fn_ncclGetErrorString)(int);
 static void* rccl_open() {
   static void* lib = nullptr;
   if (lib) return lib;
+  // $HBO_RCCL_LIB: another library with the same five entry points (ncclGetUniqueId, ncclCommInitRank, ncclAllReduce,
+  // ncclCommDestroy, ncclCommAbort) -- how tests/fake_rccl.c lets two ranks share ONE GPU, which RCCL itself refuses
+  if (const char* over = getenv("HBO_RCCL_LIB")) {
+    if (*over) { lib = dlopen(over, RTLD_NOW | RTLD_GLOBAL); return lib; }
+  }
   for (const char* name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
     lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
     if (lib) break;
@@ -46,6 +52,7 @@ extern "C" int hbo_comm_init(hbo_ctx* c, int rank, int nranks, const void* uniqu
   hbo_nccl_id id; memcpy(&id, unique_id128, HBO_UNIQUE_ID_BYTES);
   int rc = f(&c->comm, nranks, id, rank);
   if (rc != 0) { c->comm = nullptr; return fail(c, HBO_ERR_COMM, "ncclCommInitRank failed with code " + std::to_string(rc)); }
+  c->comm_aborted = false;
   return HBO_OK;
 }
 extern "C" int hbo_comm_allreduce_sum(hbo_ctx* c, double* buf, int32_t count) {
@@ -80,6 +87,7 @@ int comm_abort(hbo_ctx* c) {
     auto f = (fn_ncclCommDestroy)dlsym(c->rccl_lib, "ncclCommAbort");
     if (f) f(c->comm);
     c->comm = nullptr;
+    c->comm_aborted = true;   // a null communicator otherwise reads as "single rank, no collective" (objective_impl)
   }
   return HBO_OK;
 }
@@ -90,6 +98,7 @@ extern "C" int hbo_comm_destroy(hbo_ctx* c) {
     if (f) f(c->comm);
   }
   c->comm = nullptr;
+  c->comm_aborted = false;
   if (c->d_comm_buf) { hipFree(c->d_comm_buf); c->d_comm_buf = nullptr; c->comm_buf_count = 0; }
   return HBO_OK;
 }

@@ -84,6 +84,8 @@ struct hbo_ctx {
   // RCCL
   void* rccl_lib = nullptr;
   void* comm = nullptr;
+  int opt_fault_shard = 0;     // hbo_tune("fault_shard"): ONE-SHOT fault injection for the tests of the sharded objective's failure paths
+  bool comm_aborted = false;   // set by comm_abort: sharded calls fail with HBO_ERR_COMM until hbo_comm_init builds a new communicator
   double* d_comm_buf = nullptr;
   int comm_buf_count = 0;
 };

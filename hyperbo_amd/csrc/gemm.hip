@@ -982,6 +982,10 @@ void launch_gemm_t(const GemmArgs& a_in, dim3 grid, hipStream_t st) {
   if (a.mode != GEMM_SYRK && !((a.mode == GEMM_TRTRI_A || a.mode == GEMM_TRTRI_B) && a.work_counter && grid.z == 1) && !(sweep_mode && a.work_counter) &&
       !(a.mode == GEMM_LAUUM && a.work_counter && grid.z == 1 && !a.small_tiles) && !(a.mode == GEMM_POST && a.work_counter && grid.z == 1))
     a.persistent = 0;
+  // a resident grid needs at least one workgroup: on a small device / partition (or with a placement knob >= the CU count) the
+  // callers' 2*(CUs - free) is <= 0 -- fall back to the plain grid AND drop the counter, or the kernel would take the counter branch
+  // of a launch whose resident size is zero and compute no tile
+  if (a.persistent <= 0) { a.persistent = 0; a.work_counter = nullptr; }
   a.ptasks = 0;
   // dynamic LDS of a 128-tile workgroup: one stage per operand for the pipelined cores, two for gemm_tile
 #ifdef HBO_GEMM_V1

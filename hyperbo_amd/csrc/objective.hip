@@ -320,9 +320,15 @@ static int objective_local(hbo_ctx* c, const hbo_model* m_in, hbo_dataset* ds, i
 static int objective_impl(hbo_ctx* c, const hbo_model* m_in, hbo_dataset* ds, int objective, double* nll_sum,
                           double* nll_per_task, double* grad_sum, const ShardReq* sh) {
   if (!sh) return objective_local(c, m_in, ds, objective, nll_sum, nll_per_task, grad_sum, nullptr, nullptr);
+  if (c && c->comm_aborted)
+    return fail(c, HBO_ERR_COMM, "hbo_objective_sharded: the communicator was aborted after a failed evaluation; call hbo_comm_init again");
   ShardOut so;
-  const int rc_local = objective_local(c, m_in, ds, objective, nll_sum, nll_per_task, grad_sum, sh, &so);
+  int rc_local = objective_local(c, m_in, ds, objective, nll_sum, nll_per_task, grad_sum, sh, &so);
   if (!c || !nll_sum || !m_in) return rc_local;   // argument errors are the same on every rank: nobody reaches the collective
+  // one-shot fault injection (hbo_tune "fault_shard", tests only): 1 = this rank's local part counts as failed (NaN contribution
+  // path below), 2 = and it cannot even produce the NaN buffer (abort path)
+  const int fault = c->opt_fault_shard; c->opt_fault_shard = 0;
+  if (fault && rc_local == HBO_OK) { rc_local = fail(c, HBO_ERR_HIP, "hbo_objective_sharded: injected local failure (fault_shard)"); so.d_red = nullptr; }
   hipStream_t st = c->stream;
   int red_count = so.red_count;
   if (red_count <= 0) {   // failed before the model was looked at: the layout still fixes the length the peers reduce
@@ -331,11 +337,14 @@ static int objective_impl(hbo_ctx* c, const hbo_model* m_in, hbo_dataset* ds, in
     red_count = 2 + (grad_sum ? lay.total : 0);
   }
   if (rc_local != HBO_OK || !so.d_red) {
-    // local failure: NaN into every slot of the collective (0x7FF800007FF80000 is a quiet NaN)
+    // local failure: NaN into every slot of the collective (0x7FF800007FF80000 is a quiet NaN).  The failed pipeline may have left
+    // launches queued on the side streams (look-ahead panels, the early inverse): join them before the workspaces are reused
+    (void)hipGetLastError();
+    for (hipStream_t q : {c->stream2, c->stream3, c->stream4}) if (q) (void)hipStreamSynchronize(q);
     (void)hipGetLastError();
     so.d_red = static_cast<double*>(ws_get(c, WS_SHARD_RED, sizeof(double) * red_count));
     so.ev0 = pool_event_timed(c, 0); so.ev1 = pool_event_timed(c, 1);
-    const bool ok = so.d_red && hipEventRecord(so.ev0, st) == hipSuccess &&
+    const bool ok = fault != 2 && so.d_red && hipEventRecord(so.ev0, st) == hipSuccess &&
                     hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(so.d_red), 0x7FF80000, 2 * (size_t)red_count, st) == hipSuccess &&
                     hipEventRecord(so.ev1, st) == hipSuccess;
     if (!ok) { if (c->comm) comm_abort(c); return rc_local ? rc_local : HBO_ERR_HIP; }

@@ -527,8 +527,10 @@ void launch_syrk3(const Syrk3Args& a, int ntiles, int ntasks, hipStream_t st) {
   static unsigned long long seen = 0;
   if (hbo_first_use_on_device(seen))
     hipFuncSetAttribute(reinterpret_cast<const void*>(&syrk3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, POST3_LDS_BYTES + 16);
-  const int grid = a.persistent > 0 ? std::min(a.persistent, ntiles) : ntiles;
-  hipLaunchKernelGGL(syrk3_kernel, dim3(grid, 1, ntasks), dim3(256), POST3_LDS_BYTES + 16, st, a);
+  Syrk3Args b = a;
+  if (b.persistent <= 0 || !b.work_counter) { b.persistent = 0; b.work_counter = nullptr; }   // no resident grid without a workgroup (small device / knob >= CUs) or a counter
+  const int grid = b.persistent > 0 ? std::min(b.persistent, ntiles) : ntiles;
+  hipLaunchKernelGGL(syrk3_kernel, dim3(grid, 1, ntasks), dim3(256), POST3_LDS_BYTES + 16, st, b);
 }
 
 void launch_split3_block(const Split3Block& a, int ngrp, bool transposed, hipStream_t st) {

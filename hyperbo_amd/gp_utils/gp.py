@@ -54,11 +54,13 @@ def _value_and_grad_of(objective):
 
 
 def sample_from_gp(key, mean_func, cov_func, params, x, warp_func=None, num_samples=1, method='cholesky', eps=1e-6):
-  """gp.py:198-240: (n, num_samples) draws of N(mean(x), K(x,x) + (noise + eps) I).  Gram and Cholesky run on
-  the device (hbo_gram, hbo_spd_solve); the O(n^2) product with the normal draws is on the host.
-  `key`: NumPy Generator or seed; `method` other than 'cholesky' is not offered."""
-  if method != 'cholesky':
-    raise NotImplementedError("sample_from_gp: only method='cholesky'")
+  """gp.py:198-240: (n, num_samples) draws of N(mean(x), K(x,x) + (noise + eps) I).  The Gram matrix comes from the device
+  (hbo_gram); the factor `F` with F F^T = cov follows jax.random.multivariate_normal's three methods: 'cholesky' on the device
+  (hbo_spd_solve), 'svd' (F = U sqrt(s)) and 'eigh' (F = V sqrt(w)) on host LAPACK like the SVD of the SVD-NLL (a reporting
+  path); the O(n^2 S) product with the normal draws is on the host.  `key`: NumPy Generator or seed (the
+  threefry streams of a JAX PRNG key cannot be reproduced without jax)."""
+  if method not in ('cholesky', 'svd', 'eigh'):
+    raise ValueError("method must be one of {'svd', 'eigh', 'cholesky'}")   # the message of jax.random.multivariate_normal
   from hyperbo_amd.basics import linalg
   rng = key if isinstance(key, np.random.Generator) else np.random.default_rng(0 if key is None else key)
   x = np.asarray(x)
@@ -67,8 +69,15 @@ def sample_from_gp(key, mean_func, cov_func, params, x, warp_func=None, num_samp
   noise_variance, = params_utils.retrieve_params(params, ['noise_variance'], warp_func=warp_func)
   cov = np.asarray(cov_func(params, x, warp_func=warp_func), dtype=np.float64)
   cov = cov + np.eye(n) * (float(np.squeeze(noise_variance)) + eps)
-  chol, _ = linalg.solve_linear_system(cov, np.zeros((n, 1)))
-  return mu[:, None] + chol @ rng.standard_normal((n, num_samples))
+  if method == 'cholesky':
+    factor, _ = linalg.solve_linear_system(cov, np.zeros((n, 1)))
+  elif method == 'svd':
+    u, sv, _ = np.linalg.svd(cov)
+    factor = u * np.sqrt(sv[None, :])
+  else:
+    w, v = np.linalg.eigh(cov)
+    factor = v * np.sqrt(w[None, :])
+  return mu[:, None] + factor @ rng.standard_normal((n, num_samples))
 
 
 def infer_parameters(mean_func, cov_func, init_params, dataset, warp_func=None,

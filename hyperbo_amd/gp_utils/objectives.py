@@ -284,10 +284,10 @@ def nll_value_and_grad(mean_func, cov_func, params, dataset, warp_func=None, exc
     buf = np.concatenate([[nll_sum, count], grad])
     buf = comm.allreduce_sum(buf)
     nll_sum, count, grad = buf[0], buf[1], buf[2:]
-  if count > 0:
-    value, grad = nll_sum / count, grad / count
-  else:
+  if count <= 0:
     value, grad = 0., grad * 0.
+  else:   # (a NaN count -- a peer that failed locally contributes NaN to every slot -- takes this branch: the objective is NaN)
+    value, grad = nll_sum / count, grad / count
   grads = bm.unflatten_grad(grad)
   if 'priors' in params.config:
     value = _apply_priors(value, params, warp_func)
@@ -328,9 +328,9 @@ def _divergence(objective_id, mean_func, cov_func, params, dataset, warp_func, w
   if comm is not None and not native:
     buf = comm.allreduce_sum(np.concatenate([[total, count], grad]))
     total, count, grad = buf[0], buf[1], buf[2:]
-  if count > 0:
-    return total / count, bm.unflatten_grad(grad / count)
-  return 0., bm.unflatten_grad(grad * 0.)
+  if count <= 0:
+    return 0., bm.unflatten_grad(grad * 0.)
+  return total / count, bm.unflatten_grad(grad / count)   # (incl. a NaN count: a peer failed locally)
 
 
 def _divergence_host(mean_func, cov_func, params, dataset, warp_func, distance):

@@ -322,4 +322,6 @@ def sharded_mean_nll(local_nll_sum: float, local_count: int, local_grad_sum: np.
   total, count, grad = buf[0], buf[1], buf[2:]
   if count <= 0:
     return 0.0, grad * 0.0, 0
+  if np.isnan(count):   # a peer contributed NaN (local failure): the objective is NaN, not zero
+    return float('nan'), grad * np.nan, 0
   return total / count, grad / count, int(round(count))

@@ -23,6 +23,10 @@
  *   split_f1      0..2     the update of the next group's block columns (F1): only the next column on the panel stream, the later
  *                          ones on a third stream -- 0 never, 1 batches (default: 64 tasks 14.32 -> 14.12 ms), 2 always
  *   sweep_big     >=0      sweep launches of small / batched shapes with at least this many 128-tiles (x tasks) use 128-tiles (4000)
+ *   fault_shard   0..2     ONE-SHOT fault injection into the next hbo_objective_sharded call of this context (tests of the failure
+ *                          paths): 1 = the rank's local part counts as failed -> it joins the all-reduce with NaN in every slot;
+ *                          2 = and it cannot produce that buffer either -> ncclCommAbort, the peers' all-reduce fails, later sharded
+ *                          calls return HBO_ERR_COMM until hbo_comm_init
  *   batch_bg      -1..2    batches: the sweep's launches beside the chain as plain grids (0), persistent over tiles x tasks
  *                          from one counter (1), and also polling the per-CU yield table the chain's kernels then fill (2);
  *                          -1 (default): 1 up to 8 tasks, 0 above (8 tasks 2.52 -> 2.44 ms, 64 tasks 14.13 / 14.31) */

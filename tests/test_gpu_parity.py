@@ -981,6 +981,85 @@ def test_hgp_samples_as_one_batch_match_the_loop_over_samples(gpu_ctx, kname, ml
     assert got.shape == (53, 1) and helpers.rel_err(got, np.mean(refs, axis=0)) < 1e-7
 
 
+@pytest.mark.parametrize('acq', ['ei', 'pi', 'ucb'])
+@pytest.mark.parametrize('kname,mlp,mname,n_obs', [('squared_exponential', False, 'constant', 150), ('matern52', True, 'linear_mlp', 131),
+                                                     ('matern32', False, 'linear', 0)])
+def test_hgp_acquisition_value_and_grad_is_the_mean_over_samples(gpu_ctx, acq, kname, mlp, mname, n_obs):
+  """d acquisition / d x on an HGP (acfun.py:72-82 under bayesopt.py:116-125: jax differentiates the MEAN over the parameter
+  samples): value and gradient against the oracle's mean over samples; the per-sample factorisations are cached across calls
+  (an L-BFGS-B inner loop calls this dozens of times), the samples' fingerprint sees in-place edits, and -- like the reference's
+  loop over samples -- the call leaves the LAST sample in params.model."""
+  defs, _, acfun, gp, kernel, mean, _, utils = _native()
+  rng = np.random.default_rng(41)
+  d, S = 3, 4
+  cfg = {'mlp_features': helpers.MLP_FEATURES}
+  samples = [helpers.make_model(np.random.default_rng(300 + i), mname, mlp, d) for i in range(S)]
+  x, y = helpers.synthetic_task(rng, max(n_obs, 1), d)
+  x2, y2 = helpers.synthetic_task(rng, 20, d)
+  key = 'test'
+  ds = {'other': defs.SubDataset(x2, y2), 'third': defs.SubDataset(x2[:5], y2[:5])}
+  if n_obs:
+    ds[key] = defs.SubDataset(x, y)
+  xq = rng.uniform(size=(9, d))
+  cov_n = getattr(kernel, kname + ('_mlp' if mlp else '')); cov_o = getattr(o, kname + ('_mlp' if mlp else ''))
+  hgp = gp.HGP(ds, getattr(mean, mname), cov_n, defs.GPParams(model=samples[0], samples=samples, config=dict(cfg)), utils.DEFAULT_WARP_FUNC)
+  fn = {'ei': acfun.expected_improvement, 'pi': acfun.probability_of_improvement, 'ucb': acfun.ucb}[acq]
+  param = {'ei': float(np.max(y)) if n_obs else 0.0, 'pi': float(np.max(y)) + 0.1 if n_obs else 0.0, 'ucb': 3.0}[acq]
+  n_iid = len(ds)
+
+  def oracle_mean(smps):
+    vs, gs = [], []
+    for smp in smps:
+      po = o.GPParams(model=smp, config=dict(cfg))
+      noise = float(np.squeeze(o.retrieve_params(po, ['noise_variance'], WFO)[0]))
+      v, g = o.acquisition_value_and_grad(acq, getattr(o, mname), cov_o, po, x if n_obs else None, y if n_obs else None, xq, param, WFO,
+                                          add_noise=noise, scale=n_iid / (n_iid - 1.0))
+      vs.append(v); gs.append(g)
+    return np.mean(vs, axis=0), np.mean(gs, axis=0)
+
+  vo, go = oracle_mean(samples)
+  val, grad = fn.value_and_grad(model=hgp, sub_dataset_key=key, x_queries=xq)
+  assert val.shape == (9, 1) and grad.shape == (9, d)
+  np.testing.assert_allclose(val, vo, rtol=1e-8, atol=1e-10)
+  assert np.max(np.abs(grad - go)) <= 1e-7 * max(np.max(np.abs(go)), 1e-3)
+  assert hgp.params.model is samples[-1] and hgp.params.cache == {}          # gp.py:674-678
+  np.testing.assert_allclose(val, fn(model=hgp, sub_dataset_key=key, x_queries=xq), rtol=1e-8, atol=1e-10)
+  if n_obs:
+    handles = hgp._hbo_sample_caches[1]
+    val2, grad2 = fn.value_and_grad(model=hgp, sub_dataset_key=key, x_queries=xq)
+    assert hgp._hbo_sample_caches[1] is handles and np.array_equal(val2, val) and np.array_equal(grad2, grad)   # cached factors
+    # an in-place edit that keeps every leaf's sum (swap two lengthscales) must be seen
+    ls = samples[1]['lengthscale']
+    if ls.size >= 2 and ls[0] != ls[1]:
+      ls[[0, 1]] = ls[[1, 0]]
+      vo3, go3 = oracle_mean(samples)
+      val3, grad3 = fn.value_and_grad(model=hgp, sub_dataset_key=key, x_queries=xq)
+      assert hgp._hbo_sample_caches[1] is not handles
+      np.testing.assert_allclose(val3, vo3, rtol=1e-8, atol=1e-10)
+      assert np.max(np.abs(grad3 - go3)) <= 1e-7 * max(np.max(np.abs(go3)), 1e-3)
+      np.testing.assert_allclose(fn(model=hgp, sub_dataset_key=key, x_queries=xq), vo3, rtol=1e-8, atol=1e-10)   # the batched values too
+
+
+def test_hgp_samples_go_in_chunks_that_fit_the_device(gpu_ctx, monkeypatch):
+  """acfun.hgp_sample_values: the S caches of one hbo_acq_samples call are bounded by the device's memory -- more samples go in
+  several calls with the same result; here the bound is forced down to 3 samples per call, and the entry point's own limit
+  (S <= 4096) can no longer be hit from Python."""
+  defs, _, acfun, gp, kernel, mean, _, utils = _native()
+  rng = np.random.default_rng(43)
+  d, S = 2, 11
+  samples = [helpers.make_model(np.random.default_rng(400 + i), 'constant', False, d) for i in range(S)]
+  x, y = helpers.synthetic_task(rng, 140, d)
+  xq = rng.uniform(size=(17, d))
+  hgp = gp.HGP({0: defs.SubDataset(x, y)}, mean.constant, kernel.squared_exponential, defs.GPParams(model=samples[0], samples=samples),
+               utils.DEFAULT_WARP_FUNC)
+  whole = acfun.hgp_sample_values(hgp, 0, xq, 0, float(np.max(y)))
+  assert acfun._samples_per_call(140, np.float64, S) == S
+  assert acfun._samples_per_call(60000, np.float64, 4096) < 10            # 3 x 29 GB per sample
+  monkeypatch.setattr(acfun, '_samples_per_call', lambda n, dtype, s: 3)
+  parts = acfun.hgp_sample_values(hgp, 0, xq, 0, float(np.max(y)))
+  assert np.array_equal(parts, whole)
+
+
 def test_hgp_samples_batch_fp32_and_a_sample_that_is_not_positive_definite(gpu_ctx):
   defs, _, acfun, gp, kernel, mean, _, utils = _native()
   rng = np.random.default_rng(32)
@@ -1518,6 +1597,27 @@ def test_sample_from_gp_and_random_dataset(gpu_ctx):
   assert dataset[3].x.shape == (5, d) and queried.x.shape == (40, d) and queried.y.shape == (40, 1)
 
 
+@pytest.mark.parametrize('method', ['svd', 'eigh', 'cholesky'])
+def test_sample_from_gp_methods(gpu_ctx, method):
+  """gp_test.py:279-303 (shape for 'svd' and 'cholesky') + the law of the draws: for every factorisation method of
+  jax.random.multivariate_normal the draws are mean + F z with F F^T = K + (noise + eps) I, so z recovered through the oracle's
+  covariance must be white: F^-1 (y - mu) with F = chol(cov) has identity covariance."""
+  defs, _, _, gp, kernel, mean, _, utils = _native()
+  rng = np.random.default_rng(5)
+  nx, num_samples = 20, 10
+  vx = rng.normal(size=(nx, 1))
+  params = defs.GPParams(model={'constant': 5., 'lengthscale': 1., 'signal_variance': 1.0, 'noise_variance': 0.01})
+  vy = gp.sample_from_gp(0, mean.constant, kernel.squared_exponential, params, vx, num_samples=num_samples, method=method)
+  assert vy.shape == (nx, num_samples)
+  big = gp.sample_from_gp(1, mean.constant, kernel.squared_exponential, params, vx, num_samples=40000, method=method)
+  po = o.GPParams(model=params.model)
+  cov = o.squared_exponential(po, vx) + np.eye(nx) * (0.01 + 1e-6)
+  white = spla.solve_triangular(np.linalg.cholesky(cov), big - 5.0, lower=True)
+  assert np.max(np.abs(np.cov(white) - np.eye(nx))) < 0.04 and np.max(np.abs(white.mean(axis=1))) < 0.03
+  with pytest.raises(ValueError):
+    gp.sample_from_gp(0, mean.constant, kernel.squared_exponential, params, vx, method='qr')
+
+
 def test_continuous_bayesopt_loop(gpu_ctx):
   """bayesopt.py:75-133 with the native acquisition gradient driving SciPy's L-BFGS-B: every proposed point is
   at least as good (in acquisition value) as the best random candidate it started from, and the incumbent improves."""
@@ -1853,6 +1953,109 @@ def test_rccl_two_rank_sharded_objective(gpu_ctx):
     assert not o_['torch'] and len(o_['timing']) == 2      # the device-resident route (hbo_objective_sharded) was taken
     assert abs(o_['value'] - outs[0]['single']) <= 1e-11 * abs(outs[0]['single'])
     np.testing.assert_allclose(o_['grad'], outs[0]['single_grad'], rtol=1e-9, atol=1e-11)
+
+
+_FAKE_RCCL_2RANK = r"""
+import os, sys, json
+import numpy as np
+sys.path.insert(0, os.environ['HBO_ROOT']); sys.path.insert(0, os.path.join(os.environ['HBO_ROOT'], 'tests'))
+import bench, helpers
+from hyperbo_amd import _native as nat, parallel
+from hyperbo_amd.basics import definitions as defs
+from hyperbo_amd.gp_utils import kernel, mean, objectives, utils
+rank, world = int(os.environ['RANK']), 2
+group = parallel.SocketGroup(rank, world, int(os.environ['HBO_TEST_PORT']), token='fake2')
+ctx = nat.default_context()
+comm = parallel.RcclComm(ctx, rank, world, group.bcast_bytes)           # rank 1: hbo_comm_init(rank > 0) with the broadcast id
+data, raw = bench.cfg4_inputs()
+full = {k: defs.SubDataset(xx, yy) for k, (xx, yy) in data.items()}
+mine = parallel.shard_dataset(full, rank, world)
+p = defs.GPParams(model=raw)
+wf = utils.DEFAULT_WARP_FUNC
+dev = objectives.DeviceDataset(mine)
+out = {'rank': rank, 'local_tasks': len(mine), 'torch': 'torch' in sys.modules}
+# (1) the sharded mean NLL + gradient through the device-buffer all-reduce
+v, g = objectives.nll_value_and_grad(mean.constant, kernel.squared_exponential, p, dev, wf, comm=comm)
+out['value'] = v; out['grad'] = helpers.flatten(g).tolist(); out['timing'] = list(comm.last_timing or ())
+# (2) NaN-contribution path: rank 1's local part fails (one-shot injection) -> it still joins the ONE collective, with NaN in
+#     every slot: rank 0's call returns a NaN objective (not a hang), rank 1's its own error code
+group.barrier()
+if rank == 1:
+  ctx.set_option('fault_shard', 1)
+try:
+  v2, g2 = objectives.nll_value_and_grad(mean.constant, kernel.squared_exponential, p, dev, wf, comm=comm)
+  out['nan_value'] = bool(np.isnan(v2)); out['nan_grad'] = bool(np.all(np.isnan(helpers.flatten(g2)))); out['nan_raised'] = None
+except nat.HboError as e:
+  out['nan_raised'] = e.code
+# (3) the communicator is still in step: the next evaluation is right again
+group.barrier()
+v3, g3 = objectives.nll_value_and_grad(mean.constant, kernel.squared_exponential, p, dev, wf, comm=comm)
+out['value_after'] = v3
+# (4) abort path: rank 1 cannot produce even the NaN buffer -> ncclCommAbort; rank 0's all-reduce fails (HBO_ERR_COMM) instead of
+#     waiting for ever; on rank 1 later sharded calls report HBO_ERR_COMM until hbo_comm_init builds a new communicator
+group.barrier()
+if rank == 1:
+  ctx.set_option('fault_shard', 2)
+codes = []
+for _ in range(2):
+  try:
+    objectives.nll_value_and_grad(mean.constant, kernel.squared_exponential, p, dev, wf, comm=comm)
+    codes.append(0)
+  except nat.HboError as e:
+    codes.append(e.code)
+  if rank == 0:
+    break
+out['abort_codes'] = codes
+group.barrier()
+comm.close()
+# (5) a new communicator (new id) after the abort: both ranks in step again
+comm = parallel.RcclComm(ctx, rank, world, group.bcast_bytes)
+v5, _ = objectives.nll_value_and_grad(mean.constant, kernel.squared_exponential, p, dev, wf, comm=comm)
+out['value_reinit'] = v5
+group.barrier(); comm.close(); dev.close(); group.close()
+print(json.dumps(out))
+"""
+
+
+def test_two_ranks_on_one_gpu_through_a_stand_in_collective_library(gpu_ctx):
+  """The N > 1 code of the sharded objective, executed on the one GPU of the test box: RCCL refuses two ranks on one device, so
+  both ranks load tests/libfake_rccl.so (the five nccl entry points over POSIX shm + hipMemcpy, $HBO_RCCL_LIB) and go through
+  hbo_comm_init(rank 1) with the broadcast unique id, hbo_objective_sharded's device-buffer all-reduce on BASELINE cfg 4 (the
+  2-rank mean NLL + gradient against tests/golden/cfg4_t64_oracle.npz), the NaN-contribution path, the ncclCommAbort path and
+  re-initialisation.  The real RCCL transport (xGMI) is NOT exercised here -- no multi-GPU hardware curve exists yet."""
+  import json, socket, subprocess, sys
+  root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+  fake = os.path.join(root, 'tests', 'libfake_rccl.so')
+  if not os.path.exists(fake):
+    subprocess.check_call(['gcc', '-O2', '-shared', '-fPIC', '-D__HIP_PLATFORM_AMD__', '-I/opt/rocm/include',
+                           os.path.join(root, 'tests', 'fake_rccl.c'), '-o', fake, '-L/opt/rocm/lib', '-lamdhip64', '-lrt'])
+  fx = np.load(os.path.join(GOLDEN, 'cfg4_t64_oracle.npz'))
+  s = socket.socket(); s.bind(('127.0.0.1', 0)); port = s.getsockname()[1]; s.close()
+  env = {k: v for k, v in os.environ.items() if k not in ('WORLD_SIZE', 'LOCAL_RANK')}
+  procs = [subprocess.Popen([sys.executable, '-c', _FAKE_RCCL_2RANK], stdout=subprocess.PIPE, text=True,
+                            env=dict(env, RANK=str(r), HBO_DEVICE='0', HBO_TEST_PORT=str(port), HBO_ROOT=root, HBO_RCCL_LIB=fake))
+           for r in range(2)]
+  outs = []
+  for p in procs:
+    txt = p.communicate(timeout=600)[0]
+    assert p.returncode == 0, txt
+    outs.append(json.loads(txt.strip().splitlines()[-1]))
+  outs.sort(key=lambda d: d['rank'])
+  from hyperbo_amd import _native as nat
+  assert outs[0]['local_tasks'] + outs[1]['local_tasks'] == 64 and min(o_['local_tasks'] for o_ in outs) >= 24
+  nll, gref = float(fx['nll_mean']), fx['grad_mean_flat']
+  for o_ in outs:
+    assert not o_['torch'] and len(o_['timing']) == 2
+    assert abs(o_['value'] - nll) <= 1e-10 * abs(nll)
+    assert np.max(np.abs(np.array(o_['grad']) - gref)) <= 1e-8 * np.max(np.abs(gref))
+    assert abs(o_['value_after'] - nll) <= 1e-10 * abs(nll) and abs(o_['value_reinit'] - nll) <= 1e-10 * abs(nll)
+  assert outs[0]['value'] == outs[1]['value'] and outs[0]['grad'] == outs[1]['grad']      # rank-ordered sum: the same bits
+  # NaN contribution: rank 0 sees NaN everywhere (or NOT_PD surfaced as NaN), rank 1 its own error
+  assert outs[0]['nan_raised'] is None and outs[0]['nan_value'] and outs[0]['nan_grad']
+  assert outs[1]['nan_raised'] == nat.HBO_ERR_HIP
+  # abort: rank 1 fails locally, then HBO_ERR_COMM until re-init; rank 0's collective fails instead of hanging
+  assert outs[1]['abort_codes'] == [nat.HBO_ERR_HIP, nat.HBO_ERR_COMM]
+  assert outs[0]['abort_codes'] == [nat.HBO_ERR_COMM]
 
 
 def test_bench_spawns_its_own_ranks_without_torch(gpu_ctx):
