@@ -195,6 +195,9 @@ void launch_grad_feat_mean(int dtype, const TaskDesc* tasks, int ntasks, int64_t
                            int fdim, hipStream_t st);
 void launch_dense_bwd(int dtype, const void* in, const void* out, const void* w, double* dout, double* din,
                       double* dW, double* db, int64_t n, int fin, int fout, hipStream_t st);
+// NLL (+ gradient block in grad_finalize's layout) of a batch whose tasks all have n <= 128: one workgroup per task (small.hip)
+void launch_small_eval(int dtype, const TaskDesc* tasks, int ntasks, const ModelDev* md, int kernel_id, int fdim, int* info,
+                       double* nll_out, double* grad_out, int out_stride, hipStream_t st);
 struct PostArgs {
   const void* Kxq; int64_t ldq; int npad; int n; int nblk;   // cross Gram (npad x ldq)
   const void* alpha;    // kinvy [npad] (first column)

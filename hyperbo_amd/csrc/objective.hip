@@ -131,6 +131,14 @@ static int objective_local(hbo_ctx* c, const hbo_model* m_in, hbo_dataset* ds, i
   HIPCHK(c, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ds->d_info), INT_MAX, T, st));
 
   const int max_nblk = ds->max_nblk, max_npad = max_nblk * HBO_TILE;
+  // every task fits one 128-block (the reference's training regime: sub-sampled tasks of 50-100 points): ONE launch, one workgroup
+  // per task does Gram -> factorisation -> inverse -> K^-1 -> contraction in LDS (small.hip) instead of the 13 launches below
+  const bool fused_small = obj == OBJ_NLL && !needs_mlp(m) && max_nblk == 1 && c->opt_small_fused;
+  if (fused_small) {
+    ProfScope ps(c, "small_eval", 1);
+    launch_small_eval(dtype, ds->d_desc, T, c->d_model, m->kernel_id, feature_dim(m), ds->d_info, ds->d_nll,
+                      want_grad ? ds->d_gradout : nullptr, out_stride, st);
+  } else {
   {
     ProfScope ps(c, "features", 1);
     if (needs_mlp(m)) for (int k = 0; k < T; ++k) run_mlp(c, m, ds->tasks[k]->X, ds->tasks[k]->n, ds->tasks[k]->feat.acts.data());
@@ -232,6 +240,7 @@ static int objective_local(hbo_ctx* c, const hbo_model* m_in, hbo_dataset* ds, i
       }
     }
   }
+  }   // !fused_small
   if (sh) {
     // [nll, count, grad] of this rank's tasks in the caller's gradient layout, on the device: entry j of a task's gradient block
     // goes to map[j] (the scatter the host loop below does), the MLP gradient -- already summed over the tasks -- by segments

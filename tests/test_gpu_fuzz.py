@@ -273,3 +273,91 @@ def test_one_device_dataset_many_models_and_objectives(gpu_ctx):
     if grad and gn is not None:
       a, b = helpers.flatten(go), helpers.flatten(gn)
       assert np.max(np.abs(a - b)) <= 1e-7 * max(np.max(np.abs(a)), 1e-6), (rep, kname, mname, obj)
+
+
+# ---- the single-workgroup evaluation of batches whose tasks all have n <= 128 (small.hip) --------------------------------------
+@pytest.mark.parametrize('dtype,tol_blocked,tol_oracle', [(np.float64, 1e-12, 1e-9), (np.float32, 2e-5, 5e-4)])
+@pytest.mark.parametrize('kname', helpers.KERNELS)
+@pytest.mark.parametrize('mname', ['zero', 'constant', 'linear'])
+def test_single_workgroup_evaluation_vs_blocked_path_and_oracle(gpu_ctx, dtype, tol_blocked, tol_oracle, kname, mname):
+  """One workgroup per task does Gram -> potf2 -> L^-1 -> K^-1 -> contraction in LDS (one launch per batch) when every task of the
+  batch has n <= 128 -- the reference's training regime (data_utils.py:72-100 sub-samples to batch_size; gp_test.py:58-148).
+  Against the blocked pipeline on the same batch (hbo_tune small_fused = 0; fp64: 1e-12) and against the oracle; ragged batch
+  across the leaf boundaries (1, 15, 16, 17, 100, 127, 128 points), a task with several y columns (the (m,m) + scalar broadcast
+  quirk of objectives.py:153-155), value-only calls, and a batch with ONE task of 129 points, which must take the blocked path."""
+  defs, _, _, kernel, mean, objectives, utils = _native()
+  rng = np.random.default_rng(700 + helpers.KERNELS.index(kname) * 3 + len(mname))
+  d = 5
+  model = helpers.make_model(rng, mname, False, d, dtype=dtype)
+  po, pn = o.GPParams(model=model), defs.GPParams(model=model)
+  sizes = [1, 15, 16, 17, 100, 127, 128, 64]
+  dso = {}
+  for t, n in enumerate(sizes):
+    x, y = helpers.synthetic_task(rng, n, d, m=(3 if t == 4 else 1), dtype=dtype)
+    dso[t] = o.SubDataset(x, y)
+  dsn = {k: defs.SubDataset(v.x, v.y) for k, v in dso.items()}
+  ko, kn, mo, mn = getattr(o, kname), getattr(kernel, kname), getattr(o, mname), getattr(mean, mname)
+  wf = utils.DEFAULT_WARP_FUNC
+  dev = objectives.DeviceDataset(dsn)
+  try:
+    gpu_ctx.set_option('small_fused', 1)
+    gpu_ctx.profile_enable(1)
+    v1, g1 = objectives.nll_value_and_grad(mn, kn, pn, dev, wf)
+    stages = gpu_ctx.profile_get()
+    assert 'small_eval' in stages and 'potrf' not in stages, stages      # the fused launch ran, the blocked pipeline did not
+    t1, k1 = objectives.neg_log_marginal_likelihood(mn, kn, pn, dev, wf, return_key2nll=True)
+    gpu_ctx.set_option('small_fused', 0)
+    v0, g0 = objectives.nll_value_and_grad(mn, kn, pn, dev, wf)
+    assert 'potrf' in gpu_ctx.profile_get()
+    t0, k0 = objectives.neg_log_marginal_likelihood(mn, kn, pn, dev, wf, return_key2nll=True)
+  finally:
+    gpu_ctx.set_option('small_fused', 1)
+    gpu_ctx.profile_enable(0)
+    dev.close()
+  f1, f0 = helpers.flatten(g1), helpers.flatten(g0)
+  assert abs(v1 - v0) <= tol_blocked * abs(v0), (v1, v0)
+  assert np.max(np.abs(f1 - f0)) <= tol_blocked * 10 * np.max(np.abs(f0)), np.max(np.abs(f1 - f0)) / np.max(np.abs(f0))
+  assert abs(t1 - t0) <= tol_blocked * abs(t0) and abs(t1 - v1) <= tol_blocked * abs(v1)
+  for k in k0:
+    assert abs(k1[k] - k0[k]) <= tol_blocked * max(abs(k0[k]), 1.0)
+  po64 = o.GPParams(model={k_: (np.asarray(v_, np.float64) if not isinstance(v_, dict) else {a: np.asarray(b, np.float64) for a, b in v_.items()})
+                           for k_, v_ in model.items()})
+  dso64 = {k: o.SubDataset(np.asarray(v.x, np.float64), np.asarray(v.y, np.float64)) for k, v in dso.items()}
+  vo, go = o.nll_value_and_grad(mo, ko, po64, dso64, WFO)
+  fo = helpers.flatten(go)
+  assert abs(v1 - vo) <= tol_oracle * abs(vo)
+  assert np.max(np.abs(f1 - fo)) <= tol_oracle * 10 * np.max(np.abs(fo))
+  # one task beyond 128 points: the whole batch takes the blocked pipeline
+  x, y = helpers.synthetic_task(rng, 129, d, dtype=dtype)
+  dsn[99] = defs.SubDataset(x, y); dso64[99] = o.SubDataset(np.asarray(x, np.float64), np.asarray(y, np.float64))
+  gpu_ctx.profile_enable(1)
+  try:
+    v2, g2 = objectives.nll_value_and_grad(mn, kn, pn, dsn, wf)
+    assert 'potrf' in gpu_ctx.profile_get() and 'small_eval' not in gpu_ctx.profile_get()
+  finally:
+    gpu_ctx.profile_enable(0)
+  vo2, go2 = o.nll_value_and_grad(mo, ko, po64, dso64, WFO)
+  assert abs(v2 - vo2) <= tol_oracle * abs(vo2)
+  assert np.max(np.abs(helpers.flatten(g2) - helpers.flatten(go2))) <= tol_oracle * 10 * np.max(np.abs(helpers.flatten(go2)))
+
+
+def test_single_workgroup_evaluation_reports_a_matrix_that_is_not_positive_definite(gpu_ctx):
+  """A task whose Gram matrix is not positive definite (duplicated rows under a noise-free dot product with eps = 0 would be;
+  here: NaN in y poisons only the value, a NaN input poisons the factorisation): NaN for that task's NLL and gradient, the other
+  tasks of the batch unaffected -- the same outcome as the blocked path (HBO_NOT_PD, NaN-filled outputs, never an exception)."""
+  defs, _, _, kernel, mean, objectives, utils = _native()
+  rng = np.random.default_rng(11)
+  d = 3
+  model = helpers.make_model(rng, 'constant', False, d)
+  pn = defs.GPParams(model=model)
+  x0, y0 = helpers.synthetic_task(rng, 60, d)
+  x1, y1 = helpers.synthetic_task(rng, 90, d)
+  x1 = x1.copy(); x1[40, 1] = np.nan
+  ds = {0: defs.SubDataset(x0, y0), 1: defs.SubDataset(x1, y1)}
+  total, key2nll = objectives.neg_log_marginal_likelihood(mean.constant, kernel.squared_exponential, pn, ds, utils.DEFAULT_WARP_FUNC, return_key2nll=True)
+  assert np.isnan(total) and np.isnan(key2nll[1]) and np.isfinite(key2nll[0])
+  v, g = objectives.nll_value_and_grad(mean.constant, kernel.squared_exponential, pn, ds, utils.DEFAULT_WARP_FUNC)
+  assert np.isnan(v) and all(np.all(np.isnan(g[k])) for k in ('constant', 'lengthscale', 'noise_variance', 'signal_variance'))
+  po = o.GPParams(model=model)
+  vo, _ = o.nll_sub_dataset_value_and_grad(o.constant, o.squared_exponential, po, x0, y0, WFO)
+  assert abs(key2nll[0] - vo) <= 1e-10 * abs(vo)
