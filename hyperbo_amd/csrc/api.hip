@@ -231,7 +231,7 @@ extern "C" int hbo_dataset_free(hbo_ctx* c, hbo_dataset* ds) {
   for (TaskHost* t : ds->tasks) free_task(c, t);
   dev_free(c, ds->d_inputs);
   dev_free(c, ds->d_svec);
-  for (void* p : {(void*)ds->d_desc, (void*)ds->d_pack, (void*)ds->d_partials, (void*)ds->d_mlpgrad}) dev_free(c, p);
+  for (void* p : {(void*)ds->d_desc, (void*)ds->d_pack, (void*)ds->d_partials, (void*)ds->d_mlpgrad, (void*)ds->d_mlp}) dev_free(c, p);
   delete ds;
   return HBO_OK;
 }

@@ -164,6 +164,7 @@ struct hbo_dataset {
   double* d_partials = nullptr; size_t partials_bytes = 0;
   double* d_gradout = nullptr;
   double* d_mlpgrad = nullptr; size_t mlpgrad_elems = 0;
+  MlpTaskDev* d_mlp = nullptr; std::vector<MlpTaskDev> h_mlp_dev;   // per-task pointers of the batched MLP passes (what d_mlp holds)
   bool has_S = false;
 };
 

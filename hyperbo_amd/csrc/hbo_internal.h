@@ -195,9 +195,25 @@ void launch_grad_feat_mean(int dtype, const TaskDesc* tasks, int ntasks, int64_t
                            int fdim, hipStream_t st);
 void launch_dense_bwd(int dtype, const void* in, const void* out, const void* w, double* dout, double* din,
                       double* dW, double* db, int64_t n, int fin, int fout, hipStream_t st);
-// NLL (+ gradient block in grad_finalize's layout) of a batch whose tasks all have n <= 128: one workgroup per task (small.hip)
+// NLL (+ gradient block in grad_finalize's layout) of a batch whose tasks all have n <= 128: one workgroup per task (small.hip).
+// write_back: also store K^-1 (full n x n square in S), s = K^-1 r (svec) and d f / d mu (dmu) for the feature-gradient kernels of
+// an MLP model (grad_feat_kernel, grad_feat_mean_kernel), which follow as launches of their own
 void launch_small_eval(int dtype, const TaskDesc* tasks, int ntasks, const ModelDev* md, int kernel_id, int fdim, int* info,
-                       double* nll_out, double* grad_out, int out_stride, hipStream_t st);
+                       double* nll_out, double* grad_out, int out_stride, int write_back, hipStream_t st);
+// MLP basis of a whole batch, one launch per layer (mlp.hip): per-task pointers
+struct MlpTaskDev {
+  const void* x;                        // n x D inputs
+  void* acts[HBO_MAX_MLP_LAYERS];       // n x f_l activations
+  double* dF; double* dtmp;             // backward: gradient w.r.t. a layer's output, ping-pong
+  int64_t n;
+};
+void launch_mlp_forward_batch(int dtype, const MlpTaskDev* mt, int ntasks, int64_t max_n, int layer, const void* w, const void* b, int fin,
+                              int fout, hipStream_t st);
+void launch_mlp_zero_dF_batch(const MlpTaskDev* mt, int ntasks, int64_t max_n, int flast, hipStream_t st);
+// one layer of the backward pass for every task: dz in place on the current buffer (dF when cur_is_dF, else dtmp), dW / db summed
+// over rows and tasks (fp64 atomics), d input into the other buffer when want_din
+void launch_dense_bwd_batch(int dtype, const MlpTaskDev* mt, int ntasks, int64_t max_n, int layer, int cur_is_dF, const void* w, double* dW,
+                            double* db, int fin, int fout, int want_din, hipStream_t st);
 struct PostArgs {
   const void* Kxq; int64_t ldq; int npad; int n; int nblk;   // cross Gram (npad x ldq)
   const void* alpha;    // kinvy [npad] (first column)

@@ -106,6 +106,24 @@ static int objective_local(hbo_ctx* c, const hbo_model* m_in, hbo_dataset* ds, i
     }
     fill_desc(ds->h_desc[k], t, m, dtype, obj);
   }
+  int64_t max_n = 0;
+  for (int k = 0; k < T; ++k) max_n = std::max<int64_t>(max_n, ds->tasks[k]->n);
+  if (needs_mlp(m)) {
+    // per-task pointers of the batched MLP passes (mlp.hip); uploaded when an allocation moved
+    std::vector<MlpTaskDev> hm(T);
+    for (int k = 0; k < T; ++k) {
+      TaskHost* t = ds->tasks[k];
+      memset(&hm[k], 0, sizeof(MlpTaskDev));
+      hm[k].x = t->X; hm[k].n = t->n; hm[k].dF = t->dF; hm[k].dtmp = t->dtmp;
+      for (int l = 0; l < m->n_layers; ++l) hm[k].acts[l] = t->feat.acts[l];
+    }
+    if (!ds->d_mlp) HIPCHK(c, dev_alloc(c, (void**)&ds->d_mlp, sizeof(MlpTaskDev) * T));
+    if (ds->h_mlp_dev.size() != (size_t)T || memcmp(ds->h_mlp_dev.data(), hm.data(), sizeof(MlpTaskDev) * T) != 0) {
+      HIPCHK(c, hipStreamSynchronize(st));   // (the previous table may still be read by queued work; happens once per dataset)
+      ds->h_mlp_dev = hm;
+      HIPCHK(c, hipMemcpyAsync(ds->d_mlp, ds->h_mlp_dev.data(), sizeof(MlpTaskDev) * T, hipMemcpyHostToDevice, st));
+    }
+  }
   // (per-dataset buffers come from the context's pool: a fresh batch per Adam step paid three hipMalloc + three synchronising
   //  hipFree for its descriptors, results and gradient partials)
   if (!ds->d_desc) HIPCHK(c, dev_alloc(c, (void**)&ds->d_desc, sizeof(TaskDesc) * T));
@@ -133,15 +151,23 @@ static int objective_local(hbo_ctx* c, const hbo_model* m_in, hbo_dataset* ds, i
   const int max_nblk = ds->max_nblk, max_npad = max_nblk * HBO_TILE;
   // every task fits one 128-block (the reference's training regime: sub-sampled tasks of 50-100 points): ONE launch, one workgroup
   // per task does Gram -> factorisation -> inverse -> K^-1 -> contraction in LDS (small.hip) instead of the 13 launches below
-  const bool fused_small = obj == OBJ_NLL && !needs_mlp(m) && max_nblk == 1 && c->opt_small_fused;
+  const bool fused_small = obj == OBJ_NLL && max_nblk == 1 && c->opt_small_fused;
+  auto mlp_forward = [&]() {   // the basis of every task, one launch per layer
+    int fin = m->input_dim;
+    for (int l = 0; l < m->n_layers; ++l) {
+      launch_mlp_forward_batch(dtype, ds->d_mlp, T, max_n, l, c->d_mlp_w[l], c->d_mlp_b[l], fin, m->features[l], st);
+      fin = m->features[l];
+    }
+  };
   if (fused_small) {
+    if (needs_mlp(m)) { ProfScope ps(c, "features", 1); mlp_forward(); }
     ProfScope ps(c, "small_eval", 1);
     launch_small_eval(dtype, ds->d_desc, T, c->d_model, m->kernel_id, feature_dim(m), ds->d_info, ds->d_nll,
-                      want_grad ? ds->d_gradout : nullptr, out_stride, st);
+                      want_grad ? ds->d_gradout : nullptr, out_stride, want_grad && needs_mlp(m), st);
   } else {
   {
     ProfScope ps(c, "features", 1);
-    if (needs_mlp(m)) for (int k = 0; k < T; ++k) run_mlp(c, m, ds->tasks[k]->X, ds->tasks[k]->n, ds->tasks[k]->feat.acts.data());
+    if (needs_mlp(m)) mlp_forward();
     launch_aug_rows(dtype, ds->d_desc, T, max_npad, c->d_model, st);
   }
   int max_naug = 1;
@@ -211,36 +237,29 @@ static int objective_local(hbo_ctx* c, const hbo_model* m_in, hbo_dataset* ds, i
       launch_grad_finalize(dtype, ds->d_desc, T, c->d_model, m->kernel_id, fdim, obj, ds->d_partials, stride_task, ds->d_gradout, out_stride, euc ? ds->d_nll : nullptr, st,
                            ds->d_partials + stride_task * T, max_nblk); }
   }
-  if (want_grad) {
-    if (needs_mlp(m)) {
-      // d nll / d features -> MLP backward (hyperbo/gp_utils/basis_functions.py:24-36), summed over tasks
-      ProfScope ps(c, "mlp_backward", 1);
-      const int L = m->n_layers, flast = m->features[L - 1];
-      size_t tot = 0; int fin0 = m->input_dim;
-      std::vector<size_t> woff(L), boff(L);
-      for (int l = 0; l < L; ++l) { woff[l] = tot; tot += (size_t)fin0 * m->features[l]; boff[l] = tot; tot += m->features[l]; fin0 = m->features[l]; }
-      if (ds->mlpgrad_elems < tot) { if (ds->d_mlpgrad) dev_free(c, ds->d_mlpgrad); HIPCHK(c, dev_alloc(c, (void**)&ds->d_mlpgrad, tot * sizeof(double))); ds->mlpgrad_elems = tot; }
-      HIPCHK(c, hipMemsetAsync(ds->d_mlpgrad, 0, tot * sizeof(double), st));
-      for (int k = 0; k < T; ++k) HIPCHK(c, hipMemsetAsync(ds->tasks[k]->dF, 0, (size_t)ds->tasks[k]->n * flast * sizeof(double), st));
-      if (m->kernel_uses_mlp) {
-        launch_grad_feat(dtype, ds->d_desc, T, max_nblk, c->d_model, m->kernel_id, flast, obj, st);
-        if (euc) launch_scale_dF(ds->d_desc, T, (int64_t)max_npad, flast, st);
-      }
-      if (m->mean_id == HBO_MEAN_LINEAR_MLP) launch_grad_feat_mean(dtype, ds->d_desc, T, (int64_t)max_npad, c->d_model, flast, st);
-      for (int k = 0; k < T; ++k) {
-        TaskHost* t = ds->tasks[k];
-        double* cur = t->dF; double* other = t->dtmp;
-        for (int l = L - 1; l >= 0; --l) {
-          const int fin = l ? m->features[l - 1] : m->input_dim;
-          const void* in = l ? t->feat.acts[l - 1] : t->X;
-          launch_dense_bwd(dtype, in, t->feat.acts[l], c->d_mlp_w[l], cur, l ? other : nullptr,
-                           ds->d_mlpgrad + woff[l], ds->d_mlpgrad + boff[l], t->n, fin, m->features[l], st);
-          std::swap(cur, other);
-        }
-      }
+  }   // !fused_small
+  if (want_grad && needs_mlp(m)) {
+    // d nll / d features -> MLP backward (hyperbo/gp_utils/basis_functions.py:24-36), summed over tasks; every pass one launch
+    // for the whole batch (mlp.hip)
+    ProfScope ps(c, "mlp_backward", 1);
+    const int L = m->n_layers, flast = m->features[L - 1];
+    size_t tot = 0; int fin0 = m->input_dim;
+    std::vector<size_t> woff(L), boff(L);
+    for (int l = 0; l < L; ++l) { woff[l] = tot; tot += (size_t)fin0 * m->features[l]; boff[l] = tot; tot += m->features[l]; fin0 = m->features[l]; }
+    if (ds->mlpgrad_elems < tot) { if (ds->d_mlpgrad) dev_free(c, ds->d_mlpgrad); HIPCHK(c, dev_alloc(c, (void**)&ds->d_mlpgrad, tot * sizeof(double))); ds->mlpgrad_elems = tot; }
+    HIPCHK(c, hipMemsetAsync(ds->d_mlpgrad, 0, tot * sizeof(double), st));
+    launch_mlp_zero_dF_batch(ds->d_mlp, T, max_n, flast, st);
+    if (m->kernel_uses_mlp) {
+      launch_grad_feat(dtype, ds->d_desc, T, max_nblk, c->d_model, m->kernel_id, flast, obj, st);
+      if (euc) launch_scale_dF(ds->d_desc, T, (int64_t)max_npad, flast, st);
+    }
+    if (m->mean_id == HBO_MEAN_LINEAR_MLP) launch_grad_feat_mean(dtype, ds->d_desc, T, (int64_t)max_npad, c->d_model, flast, st);
+    for (int l = L - 1; l >= 0; --l) {
+      const int fin = l ? m->features[l - 1] : m->input_dim;
+      launch_dense_bwd_batch(dtype, ds->d_mlp, T, max_n, l, ((L - 1 - l) % 2) == 0, c->d_mlp_w[l], ds->d_mlpgrad + woff[l], ds->d_mlpgrad + boff[l],
+                             fin, m->features[l], l > 0, st);
     }
   }
-  }   // !fused_small
   if (sh) {
     // [nll, count, grad] of this rank's tasks in the caller's gradient layout, on the device: entry j of a task's gradient block
     // goes to map[j] (the scatter the host loop below does), the MLP gradient -- already summed over the tasks -- by segments

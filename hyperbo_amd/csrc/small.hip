@@ -37,6 +37,7 @@ struct SmallArgs {
   double* grad_out;    // [T][out_stride] or null (value only)
   int out_stride;
   int fdim;
+  int write_back;      // MLP models: K^-1 (full square) -> S, s -> svec, d f / d mu -> dmu for the feature-gradient kernels that follow
 };
 
 template <typename T, int KID>
@@ -309,6 +310,23 @@ __global__ __launch_bounds__(SMALL_THREADS) void small_eval_kernel(SmallArgs g) 
     }
   }
   // (the barrier at the head of distances() orders these stores before the contraction's reads)
+  if (g.write_back) {
+    __syncthreads();
+    T* S = static_cast<T*>(t.S);
+#pragma unroll
+    for (int a = 0; a < GA; ++a) {
+      const int row = ty + 32 * a;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int col = 8 * tx + q;
+        if (row < n && col < n) gst(S + (int64_t)row * t.ld + col, row >= col ? *tile_at(row, col) : *tile_at(col, row));
+      }
+    }
+    if (tid < NB) {
+      gst(static_cast<T*>(t.svec) + tid, sS[tid]);
+      if (tid < n) gst(static_cast<double*>(t.dmu) + tid, 2.0 * t.coef_c * (t.e_all + t.e_last) * (double)sS[tid]);
+    }
+  }
 
   // ---- contraction sum_ij G_ij dK_ij / dtheta over the lower triangle, G = lh K^-1 - c s s^T (grad_contract_kernel) -------------
   T acc[GA][8];
@@ -440,8 +458,8 @@ void small_eval_t(const SmallArgs& a, int ntasks, int kernel_id, hipStream_t st)
 
 // NLL (+ gradient block) of every task of a batch whose tasks all have n <= 128, one workgroup per task, one launch.
 void launch_small_eval(int dtype, const TaskDesc* tasks, int ntasks, const ModelDev* md, int kernel_id, int fdim, int* info,
-                       double* nll_out, double* grad_out, int out_stride, hipStream_t st) {
-  SmallArgs a = {tasks, md, info, nll_out, grad_out, out_stride, fdim};
+                       double* nll_out, double* grad_out, int out_stride, int write_back, hipStream_t st) {
+  SmallArgs a = {tasks, md, info, nll_out, grad_out, out_stride, fdim, write_back};
   if (dtype == HBO_F64) small_eval_t<double>(a, ntasks, kernel_id, st);
   else small_eval_t<float>(a, ntasks, kernel_id, st);
 }

@@ -1,7 +1,7 @@
 """The reference's training regime: T tasks x n points (default 24 x 100, D = 4), SE-ARD + constant mean, fp64.
 Prints ms per Adam step of gp.infer_parameters (batch_size > n: the dataset stays resident, no re-sampling), the time inside
 hbo_objective per evaluation, and the same with the single-workgroup evaluation switched off (hbo_tune small_fused = 0)."""
-import os, sys, time
+import copy, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tests'))
 import numpy as np
@@ -15,7 +15,8 @@ n = int(sys.argv[2]) if len(sys.argv) > 2 else 100
 steps = int(sys.argv[3]) if len(sys.argv) > 3 else 300
 d = 4
 rng = np.random.default_rng(0)
-model = helpers.make_model(rng, 'constant', False, d)
+KN = os.environ.get('KERNEL', 'squared_exponential'); MN = os.environ.get('MEAN', 'constant')
+model = helpers.make_model(rng, MN, KN.endswith('_mlp'), d)
 ds = {i: defs.SubDataset(*helpers.synthetic_task(rng, n, d)) for i in range(T)}
 ctx = nat.default_context()
 L = nat.lib()
@@ -26,13 +27,13 @@ def timed(*a):
 L.hbo_objective = timed
 for fused in (1, 0, 1):
   ctx.set_option('small_fused', fused)
-  cfg = {'method': 'adam', 'batch_size': n + 1, 'max_training_step': steps, 'learning_rate': 1e-3}
-  p = defs.GPParams(model={k: np.array(v, copy=True) for k, v in model.items()}, config=cfg)
-  gp.infer_parameters(mean.constant, kernel.squared_exponential, p, ds, utils.DEFAULT_WARP_FUNC, objectives.nll, key=0)   # warm
+  cfg = {'method': 'adam', 'batch_size': n + 1, 'max_training_step': steps, 'learning_rate': 1e-3, 'mlp_features': helpers.MLP_FEATURES}
+  p = defs.GPParams(model=copy.deepcopy(model), config=cfg)
+  gp.infer_parameters(getattr(mean, MN), getattr(kernel, KN), p, ds, utils.DEFAULT_WARP_FUNC, objectives.nll, key=0)   # warm
   acc['t'] = 0; acc['n'] = 0
-  p = defs.GPParams(model={k: np.array(v, copy=True) for k, v in model.items()}, config=cfg)
+  p = defs.GPParams(model=copy.deepcopy(model), config=cfg)
   t0 = time.perf_counter()
-  gp.infer_parameters(mean.constant, kernel.squared_exponential, p, ds, utils.DEFAULT_WARP_FUNC, objectives.nll, key=0)
+  gp.infer_parameters(getattr(mean, MN), getattr(kernel, KN), p, ds, utils.DEFAULT_WARP_FUNC, objectives.nll, key=0)
   t1 = time.perf_counter()
-  print(f'{T} tasks x {n} points, small_fused={fused}: {1e3 * (t1 - t0) / steps:.4f} ms per Adam step; inside hbo_objective '
+  print(f'{KN} / {MN}: {T} tasks x {n} points, small_fused={fused}: {1e3 * (t1 - t0) / steps:.4f} ms per Adam step; inside hbo_objective '
         f'{1e6 * acc["t"] / max(acc["n"], 1):.1f} us x {acc["n"] / steps:.2f} calls per step')
