@@ -166,7 +166,7 @@ def spawn_ranks(n):
   return 0 if failed is None else max(1, abs(failed[1]))
 
 
-def bench_cfg3(ctx):
+def bench_cfg3(ctx, stages=False):
   """BASELINE.json configs[2]: Matern-5/2 on tanh-MLP(32->64) features + linear_mlp mean, N=16384, fp32: factor once,
   EI over 65 536 candidates; stage times from HIP events (hbo_profile), wall times around the two calls."""
   from hyperbo_amd.basics import definitions as defs
@@ -201,7 +201,7 @@ def bench_cfg3(ctx):
   post_tf = float(n) * n * m / (post_ms * 1e-3) / 1e12
   # the fp32 product runs on the bf16 matrix cores: both operands split exactly into three bf16 pieces, six bf16 MFMAs per
   # fp32 product (csrc/post3.hip) -- executed bf16 flops = 6 x the algorithmic fp32 flops
-  return {'workload': 'cfg3: Matern-5/2 o tanh-MLP(32->64) + linear_mlp mean, N=16384, fp32, factor + EI over 65536 candidates',
+  out = {'workload': 'cfg3: Matern-5/2 o tanh-MLP(32->64) + linear_mlp mean, N=16384, fp32, factor + EI over 65536 candidates',
           'factor_ms': round(tf * 1e3, 2), 'potrf_ms': round(pf['potrf'][0], 2), 'trtri_ms': round(pf['trtri'][0], 2),
           'ei_ms': round(te * 1e3, 2), 'post_gemm_ms': round(post_ms, 2), 'post_gemm_tflops': round(post_tf, 1),
           'post_gemm_path': 'bf16x3 (exact 3-way split of fp32 operands, 6 bf16 MFMAs per product, fp32 accumulate)',
@@ -210,6 +210,10 @@ def bench_cfg3(ctx):
           'note': 'wall times include the host<->device copies of x_query / EI; post_gemm = V = L^-1 Kxq (algorithmic fp32 flops N^2 M); '
                   'frac_bf16_executed = 6 x algorithmic flops (the bf16 MFMAs the product executes) against the dense bf16 MFMA peak; '
                   'factor_frac_fp32 = N^3/3 over the potrf stage time against the fp32 MFMA peak'}
+  if stages:
+    out['stages_ei'] = {k: (round(v[0], 3), v[1]) for k, v in pe.items()}
+    out['stages_factor'] = {k: (round(v[0], 3), v[1]) for k, v in pf.items()}
+  return out
 
 
 def bench_cfg5(ctx):
@@ -294,6 +298,41 @@ def bench_train():
     g.params.model = model()
     t0 = time.perf_counter(); g.train(key=2); el = time.perf_counter() - t0
     out[f'{method}_ms_per_step'] = round(el / st * 1e3, 3)
+  # the reference's own training regime (gp_test.py:58-148, data_utils.py:72-100): many small sub-datasets -- every task fits one
+  # 128-block, so an evaluation is ONE launch (small.hip) + the batched MLP passes (mlp.hip); blocked = the same with
+  # hbo_tune small_fused = 0
+  from hyperbo_amd import _native as nat
+  ctx = nat.default_context()
+  small = {'workload': 'Adam steps on 24 sub-datasets x 100 points, D=4, fp64 (batch_size > n: resident)'}
+  tasks, n = 24, 100
+  data = {}
+  for k in range(tasks):
+    x = rng.uniform(size=(n, d)); w = rng.normal(size=d)
+    data[k] = defs.SubDataset(x, np.sin(2 * np.pi * x @ w)[:, None] + 0.1 * rng.normal(size=(n, 1)))
+  feats = (8, 8)
+  def mlp_model():
+    mm = model(); mm['lengthscale'] = np.zeros(feats[-1]); fin = d
+    mm['mlp_params'] = {}
+    for l, f in enumerate(feats):
+      mm['mlp_params'][f'Dense_{l}'] = {'kernel': rng.normal(size=(fin, f)) / np.sqrt(fin), 'bias': np.zeros(f)}; fin = f
+    mm['linear_mean'] = {'kernel': rng.normal(size=(feats[-1], 1)) / np.sqrt(feats[-1]), 'bias': np.zeros(1)}
+    return mm
+  st = 200
+  for name, mk, cov, mu in (('se_constant', model, kernel.squared_exponential, mean.constant),
+                            ('matern52_mlp_linear_mlp', mlp_model, kernel.matern52_mlp, mean.linear_mlp)):
+    for fused in (1, 0):
+      ctx.set_option('small_fused', fused)
+      try:
+        el = None
+        for rep in range(2):
+          p = defs.GPParams(model=mk(), config={'method': 'adam', 'batch_size': n + 1, 'max_training_step': st, 'learning_rate': 1e-3,
+                                                'objective': objectives.nll, 'mlp_features': feats})
+          g = gp.GP(data, mu, cov, p, utils.DEFAULT_WARP_FUNC)
+          t0 = time.perf_counter(); g.train(key=rep); el = time.perf_counter() - t0
+      finally:
+        ctx.set_option('small_fused', 1)
+      small[f'{name}_ms_per_step' + ('' if fused else '_blocked')] = round(el / st * 1e3, 4)
+  out['small_tasks'] = small
   return out
 
 
@@ -720,6 +759,15 @@ def main():
       for i in range(10):
         f8(i)
       multitask['shard_of_8'] = {'tasks': len(shard8), 'ms_per_eval': round((time.perf_counter() - t0) / 10 * 1e3, 3)}
+      # the partition's cost model (parallel.SHARD_COST_MODEL: latency of the longest chain + throughput over n^3, measured by
+      # tools/scan_cost_model.py) next to the clock: the timed shard, all eight shards as modelled, their imbalance
+      sizes = {k: v.x.shape[0] for k, v in full.items()}
+      parts = parallel.lpt_partition(sizes, 8)
+      model_ms = [parallel.shard_cost_ms([sizes[k] for k in part]) for part in parts]
+      multitask['shard_of_8'].update({'model_ms': round(parallel.shard_cost_ms([v.x.shape[0] for v in shard8.values()]), 3),
+                                      'model_ms_all_shards': [round(v, 3) for v in model_ms],
+                                      'model_imbalance': round(max(model_ms) / (sum(model_ms) / len(model_ms)), 4),
+                                      'model': dict(parallel.SHARD_COST_MODEL, form='c0 + a * max nblk + b * sum n^3 [ms]')})
       dev8.close()
     dev4.close()
 

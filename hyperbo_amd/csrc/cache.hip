@@ -221,7 +221,7 @@ static int posterior(hbo_ctx* c, const hbo_model* m, hbo_cache* k, const void* x
   const int64_t ldq_max = padded_ld(mpad_max, dtype);
   const int lane = (ov && nbuf == 1) ? ov->lane : 0;
   const int wso = 4096 * lane;   // workspace slots of this lane
-  hipStream_t sa = lane == 1 ? c->stream2 : (lane == 2 ? c->stream4 : c->stream), sb = nbuf == 2 ? c->stream2 : sa;
+  hipStream_t sa = lane == 1 ? c->stream2 : (lane == 2 ? c->stream4 : c->stream), sb = (nbuf == 2 && !c->opt_post_serial) ? c->stream2 : sa;
   char *d_xq = nullptr, *d_mu0 = nullptr, *d_kd = nullptr, *d_K = nullptr, *d_colsq = nullptr, *d_mupart = nullptr;
   void *d_mu = nullptr, *d_var = nullptr, *d_acq = nullptr, *d_V = nullptr, *d_Kqq = nullptr, *d_cov = nullptr;
   char* fq_acts[HBO_MAX_MLP_LAYERS] = {nullptr};

@@ -85,6 +85,7 @@ struct hbo_ctx {
   void* rccl_lib = nullptr;
   void* comm = nullptr;
   int opt_small_fused = 1;     // hbo_tune("small_fused"): batches whose tasks all have n <= 128 take the single-workgroup evaluation (small.hip)
+  int opt_post_serial = 0;     // hbo_tune("post_serial"): the streamed posterior's producer side (cross Gram) on the SAME stream as its products: isolated stage times
   int opt_fault_shard = 0;     // hbo_tune("fault_shard"): ONE-SHOT fault injection for the tests of the sharded objective's failure paths
   bool comm_aborted = false;   // set by comm_abort: sharded calls fail with HBO_ERR_COMM until hbo_comm_init builds a new communicator
   double* d_comm_buf = nullptr;

@@ -26,17 +26,36 @@ from typing import Callable, Dict, Hashable, List, Sequence
 import numpy as np
 
 
-def lpt_partition(sizes: Dict[Hashable, int], num_shards: int, power: float = 3.0) -> List[List[Hashable]]:
-  """Greedy longest-processing-time assignment of tasks (cost n^power) to shards; deterministic."""
+# Measured cost of one rank's shard on an MI355X (tools/scan_cost_model.py, fp64 SE-ARD D = 4, batches of 2-16 tasks of 1024-2560
+# points, profiles/r05_shard_cost_model.txt):  T [ms] = c0 + a * max_k nblk_k + b * sum_k n_k^3  (nblk = ceil(n / 128)).
+# The chain of dependent panel steps is as long as the LARGEST task of the batch (the batch moves in lockstep: a), everything
+# else is throughput (b = 1 / 50 TFLOP/s over n^3).  rms residual 5 %, worst 14 %.
+SHARD_COST_MODEL = {'c0': 0.363, 'a': 0.0362, 'b': 2.016e-11}
+
+
+def shard_cost_ms(sizes: Sequence[int], model: Dict[str, float] = None) -> float:
+  """Modelled milliseconds of one NLL + gradient evaluation of a shard holding tasks of these sizes (0 for an empty shard)."""
+  m = model or SHARD_COST_MODEL
+  sizes = [int(n) for n in sizes if int(n) > 0]
+  if not sizes:
+    return 0.0
+  return m['c0'] + m['a'] * max(-(-n // 128) for n in sizes) + m['b'] * sum(float(n)**3 for n in sizes)
+
+
+def lpt_partition(sizes: Dict[Hashable, int], num_shards: int, power: float = 3.0, model: Dict[str, float] = None) -> List[List[Hashable]]:
+  """Greedy longest-processing-time assignment of tasks to shards; deterministic.  Tasks in descending n^power; each goes to the
+  shard whose MODELLED time after taking it (shard_cost_ms: latency of the longest chain + throughput over n^3) is the smallest --
+  with tasks of similar block counts this is the classic LPT on n^3, and a shard that already holds a long chain is the cheaper
+  home for the next long task."""
   if num_shards <= 0:
     raise ValueError('num_shards must be positive')
   order = sorted(sizes.items(), key=lambda kv: (-float(kv[1])**power, str(kv[0])))
-  loads = [0.0] * num_shards
+  held: List[List[int]] = [[] for _ in range(num_shards)]
   shards: List[List[Hashable]] = [[] for _ in range(num_shards)]
   for key, n in order:
-    s = min(range(num_shards), key=lambda i: (loads[i], i))
+    s = min(range(num_shards), key=lambda i: (shard_cost_ms(held[i] + [n], model), i))
     shards[s].append(key)
-    loads[s] += float(n)**power
+    held[s].append(int(n))
   return shards
 
 

@@ -23,6 +23,9 @@
  *   split_f1      0..2     the update of the next group's block columns (F1): only the next column on the panel stream, the later
  *                          ones on a third stream -- 0 never, 1 batches (default: 64 tasks 14.32 -> 14.12 ms), 2 always
  *   sweep_big     >=0      sweep launches of small / batched shapes with at least this many 128-tiles (x tasks) use 128-tiles (4000)
+ *   post_serial   0/1      streamed posterior: features + cross Gram of chunk i+1 on the SAME stream as the product of chunk i
+ *                          (nothing overlaps: the stage times of hbo_profile are then each kernel's isolated time; bench.py cfg3)
+ *   small_fused   0/1      batches whose tasks all have n <= 128: the single-workgroup evaluation (small.hip; default 1)
  *   fault_shard   0..2     ONE-SHOT fault injection into the next hbo_objective_sharded call of this context (tests of the failure
  *                          paths): 1 = the rank's local part counts as failed -> it joins the all-reduce with NaN in every slot;
  *                          2 = and it cannot produce that buffer either -> ncclCommAbort, the peers' all-reduce fails, later sharded

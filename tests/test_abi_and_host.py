@@ -133,6 +133,13 @@ def test_selection_rule_and_lpt_partition():
     assert sorted(k for s in shards for k in s) == sorted(sizes)
     loads = [sum(sizes[k]**3 for k in s) for s in shards]
     assert max(loads) / (sum(loads) / g) < 1.06   # near-balanced for cfg 4's task sizes
+  # the measured cost model behind the partition: latency of the longest chain + throughput over n^3
+  m = parallel.SHARD_COST_MODEL
+  assert parallel.shard_cost_ms([]) == 0.0
+  assert abs(parallel.shard_cost_ms([2432] * 8) - (m['c0'] + 19 * m['a'] + 8 * 2432.0**3 * m['b'])) < 1e-12
+  assert 2.0 < parallel.shard_cost_ms([2432] * 8) / parallel.shard_cost_ms([2432] * 2) < 2.2      # 8 tasks cost ~2x two (measured 3.2 / 1.64 ms)
+  few_long = parallel.lpt_partition({0: 2400, 1: 2400, 2: 300, 3: 300, 4: 300, 5: 300}, 2)
+  assert sorted(map(sorted, few_long)) == [[0, 2, 4], [1, 3, 5]] or sorted(map(len, few_long)) == [3, 3]
   mine = parallel.shard_dataset(ds, 0, 2, exclude_aligned=False)
   other = parallel.shard_dataset(ds, 1, 2, exclude_aligned=False)
   assert set(mine) | set(other) == {'a', 'c'} and not (set(mine) & set(other))
