@@ -194,6 +194,15 @@ def bench_cfg3(ctx, stages=False):
     cur = (t1 - t0, t2 - t1, pf, pe)
     if best is None or cur[0] + cur[1] < best[0] + best[1]:
       best = cur
+  # every stage of the streamed posterior ALONE on the machine (hbo_tune post_serial: the cross Gram of chunk i + 1 no longer runs
+  # beside the product of chunk i): what the co-running cross-Gram kernel costs in isolation, and what the product loses beside it
+  ctx.set_option('post_serial', 1)
+  try:
+    acfun.expected_improvement(model=g, sub_dataset_key=0, x_queries=xq)
+    t0 = time.perf_counter(); acfun.expected_improvement(model=g, sub_dataset_key=0, x_queries=xq); te_serial = time.perf_counter() - t0
+    ps_ = ctx.profile_get()
+  finally:
+    ctx.set_option('post_serial', 0)
   ctx.profile_enable(0)
   assert np.isfinite(ei).all() and (ei >= 0).all()
   tf, te, pf, pe = best
@@ -210,6 +219,20 @@ def bench_cfg3(ctx, stages=False):
           'note': 'wall times include the host<->device copies of x_query / EI; post_gemm = V = L^-1 Kxq (algorithmic fp32 flops N^2 M); '
                   'frac_bf16_executed = 6 x algorithmic flops (the bf16 MFMAs the product executes) against the dense bf16 MFMA peak; '
                   'factor_frac_fp32 = N^3/3 over the potrf stage time against the fp32 MFMA peak'}
+  chunks = ps_['cross_gram'][1]
+  xg_ms = ps_['cross_gram'][0] / chunks
+  ch = m // chunks
+  xg_flops = float(n) * ch * (3 * f + 24)      # per pair: F x (subtract, multiply, add) + sqrt, exp, Matern polynomial
+  out['roofline_xgram'] = {
+      'kernel': 'gram_kernel<float,true,2>: cross Gram k(X, Xq) of one chunk of %d candidates x %d training points, %d features' % (ch, n, f),
+      'isolated_ms_per_chunk': round(xg_ms, 3), 'beside_the_product_ms_per_chunk': round(pe['cross_gram'][0] / pe['cross_gram'][1], 3),
+      'hbm_written_gb': round(4.0 * n * ch / 1e9, 3), 'hbm_tbps': round(4.0 * n * ch / (xg_ms * 1e-3) / 1e12, 3),
+      'hbm_frac': round(4.0 * n * ch / (xg_ms * 1e-3) / 1e12 / HBM_PEAK_TBPS, 4),
+      'valu_tflops': round(xg_flops / (xg_ms * 1e-3) / 1e12, 2), 'valu_frac_fp32': round(xg_flops / (xg_ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
+      'post_gemm_isolated_ms': round(ps_['post_gemm'][0], 2), 'post_gemm_beside_the_gram_ms': round(post_ms, 2),
+      'ei_ms_serialised': round(te_serial * 1e3, 2),
+      'note': 'isolated = hbo_tune post_serial 1 (producer and consumer of the streamed posterior on one stream); the default overlaps '
+              'the cross Gram of chunk i + 1 with the product of chunk i, where it runs in the slots the resident product grid leaves'}
   if stages:
     out['stages_ei'] = {k: (round(v[0], 3), v[1]) for k, v in pe.items()}
     out['stages_factor'] = {k: (round(v[0], 3), v[1]) for k, v in pf.items()}
@@ -603,6 +626,29 @@ def main():
                      'achieved': round(gtb * 1e3, 1), 'peak': HBM_PEAK_TBPS * 1e3, 'unit': 'GB/s', 'frac': round(gtb / HBM_PEAK_TBPS, 4),
                      'algorithmic_bytes': gram_bytes, 'ms': stages['gram'], 'traffic': gram_traffic(),
                      'note': 'bound by VALU issue, not by HBM (profiles/r04_elementwise.md): the stores are 272 MB at this size'}
+  if roofline_gram is not None and rank == 0 and world == 1 and not args.no_extra:
+    # the same kernel at D = 4 and D = 64 (the Gram stage of a value-only evaluation, HIP events): the distance loop costs 2 VALU
+    # instructions per pair and feature, the epilogue ~27 per pair (fp64 exp), so D moves the kernel between its two bounds
+    # (profiles/r05_gram_isa.md)
+    other = {}
+    for dd in (4, 64):
+      try:
+        xg, yg, rawg = cfg2_inputs(seed=2, n=args.n, d=dd)
+        devg = objectives.DeviceDataset({0: defs.SubDataset(xg, yg)})
+        ctx.profile_enable(1)
+        pg = defs.GPParams(model=rawg)
+        best_g = None
+        for _ in range(3):
+          objectives.neg_log_marginal_likelihood(mean.constant, kernel.squared_exponential, pg, devg, wf)
+          gms = ctx.profile_get()['gram'][0]
+          best_g = gms if best_g is None else min(best_g, gms)
+        ctx.profile_enable(0)
+        devg.close()
+        gb = 8.0 * (nblk_g * (nblk_g + 1) / 2 * 128 * 128 + args.n * dd)
+        other[f'd{dd}'] = {'ms': round(best_g, 4), 'achieved': round(gb / (best_g * 1e-3) / 1e9, 1), 'frac': round(gb / (best_g * 1e-3) / 1e12 / HBM_PEAK_TBPS, 4)}
+      except Exception as e:  # pylint: disable=broad-except
+        other[f'd{dd}'] = {'error': str(e)[:100]}
+    roofline_gram['other_feature_dims'] = other
   peak_ubench = None
   try:
     import ctypes as _C2

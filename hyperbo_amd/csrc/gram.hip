@@ -94,8 +94,18 @@ __global__ __launch_bounds__(256) void gram_kernel(GramArgs g, const ModelDev* _
       for (int qb = 0; qb < 8 / VEC; ++qb) {
         vec_t vv;
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) vv[e] = kfun(kid, acc[a][qb * VEC + e], sv, inv_sigma2, bias2, ec);
+        for (int e = 0; e < VEC; ++e) {
+#ifdef HBO_GRAM_NOEXP
+          vv[e] = acc[a][qb * VEC + e] * sv;
+#else
+          vv[e] = kfun(kid, acc[a][qb * VEC + e], sv, inv_sigma2, bias2, ec);
+#endif
+        }
+#ifdef HBO_GRAM_NOSTORE
+        if (vv[0] == (T)123.456) gst(reinterpret_cast<vec_t*>(orow + 16 * VEC * qb), vv);
+#else
         gst(reinterpret_cast<vec_t*>(orow + 16 * VEC * qb), vv);
+#endif
       }
     }
     return;
