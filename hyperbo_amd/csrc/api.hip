@@ -255,7 +255,7 @@ extern "C" int hbo_dataset_create(hbo_ctx* c, int dtype, int input_dim, const hb
     if (tk.n <= 0) continue;  // objectives.py:184-185: empty sub-datasets are skipped
     if (tk.m <= 0 || !tk.x || !tk.y) { hbo_dataset_free(c, ds); return fail(c, HBO_ERR_ARG, "hbo_dataset_create: bad task"); }
     total += al((size_t)tk.n * input_dim * es) + al((size_t)tk.n * es);
-    if (tk.m + 1 <= HBO_TILE) total += al((size_t)(tk.m + 1) * tk.n * es);
+    total += al((size_t)(tk.m + 1) * tk.n * es);
   }
   unsigned char* stage = nullptr;
   if (total) {
@@ -283,7 +283,7 @@ extern "C" int hbo_dataset_create(hbo_ctx* c, int dtype, int input_dim, const hb
       if (dtype == HBO_F64) ((double*)(stage + off))[i] = sum; else ((float*)(stage + off))[i] = (float)sum;
     }
     off += al((size_t)tk.n * es);
-    if (tk.m + 1 <= HBO_TILE) {
+    {
       // sample statistics of objectives.py:57-58: mu_data = mean over the m aligned columns, cov_data =
       // (1/m) sum_a yc_a yc_a^T (jnp.cov(bias=True)); kept as its m rank-1 factors.
       t->ydiv = (char*)ds->d_inputs + off;

@@ -221,6 +221,8 @@ static void fill_desc(TaskDesc& d, TaskHost* t, const hbo_model* m, int dtype, i
       d.naug = t->m; d.e_all = -1.0; d.coef_c = 0.5; d.coef_lh = 0.5;
       break;
   }
+  d.last_src = d.naug - 1;
+  if ((role == OBJ_EKL || role == OBJ_EUC) && t->m + 1 > HBO_TILE) { d.naug = 1; d.last_src = t->m; d.nvec = t->m + 1; }   // see TaskDesc::nvec
   d.n = (int)t->n; d.npad = t->npad; d.nblk = t->nblk; d.m = t->m; d.ld = t->ld;
   const void* last = needs_mlp(m) ? t->feat.acts[m->n_layers - 1] : nullptr;
   d.F = m->kernel_uses_mlp ? last : t->X;

@@ -20,10 +20,11 @@ namespace {
 template <typename T>
 __device__ __forceinline__ const T* outer_vecs(const TaskDesc& t, int obj, int64_t& stride, int& count) {
   if (obj == OBJ_EUC) {
+    if (t.nvec) { stride = t.npad; count = t.nvec - 1; return static_cast<const T*>(t.svec) + t.npad; }   // data rows in svec columns 1..m
     stride = t.ld; count = t.naug - 1;
     return static_cast<const T*>(t.A) + (int64_t)t.npad * t.ld;
   }
-  stride = t.npad; count = t.naug;
+  stride = t.npad; count = t.nvec ? t.nvec : t.naug;
   return static_cast<const T*>(t.svec);
 }
 // MULTI = false: the NLL fast path (one outer-product vector, no Frobenius accumulator)

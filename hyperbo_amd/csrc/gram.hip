@@ -203,7 +203,7 @@ __global__ void aug_rows_kernel(const TaskDesc* tasks, const ModelDev* __restric
     T v = (T)0;
     if (a < t.naug && j < t.n) {
       const T e = (T)(t.e_all + (a == t.naug - 1 ? t.e_last : 0.0));
-      v = ys[(int64_t)a * t.n + j] + e * mu;
+      v = ys[(int64_t)(a == t.naug - 1 ? t.last_src : a) * t.n + j] + e * mu;
     }
     Ar[(int64_t)a * t.ld] = v;
   }
@@ -292,6 +292,22 @@ __global__ void wtz_final_kernel(const TaskDesc* tasks, int out_col, int out_ld,
   else static_cast<T*>(t.svec)[(int64_t)out_col * t.npad + j] = s;   // per-task stride (ragged tasks)
 }
 
+// rows of n elements -> rows of npad elements, zero padded (the data rows of a divergence objective with more than 127 aligned columns)
+template <typename T>
+__global__ void expand_rows_kernel(const T* __restrict__ src, int64_t n, int npad, T* __restrict__ dst) {
+  const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= npad) return;
+  dst[(int64_t)blockIdx.y * npad + j] = j < n ? src[(int64_t)blockIdx.y * n + j] : (T)0;
+}
+// value[0] += coef * sum over `count` rows of npad elements of z^2 (one workgroup: the rows are few and short)
+template <typename T>
+__global__ __launch_bounds__(256) void add_sumsq_kernel(const T* __restrict__ z, int64_t total, double coef, double* value) {
+  __shared__ double sred[4];
+  double q = 0;
+  for (int64_t i = threadIdx.x; i < total; i += 256) { const double v = (double)z[i]; q += v * v; }
+  q = block_sum(q, sred);
+  if (threadIdx.x == 0) value[0] += coef * q;
+}
 template <typename T>
 __global__ void extract_lower_kernel(const T* __restrict__ A, int64_t ld, int64_t n, T* out) {
   const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -353,6 +369,17 @@ void launch_gram_t(const GramArgs& a, const ModelDev* md, dim3 grid, hipStream_t
 
 void launch_gram(int dtype, const GramArgs& a, const ModelDev* md, dim3 grid, hipStream_t st) {
   DISPATCH(dtype, launch_gram_t, a, md, grid, st);
+}
+void launch_expand_rows(int dtype, const void* src, int64_t n, int npad, void* dst, int count, hipStream_t st) {
+  if (count <= 0) return;
+  const dim3 grid((npad + 255) / 256, count);
+  if (dtype == HBO_F64) hipLaunchKernelGGL((expand_rows_kernel<double>), grid, dim3(256), 0, st, (const double*)src, n, npad, (double*)dst);
+  else hipLaunchKernelGGL((expand_rows_kernel<float>), grid, dim3(256), 0, st, (const float*)src, n, npad, (float*)dst);
+}
+void launch_add_sumsq(int dtype, const void* z, int npad, int count, double coef, double* value, hipStream_t st) {
+  if (count <= 0) return;
+  if (dtype == HBO_F64) hipLaunchKernelGGL((add_sumsq_kernel<double>), dim3(1), dim3(256), 0, st, (const double*)z, (int64_t)npad * count, coef, value);
+  else hipLaunchKernelGGL((add_sumsq_kernel<float>), dim3(1), dim3(256), 0, st, (const float*)z, (int64_t)npad * count, coef, value);
 }
 void launch_kdiag(int dtype, const void* f, int64_t n, int fdim, const ModelDev* md, void* out, hipStream_t st) {
   if (n <= 0) return;

@@ -40,6 +40,11 @@ struct TaskDesc {
   //   EKL (objectives.py:29-101 with utils.partial_kl_mvn): rows yc_a/sqrt(m), last row -mu0, e_last = +1, c = 1, lh = 1
   //   factor path: m rows y_a, e_all = -1
   int naug;
+  // divergence objectives with more than 127 aligned columns (m + 1 rows do not fit the augmented tile-row): only the LAST source row
+  // (mu - mean_a y) rides in the tile (naug = 1, last_src = m); the m data rows are vectors of their own in svec columns 1..m --
+  // EKL: alpha_b = W^T (W row_b) computed behind the inverse, EUC: the rows themselves (objective.hip: extra_rows) -- nvec = m + 1
+  int nvec;          // outer-product vectors in svec (0: the naug vectors of the tile rows)
+  int last_src;      // source row (of ysum / ydiv) behind tile row naug - 1; naug - 1 unless nvec
   double e_last, e_all, coef_c, coef_lh, coef_const;
   void* dmu;         // npad doubles: d f / d mu_i
   double* fnorm;     // 2 doubles: [0] |C0 - K1|_F, [1] |mu1 - mu0|  (EUC)
@@ -295,5 +300,9 @@ void launch_extract_lower(int dtype, const void* A, int64_t ld, int64_t n, void*
 void launch_symmetrize_from_lower(int dtype, const void* S, int64_t ld, int64_t n, void* out, hipStream_t st);
 void launch_fill_spd(int dtype, const void* a_dense, int64_t n, void* A, int64_t ld, int npad, hipStream_t st);
 void launch_set_aug(int dtype, const void* b, int64_t n, int m, void* A, int64_t ld, int npad, hipStream_t st);
+// divergence objectives beyond 127 aligned columns: dst[b][j] = j < n ? src[b][j] : 0 for `count` rows of n -> npad elements, and
+// value[0] += coef * sum_b sum_j z[b][j]^2
+void launch_expand_rows(int dtype, const void* src, int64_t n, int npad, void* dst, int count, hipStream_t st);
+void launch_add_sumsq(int dtype, const void* z, int npad, int count, double coef, double* value, hipStream_t st);
 void launch_tri_matvec(int dtype, const void* W, int64_t ld, int npad, const void* x, int64_t xld, int m,
                        int trans, void* out, int64_t old, hipStream_t st);

@@ -58,7 +58,10 @@ static int objective_local(hbo_ctx* c, const hbo_model* m_in, hbo_dataset* ds, i
     so->d_red = d_red; so->ev0 = ev0; so->ev1 = ev1;
     return HBO_OK;
   }
-  if (obj != OBJ_NLL) for (TaskHost* t : ds->tasks) if (!t->ydiv) return fail(c, HBO_ERR_UNSUPPORTED, "hbo_objective: divergence objectives need m + 1 <= 128 aligned columns");
+  if (obj != OBJ_NLL) for (TaskHost* t : ds->tasks) if (!t->ydiv) return fail(c, HBO_ERR_ARG, "hbo_objective: the dataset carries no divergence rows");
+  // tasks with more than 127 aligned columns: their data rows do not ride in the augmented tile-row (TaskDesc::nvec)
+  bool extras = false;
+  if (obj != OBJ_NLL) for (TaskHost* t : ds->tasks) if (t->m + 1 > HBO_TILE) extras = true;
   const int dtype = ds->dtype;
   prof_begin(c);
   hipEvent_t ev_sh0 = nullptr;
@@ -88,7 +91,7 @@ static int objective_local(hbo_ctx* c, const hbo_model* m_in, hbo_dataset* ds, i
   ds->h_desc.resize(T);
   for (int k = 0; k < T; ++k) {
     TaskHost* t = ds->tasks[k];
-    rc = ensure_task_workspace(c, dtype, t, want_grad && !euc, obj == OBJ_NLL ? 1 : t->m + 1);
+    rc = ensure_task_workspace(c, dtype, t, (want_grad || (extras && t->m + 1 > HBO_TILE)) && !euc, obj == OBJ_NLL ? 1 : t->m + 1);
     if (rc) return rc;
     if (needs_mlp(m)) { rc = t->feat.ensure(c, m, t->n); if (rc) return rc; }
     if (needs_mlp(m) && want_grad) {
@@ -199,6 +202,30 @@ static int objective_local(hbo_ctx* c, const hbo_model* m_in, hbo_dataset* ds, i
     { ProfScope ps(c, "nll_reduce", 1, side); launch_nll_reduce(dtype, ds->d_desc, T, ds->d_info, ds->d_nll, side); }
   }
 
+  // the data rows of tasks with more than 127 aligned columns, as outer-product vectors in svec columns 1..m (objectives.py:29-106
+  // has no limit on m).  EUC: the rows themselves.  EKL: tr(K1^-1 C0) = sum_b |W row_b|^2 and alpha_b = W^T W row_b from the explicit
+  // inverse (two triangular products over all m rows), the quadratic forms added to the task's value.  Main stream, W complete.
+  auto extra_rows = [&]() -> int {
+    for (int k = 0; k < T; ++k) {
+      if (!ds->h_desc[k].nvec) continue;
+      TaskHost* t = ds->tasks[k];
+      const size_t es = esize(dtype);
+      char* cols = static_cast<char*>(t->svec) + (size_t)t->npad * es;   // column 1
+      launch_expand_rows(dtype, t->ydiv, t->n, t->npad, cols, t->m, st);
+      if (euc) continue;
+      void* zb = ws_get(c, WS_EXTRA_Z, (size_t)t->m * t->npad * es);
+      if (!zb) return HBO_ERR_HIP;
+      launch_tri_matvec(dtype, t->W, t->ld, t->npad, cols, t->npad, t->m, 0, zb, t->npad, st);
+      launch_add_sumsq(dtype, zb, t->npad, t->m, ds->h_desc[k].coef_c, ds->d_nll + k, st);
+      launch_tri_matvec(dtype, t->W, t->ld, t->npad, zb, t->npad, t->m, 1, cols, t->npad, st);
+    }
+    return HBO_OK;
+  };
+  if (extras && !euc && !want_grad) {   // value only: the inverse is needed for the extra rows all the same
+    { ProfScope ps(c, "trtri", 1); run_trtri(c, dtype, ds->d_desc, T, max_nblk, &trtri_pg); }
+    ProfScope ps(c, "extra_rows", 1);
+    rc = extra_rows(); if (rc) return rc;
+  }
   const int fdim = feature_dim(m);
   const int nacc = grad_nacc(m->kernel_id, fdim);
   const int64_t stride_task = (int64_t)(max_nblk * (max_nblk + 1)) * nacc;   // two half-tile slots per lower tile
@@ -231,6 +258,7 @@ static int objective_local(hbo_ctx* c, const hbo_model* m_in, hbo_dataset* ds, i
       { ProfScope ps(c, "lauum", 1); run_lauum(c, dtype, ds->d_desc, T, max_nblk); }
       if (ev_side) hipStreamWaitEvent(st, ev_side, 0);
     }
+    if (extras) { ProfScope ps(c, "extra_rows", 1); rc = extra_rows(); if (rc) return rc; }
     { ProfScope ps(c, "grad_contract", 1);
       if (!ev_side) launch_dmu(dtype, ds->d_desc, T, obj, st);
       launch_grad_contract(dtype, ds->d_desc, T, max_nblk, c->d_model, m->kernel_id, fdim, obj, ds->d_partials, stride_task, st);

@@ -142,7 +142,8 @@ int hbo_nll(hbo_ctx* ctx, const hbo_model* model, hbo_dataset* ds, double* nll_s
  *        HBO_OBJ_EKL  utils.py:84-148 kl_multivariate_normal(partial=True, eps=0, weight=1)  ('ekl' / 'kl')
  *        HBO_OBJ_EUC  utils.py:151-173 euclidean_multivariate_normal(mean_weight=cov_weight=1) ('euc')
  *      Same output convention as hbo_nll (sums over tasks; the caller divides by the task count,
- *      objectives.py:98-101).  Requires m + 1 <= 128, else HBO_ERR_UNSUPPORTED. */
+ *      objectives.py:98-101).  Any number m of aligned columns: up to 127 ride through the factorisation as augmented rows, beyond
+ *      that the data rows go through the explicit inverse (objective.hip: extra_rows). */
 enum hbo_objective_id { HBO_OBJ_NLL = 0, HBO_OBJ_EKL = 1, HBO_OBJ_EUC = 2 };
 int hbo_objective(hbo_ctx* ctx, const hbo_model* model, hbo_dataset* ds, int objective, double* value_sum,
                   double* value_per_task, double* grad_sum);

@@ -1183,6 +1183,58 @@ def test_divergence_value_and_grad_vs_oracle_fp64(gpu_ctx, kind, kname, mlp, mna
     assert v_dist == v_only
 
 
+@pytest.mark.parametrize('kind', ['ekl', 'euc'])
+@pytest.mark.parametrize('kname,mlp,mname,dtype', [('squared_exponential', False, 'constant', np.float64), ('matern52', True, 'linear_mlp', np.float64),
+                                                    ('matern32', False, 'linear', np.float64), ('squared_exponential', False, 'zero', np.float32)])
+def test_divergence_with_more_than_127_aligned_columns(gpu_ctx, kind, kname, mlp, mname, dtype):
+  """objectives.py:29-106 puts no limit on the number m of aligned columns; the augmented tile-row holds 128 rows.  Beyond that the
+  data rows become outer-product vectors of their own (EKL: through the explicit inverse, EUC: as they are): value and gradient
+  against the oracle for m = 128 (the first size that does not fit), m = 300 with n = 200 (two blocks), next to a sub-dataset
+  that still takes the tile path, value-only calls, and the same batch sub-sampled on the device."""
+  defs, _, _, _, kernel, mean, objectives, utils = _native()
+  rng = np.random.default_rng(57)
+  d = 3
+  model = helpers.make_model(rng, mname, mlp, d, dtype=dtype)
+  cfg = {'mlp_features': helpers.MLP_FEATURES}
+  po = o.GPParams(model=_to64(model), config=dict(cfg)); pn = defs.GPParams(model=model, config=dict(cfg))
+  dso = {}
+  for key, (n, m) in {'tile': (90, 40), 'first': (70, 128), 'big': (200, 300)}.items():
+    x = rng.uniform(size=(n, d))
+    y = np.sin(3 * x.sum(axis=1, keepdims=True) + rng.normal(size=(1, m))) + 0.3 * rng.normal(size=(n, m))
+    dso[key] = o.SubDataset(x, y, aligned=key)
+  dsn = {k: defs.SubDataset(v.x.astype(dtype), v.y.astype(dtype), v.aligned) for k, v in dso.items()}
+  ko = getattr(o, kname + ('_mlp' if mlp else '')); kn = getattr(kernel, kname + ('_mlp' if mlp else ''))
+  vo, go = o.divergence_value_and_grad(kind, getattr(o, mname), ko, po, dso, WFO)
+  fn = objectives.ekl if kind == 'ekl' else objectives.euc
+  vn, gn = fn.value_and_grad(getattr(mean, mname), kn, pn, dsn, utils.DEFAULT_WARP_FUNC)
+  vtol, gtol = (1e-10 * (50 if kind == 'ekl' else 1), 1e-8) if dtype == np.float64 else (2e-3, 2e-2)
+  assert abs(vn - vo) <= vtol * max(abs(vo), 1.0), (vn, vo)
+  fo, fng = helpers.flatten(go), helpers.flatten(gn)
+  assert np.max(np.abs(fo - fng)) <= gtol * np.max(np.abs(fo)), np.max(np.abs(fo - fng)) / np.max(np.abs(fo))
+  v_only = fn(getattr(mean, mname), kn, pn, dsn, utils.DEFAULT_WARP_FUNC)
+  assert abs(v_only - vn) <= (1e-12 if dtype == np.float64 else 1e-5) * max(abs(vn), 1.0)
+  if dtype == np.float64:
+    # each sub-dataset alone (the value-only path of a batch that holds ONLY big-m tasks runs the inverse for the extra rows)
+    for key in ('first', 'big'):
+      v1 = fn(getattr(mean, mname), kn, pn, {key: dsn[key]}, utils.DEFAULT_WARP_FUNC)
+      v1o, _ = o.divergence_value_and_grad(kind, getattr(o, mname), ko, po, {key: dso[key]}, WFO)
+      assert abs(v1 - v1o) <= vtol * max(abs(v1o), 1.0), (key, v1, v1o)
+    # rows gathered on the device (hbo_dataset_subsample carries the divergence rows of every column along)
+    dev = objectives.DeviceBatch(dsn)
+    idx = {'tile': None, 'first': np.arange(0, 70, 2, dtype=np.int32), 'big': rng.permutation(200)[:150].astype(np.int32)}
+    sub = dev.subsample(idx)
+    vs, gs = fn.value_and_grad(getattr(mean, mname), kn, pn, sub, utils.DEFAULT_WARP_FUNC)
+    dso_s = {k: (v if idx[k] is None else o.SubDataset(v.x[idx[k]], v.y[idx[k]], v.aligned)) for k, v in dso.items()}
+    vso, gso = o.divergence_value_and_grad(kind, getattr(o, mname), ko, po, dso_s, WFO)
+    assert abs(vs - vso) <= vtol * max(abs(vso), 1.0)
+    assert np.max(np.abs(helpers.flatten(gs) - helpers.flatten(gso))) <= gtol * np.max(np.abs(helpers.flatten(gso)))
+    sub.close(); dev.close()
+
+
+def _to64(tree):
+  return {k: _to64(v) for k, v in tree.items()} if isinstance(tree, dict) else np.asarray(tree, dtype=np.float64)
+
+
 @pytest.mark.parametrize('qs', [0, 1, 2, 8])
 @pytest.mark.parametrize('kname,mlp,mname', [('squared_exponential', False, 'constant'), ('matern52', True, 'linear_mlp'), ('dot_product', False, 'linear'),
                                              ('matern32', True, 'zero')])
