@@ -213,11 +213,12 @@ def bench_cfg3(ctx, stages=False):
   out = {'workload': 'cfg3: Matern-5/2 o tanh-MLP(32->64) + linear_mlp mean, N=16384, fp32, factor + EI over 65536 candidates',
           'factor_ms': round(tf * 1e3, 2), 'potrf_ms': round(pf['potrf'][0], 2), 'trtri_ms': round(pf['trtri'][0], 2),
           'ei_ms': round(te * 1e3, 2), 'post_gemm_ms': round(post_ms, 2), 'post_gemm_tflops': round(post_tf, 1),
-          'post_gemm_path': 'bf16x3 (exact 3-way split of fp32 operands, 6 bf16 MFMAs per product, fp32 accumulate)',
-          'frac_bf16_executed': round(6.0 * post_tf / BF16_MFMA_PEAK_TFLOPS, 4), 'ei_flops': float(n) * n * m,
+          'post_gemm_path': 'f16x2 (two-way fp16 split of both fp32 operands scaled by powers of two, 3 fp16 MFMAs per product, fp32 '
+                            'accumulate; 2^-22 per product, as close to fp64 as the fp32-MFMA product: csrc/post2h.hip; round 4: bf16x3, 6 MFMAs)',
+          'frac_f16_executed': round(3.0 * post_tf / BF16_MFMA_PEAK_TFLOPS, 4), 'ei_flops': float(n) * n * m,
           'factor_frac_fp32': round(float(n)**3 / 3 / (pf['potrf'][0] * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
           'note': 'wall times include the host<->device copies of x_query / EI; post_gemm = V = L^-1 Kxq (algorithmic fp32 flops N^2 M); '
-                  'frac_bf16_executed = 6 x algorithmic flops (the bf16 MFMAs the product executes) against the dense bf16 MFMA peak; '
+                  'frac_f16_executed = 3 x algorithmic flops (the fp16 MFMAs the product executes) against the dense fp16 / bf16 MFMA peak; '
                   'factor_frac_fp32 = N^3/3 over the potrf stage time against the fp32 MFMA peak'}
   chunks = ps_['cross_gram'][1]
   xg_ms = ps_['cross_gram'][0] / chunks

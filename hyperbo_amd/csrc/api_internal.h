@@ -243,6 +243,8 @@ struct hbo_cache {
   void* zvec = nullptr;    // m x npad : z = L^-1 (y - mu), kept for O(N^2) row appends
   // fp32 caches: W = L^-1 split into three bf16 planes for the posterior product (post3.hip), built at the first use
   unsigned short* w3 = nullptr; size_t w3_elems = 0; bool w3_valid = false;
+  int w3_planes = 0;                 // 3: bf16x3 planes, 2: fp16 planes scaled by the power of two behind *d_wmax (post2h.hip)
+  unsigned int* d_wmax = nullptr;    // device: bits of max |W|
 };
 
 static void fill_nan(void* p, size_t count, int dtype) {

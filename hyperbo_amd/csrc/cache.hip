@@ -281,10 +281,17 @@ static int posterior(hbo_ctx* c, const hbo_model* m, hbo_cache* k, const void* x
   bool use3 = k && dtype == HBO_F32 && c->opt_post_bf16x3 && !full_cov && kchunk == 0;
   unsigned short* d_K3 = nullptr; size_t k3_b = 0;
   const int nkb = k ? t->npad / 16 : 0;
+  // stationary covariances (|k| <= signal variance: the cross Gram's scale is known without a pass over it): two-way fp16 split,
+  // three MFMAs per product instead of six (post2h.hip)
+  const bool use2h = use3 && c->opt_post_f16x2 && m->kernel_id != HBO_KERNEL_DOT;
+  const int planes = use2h ? 2 : 3;
+  const float kscale = use2h ? post2h_scale_for(m->signal_variance) : 1.f;
+  if (use3 && k->w3_valid && k->w3_planes != planes) k->w3_valid = false;
   if (use3 && !k->w3_valid) {
-    // the split copy of W costs 1.5 x its bytes: when the device cannot spare them the fp32-MFMA product takes over
-    const size_t elems = (size_t)t->npad * t->npad * 3;
-    if (!k->w3 || k->w3_elems != elems) {
+    // the split copy of W costs 1.5 x its bytes (fp16: 1 x): when the device cannot spare them the fp32-MFMA product takes over
+    const size_t elems = (size_t)t->npad * t->npad * planes;
+    if (use2h && !k->d_wmax && hbo_malloc(c, (void**)&k->d_wmax, sizeof(unsigned int)) != hipSuccess) { (void)hipGetLastError(); k->d_wmax = nullptr; use3 = false; }
+    if (use3 && (!k->w3 || k->w3_elems != elems)) {
       if (k->w3) hipFree(k->w3);
       k->w3 = nullptr; k->w3_elems = 0;
       if (hbo_malloc(c, (void**)&k->w3, elems * sizeof(unsigned short)) != hipSuccess) { (void)hipGetLastError(); k->w3 = nullptr; use3 = false; }
@@ -292,12 +299,17 @@ static int posterior(hbo_ctx* c, const hbo_model* m, hbo_cache* k, const void* x
     }
     if (use3) {
       ProfScope ps(c, "split_w", 1, sa);
-      launch_split3_rows(static_cast<const float*>(t->W), t->ld, t->nblk, k->w3, nkb, sa);
-      k->w3_valid = true;
+      if (use2h) {
+        launch_absmax_lower(static_cast<const float*>(t->W), t->ld, t->nblk, k->d_wmax, sa);
+        launch_split2h_rows(static_cast<const float*>(t->W), t->ld, t->nblk, k->w3, nkb, k->d_wmax, sa);
+      } else {
+        launch_split3_rows(static_cast<const float*>(t->W), t->ld, t->nblk, k->w3, nkb, sa);
+      }
+      k->w3_valid = true; k->w3_planes = planes;
     }
   }
   if (use3) {
-    k3_b = al((size_t)mpad_max * t->npad * 3 * sizeof(unsigned short));   // (mpad / 128) x nkb blocks of 3 x 128 x 16
+    k3_b = al((size_t)mpad_max * t->npad * planes * sizeof(unsigned short));   // (mpad / 128) x nkb blocks of `planes` x 128 x 16
     d_K3 = (unsigned short*)ws_get(c, WS_K3 + wso, k3_b * nbuf);
     if (!d_K3) { c->err.clear(); use3 = false; }
   }
@@ -356,11 +368,21 @@ static int posterior(hbo_ctx* c, const hbo_model* m, hbo_cache* k, const void* x
     unsigned short* K3_d = use3 ? d_K3 + (size_t)b * (k3_b / sizeof(unsigned short)) : nullptr;
     if (use3) {
       ProfScope ps(c, "split_kxq", 1, sb);
-      launch_split3_transpose(reinterpret_cast<const float*>(K_d), ldq, t->npad, mpad, K3_d, nkb, sb);
+      if (use2h) launch_split2h_transpose(reinterpret_cast<const float*>(K_d), ldq, t->npad, mpad, K3_d, nkb, kscale, sb);
+      else launch_split3_transpose(reinterpret_cast<const float*>(K_d), ldq, t->npad, mpad, K3_d, nkb, sb);
     }
     if (nbuf == 2) { ev_ready[b] = pool_event(c, evi++); hipEventRecord(ev_ready[b], sb); hipStreamWaitEvent(sa, ev_ready[b], 0); }
     // ---- consumer side (sa): V = L^-1 Kxq on MFMA (column sums of squares), then mean / variance / acquisition ----
-    if (use3) {
+    if (use3 && use2h) {
+      ProfScope ps(c, "post_gemm", 1, sa);
+      Post2hArgs a = {}; a.Wp = k->w3; a.Kp = K3_d; a.nkb = nkb; a.wmax_bits = k->d_wmax; a.kscale = kscale;
+      a.colsq = reinterpret_cast<float*>(colsq_d); a.ldc = ldq; a.nblk = t->nblk;
+      if (c->opt_lauum_persist && !ov) {
+        int* counters = (int*)ws_get(c, WS_COUNTERS, sizeof(int) * HBO_N_COUNTERS);
+        if (counters) { a.work_counter = counters + HBO_N_COUNTERS - 8 + (b & 1); hipMemsetAsync(a.work_counter, 0, sizeof(int), sa); }
+      }
+      launch_post2h(a, mpad / HBO_TILE, sa);
+    } else if (use3) {
       ProfScope ps(c, "post_gemm", 1, sa);
       Post3Args a = {}; a.Wp = k->w3; a.Kp = K3_d; a.nkb = nkb;
       a.colsq = reinterpret_cast<float*>(colsq_d); a.ldc = ldq; a.V = nullptr; a.ldv = 0; a.nblk = t->nblk;

@@ -245,6 +245,23 @@ struct Post3Args {
   int col_tiles;              // (set by launch_post3)
   int* work_counter;          // non-null: a resident grid draws the (row tile, column tile) pairs from this zeroed counter, long rows first
 };
+// fp32 posterior product on the fp16 matrix cores from two-way splits (post2h.hip): operands scaled by powers of two into fp16's range
+struct Post2hArgs {
+  const unsigned short* Wp;   // W = L^-1 split into fp16 panel blocks (two planes; layout: post2h.hip), scaled by scale_for(*wmax_bits)
+  const unsigned short* Kp;   // Kxq^T split the same way, scaled by kscale
+  int nkb;
+  float* colsq; int64_t ldc;  // [nblk][ldc] per-row-block column sums of V^2
+  int nblk;
+  int col_tiles;              // (set by launch_post2h)
+  int* work_counter;          // as Post3Args
+  const unsigned int* wmax_bits;   // device: bits of max |W| (launch_absmax_lower)
+  float kscale;
+};
+void launch_absmax_lower(const float* in, int64_t ld, int nblk, unsigned int* out, hipStream_t st);
+void launch_split2h_rows(const float* in, int64_t ld, int row_tiles, unsigned short* out, int nkb, const unsigned int* amax_bits, hipStream_t st);
+void launch_split2h_transpose(const float* in, int64_t ld, int krows, int jcols, unsigned short* out, int nkb, float scale, hipStream_t st);
+float post2h_scale_for(double bound);
+void launch_post2h(const Post2hArgs& a, int col_tiles, hipStream_t st);
 // fp32 trailing updates of the blocked Cholesky on the bf16 matrix cores (post3.hip: split3_panel_kernel, syrk3_kernel)
 struct Syrk3Args {
   const TaskDesc* tasks;

@@ -2,6 +2,7 @@
 // gradient in one pass: features -> Gram -> blocked Cholesky with the augmented rows -> inverse -> K^-1 -> contraction) and its
 // task-sharded form hbo_objective_sharded (device-side reduction + one in-place all-reduce).
 #include "api_internal.h"
+#include <chrono>
 
 extern "C" int hbo_nll(hbo_ctx* c, const hbo_model* m, hbo_dataset* ds, double* nll_sum, double* nll_per_task,
                        double* grad_sum) {
@@ -64,6 +65,7 @@ static int objective_local(hbo_ctx* c, const hbo_model* m_in, hbo_dataset* ds, i
   if (obj != OBJ_NLL) for (TaskHost* t : ds->tasks) if (t->m + 1 > HBO_TILE) extras = true;
   const int dtype = ds->dtype;
   prof_begin(c);
+  const auto host_t0 = std::chrono::steady_clock::now();   // host time spent queueing this evaluation (stage "host_enqueue", level 1)
   hipEvent_t ev_sh0 = nullptr;
   if (sh) { ev_sh0 = pool_event_timed(c, 0); HIPCHK(c, hipEventRecord(ev_sh0, st)); }
   rc = upload_model(c, m);
@@ -336,9 +338,11 @@ static int objective_local(hbo_ctx* c, const hbo_model* m_in, hbo_dataset* ds, i
     h_mlp.resize(ds->mlpgrad_elems);
     HIPCHK(c, hipMemcpyAsync(h_mlp.data(), ds->d_mlpgrad, sizeof(double) * ds->mlpgrad_elems, hipMemcpyDeviceToHost, st));
   }
+  const double host_enqueue_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - host_t0).count();
   HIPCHK(c, hipStreamSynchronize(st));
   HIPCHK(c, hipGetLastError());
   prof_collect(c);
+  if (c->prof_level >= 1) { c->prof_names.push_back("host_enqueue"); c->prof_ms.push_back(host_enqueue_ms); c->prof_count.push_back(1); }
 
   bool notpd = false;
   double total = 0;

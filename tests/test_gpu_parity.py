@@ -2277,7 +2277,7 @@ def test_fp32_posterior_on_bf16_matrix_cores_is_as_accurate_as_fp32_mfma(gpu_ctx
   kernel of the registry, ragged sizes, several chunks; and the planes of W follow a row append of the cache."""
   defs, _, acfun, gp, kernel, mean, _, utils = _native()
   rng = np.random.default_rng(77)
-  d, n, M = 6, 1300, 900
+  d, n, M = 6, 1300, 7000      # (enough candidates for the matrix-core product: below 2 x CUs tiles the split-K fp32 path takes over)
   isp = lambda v: np.log(np.expm1(np.asarray(v, dtype=np.float64)))
   model = {'lengthscale': isp(np.full(d, 0.8)), 'signal_variance': isp(1.2), 'noise_variance': isp(3e-2), 'constant': np.array(0.3),
            'dot_prod_sigma': isp(1.5), 'dot_prod_bias': np.array(0.4)}
@@ -2286,9 +2286,10 @@ def test_fp32_posterior_on_bf16_matrix_cores_is_as_accurate_as_fp32_mfma(gpu_ctx
   cov = getattr(kernel, kname)
   out = {}
   try:
-    gpu_ctx.set_option('post_chunk', 384)
-    for name, dt, opt in (('f64', np.float64, 0), ('mfma', np.float32, 0), ('bf16x3', np.float32, 1)):
+    gpu_ctx.set_option('post_chunk', 2048)
+    for name, dt, opt, opt2 in (('f64', np.float64, 0, 0), ('mfma', np.float32, 0, 0), ('bf16x3', np.float32, 1, 0), ('f16x2', np.float32, 1, 1)):
       gpu_ctx.set_option('post_bf16x3', opt)
+      gpu_ctx.set_option('post_f16x2', opt2)
       cast = lambda t: {k: cast(v) for k, v in t.items()} if isinstance(t, dict) else np.asarray(t, dtype=dt)
       g = gp.GP({0: defs.SubDataset(x[:n - 40].astype(dt), y[:n - 40].astype(dt))}, mean.constant, cov, defs.GPParams(model=cast(model)),
                 utils.DEFAULT_WARP_FUNC)
@@ -2300,16 +2301,23 @@ def test_fp32_posterior_on_bf16_matrix_cores_is_as_accurate_as_fp32_mfma(gpu_ctx
       out[name] = [np.asarray(a, np.float64).ravel() for a in (mu, var, ei, mu2, var2)]
   finally:
     gpu_ctx.set_option('post_bf16x3', 1)
+    gpu_ctx.set_option('post_f16x2', 1)
     gpu_ctx.set_option('post_chunk', 8192)
   for j, what in enumerate(('mean', 'variance', 'EI', 'mean after append', 'variance after append')):
     ref = out['f64'][j]
     scale = max(np.abs(ref).max(), 1e-6)
     e_mfma = np.abs(out['mfma'][j] - ref).max() / scale
-    e_b3 = np.abs(out['bf16x3'][j] - ref).max() / scale
-    assert np.isfinite(out['bf16x3'][j]).all(), what
-    # fp32-level agreement with fp64, and no worse than the fp32-MFMA product (1.5x + 2 ulp of slack for the max statistic)
-    assert e_b3 <= 1.5 * e_mfma + 2.4e-7, (kname, what, e_b3, e_mfma)
-    assert e_b3 < 2e-3, (kname, what, e_b3)
+    # bf16x3: exact products; f16x2 (the default for the stationary covariances; the dot product keeps bf16x3): two-way fp16 split,
+    # 2^-22 per product -- both must be fp32-accurate: no worse than the fp32-MFMA product (1.5x + 2 ulp of slack for the max statistic)
+    for path in ('bf16x3', 'f16x2'):
+      e_p = np.abs(out[path][j] - ref).max() / scale
+      assert np.isfinite(out[path][j]).all(), (path, what)
+      assert e_p <= 1.5 * e_mfma + 2.4e-7, (kname, path, what, e_p, e_mfma)
+      assert e_p < 2e-3, (kname, path, what, e_p)
+  if kname == 'dot_product':
+    assert all(np.array_equal(a, b) for a, b in zip(out['f16x2'], out['bf16x3']))      # unbounded kernel: the f16x2 option does not apply
+  else:
+    assert not np.array_equal(out['f16x2'][1], out['bf16x3'][1])                      # the other path did run
 
 
 @pytest.mark.gpu
