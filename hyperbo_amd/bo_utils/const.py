@@ -33,19 +33,7 @@ EPS = 1e-6
 HYPERBO_DATASETS = {'pd1': data.pd1, 'random': data.random}   # const.py:54-59
 INPUT_SAMPLERS = {}                                             # const.py:61 (empty in the reference too)
 
-# method names of the offline experiment manager (const.py:63-81)
-RAND = 'rand'
-STBO = 'stbo'
-MTBO = 'mtbo'
-STBOV = 'gp'
-HBO = 'hyperbo'
+# Of the method names of the reference's offline experiment manager (const.py:63-81) only what this package reads: which method draws
+# hyper-parameter samples (an HGP instead of a GP, bayesopt.py).  The experiment manager itself is out of scope.
 HBO_SS = 'hyperbo_ss'
-HBO_NLL = 'hyperbo_nll'
-HBO_NLLKL = 'hyperbo_nllkl'
-HBO_NLLEUC = 'hyperbo_nlleuc'
-CONTEXTUAL_METHODS = ['rfgp', 'mimo', STBOV]
-HBO_METHODS = [HBO_SS, HBO_NLL, HBO_NLLKL, HBO_NLLEUC]
-OFFLINE_METHODS = [RAND, STBO, MTBO, HBO, HBO_SS] + CONTEXTUAL_METHODS
-ONLINE_METHODS = [STBO, MTBO] + HBO_METHODS
 USE_HGP = [HBO_SS]
-ST_METHODS = [STBO, STBOV]
