@@ -19,9 +19,9 @@ hipEvent_t pool_event(hbo_ctx* c, size_t i) {
 
 
 // Matrices of up to this many 128-blocks take 64 x 64 GEMM tiles in the inverse, K^-1 = W^T W and the sweep (option small_nblk; auto:
-// fp64 40 -- measured with the pipelined cores, 32 / 40: N = 4608 3.31 / 3.19 ms, 5120 4.02 / 3.82, 6144 (48 blocks) 5.71 / 5.69 at 48 --
+// fp64 48 -- tools/scan_thresholds.py, profiles/r05_sched_thresholds.md: 40 / 48 at N = 6144 (48 blocks) 5.73 / 5.64 ms, equal below, 64 loses at 56 blocks --
 // fp32 32, where the larger matrices' products move to the bf16 cores instead)
-static int small_limit(const hbo_ctx* c, int dtype) { return c->opt_small_nblk >= 0 ? c->opt_small_nblk : (dtype == HBO_F64 ? 40 : 32); }
+static int small_limit(const hbo_ctx* c, int dtype) { return c->opt_small_nblk >= 0 ? c->opt_small_nblk : (dtype == HBO_F64 ? 48 : 32); }
 // Batches: the sweep's launches beside the panel chain as plain grids (0), persistent and slot-limited over tiles x tasks from one
 // counter (1), also polling the chain's yield table (2).  Auto: persistent up to 8 tasks -- measured with the pipelined cores, ms per
 // NLL + gradient, plain / persistent: 4 tasks 1.781 / 1.747, 8 tasks 2.521 / 2.442, 16 tasks 4.200 / 4.223, 32 tasks 7.520 / 7.603,
