@@ -216,7 +216,7 @@ int hbo_profile_get(hbo_ctx* ctx, char names[][32], double* ms, int32_t* launche
  *                         it pays -- more than 4 blocks and (>= 18 blocks or tasks x blocks >= 80); below that everything runs
  *                         on one stream in order (5-13 % faster there).  0 = never, 2 = whenever there is more than one block
  *   small_nblk      int   matrices up to this many 128-blocks use 64x64 tiles in the inverse and in K^-1 = W^T W (default -1: auto --
- *                         40 blocks in fp64, 32 in fp32)
+ *                         48 blocks in fp64, 32 in fp32)
  *   pool_cap_mb     >=0   device buffers of freed datasets / caches are parked for the next one of the same shape (GP.train()
  *                         re-creates its sub-sampled batch every step); at most this many MB stay parked (default: a quarter
  *                         of the device memory, at most 49152; 0 = off)
@@ -226,7 +226,10 @@ int hbo_profile_get(hbo_ctx* ctx, char names[][32], double* ms, int32_t* launche
  *   bf16x3          0/1   fp32 only: the GEMM-shaped work -- trailing updates of the factorisation, the products of the inverse
  *                         and K^-1 = W^T W (above small_nblk blocks), the posterior product V = L^-1 Kxq -- runs on the bf16 matrix cores
  *                         from exact three-way splits of both operands (six bf16 MFMAs per fp32 product, fp32 accumulate:
- *                         fp32-class accuracy at 1.3-1.5x the fp32-MFMA rate).  Default 1; 0 = fp32 MFMA */
+ *                         fp32-class accuracy at 1.3-1.5x the fp32-MFMA rate).  Default 1; 0 = fp32 MFMA.  The posterior product of
+ *                         the stationary covariances goes one step further (hbo_tune post_f16x2, default on): two-way fp16 splits of
+ *                         operands scaled by powers of two, three fp16 MFMAs per product (2^-22 per product: as close to fp64 as
+ *                         the fp32-MFMA product) -- cfg 3's EI 97 -> 59 ms */
 int hbo_set_option(hbo_ctx* ctx, const char* name, int64_t value);
 
 /* ---- multi-GPU: one process per GPU; sum-all-reduce of [nll, grads] over RCCL (xGMI) ------ */

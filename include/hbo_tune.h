@@ -23,6 +23,8 @@
  *   split_f1      0..2     the update of the next group's block columns (F1): only the next column on the panel stream, the later
  *                          ones on a third stream -- 0 never, 1 batches (default: 64 tasks 14.32 -> 14.12 ms), 2 always
  *   sweep_big     >=0      sweep launches of small / batched shapes with at least this many 128-tiles (x tasks) use 128-tiles (4000)
+ *   post_f16x2    0/1      fp32 posterior product of the stationary covariances on the fp16 matrix cores from two-way splits (post2h.hip;
+ *                          default 1; 0 = bf16x3's exact three-way split)
  *   post_serial   0/1      streamed posterior: features + cross Gram of chunk i+1 on the SAME stream as the product of chunk i
  *                          (nothing overlaps: the stage times of hbo_profile are then each kernel's isolated time; bench.py cfg3)
  *   small_fused   0/1      batches whose tasks all have n <= 128: the single-workgroup evaluation (small.hip; default 1)
