@@ -574,7 +574,7 @@ def main():
     # HBM traffic per launch from committed rocprofv3 PMC passes of this same command (separate
     # --pmc FETCH_SIZE / WRITE_SIZE runs; FETCH_SIZE doubled per MI355X_MICROARCH.md: on gfx950 it
     # reports half the bytes of wide coalesced streaming reads).  bench.py cannot run rocprof itself.
-    pmc_path = next((pth for pth in (os.path.join(ROOT, 'profiles', f) for f in ('r04_pmc_hbm.json', 'r03_pmc_hbm.json')) if os.path.exists(pth)), None)
+    pmc_path = next((pth for pth in (os.path.join(ROOT, 'profiles', f) for f in ('r05_pmc_hbm.json', 'r04_pmc_hbm.json', 'r03_pmc_hbm.json')) if os.path.exists(pth)), None)
     if pmc_path:
       pmc_all = json.load(open(pmc_path))
       pmc = pmc_all.get('gemm_kernel<double, true, true, 128>')
@@ -612,8 +612,8 @@ def main():
                    'flops': float(args.n)**3, 'ms': round(ms_per_step, 4), 'achieved': round(eval_tf, 3), 'peak': FP64_MFMA_PEAK_TFLOPS,
                    'unit': 'TFLOP/s', 'frac': round(eval_tf / FP64_MFMA_PEAK_TFLOPS, 4)}
   def gram_traffic():
-    pth = os.path.join(ROOT, 'profiles', 'r04_pmc_hbm.json')
-    if not os.path.exists(pth):
+    pth = next((q for q in (os.path.join(ROOT, 'profiles', f) for f in ('r05_pmc_hbm.json', 'r04_pmc_hbm.json')) if os.path.exists(q)), None)
+    if pth is None:
       return None
     g = json.load(open(pth)).get('gram_kernel<double, true, 0>')
     return int((2 * g['FETCH_SIZE_KB'] + g['WRITE_SIZE_KB']) * 1024) if g else None

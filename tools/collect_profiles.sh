@@ -20,6 +20,8 @@ stats bench python $ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-mu
 stats cfg3 python $ROOT/tools/prof_cfg3.py
 stats cfg4 python $ROOT/tools/prof_multitask.py 64
 stats cfg4_shard8 python $ROOT/tools/prof_multitask.py shard8
+stats small_tasks python $ROOT/tools/train_small.py 24 100 60
+KERNEL=matern52_mlp MEAN=linear_mlp stats small_tasks_mlp python $ROOT/tools/train_small.py 24 100 60
 for ctr in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pmc_$ctr
   rocprofv3 --kernel-trace --pmc $ctr --output-format csv -d /tmp/pmc_$ctr -- python $ROOT/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-multitask --no-extra > $OUT/${TAG}_pmc_$ctr.log 2>&1
