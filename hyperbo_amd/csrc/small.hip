@@ -29,6 +29,11 @@ constexpr int small_lds_bytes() {
          + (SMALL_WAVES * (DC + 4) + SM_RED) * (int)sizeof(double);
 }
 
+// (I, J) of the lower 16 x 16 tiles in tri_index order
+struct SmallTiles {
+  static constexpr int I[36] = {0, 1, 1, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 4, 5, 5, 5, 5, 5, 5, 6, 6, 6, 6, 6, 6, 6, 7, 7, 7, 7, 7, 7, 7, 7};
+  static constexpr int J[36] = {0, 0, 1, 0, 1, 2, 0, 1, 2, 3, 0, 1, 2, 3, 4, 0, 1, 2, 3, 4, 5, 0, 1, 2, 3, 4, 5, 6, 0, 1, 2, 3, 4, 5, 6, 7};
+};
 struct SmallArgs {
   const TaskDesc* tasks;
   const ModelDev* md;
@@ -59,14 +64,24 @@ __global__ __launch_bounds__(SMALL_THREADS) void small_eval_kernel(SmallArgs g) 
   const ModelDev* md = g.md;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, lq = lane >> 4;
-  const int tx = tid & 15, ty = tid >> 4;        // element phases: columns 8 tx .. 8 tx + 7, rows ty + 32 a
   const int n = t.n, fdim = g.fdim;
   constexpr int kid = KID;
   constexpr bool is_dot = (kid == HBO_KERNEL_DOT);
-  constexpr int GA = 4;                          // rows per thread
   const T* F = static_cast<const T*>(t.F);
   const int nleaf = (n + 15) / 16;
+  const int ntile = nleaf * (nleaf + 1) / 2;     // lower tiles that hold data, in tri_index order
   int* info_slot = g.info + blockIdx.x;
+
+  // Element phases (Gram, contraction): the lower tiles are walked in tri_index order, thread = one element position of a 16 x 16
+  // tile, two tiles per pass of the 512 threads -- element e of the thread: tile (tid >> 8) + 2 e, row 16 I + ri, column 16 J + ci.
+  // (A 4 x 8 micro-tile over the 128 x 128 square, as gram_kernel has it, spends half of its lanes on tiles above the diagonal.)
+  constexpr int EPT = 18;                        // 36 tiles / 2
+  const int ri = (tid & 255) >> 4, ci = tid & 15, thalf = tid >> 8;
+  auto tile_ij = [](int tix, int& I, int& J) {
+    int ii = 0;
+    while ((ii + 1) * (ii + 2) / 2 <= tix) ++ii;
+    I = ii; J = tix - ii * (ii + 1) / 2;
+  };
 
   auto stage = [&](int d0, bool scale) {         // features [d0, d0 + DC) of every row into sX[dd][row]
     const int dd = tid & 15, rr0 = tid >> 4;
@@ -80,32 +95,6 @@ __global__ __launch_bounds__(SMALL_THREADS) void small_eval_kernel(SmallArgs g) 
       sX[dd * SXS + row] = v;
     }
   };
-  auto distances = [&](T (&acc)[GA][8]) {        // acc = scaled squared distances (dot product: inner products) of the micro-tile
-#pragma unroll
-    for (int a = 0; a < GA; ++a)
-#pragma unroll
-      for (int q = 0; q < 8; ++q) acc[a][q] = (T)0;
-    for (int d0 = 0; d0 < fdim; d0 += DC) {
-      __syncthreads();
-      stage(d0, !is_dot);
-      __syncthreads();
-      const int dlim = (fdim - d0) < DC ? (fdim - d0) : DC;
-      for (int dd = 0; dd < dlim; ++dd) {
-        T av[GA], bv[8];
-#pragma unroll
-        for (int a = 0; a < GA; ++a) av[a] = sX[dd * SXS + ty + 32 * a];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) bv[q] = sX[dd * SXS + 8 * tx + q];
-#pragma unroll
-        for (int a = 0; a < GA; ++a)
-#pragma unroll
-          for (int q = 0; q < 8; ++q) {
-            if (is_dot) acc[a][q] += av[a] * bv[q];
-            else { const T df = av[a] - bv[q]; acc[a][q] += df * df; }
-          }
-      }
-    }
-  };
   auto tile_at = [&](int row, int col) -> T* {   // element (row, col), row tile >= column tile
     return sT + tri_index(row >> 4, col >> 4) * TILE_ELEMS + (row & 15) * TS + (col & 15);
   };
@@ -116,6 +105,7 @@ __global__ __launch_bounds__(SMALL_THREADS) void small_eval_kernel(SmallArgs g) 
   const T bias2 = (T)(md->dot_bias * md->dot_bias);
 
   // ---- residual row (aug_rows_kernel) and the Gram matrix + (noise + eps) I with identity padding (gram_kernel) ----------------
+  if (tid == 0) *info_slot = 0x7fffffff;         // (the caller no longer clears the info words of a batch that comes here)
   if (tid < NB) {
     T v = (T)0;
     if (tid < n) {
@@ -124,31 +114,56 @@ __global__ __launch_bounds__(SMALL_THREADS) void small_eval_kernel(SmallArgs g) 
     }
     sR[tid] = v;
   }
+  // scaled squared distances (dot product: inner products) and covariances of the thread's elements: kept in registers for the
+  // contraction at the end (the blocked pipeline recomputes both from the features)
+  T uu[EPT], kk[EPT];
+#pragma unroll
+  for (int e = 0; e < EPT; ++e) uu[e] = (T)0;
+  // row / column of element e: tile thalf + 2 e -- e is a compile-time index in the unrolled loops and thalf is uniform per wave,
+  // so the tile's (I, J) are two scalar selects from the tables (kept as index arrays they cost 36 registers for the whole kernel)
+#define EROW(e) (16 * (thalf ? SmallTiles::I[2 * (e) + 1] : SmallTiles::I[2 * (e)]) + ri)
+#define ECOL(e) (16 * (thalf ? SmallTiles::J[2 * (e) + 1] : SmallTiles::J[2 * (e)]) + ci)
+  for (int d0 = 0; d0 < fdim; d0 += DC) {
+    __syncthreads();
+    stage(d0, !is_dot);
+    __syncthreads();
+    const int dlim = (fdim - d0) < DC ? (fdim - d0) : DC;
+    for (int dd = 0; dd < dlim; ++dd) {
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) {
+        if (thalf + 2 * e >= ntile) continue;
+        const T a = sX[dd * SXS + EROW(e)], b = sX[dd * SXS + ECOL(e)];
+        if (is_dot) uu[e] += a * b;
+        else { const T df = a - b; uu[e] += df * df; }
+      }
+    }
+  }
   {
-    T acc[GA][8];
-    distances(acc);
     const T diag_add = (T)(md->noise + md->eps);
 #pragma unroll
-    for (int a = 0; a < GA; ++a) {
-      const int row = ty + 32 * a;
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const int col = 8 * tx + q;
-        if ((row >> 4) < (col >> 4)) continue;   // tiles above the diagonal are not stored (diagonal tiles: both triangles)
-        T v;
-        if (row < n && col < n) {
-          v = kfun(kid, acc[a][q], sv, inv_sigma2, bias2, ec);
-          if (row == col) v += diag_add;
-        } else {
-          v = (row == col) ? (T)1 : (T)0;
-        }
-        *tile_at(row, col) = v;
+    for (int e = 0; e < EPT; ++e) {
+      const int tix = thalf + 2 * e;
+      kk[e] = (T)0;
+      if (tix >= ntile) continue;
+      const int row = EROW(e), col = ECOL(e);
+      T v;
+      if (row < n && col < n) {
+        kk[e] = kfun(kid, uu[e], sv, inv_sigma2, bias2, ec);
+        v = kk[e];
+        if (row == col) v += diag_add;
+      } else {
+        v = (row == col) ? (T)1 : (T)0;
       }
+      sT[tix * TILE_ELEMS + ri * TS + ci] = v;   // (diagonal tiles: both triangles)
     }
   }
   __syncthreads();
 
-  // ---- potf2 in LDS: the loop of chol.hip:potf2_body on tiles that are already resident; the leaf inverses are all kept ---------
+  // ---- potf2 in LDS: the loop of chol.hip:potf2_body on tiles that are already resident, all leaf inverses kept.  The helper waves
+  //      also build W = L^-1 row block by row block IN PLACE behind the leaf chain:  W[i,j] = -M_i sum_{k=j..i-1} L[i,k] W[k,j]  needs
+  //      row block i of L (final since step j of each of its tiles), the rows < i of W and the leaf inverse M_i -- all there one
+  //      step after leaf i; nothing else reads row block i of L any more, so W[i,j] overwrites L[i,j] (the waves take different j:
+  //      the L[i,k] a wave reads have k >= its j).  (A separate in-LDS inverse after the loop took 8 of the kernel's 56 us.)
   T* Wb = static_cast<T*>(t.W);                  // (leaf_cholesky4 also stores each leaf inverse to W: 8 x 256 elements, unused here)
   const int64_t ldw = t.ld;
   auto factor_leaf = [&](int jb) {               // wave 0 only
@@ -164,7 +179,7 @@ __global__ __launch_bounds__(SMALL_THREADS) void small_eval_kernel(SmallArgs g) 
     const T* sM = sMall + jb * TILE_ELEMS;
     acc_t acc = {0, 0, 0, 0};
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) acc = Mma<T>::mma(xt[l15 * TS + kk * 4 + lq], sM[l15 * TS + kk * 4 + lq], acc);
+    for (int kk4 = 0; kk4 < 4; ++kk4) acc = Mma<T>::mma(xt[l15 * TS + kk4 * 4 + lq], sM[l15 * TS + kk4 * 4 + lq], acc);
 #pragma unroll
     for (int r = 0; r < 4; ++r) xt[Mma<T>::crow(lane, r) * TS + l15] = acc[r];
   };
@@ -176,93 +191,92 @@ __global__ __launch_bounds__(SMALL_THREADS) void small_eval_kernel(SmallArgs g) 
 #pragma unroll
     for (int r = 0; r < 4; ++r) acc[r] = ct[Mma<T>::crow(lane, r) * TS + l15];
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) acc = Mma<T>::mma(-at[l15 * TS + kk * 4 + lq], bt[l15 * TS + kk * 4 + lq], acc);
+    for (int kk4 = 0; kk4 < 4; ++kk4) acc = Mma<T>::mma(-at[l15 * TS + kk4 * 4 + lq], bt[l15 * TS + kk4 * 4 + lq], acc);
 #pragma unroll
     for (int r = 0; r < 4; ++r) ct[Mma<T>::crow(lane, r) * TS + l15] = acc[r];
   };
+  // S_j = sum_{k=j..i-1} L[i,k] W[k,j]  (W[k,k] = M_k) into the scratch column, one tile per call
+  auto wrow_sum = [&](int i, int j) {
+    acc_t acc = {0, 0, 0, 0};
+    for (int k = j; k < i; ++k) {
+      const T* lt = sT + tri_index(i, k) * TILE_ELEMS;
+      const T* wt = (k == j) ? sMall + j * TILE_ELEMS : sT + tri_index(k, j) * TILE_ELEMS;
+#pragma unroll
+      for (int kk4 = 0; kk4 < 4; ++kk4) acc = Mma<T>::mma(lt[l15 * TS + kk4 * 4 + lq], wt[(kk4 * 4 + lq) * TS + l15], acc);
+    }
+    T* st = sCol + j * TILE_ELEMS;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) st[Mma<T>::crow(lane, r) * TS + l15] = acc[r];
+  };
+  // W[i,j] = -M_i S_j, over L[i,j]
+  auto wrow_finish = [&](int i, int j) {
+    const T* sM = sMall + i * TILE_ELEMS;
+    const T* st = sCol + j * TILE_ELEMS;
+    acc_t acc = {0, 0, 0, 0};
+#pragma unroll
+    for (int kk4 = 0; kk4 < 4; ++kk4) acc = Mma<T>::mma(-sM[l15 * TS + kk4 * 4 + lq], st[(kk4 * 4 + lq) * TS + l15], acc);
+    T* ot = sT + tri_index(i, j) * TILE_ELEMS;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ot[Mma<T>::crow(lane, r) * TS + l15] = acc[r];
+  };
+  // helper waves 1, 2, 3, 5, 6, 7 (wave 4 shares wave 0's SIMD: the leaf chain runs alone there, as in potf2_body)
+  const bool helper = wave != 0 && wave != 4;
+  const int hw = wave < 4 ? wave - 1 : wave - 2;  // 0..5
   if (wave == 0 && nleaf > 0) factor_leaf(0);
   __syncthreads();
   for (int jb = 0; jb < nleaf; ++jb) {
     for (int R = jb + 1 + wave; R < nleaf; R += SMALL_WAVES) solve_tile(jb, R);
     __syncthreads();
-    if (jb == nleaf - 1) break;
-    {
-      const int m = nleaf - 1 - jb;
-      const int ntiles = m * (m + 1) / 2;        // tile 0 is (jb+1, jb+1): wave 0's, followed by the next leaf
-      auto tile_of = [&](int tix, int& I, int& J) {
+    // (C) trailing update; wave 0 takes the next diagonal tile and factors it; the helpers then the sums of row block jb of W
+    //     (leaf jb and everything left of it are final)
+    const int m = nleaf - 1 - jb;
+    const int ntl = m * (m + 1) / 2;             // tile 0 is (jb+1, jb+1): wave 0's, followed by the next leaf
+    if (wave == 0) {
+      if (m > 0) { update_tile(jb, jb + 1, jb + 1); factor_leaf(jb + 1); }
+    } else if (helper) {
+      for (int tix = 1 + hw; tix < ntl; tix += 6) {
         int ii = 0;
         while ((ii + 1) * (ii + 2) / 2 <= tix) ++ii;
-        I = jb + 1 + ii; J = jb + 1 + tix - ii * (ii + 1) / 2;
-      };
-      if (wave == 0) {
-        update_tile(jb, jb + 1, jb + 1);
-        factor_leaf(jb + 1);
-      } else if (wave != 4) {                    // (wave 4 shares wave 0's SIMD: the leaf chain runs alone there, as in potf2_body)
-        const int hw = wave < 4 ? wave : wave - 1;   // 1..6
-        for (int tix = hw; tix < ntiles; tix += 6) { int I, J; tile_of(tix, I, J); update_tile(jb, I, J); }
+        update_tile(jb, jb + 1 + ii, jb + 1 + tix - ii * (ii + 1) / 2);
       }
+      for (int j = hw; j < jb; j += 6) wrow_sum(jb, j);
     }
     __syncthreads();
+    if (helper) for (int j = hw; j < jb; j += 6) wrow_finish(jb, j);
+    // (the next iteration's solve_tile touches column jb + 1 only: rows > jb + 1; row block jb is not read again)
   }
+  __syncthreads();
 
-  // ---- log-determinant from the diagonal of L (before the tiles are overwritten) ------------------------------------------------
+  // ---- log-determinant from 1 / diag L; the diagonal tiles take their leaf inverses: sT now holds W = L^-1 (lower tiles) -----------
   double ld_sum = 0;
-  if (tid < n) ld_sum = log((double)sT[tri_index(tid >> 4, tid >> 4) * TILE_ELEMS + (tid & 15) * TS + (tid & 15)]);
-
-  // ---- W = L^-1 in place, block column by block column from the last to the first:  W_jj = M_j,
-  //      W_ij = -sum_{k = j+1 .. i} W_ik (L_kj M_j)   (W_ik of the later columns is already in place; W_ii = M_i) ------------------
-  for (int j = nleaf - 2; j >= 0; --j) {
-    const T* sM = sMall + j * TILE_ELEMS;
-    for (int k = j + 1 + wave; k < nleaf; k += SMALL_WAVES) {           // T_k = L_kj M_j
-      const T* lt = sT + tri_index(k, j) * TILE_ELEMS;
-      acc_t acc = {0, 0, 0, 0};
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) acc = Mma<T>::mma(lt[l15 * TS + kk * 4 + lq], sM[(kk * 4 + lq) * TS + l15], acc);
-      T* tt = sCol + (k - j - 1) * TILE_ELEMS;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) tt[Mma<T>::crow(lane, r) * TS + l15] = acc[r];
-    }
-    __syncthreads();
-    for (int i = nleaf - 1 - wave; i > j; i -= SMALL_WAVES) {           // longest sums first
-      acc_t acc = {0, 0, 0, 0};
-      for (int k = j + 1; k <= i; ++k) {
-        const T* wt = (k == i) ? sMall + i * TILE_ELEMS : sT + tri_index(i, k) * TILE_ELEMS;
-        const T* tt = sCol + (k - j - 1) * TILE_ELEMS;
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) acc = Mma<T>::mma(-wt[l15 * TS + kk * 4 + lq], tt[(kk * 4 + lq) * TS + l15], acc);
-      }
-      T* ot = sT + tri_index(i, j) * TILE_ELEMS;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) ot[Mma<T>::crow(lane, r) * TS + l15] = acc[r];
-    }
-    __syncthreads();
-  }
-  for (int j = wave; j < nleaf; j += SMALL_WAVES) {                     // diagonal tiles: W_jj = M_j (zeros above the diagonal)
+  if (tid < n) ld_sum = -log((double)sDinv[tid]);
+  for (int j = wave; j < nleaf; j += SMALL_WAVES) {
     T* dt = sT + tri_index(j, j) * TILE_ELEMS;
     const T* sM = sMall + j * TILE_ELEMS;
     for (int e = lane; e < 256; e += 64) dt[(e >> 4) * TS + (e & 15)] = sM[(e >> 4) * TS + (e & 15)];
   }
   __syncthreads();
 
-  // ---- z = W r, s = W^T z (four threads per row / column), the quadratic form and the NLL ---------------------------------------
+  // ---- z = W r, s = W^T z (sixteen lanes per row / column, four rows per wave and pass), the quadratic form and the NLL ------------
   const int np = nleaf * 16;
-  {
-    const int i = tid >> 2, part = tid & 3;
+  for (int i0 = 0; i0 < np; i0 += 32) {
+    const int i = i0 + (tid >> 4);
     T a = (T)0;
-    if (i < np) for (int j = part; j <= i; j += 4) a += *tile_at(i, j) * sR[j];
-    a += __shfl_xor(a, 1); a += __shfl_xor(a, 2);
-    if (part == 0) sZ[i] = i < np ? a : (T)0;
+    if (i < np) for (int j = l15; j <= i; j += 16) a += *tile_at(i, j) * sR[j];
+    a += __shfl_xor(a, 1); a += __shfl_xor(a, 2); a += __shfl_xor(a, 4); a += __shfl_xor(a, 8);
+    if (l15 == 0 && i < np) sZ[i] = a;
   }
+  if (tid >= np && tid < NB) { sZ[tid] = (T)0; sS[tid] = (T)0; }
   __syncthreads();
-  double qpart = 0;
-  {
-    const int j = tid >> 2, part = tid & 3;
+  for (int j0 = 0; j0 < np; j0 += 32) {
+    const int j = j0 + (tid >> 4);
     T a = (T)0;
-    if (j < np) for (int i = j + part; i < np; i += 4) a += *tile_at(i, j) * sZ[i];
-    a += __shfl_xor(a, 1); a += __shfl_xor(a, 2);
-    if (part == 0) sS[j] = j < np ? a : (T)0;
-    if (tid < NB) { const double z = tid < n ? (double)sZ[tid] : 0.0; qpart = z * z; }
+    if (j < np) for (int i = j + l15; i < np; i += 16) a += *tile_at(i, j) * sZ[i];
+    a += __shfl_xor(a, 1); a += __shfl_xor(a, 2); a += __shfl_xor(a, 4); a += __shfl_xor(a, 8);
+    if (l15 == 0 && j < np) sS[j] = a;
   }
+  double qpart = 0;
+  if (tid < NB) { const double z = tid < n ? (double)sZ[tid] : 0.0; qpart = z * z; }
   {
     const double q = wave_sum(qpart), l = wave_sum(ld_sum);
     if (lane == 0) { swred[wave * (DC + 4)] = q; swred[wave * (DC + 4) + 1] = l; }
@@ -281,20 +295,18 @@ __global__ __launch_bounds__(SMALL_THREADS) void small_eval_kernel(SmallArgs g) 
   {
     constexpr int MAXT = (36 + SMALL_WAVES - 1) / SMALL_WAVES;
     acc_t out[MAXT];
-    const int ntile = nleaf * (nleaf + 1) / 2;
 #pragma unroll
     for (int s = 0; s < MAXT; ++s) {
       out[s] = (acc_t){0, 0, 0, 0};
       const int tix = wave + SMALL_WAVES * s;
       if (tix < ntile) {
-        int i = 0;
-        while ((i + 1) * (i + 2) / 2 <= tix) ++i;
-        const int j = tix - i * (i + 1) / 2;
+        int i, j;
+        tile_ij(tix, i, j);
         for (int k = i; k < nleaf; ++k) {
           const T* wi = sT + tri_index(k, i) * TILE_ELEMS;
           const T* wj = sT + tri_index(k, j) * TILE_ELEMS;
 #pragma unroll
-          for (int kk = 0; kk < 4; ++kk) out[s] = Mma<T>::mma(wi[(kk * 4 + lq) * TS + l15], wj[(kk * 4 + lq) * TS + l15], out[s]);
+          for (int kk4 = 0; kk4 < 4; ++kk4) out[s] = Mma<T>::mma(wi[(kk4 * 4 + lq) * TS + l15], wj[(kk4 * 4 + lq) * TS + l15], out[s]);
         }
       }
     }
@@ -303,24 +315,18 @@ __global__ __launch_bounds__(SMALL_THREADS) void small_eval_kernel(SmallArgs g) 
     for (int s = 0; s < MAXT; ++s) {
       const int tix = wave + SMALL_WAVES * s;
       if (tix < ntile) {
-        T* ot = sT + tix * TILE_ELEMS;           // tri_index(i, j) == tix by construction
+        T* ot = sT + tix * TILE_ELEMS;
 #pragma unroll
         for (int r = 0; r < 4; ++r) ot[Mma<T>::crow(lane, r) * TS + l15] = out[s][r];
       }
     }
   }
-  // (the barrier at the head of distances() orders these stores before the contraction's reads)
+  __syncthreads();
   if (g.write_back) {
-    __syncthreads();
     T* S = static_cast<T*>(t.S);
-#pragma unroll
-    for (int a = 0; a < GA; ++a) {
-      const int row = ty + 32 * a;
-#pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const int col = 8 * tx + q;
-        if (row < n && col < n) gst(S + (int64_t)row * t.ld + col, row >= col ? *tile_at(row, col) : *tile_at(col, row));
-      }
+    for (int e0 = tid; e0 < NB * NB; e0 += SMALL_THREADS) {
+      const int row = e0 >> 7, col = e0 & 127;
+      if (row < n && col < n) gst(S + (int64_t)row * t.ld + col, row >= col ? *tile_at(row, col) : *tile_at(col, row));
     }
     if (tid < NB) {
       gst(static_cast<T*>(t.svec) + tid, sS[tid]);
@@ -328,30 +334,26 @@ __global__ __launch_bounds__(SMALL_THREADS) void small_eval_kernel(SmallArgs g) 
     }
   }
 
-  // ---- contraction sum_ij G_ij dK_ij / dtheta over the lower triangle, G = lh K^-1 - c s s^T (grad_contract_kernel) -------------
-  T acc[GA][8];
-  distances(acc);
+  // ---- contraction sum_ij G_ij dK_ij / dtheta over the lower triangle, G = lh K^-1 - c s s^T (grad_contract_kernel), from the
+  //      distances and covariances of the Gram phase ----------------------------------------------------------------------------
   const T lh = (T)t.coef_lh, cc = (T)t.coef_c;
   double a_gk = 0, a_tr = 0, a_g = 0;
 #pragma unroll
-  for (int a = 0; a < GA; ++a) {
-    const int row = ty + 32 * a;
-    const T si = sS[row];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int col = 8 * tx + q;
-      T gw = (T)0;
+  for (int e = 0; e < EPT; ++e) {
+    const int tix = thalf + 2 * e;
+    T gw = (T)0;
+    if (tix < ntile) {
+      const int row = EROW(e), col = ECOL(e);
       if (row < n && col <= row) {
-        const T u = acc[a][q];
-        const T k = kfun(kid, u, sv, inv_sigma2, bias2, ec);
-        const T G0 = lh * *tile_at(row, col) - cc * (si * sS[col]);
+        const T u = uu[e], k = kk[e];
+        const T G0 = lh * sT[tix * TILE_ELEMS + ri * TS + ci] - cc * (sS[row] * sS[col]);
         const T G = (row == col) ? G0 : G0 * (T)2;      // an element below the diagonal stands for its mirror image too
         if (is_dot) { a_gk += (double)(G * u); a_g += (double)G; }
         else { a_gk += (double)(G * k); gw = G * dk_du(kid, u, k, sv, ec); }
         if (row == col) a_tr += (double)G;
       }
-      acc[a][q] = gw;
     }
+    uu[e] = gw;                                  // (re-uses the register)
   }
   a_gk = wave_sum(a_gk); a_tr = wave_sum(a_tr); a_g = wave_sum(a_g);
   __syncthreads();                               // (swred held the NLL partial sums: thread 0 has read them)
@@ -369,16 +371,13 @@ __global__ __launch_bounds__(SMALL_THREADS) void small_eval_kernel(SmallArgs g) 
       __syncthreads();
       const int dlim = (fdim - d0) < DC ? (fdim - d0) : DC;
       for (int dd = 0; dd < dlim; ++dd) {
-        T av[GA], bv[8];
-#pragma unroll
-        for (int a = 0; a < GA; ++a) av[a] = sX[dd * SXS + ty + 32 * a];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) bv[q] = sX[dd * SXS + 8 * tx + q];
         T s = (T)0;
 #pragma unroll
-        for (int a = 0; a < GA; ++a)
-#pragma unroll
-          for (int q = 0; q < 8; ++q) { const T df = av[a] - bv[q]; s += acc[a][q] * df * df; }
+        for (int e = 0; e < EPT; ++e) {
+          if (thalf + 2 * e >= ntile) continue;
+          const T df = sX[dd * SXS + EROW(e)] - sX[dd * SXS + ECOL(e)];
+          s += uu[e] * df * df;
+        }
         const double ws = wave_sum((double)s);
         if (lane == 0) swred[wave * (DC + 4) + 4 + dd] = ws;
       }
@@ -414,27 +413,29 @@ __global__ __launch_bounds__(SMALL_THREADS) void small_eval_kernel(SmallArgs g) 
       o[n_ls] = 0;
     }
   }
+  // mean parameters: wave w takes output w - 1 (-1: the sum of d f / d mu = constant / bias; d >= 0: linear weight d)
   const double dmu_scale = 2.0 * t.coef_c * (t.e_all + t.e_last);
   const bool lin = (md->mean_id == HBO_MEAN_LINEAR || md->mean_id == HBO_MEAN_LINEAR_MLP);
   const T* fm = static_cast<const T*>(t.Fm);
   const int lin0 = n_ls + 5;
-  // one pass per output: constant / bias (sum of d mu), then the linear weights
-  for (int d = -1; d < (lin ? t.fmean : 0); ++d) {
+  for (int d = wave - 1; d < (lin ? t.fmean : 0); d += SMALL_WAVES) {
     double s = 0;
-    if (tid < n) { s = dmu_scale * (double)sS[tid]; if (d >= 0) s *= (double)gld(fm + (int64_t)tid * t.fmean + d); }
+    for (int i = lane; i < n; i += 64) {
+      double v = dmu_scale * (double)sS[i];
+      if (d >= 0) v *= (double)gld(fm + (int64_t)i * t.fmean + d);
+      s += v;
+    }
     s = wave_sum(s);
-    __syncthreads();
-    if (lane == 0) swred[wave * (DC + 4)] = s;
-    __syncthreads();
-    if (tid == 0) {
-      double tot = 0;
-      for (int w = 0; w < SMALL_WAVES; ++w) tot += swred[w * (DC + 4)];
-      if (d < 0) { o[n_ls + 2] = (md->mean_id == HBO_MEAN_CONSTANT) ? tot : 0.0; o[lin0 + t.fmean] = lin ? tot : 0.0; }
-      else o[lin0 + d] = tot;
+    if (lane == 0) {
+      if (d < 0) { o[n_ls + 2] = (md->mean_id == HBO_MEAN_CONSTANT) ? s : 0.0; o[lin0 + t.fmean] = lin ? s : 0.0; }
+      else o[lin0 + d] = s;
     }
   }
   if (!lin && tid == 0) for (int d = 0; d < t.fmean; ++d) o[lin0 + d] = 0.0;
 }
+
+#undef EROW
+#undef ECOL
 
 template <typename T>
 void small_eval_t(const SmallArgs& a, int ntasks, int kernel_id, hipStream_t st) {
