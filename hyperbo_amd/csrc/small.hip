@@ -129,10 +129,15 @@ __global__ __launch_bounds__(SMALL_THREADS) void small_eval_kernel(SmallArgs g) 
     __syncthreads();
     const int dlim = (fdim - d0) < DC ? (fdim - d0) : DC;
     for (int dd = 0; dd < dlim; ++dd) {
+      // (all 18 elements, also those of tiles beyond the data: straight-line code; their values are never used)
+      T xa[8], xb[EPT];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) xa[q] = sX[dd * SXS + 16 * q + ri];
+#pragma unroll
+      for (int e = 0; e < EPT; ++e) xb[e] = sX[dd * SXS + ECOL(e)];
 #pragma unroll
       for (int e = 0; e < EPT; ++e) {
-        if (thalf + 2 * e >= ntile) continue;
-        const T a = sX[dd * SXS + EROW(e)], b = sX[dd * SXS + ECOL(e)];
+        const T a = thalf ? xa[SmallTiles::I[2 * e + 1]] : xa[SmallTiles::I[2 * e]], b = xb[e];
         if (is_dot) uu[e] += a * b;
         else { const T df = a - b; uu[e] += df * df; }
       }
@@ -159,6 +164,9 @@ __global__ __launch_bounds__(SMALL_THREADS) void small_eval_kernel(SmallArgs g) 
   }
   __syncthreads();
 
+#if defined(HBO_SMALL_STOP) && HBO_SMALL_STOP == 1   // (phase timing builds: tools/README.md)
+  return;
+#endif
   // ---- potf2 in LDS: the loop of chol.hip:potf2_body on tiles that are already resident, all leaf inverses kept.  The helper waves
   //      also build W = L^-1 row block by row block IN PLACE behind the leaf chain:  W[i,j] = -M_i sum_{k=j..i-1} L[i,k] W[k,j]  needs
   //      row block i of L (final since step j of each of its tiles), the rows < i of W and the leaf inverse M_i -- all there one
@@ -247,6 +255,9 @@ __global__ __launch_bounds__(SMALL_THREADS) void small_eval_kernel(SmallArgs g) 
   }
   __syncthreads();
 
+#if defined(HBO_SMALL_STOP) && HBO_SMALL_STOP == 2
+  return;
+#endif
   // ---- log-determinant from 1 / diag L; the diagonal tiles take their leaf inverses: sT now holds W = L^-1 (lower tiles) -----------
   double ld_sum = 0;
   if (tid < n) ld_sum = -log((double)sDinv[tid]);
@@ -291,6 +302,9 @@ __global__ __launch_bounds__(SMALL_THREADS) void small_eval_kernel(SmallArgs g) 
   }
   if (!g.grad_out) return;
 
+#if defined(HBO_SMALL_STOP) && HBO_SMALL_STOP == 4
+  return;
+#endif
   // ---- K^-1 = W^T W on the lower tiles, in place: every wave holds its tiles in registers until all reads are done ---------------
   {
     constexpr int MAXT = (36 + SMALL_WAVES - 1) / SMALL_WAVES;
@@ -334,6 +348,9 @@ __global__ __launch_bounds__(SMALL_THREADS) void small_eval_kernel(SmallArgs g) 
     }
   }
 
+#if defined(HBO_SMALL_STOP) && HBO_SMALL_STOP == 5
+  return;
+#endif
   // ---- contraction sum_ij G_ij dK_ij / dtheta over the lower triangle, G = lh K^-1 - c s s^T (grad_contract_kernel), from the
   //      distances and covariances of the Gram phase ----------------------------------------------------------------------------
   const T lh = (T)t.coef_lh, cc = (T)t.coef_c;
