@@ -209,6 +209,12 @@ static int objective_local(hbo_ctx* c, const hbo_model* m_in, hbo_dataset* ds, i
   // has no limit on m).  EUC: the rows themselves.  EKL: tr(K1^-1 C0) = sum_b |W row_b|^2 and alpha_b = W^T W row_b from the explicit
   // inverse (two triangular products over all m rows), the quadratic forms added to the task's value.  Main stream, W complete.
   auto extra_rows = [&]() -> int {
+    // one scratch buffer for the largest of them, taken BEFORE the loop: growing it between two tasks would free memory that the
+    // first task's queued products still read
+    size_t zbytes = 0;
+    if (!euc) for (int k = 0; k < T; ++k) if (ds->h_desc[k].nvec) zbytes = std::max(zbytes, (size_t)ds->tasks[k]->m * ds->tasks[k]->npad * esize(dtype));
+    void* const zb = zbytes ? ws_get(c, WS_EXTRA_Z, zbytes) : nullptr;
+    if (zbytes && !zb) return HBO_ERR_HIP;
     for (int k = 0; k < T; ++k) {
       if (!ds->h_desc[k].nvec) continue;
       TaskHost* t = ds->tasks[k];
@@ -216,8 +222,6 @@ static int objective_local(hbo_ctx* c, const hbo_model* m_in, hbo_dataset* ds, i
       char* cols = static_cast<char*>(t->svec) + (size_t)t->npad * es;   // column 1
       launch_expand_rows(dtype, t->ydiv, t->n, t->npad, cols, t->m, st);
       if (euc) continue;
-      void* zb = ws_get(c, WS_EXTRA_Z, (size_t)t->m * t->npad * es);
-      if (!zb) return HBO_ERR_HIP;
       launch_tri_matvec(dtype, t->W, t->ld, t->npad, cols, t->npad, t->m, 0, zb, t->npad, st);
       launch_add_sumsq(dtype, zb, t->npad, t->m, ds->h_desc[k].coef_c, ds->d_nll + k, st);
       launch_tri_matvec(dtype, t->W, t->ld, t->npad, zb, t->npad, t->m, 1, cols, t->npad, st);
