@@ -383,9 +383,8 @@ __global__ __launch_bounds__(SMALL_THREADS) void small_eval_kernel(SmallArgs g) 
   }
   if (!is_dot) {
     for (int d0 = 0; d0 < fdim; d0 += DC) {
-      __syncthreads();
-      stage(d0, true);
-      __syncthreads();
+      // (up to DC features: the scaled chunk the Gram phase staged is still in sX)
+      if (fdim > DC) { __syncthreads(); stage(d0, true); __syncthreads(); }
       const int dlim = (fdim - d0) < DC ? (fdim - d0) : DC;
       for (int dd = 0; dd < dlim; ++dd) {
         T s = (T)0;
