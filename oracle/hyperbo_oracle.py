@@ -14,7 +14,9 @@ pinned by (tests/test_oracle_*.py):
   (3) an independent torch.autograd re-expression of the same formulas (CPU),
   (4) identities the reference's tests assert (SVD-NLL == Cholesky-NLL,
       diag(full_cov) == var, GP.predict == predict + noise, Gram symmetric PSD),
-  (5) the NumPy-seeded matrices of hyperbo/basics/linalg_test.py:57-110.
+  (5) the NumPy-seeded matrices of hyperbo/basics/linalg_test.py:57-110,
+  (6) scikit-learn's GaussianProcessRegressor (an independent third-party implementation of the same formulas: Gram, log
+      marginal likelihood + gradient, posterior) for SE / Matern-3/2 / 5/2.
 Golden fixtures generated from this file live in tests/golden/ (see
 tests/golden/make_golden.py).
 

@@ -523,3 +523,41 @@ def test_cpu_baseline_port_matches_oracle():
   assert abs(v2 - vo) <= 1e-10 * abs(vo)
   for k in go:
     np.testing.assert_allclose(g2[k], go[k], rtol=1e-8, atol=1e-10)
+
+
+# ---- an independent third-party implementation of the same Gaussian-process formulas ------------------------------------------
+@pytest.mark.parametrize('kname', ['squared_exponential', 'matern32', 'matern52'])
+def test_oracle_against_scikit_learn_gaussian_process(kname):
+  """The oracle (and through it the HIP path) against scikit-learn's GaussianProcessRegressor -- NOT the reference, but an
+  independent, widely used implementation of the formulas the reference's path evaluates (Rasmussen & Williams alg. 2.1):
+  ARD kernel values, log marginal likelihood, its gradient with respect to the (log) hyper-parameters, posterior mean and
+  standard deviation.  Mapping: hyperbo's K = sv k(r / ls) + (noise + 1e-6) I  <->  ConstantKernel(sv) * RBF / Matern(ls) +
+  WhiteKernel(noise + 1e-6); sklearn's theta is the log of (sv, ls_1..D, noise), so d/dtheta = value * d/dvalue."""
+  from sklearn.gaussian_process import GaussianProcessRegressor
+  from sklearn.gaussian_process.kernels import ConstantKernel, Matern, RBF, WhiteKernel
+  rng = np.random.default_rng(8)
+  n, d, nq = 60, 3, 17
+  x, y = helpers.synthetic_task(rng, n, d)
+  xq = rng.uniform(size=(nq, d))
+  ls = np.array([0.4, 0.9, 1.7]); sv, noise = 1.3, 0.07
+  wf = {k: o.identity_warp for k in ('lengthscale', 'signal_variance', 'noise_variance')}      # identity warps: raw == warped values
+  model = {'lengthscale': ls.copy(), 'signal_variance': np.array(sv), 'noise_variance': np.array(noise)}
+  p = o.GPParams(model=model)
+  base = {'squared_exponential': RBF(length_scale=ls), 'matern32': Matern(length_scale=ls, nu=1.5), 'matern52': Matern(length_scale=ls, nu=2.5)}[kname]
+  kern = ConstantKernel(sv) * base + WhiteKernel(noise + 1e-6)
+  gpr = GaussianProcessRegressor(kernel=kern, optimizer=None, alpha=0.0, normalize_y=False).fit(x, y[:, 0])
+  kfun = getattr(o, kname)
+  # Gram (without the white noise)
+  np.testing.assert_allclose(kfun(p, x, warp_func=wf), (ConstantKernel(sv) * base)(x), rtol=1e-12, atol=1e-14)
+  # log marginal likelihood and its gradient
+  lml, dlml = gpr.log_marginal_likelihood(gpr.kernel_.theta, eval_gradient=True)
+  v, g = o.nll_value_and_grad(o.zero, kfun, p, {0: o.SubDataset(x, y)}, wf)
+  assert abs(v + lml) <= 1e-10 * abs(lml), (v, lml)
+  theta_grad = np.concatenate([[g['signal_variance'] * sv], np.asarray(g['lengthscale']) * ls, [g['noise_variance'] * (noise + 1e-6)]])
+  np.testing.assert_allclose(-theta_grad, dlml, rtol=1e-7, atol=1e-9)
+  # posterior (sklearn's WhiteKernel also sits on the diagonal of the PRIOR at the queries: its variance = latent variance + noise,
+  # which is GP.predict(with_noise=True) of the reference up to the 1e-6 jitter)
+  mu_s, sd_s = gpr.predict(xq, return_std=True)
+  mu_o, var_o = o.predict(o.zero, kfun, p, x, y, xq, wf)
+  np.testing.assert_allclose(mu_o[:, 0], mu_s, rtol=1e-9, atol=1e-11)
+  np.testing.assert_allclose(np.sqrt(var_o[:, 0] + noise + 1e-6), sd_s, rtol=1e-7, atol=1e-9)
