@@ -356,6 +356,23 @@ def bench_train():
       finally:
         ctx.set_option('small_fused', 1)
       small[f'{name}_ms_per_step' + ('' if fused else '_blocked')] = round(el / st * 1e3, 4)
+  # the same with a FRESH batch per step (sub-datasets of 400 points, batch_size 100: rows gathered on the device from the resident
+  # dataset; the indices of a batch are one vectorised draw on a helper thread)
+  data4 = {}
+  for k in range(tasks):
+    x = rng.uniform(size=(400, d)); w = rng.normal(size=d)
+    data4[k] = defs.SubDataset(x, np.sin(2 * np.pi * x @ w)[:, None] + 0.1 * rng.normal(size=(400, 1)))
+  for fused in (1, 0):
+    ctx.set_option('small_fused', fused)
+    try:
+      el = None
+      for rep in range(2):
+        p = defs.GPParams(model=model(), config={'method': 'adam', 'batch_size': 100, 'max_training_step': st, 'learning_rate': 1e-3, 'objective': objectives.nll})
+        g = gp.GP(data4, mean.constant, kernel.squared_exponential, p, utils.DEFAULT_WARP_FUNC)
+        t0 = time.perf_counter(); g.train(key=rep); el = time.perf_counter() - t0
+    finally:
+      ctx.set_option('small_fused', 1)
+    small['se_constant_resampled_400_to_100_ms_per_step' + ('' if fused else '_blocked')] = round(el / st * 1e3, 4)
   out['small_tasks'] = small
   return out
 

@@ -71,8 +71,16 @@ static int objective_local(hbo_ctx* c, const hbo_model* m_in, hbo_dataset* ds, i
   rc = upload_model(c, m);
   if (rc) return rc;
 
-  // workspaces + descriptors
-  if (!ds->d_svec && T > 1) {
+  // workspaces + descriptors.  A batch that takes the single-workgroup evaluation (small.hip) without an MLP keeps its matrices in
+  // LDS: no A / W / S / alpha buffers at all (a freshly sub-sampled batch per Adam step paid ~150 pool operations and two fills for
+  // buffers its one launch never reads); the leaf inverses that leaf_cholesky4 also stores go to one shared scratch block
+  const bool lds_only = obj == OBJ_NLL && ds->max_nblk == 1 && c->opt_small_fused && !needs_mlp(m);
+  void* small_scratch = nullptr;
+  if (lds_only) {
+    small_scratch = ws_get(c, WS_SMALL_W, (size_t)HBO_TILE * padded_ld(HBO_TILE, ds->dtype) * esize(ds->dtype));
+    if (!small_scratch) return HBO_ERR_HIP;
+  }
+  if (!lds_only && !ds->d_svec && T > 1) {
     // first evaluation of this dataset: every task's alpha vector from ONE zeroed block
     auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
     const size_t es = esize(ds->dtype);
@@ -93,8 +101,10 @@ static int objective_local(hbo_ctx* c, const hbo_model* m_in, hbo_dataset* ds, i
   ds->h_desc.resize(T);
   for (int k = 0; k < T; ++k) {
     TaskHost* t = ds->tasks[k];
-    rc = ensure_task_workspace(c, dtype, t, (want_grad || (extras && t->m + 1 > HBO_TILE)) && !euc, obj == OBJ_NLL ? 1 : t->m + 1);
-    if (rc) return rc;
+    if (!lds_only) {
+      rc = ensure_task_workspace(c, dtype, t, (want_grad || (extras && t->m + 1 > HBO_TILE)) && !euc, obj == OBJ_NLL ? 1 : t->m + 1);
+      if (rc) return rc;
+    }
     if (needs_mlp(m)) { rc = t->feat.ensure(c, m, t->n); if (rc) return rc; }
     if (needs_mlp(m) && want_grad) {
       int maxf = m->input_dim;
@@ -110,6 +120,7 @@ static int objective_local(hbo_ctx* c, const hbo_model* m_in, hbo_dataset* ds, i
       }
     }
     fill_desc(ds->h_desc[k], t, m, dtype, obj);
+    if (lds_only && !ds->h_desc[k].W) ds->h_desc[k].W = small_scratch;   // (every task writes its leaf inverses there: never read)
   }
   int64_t max_n = 0;
   for (int k = 0; k < T; ++k) max_n = std::max<int64_t>(max_n, ds->tasks[k]->n);

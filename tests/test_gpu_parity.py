@@ -1834,7 +1834,7 @@ def test_append_stops_at_a_row_that_breaks_the_factorisation(gpu_ctx):
 def test_adam_batches_gathered_on_the_device_match_host_sub_sampling(gpu_ctx, objective_name):
   """infer_parameters' Adam loop keeps the dataset resident in HBM and gathers every step's batch there from freshly drawn row
   indices (hbo_dataset_subsample) -- the reference indexes device arrays with jax.random.permutation (data_utils.py:72-100,
-  gp.py:101-111).  Same seed, same draws: the trajectory must equal, to the bit, the one through the host iterator
+  gp.py:101-111).  Same seed, same draws: the trajectory must equal, to rounding, the one through the host iterator
   (sub_sample_dataset_iterator + one upload per step), taken here by hiding the objective's device-batch capability.
   Ragged tasks, one of them smaller than the batch (kept whole), aligned sub-datasets for the divergence objective."""
   defs, _, _, gp, kernel, mean, objectives, utils = _native()
@@ -1861,8 +1861,10 @@ def test_adam_batches_gathered_on_the_device_match_host_sub_sampling(gpu_ctx, ob
     res = gp.infer_parameters(mean.constant, kernel.squared_exponential, p, data, utils.DEFAULT_WARP_FUNC, obj_fn, key=5,
                               callback=lambda i, m_, l_: losses.append(l_))
     out.append((losses, helpers.flatten(res.model)))
-  assert out[0][0] == out[1][0], (out[0][0], out[1][0])
-  assert np.array_equal(out[0][1], out[1][1])
+  # (the same rows in every batch; the library orders a batch's tasks by size, and a gathered batch inherits the resident order among
+  #  equal sizes while an uploaded one keeps the dict's: the sum over tasks is taken in another order -- last-bit differences)
+  np.testing.assert_allclose(out[0][0], out[1][0], rtol=1e-13)
+  np.testing.assert_allclose(out[0][1], out[1][1], rtol=1e-11, atol=1e-13)
 
 
 # ---- multi-GPU plumbing: libhbo's RCCL binding and the self-spawning bench ------------------------------------------
