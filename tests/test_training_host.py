@@ -369,3 +369,25 @@ def test_oracle_sub_sample_iterator_rules():
   assert b1['a'].x.shape == (4, 2) and b1['b'].x.shape == (3, 2) and b1['b'].aligned == 1
   assert not np.array_equal(b1['a'].x, b2['a'].x)
   np.testing.assert_allclose(b1['a'].x[:, 0] / 2, b1['a'].y[:, 0])
+
+
+def test_draw_batch_indices_vectorised_draw():
+  """data_utils.draw_batch_indices: one vectorised draw for a whole batch -- distinct in-range rows per sub-dataset, None where a
+  sub-dataset is smaller than the batch (kept whole), batch_size == n is a permutation, ragged sizes never index beyond a task's
+  own rows, every row equally likely, and the task-by-task fallback for very large sub-datasets obeys the same rules."""
+  rng = np.random.default_rng(0)
+  sizes = [30, 5, 12, 8, 200]
+  for _ in range(20):
+    out = data_utils.draw_batch_indices(rng, sizes, 8)
+    assert out[1] is None and all(o is not None for i, o in enumerate(out) if i != 1)
+    for n, ix in zip(sizes, out):
+      if ix is not None:
+        assert ix.dtype == np.int32 and ix.shape == (8,) and len(set(ix.tolist())) == 8 and 0 <= ix.min() and ix.max() < n
+  assert sorted(data_utils.draw_batch_indices(rng, sizes, 8)[3].tolist()) == list(range(8))       # n == batch_size: a permutation
+  counts = np.zeros(12)
+  for _ in range(6000):
+    counts[data_utils.draw_batch_indices(rng, [12, 40], 3)[0]] += 1
+  assert np.all(np.abs(counts / 6000 - 0.25) < 0.03)                                              # 3 of 12 rows: p = 1/4 each
+  big = data_utils.draw_batch_indices(rng, [3_000_000, 2_500_000], 16)                            # beyond the key-matrix limit
+  assert all(len(set(b.tolist())) == 16 for b in big) and big[1].max() < 2_500_000
+  assert data_utils.draw_batch_indices(rng, [3, 4], 10) == [None, None]
