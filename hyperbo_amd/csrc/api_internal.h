@@ -57,6 +57,18 @@ static double host_elem(const void* p, int dtype, int64_t i) {
   return dtype == HBO_F64 ? ((const double*)p)[i] : (double)((const float*)p)[i];
 }
 
+// max_i A_ii of Gram + (noise + jitter) I for a stationary covariance (k(x, x) = signal variance): what the fp32 factorisation's
+// f16x2 products scale the factor's entries by (ctx.h: chol_diag_bound); 0 = unknown (dot-product kernel, parameters not finite)
+static inline double chol_diag_bound_of(const hbo_model* m) {
+  if (m->kernel_id == HBO_KERNEL_DOT) return 0.0;
+  const double b = (double)m->signal_variance + (double)m->noise_variance + (double)m->eps;
+  return (b > 0 && b < 1e30) ? b : 0.0;
+}
+struct CholBoundScope {   // valid from run_potrf to the last product of the inverse / K^-1 of the same matrices
+  hbo_ctx* c;
+  CholBoundScope(hbo_ctx* ctx, double b) : c(ctx) { c->chol_diag_bound = b; }
+  ~CholBoundScope() { c->chol_diag_bound = 0; }
+};
 // the device-side form of an (already warped) model
 static void fill_model_dev(ModelDev& h, const hbo_model* m) {
   memset(&h, 0, sizeof h);

@@ -50,6 +50,7 @@ extern "C" int hbo_factor(hbo_ctx* c, const hbo_model* m, const void* x, int64_t
   TrtriProgress trtri_pg;
   const bool early_trtri = use_lookahead(c, 1, t->nblk) && c->opt_overlap_trtri && t->nblk >= 4;
   c->trtri_host_task = k->h_desc;
+  CholBoundScope bound_scope(c, chol_diag_bound_of(m));
   { ProfScope ps(c, "potrf", 1); run_potrf(c, dtype, k->d_desc, 1, t->nblk, k->d_info, early_trtri ? &trtri_pg : nullptr); }
   HIPCHK_K(hipMemcpy2DAsync(k->zvec, (size_t)t->npad * es, (char*)t->A + (size_t)t->npad * t->ld * es, (size_t)t->ld * es, (size_t)t->npad * es, mcols, hipMemcpyDeviceToDevice, st));
   { ProfScope ps(c, "trtri", 1); run_trtri(c, dtype, k->d_desc, 1, t->nblk, &trtri_pg); }
@@ -570,6 +571,9 @@ extern "C" int hbo_acq_samples(hbo_ctx* c, const hbo_model* models, int32_t S, c
   TrtriProgress trtri_pg;
   const bool early_trtri = use_lookahead(c, S, nblk) && c->opt_overlap_trtri && nblk >= 4;
   c->trtri_host_task = S == 1 ? h_batch[0] : TaskDesc{};
+  double bound_all = chol_diag_bound_of(&models[0]);
+  for (int s = 1; s < S; ++s) { const double b = chol_diag_bound_of(&models[s]); bound_all = (b > 0 && bound_all > 0) ? std::max(bound_all, b) : 0.0; }
+  CholBoundScope bound_scope(c, bound_all);
   { ProfScope ps(c, "potrf", 1); run_potrf(c, dtype, d_batch, S, nblk, d_infos, early_trtri ? &trtri_pg : nullptr); }
   { ProfScope ps(c, "trtri", 1); run_trtri(c, dtype, d_batch, S, nblk, &trtri_pg); }
   { ProfScope ps(c, "wt_z", 1);

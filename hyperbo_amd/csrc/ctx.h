@@ -35,6 +35,10 @@ struct hbo_ctx {
   int opt_syrk3_sep = 0;       // debug: 1 = the panels are split by a kernel of their own instead of inside the panel solve
   int opt_syrk3_free = 32;     // ... CUs the bulk update of that form leaves with a single workgroup (room for the panel kernels)
   int opt_syrk_bf16x3 = 1;     // fp32 factorisations: trailing updates on the bf16 matrix cores (exact three-way split of the panels, post3.hip)
+  int opt_chol_f16x2 = 1;      // fp32 factorisations of the stationary covariances: trailing updates, inverse levels and K^-1 = W^T W on two-way fp16 splits
+                               // (three MFMAs per product instead of bf16x3's six; needs chol_diag_bound, i.e. a caller that knows max_i A_ii)
+  unsigned int* h2_words = nullptr;   // run_potrf -> trtri_level3 / run_lauum: measured operand maxima of the f16x2 products (null: bf16x3)
+  double chol_diag_bound = 0;  // set by the objective / factor paths around run_potrf: max_i A_ii (signal variance + noise + jitter); 0: unknown
   int opt_post_f16x2 = 1;      // fp32 posterior product of the stationary covariances: two-way fp16 split, three MFMAs per product (post2h.hip) instead of bf16x3's six
   int opt_post_bf16x3 = 1;     // fp32 posterior product on the bf16 matrix cores (three-way exact split of both operands, post3.hip); 0: fp32 MFMA
   int opt_trtri_at = 0;        // single matrix: panel count (in 64ths of the block count) after which the inverse starts beside the chain (0: 5/8)

@@ -124,6 +124,22 @@ __device__ __forceinline__ void hbo_split3(float x, unsigned short& h, unsigned 
   const __bf16 bl = (__bf16)r2;
   h = __builtin_bit_cast(unsigned short, bh); m = __builtin_bit_cast(unsigned short, bm); l = __builtin_bit_cast(unsigned short, bl);
 }
+// x s = h + l + r, |r| <= 2^-22 |x s|: two fp16 numbers (the caller scales by a power of two so that the operand's largest magnitude
+// lands in [2^13, 2^14), hbo_h2_scale_for) -- the operand form of the fp32 products on the fp16 matrix cores (post2h.hip, post3.hip)
+__device__ __forceinline__ void hbo_split2h(float x, unsigned short& h, unsigned short& l) {
+  const _Float16 hh = (_Float16)x;
+  const _Float16 ll = (_Float16)(x - (float)hh);
+  h = __builtin_bit_cast(unsigned short, hh); l = __builtin_bit_cast(unsigned short, ll);
+}
+// power of two that maps `amax` into [2^13, 2^14)  (1 for amax = 0 / not finite: the planes then carry NaN / inf along; the
+// exponent is clamped so that neither the scale nor a ratio of two scales leaves the fp32 range)
+__device__ __forceinline__ float hbo_h2_scale_for(float amax) {
+  if (!(amax > 0.f) || !(amax < INFINITY)) return 1.f;
+  int e;
+  (void)frexpf(amax, &e);   // amax = f 2^e, f in [0.5, 1)
+  e = e < -40 ? -40 : e;
+  return ldexpf(1.f, 14 - e);
+}
 // a panel-chain workgroup announces itself on its CU (background GEMM workgroups there pause, see GemmArgs::yield_flag)
 __device__ __forceinline__ int yield_enter(int* tab) {
   const int tok = cu_token();
@@ -286,17 +302,32 @@ struct Syrk3Args {
   // A tile it of group g at ((g * s + it) * nkb), B tile jt at ((g * s + jt) * nkb), nkb = 8 s blocks.
   int mode, s, grp_lo, ngrp, vlast;   // vlast: tile rows of the LAST group of the launch (a cut lower half), s for the others
   unsigned short* Yp;
+  // h2 = 1: the f16x2 form -- operands as TWO fp16 planes of values scaled by a power of two (hbo_split2h), three MFMAs per pair of
+  // fragments instead of six, the result scaled back in the epilogue.  sx / sy: scales of the A / B operand known to the host
+  // (the factor's entries: |L_ij| <= sqrt(max_i A_ii)); sx_bits / sy_bits: device words that override them -- the bits of a measured
+  // maximum, from which split and product derive the same power of two (hbo_h2_scale_for).  Mode 0: the augmented tile-row has no a-priori bound (z = L^-1 r): its split takes
+  // the maximum of every 16 rows x 64 panel columns and writes the scale to aug_scale[task][k block / 4][row / 16]; the product
+  // rescales its accumulators of that tile-row where the scale changes (exact: powers of two).
+  int h2;
+  float sx, sy;
+  const unsigned int* sx_bits; const unsigned int* sy_bits;
+  float* aug_scale; int64_t aug_stride;
+  unsigned int* max_out;   // != null: atomicMax of the bits of max |result| over the launch's tiles (scale of a later split)
 };
 // split of a (row tiles x 128 nkb/8 ...) fp32 block into panel blocks: rows of `in` are the operand rows (k along the row) --
 // or, transposed, columns of `in` are the operand rows (k along the column).  grid z = group, stepping `in` by gstep elements and
 // `out` by gstride elements
 struct Split3Block { const float* in; int64_t ld, gstep; unsigned short* out; int64_t gstride; int row_tiles, nkb, tri;
-                     int last_rows, last_krows; };   // the LAST group: operand row tiles / k rows that exist (a cut lower half)
+                     int last_rows, last_krows;   // the LAST group: operand row tiles / k rows that exist (a cut lower half)
+                     // h2: two fp16 planes scaled by `scale` (host-known) -- or by the scale of a measured maximum: *scale_bits,
+                     // or (max_out) taken by a first pass over the same elements into *max_out (zeroed by the caller, or extended)
+                     int h2; float scale; const unsigned int* scale_bits; unsigned int* max_out; };
 void launch_split3_block(const Split3Block& a, int ngrp, bool transposed, hipStream_t st);
 void launch_split3_panel(const Syrk3Args& a, int row_tiles, int ntasks, hipStream_t st);
 void launch_syrk3(const Syrk3Args& a, int ntiles, int ntasks, hipStream_t st);
 void launch_split3_rows(const float* in, int64_t ld, int row_tiles, unsigned short* out, int nkb, hipStream_t st);
 void launch_split3_transpose(const float* in, int64_t ld, int krows, int jcols, unsigned short* out, int nkb, hipStream_t st, int lower_only = 0);
+void launch_split2h_transpose_measured(const float* in, int64_t ld, int krows, int jcols, unsigned short* out, int nkb, unsigned int* amax_bits, hipStream_t st, int lower_only);
 void launch_post3(const Post3Args& a, int col_tiles, hipStream_t st);
 
 struct AcqGradArgs {

@@ -31,6 +31,7 @@ static int objective_local(hbo_ctx* c, const hbo_model* m_in, hbo_dataset* ds, i
   hbo_model mcopy = *m_in;
   if (objective != HBO_OBJ_NLL) mcopy.eps = 0.0;   // objectives.py:63-65: cov_model = K + noise I, no jitter
   const hbo_model* m = &mcopy;
+  CholBoundScope bound_scope(c, 0.0);   // (set where the factorisation starts; cleared on every way out)
   const int obj = objective;
   const bool euc = obj == OBJ_EUC;
   int rc = validate_model(c, m);
@@ -207,6 +208,7 @@ static int objective_local(hbo_ctx* c, const hbo_model* m_in, hbo_dataset* ds, i
     {
       c->trtri_host_task = TaskDesc{};
       if (T == 1) c->trtri_host_task = ds->h_desc[0];
+      c->chol_diag_bound = chol_diag_bound_of(m);   // (cleared where the evaluation leaves: bound_scope)
       ProfScope ps(c, "potrf", 1); run_potrf(c, dtype, ds->d_desc, T, max_nblk, ds->d_info, early_trtri ? &trtri_pg : nullptr, sweep ? &sweep_st : nullptr);
     }
     // the small reductions (log-determinant + quadratic form now, alpha = W^T z and d nll / d mu after the inverse) run on

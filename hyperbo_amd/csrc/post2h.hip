@@ -27,19 +27,6 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 struct alignas(16) U16x8 { u16 v[8]; };
 constexpr int P2_CHUNK = HBO_TILE * 16;   // elements of one plane of one block
 
-__device__ __forceinline__ void split2h(float x, u16& h, u16& l) {
-  const _Float16 hh = (_Float16)x;
-  const _Float16 ll = (_Float16)(x - (float)hh);
-  h = __builtin_bit_cast(u16, hh); l = __builtin_bit_cast(u16, ll);
-}
-// power of two that maps `amax` into [2^13, 2^14)  (1 for amax = 0 / not finite: the planes then carry NaN / inf along)
-__device__ __forceinline__ float scale_for(float amax) {
-  if (!(amax > 0.f) || !(amax < INFINITY)) return 1.f;
-  int e;
-  (void)frexpf(amax, &e);   // amax = f 2^e, f in [0.5, 1)
-  return ldexpf(1.f, 14 - e);
-}
-
 // max |W| over the lower triangle (by 128-blocks) -> *out (as the bits of a non-negative float: integer max orders them)
 __global__ __launch_bounds__(256) void absmax_lower_kernel(const float* __restrict__ in, int64_t ld, unsigned int* out) {
   const int R = blockIdx.y, C = blockIdx.x;
@@ -62,7 +49,7 @@ __global__ __launch_bounds__(256) void split2h_rows_kernel(const float* __restri
                                                            const unsigned int* __restrict__ amax_bits) {
   const int R = blockIdx.y, kb0 = blockIdx.x * 4;
   if (kb0 >= (R + 1) * (HBO_TILE / 16)) return;
-  const float s = scale_for(__uint_as_float(*amax_bits));
+  const float s = hbo_h2_scale_for(__uint_as_float(*amax_bits));
   const int row = threadIdx.x >> 1, half = threadIdx.x & 1;
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
@@ -73,7 +60,7 @@ __global__ __launch_bounds__(256) void split2h_rows_kernel(const float* __restri
     const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
     U16x8 h, l;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) split2h(x[e] * s, h.v[e], l.v[e]);
+    for (int e = 0; e < 8; ++e) hbo_split2h(x[e] * s, h.v[e], l.v[e]);
     u16* o = out + ((int64_t)R * nkb + kb) * 2 * P2_CHUNK + threadIdx.x * 8;
     *reinterpret_cast<U16x8*>(o) = h;
     *reinterpret_cast<U16x8*>(o + P2_CHUNK) = l;
@@ -100,7 +87,7 @@ __global__ __launch_bounds__(256) void split2h_transpose_kernel(const float* __r
     const int ko = kbl * 16 + half * 8;
     U16x8 h, l;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) split2h(tile[ko + e][j] * s, h.v[e], l.v[e]);
+    for (int e = 0; e < 8; ++e) hbo_split2h(tile[ko + e][j] * s, h.v[e], l.v[e]);
     const int jr = j0 + j;
     u16* o = out + ((int64_t)(jr / HBO_TILE) * nkb + (k0 / 16 + kbl)) * 2 * P2_CHUNK + (jr % HBO_TILE) * 16 + half * 8;
     *reinterpret_cast<U16x8*>(o) = h;
@@ -117,7 +104,7 @@ constexpr int POST2H_LDS_BYTES = 2 * 2 * 2 * P2_ARR;   // stages x operands x pl
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void post2h_kernel(Post2hArgs g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const float inv_scale = 1.f / (scale_for(__uint_as_float(*g.wmax_bits)) * g.kscale);
+  const float inv_scale = 1.f / (hbo_h2_scale_for(__uint_as_float(*g.wmax_bits)) * g.kscale);
   __shared__ int s_tile;
   for (int tile = (int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x;;) {
   if (g.work_counter) {
@@ -233,7 +220,7 @@ void launch_split2h_transpose(const float* in, int64_t ld, int krows, int jcols,
   if (krows <= 0 || jcols <= 0) return;
   hipLaunchKernelGGL(split2h_transpose_kernel, dim3(jcols / 64, krows / 64), dim3(256), 0, st, in, ld, out, nkb, scale);
 }
-// power of two that maps a bound on |Kxq| into [2^13, 2^14): the host-side twin of scale_for
+// power of two that maps a bound on |Kxq| into [2^13, 2^14): the host-side twin of hbo_h2_scale_for
 float post2h_scale_for(double bound) {
   if (!(bound > 0) || !(bound < 1e30)) return 1.f;
   int e;

@@ -28,9 +28,11 @@ static inline hipError_t hbo_malloc(hbo_ctx* c, void** out, size_t bytes) {
 }
 
 // grow-only scratch buffer for `slot`; nullptr on allocation failure (ctx->err is set)
+#define HBO_H2_LEVELS 16
+#define HBO_H2_WORDS (3 * HBO_H2_LEVELS + 4)   // per level of the inverse: max |W11|, |S21|, |W22|; the last word: max |W| for K^-1 = W^T W
 enum WsSlot { WS_XQ = 1, WS_MU0, WS_KD, WS_MU, WS_VAR, WS_ACQ, WS_K, WS_COLSQ, WS_V, WS_KQQ, WS_COV,
               WS_AP_KX, WS_AP_L, WS_AP_W, WS_AP_MU, WS_AP_KD, WS_AP_Y, WS_VPART, WS_GATHER, WS_COUNTERS, WS_MUPART,
-              WS_AG_K, WS_AG_L, WS_AG_B, WS_AG_GF, WS_AG_DMU, WS_AG_GX, WS_AG_T0, WS_AG_T1, WS_AG_DW, WS_SHARD_RED, WS_SHARD_MAP, WS_SYRK3_A, WS_SYRK3_B, WS_TRTRI3_X, WS_TRTRI3_Y, WS_LAUUM3, WS_SMP_MODELS, WS_SMP_DESC, WS_SMP_INFO, WS_SMP_ACQ, WS_SMP_MLP, WS_SMP_XQ, WS_EXTRA_Z, WS_SMALL_W, WS_FQ0 /* + layer */,
+              WS_AG_K, WS_AG_L, WS_AG_B, WS_AG_GF, WS_AG_DMU, WS_AG_GX, WS_AG_T0, WS_AG_T1, WS_AG_DW, WS_SHARD_RED, WS_SHARD_MAP, WS_SYRK3_A, WS_SYRK3_B, WS_TRTRI3_X, WS_TRTRI3_Y, WS_LAUUM3, WS_SMP_MODELS, WS_SMP_DESC, WS_SMP_INFO, WS_SMP_ACQ, WS_SMP_MLP, WS_SMP_XQ, WS_EXTRA_Z, WS_SMALL_W, WS_H2_AUG, WS_H2_SCALES, WS_FQ0 /* + layer */,
               WS_FQ_LAST = WS_FQ0 + HBO_MAX_MLP_LAYERS - 1, WS_K3, WS_SLOT_END };
 // every slot is distinct by construction (auto-numbered; the per-layer range WS_FQ0.. is closed by WS_FQ_LAST before WS_K3), and the
 // posterior's per-lane offset (cache.hip: 4096 * lane) must clear the whole range

@@ -5,6 +5,7 @@
 #include "sched.h"
 
 #include <algorithm>
+#include <cmath>
 
 // ---- blocked factorisation drivers -----------------------------------------------------------
 
@@ -108,12 +109,28 @@ void run_potrf(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, int m
     s3buf[1] = static_cast<unsigned short*>(ws_get(c, WS_SYRK3_B, bytes));
   }
   const bool use_s3 = s3 && s3buf[0] && s3buf[1];
+  // ... or, when the caller knows the largest diagonal entry (|L_ij| <= sqrt(max A_ii) gives the panels' scale without a pass), on
+  // the fp16 cores from a TWO-way split: three MFMAs per product instead of six (Syrk3Args::h2; the augmented tile-row carries
+  // measured scales per 16 rows x 64 columns, one array per panel buffer)
+  float* h2_aug = nullptr;
+  c->h2_words = nullptr;
+  if (dtype == HBO_F32 && c->opt_chol_f16x2 && c->chol_diag_bound > 0) {
+    // measured maxima of the inverse's operands (trtri_level3, run_lauum), zeroed once per factorisation
+    c->h2_words = static_cast<unsigned int*>(ws_get(c, WS_H2_SCALES, sizeof(unsigned int) * HBO_H2_WORDS));
+    if (c->h2_words) hipMemsetAsync(c->h2_words, 0, sizeof(unsigned int) * HBO_H2_WORDS, sm);
+  }
+  if (use_s3 && c->h2_words) {
+    s3a.aug_stride = (int64_t)(s3a.nkb / 4) * 8;
+    h2_aug = static_cast<float*>(ws_get(c, WS_H2_AUG, sizeof(float) * 2 * (size_t)s3a.aug_stride * ntasks));
+    if (h2_aug) { s3a.h2 = 1; s3a.sx = s3a.sy = post2h_scale_for(std::sqrt(c->chol_diag_bound)); }
+  }
   auto tiles_of = [&](int c_lo, int c_hi) { int n = 0; for (int cc = c_lo; cc < std::min(c_hi, max_nblk); ++cc) n += max_nblk + 1 - cc; return n; };
   int grp_index = 0;
   for (int g0 = 0; g0 < max_nblk; g0 += q, ++grp_index) {
     const int g1 = std::min(g0 + q, max_nblk);
     const int g2 = std::min(g1 + q, max_nblk);
     if (use_s3) s3a.Xp = s3buf[grp_index & 1];
+    if (s3a.h2) s3a.aug_scale = h2_aug + (grp_index & 1) * s3a.aug_stride * ntasks;
     if (la && ev_f1) hipStreamWaitEvent(sp, ev_f1, 0);
     for (int p = g0; p < g1; ++p) {
       if (p > g0 && use_s3 && c->opt_syrk3_col) {
@@ -133,7 +150,7 @@ void run_potrf(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, int m
         // (fp32 + bf16x3 updates: the solve writes its panel as three bf16 planes too -- no separate split launch on the chain)
         SplitOut so = {};
         if (use_s3) { so.xp = s3a.Xp; so.task_stride = s3a.task_stride; so.nkb = s3a.nkb; so.kb_off = (p - g0) * (HBO_TILE / 16); }
-        const bool fused = use_s3 && !c->opt_syrk3_sep && c->opt_syrk3_col;
+        const bool fused = use_s3 && !c->opt_syrk3_sep && c->opt_syrk3_col && !s3a.h2;   // (the f16x2 split needs the augmented rows' maxima first: a kernel of its own)
         { ProfScope ps(c, "trsm", 2, sp); launch_trsm(dtype, d_tasks, ntasks, p, max_nblk, sp, chain_mark, fused ? &so : nullptr); }
         if (use_s3 && !fused && p + 1 < max_nblk && (c->opt_syrk3_col || p + 1 == g1)) {
           // the column updates inside the group stay on fp32 MFMA (64x64 tiles): ONE split of the whole group behind its last
@@ -271,7 +288,15 @@ static bool trtri_level3(hbo_ctx* c, const TaskDesc* d_tasks, const TaskDesc& h,
   if (vlast <= 0) { --ngrp; vlast = s; }
   if (ngrp <= 0) return true;
   const int nkb = 8 * s;
-  const int64_t gstride = (int64_t)s * nkb * 3 * (HBO_TILE * 16);
+  // f16x2 form (run_potrf set it up: the caller knows max A_ii): L's blocks by the a-priori scale, W's and S21's by measured maxima
+  // -- one word per level and operand; W11 / W22 are measured by a pass over what is about to be split, S21 by the product
+  // that writes it.  The words only grow over the calls of a factorisation (other groups of the same level): still a bound.
+  int li = 0;
+  while ((1 << li) < s) ++li;
+  unsigned int* const words = (c->h2_words && li < HBO_H2_LEVELS) ? c->h2_words + 3 * li : nullptr;
+  const bool h2 = words != nullptr;
+  const float sL = h2 ? post2h_scale_for(std::sqrt(c->chol_diag_bound)) : 1.f;
+  const int64_t gstride = (int64_t)s * nkb * (h2 ? 2 : 3) * (HBO_TILE * 16);
   const size_t bytes = sizeof(unsigned short) * (size_t)gstride * ngrp;
   unsigned short* xp = static_cast<unsigned short*>(ws_get(c, WS_TRTRI3_X, bytes));
   unsigned short* yp = static_cast<unsigned short*>(ws_get(c, WS_TRTRI3_Y, bytes));
@@ -283,6 +308,7 @@ static bool trtri_level3(hbo_ctx* c, const TaskDesc* d_tasks, const TaskDesc& h,
   const float* S = static_cast<const float*>(h.S);
   Split3Block sb = {}; sb.ld = ld; sb.gstep = 2 * half * (ld + 1); sb.gstride = gstride; sb.nkb = nkb; sb.row_tiles = s;
   Syrk3Args g = {}; g.tasks = d_tasks; g.Xp = xp; g.Yp = yp; g.s = s; g.grp_lo = grp_lo; g.ngrp = ngrp; g.vlast = vlast;
+  g.h2 = sb.h2 = h2 ? 1 : 0;
   const bool corun = st == c->stream4 && c->opt_trtri_free > 0 && c->trtri_counters;
   const int pblocks = 2 * (c->n_cus - c->opt_trtri_free);
   const int ntiles = ((ngrp - 1) * s + vlast) * s;
@@ -303,16 +329,22 @@ static bool trtri_level3(hbo_ctx* c, const TaskDesc* d_tasks, const TaskDesc& h,
   ProfScope ps(c, "trtri_gemm", 2, st);
   if (do_a) {
     sb.in = L + (o0 + half) * ld + o0; sb.out = xp; sb.tri = 0; sb.last_rows = vlast; sb.last_krows = (int)half;
+    sb.scale = sL; sb.scale_bits = nullptr; sb.max_out = nullptr;
     launch_split3_block(sb, ngrp, false, st);                     // rows of L21
     sb.in = W + o0 * ld + o0; sb.out = yp; sb.last_rows = s; sb.last_krows = (int)half;
+    sb.max_out = h2 ? words + 0 : nullptr;
     launch_split3_block(sb, ngrp, true, st);                      // W11^T (the left half of every group is complete)
+    g.sx = sL; g.sx_bits = nullptr; g.sy_bits = h2 ? words + 0 : nullptr; g.max_out = h2 ? words + 1 : nullptr;
     launch(1);
   }
   if (do_b) {
     sb.in = W + (o0 + half) * ld + (o0 + half); sb.out = xp; sb.tri = 1; sb.last_rows = vlast; sb.last_krows = vlast * HBO_TILE;
+    sb.scale_bits = nullptr; sb.max_out = h2 ? words + 2 : nullptr;
     launch_split3_block(sb, ngrp, false, st);                     // rows of W22 (lower triangular)
     sb.in = S + (o0 + half) * ld + o0; sb.out = yp; sb.tri = 0; sb.last_rows = s; sb.last_krows = vlast * HBO_TILE;
+    sb.scale_bits = h2 ? words + 1 : nullptr; sb.max_out = nullptr;
     launch_split3_block(sb, ngrp, true, st);                      // S21^T
+    g.sx_bits = h2 ? words + 2 : nullptr; g.sy_bits = h2 ? words + 1 : nullptr; g.max_out = nullptr;
     launch(2);
   }
   return true;
@@ -515,8 +547,12 @@ void run_lauum(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, int m
     if (xp) {
       hipStream_t s = st ? st : c->stream;
       const int n = max_nblk * HBO_TILE;
-      launch_split3_transpose(static_cast<const float*>(h.W), h.ld, n, n, xp, nkb, s, 1);
       Syrk3Args g = {}; g.tasks = d_tasks; g.Xp = xp; g.nkb = nkb; g.mode = 3;
+      if (c->h2_words) {   // the f16x2 form: max |W| by one pass, W^T as two fp16 planes, three MFMAs per product
+        unsigned int* word = c->h2_words + HBO_H2_WORDS - 1;
+        launch_split2h_transpose_measured(static_cast<const float*>(h.W), h.ld, n, n, xp, nkb, word, s, 1);
+        g.h2 = 1; g.sx_bits = g.sy_bits = word;
+      } else launch_split3_transpose(static_cast<const float*>(h.W), h.ld, n, n, xp, nkb, s, 1);
       const int nt = max_nblk * (max_nblk + 1) / 2;
       int* counters = c->opt_lauum_persist && nt > 4 * c->n_cus ? (int*)ws_get(c, WS_COUNTERS, sizeof(int) * HBO_N_COUNTERS) : nullptr;
       if (counters) {   // a resident grid drawing the tiles from a counter, as the fp64 form below
