@@ -762,6 +762,61 @@ def test_fp32_objective_beyond_32_blocks_on_bf16_matrix_cores(gpu_ctx):
   assert err[1][0] <= 3 * err[0][0] + 1e-6 and err[1][1] <= 3 * err[0][1] + 1e-6, err
 
 
+@pytest.mark.parametrize('case', ['plain', 'large_targets', 'small_noise', 'matern_mlp', 'batch', 'ekl', 'dot'])
+def test_fp32_factorisation_on_two_way_fp16_splits(gpu_ctx, case):
+  """fp32 evaluations of the stationary covariances run the trailing updates, the upper levels of the inverse and K^-1 = W^T W
+  on the fp16 matrix cores from two-way splits scaled by powers of two (hbo_tune chol_f16x2, default on; post3.hip:
+  syrk3_kernel<true>): the factor's entries by the a-priori bound sqrt(max A_ii), W / S21 by measured maxima, the augmented
+  tile-row z = L^-1 r per 16 rows x 64 columns.  Against the fp64 evaluation (objectives.py:109-210 in the reference's default
+  dtype) the result must be as close as the exact three-way bf16 form (chol_f16x2 = 0) -- with targets of magnitude 1e4 (the
+  augmented rows' range), a noise variance of 1e-4 on a smooth kernel (large entries of L^-1; at 1e-5 the fp32 matrix is no longer positive definite on any path), MLP features, a batch (one set of
+  augmented-row scales per task), the divergence objective (several augmented rows) -- and the dot-product kernel, whose
+  diagonal is not constant, must not take the path at all."""
+  defs, _, _, _, kernel, mean, objectives, utils = _native()
+  rng = np.random.default_rng(21)
+  d = 5
+  n = 4500 if case != 'batch' else 0
+  mean_f, kern_f, mlp = mean.constant, kernel.squared_exponential, False
+  if case == 'matern_mlp': mean_f, kern_f, mlp = mean.linear_mlp, kernel.matern52_mlp, True
+  if case == 'dot': kern_f = kernel.dot_product
+  model = helpers.make_model(rng, 'linear_mlp' if mlp else 'constant', mlp, d)
+  if case == 'small_noise':
+    model['noise_variance'] = np.array(helpers.inv_softplus(1e-4)); model['lengthscale'] = model['lengthscale'] * 0 + helpers.inv_softplus(0.8)
+  if case == 'batch':
+    data = {k: defs.SubDataset(*helpers.synthetic_task(rng, m, d)) for k, m in enumerate((700, 1300, 515))}
+  elif case == 'ekl':
+    x, y = helpers.synthetic_task(rng, 1800, d, m=5)
+    data = {0: defs.SubDataset(x, y, aligned=0)}
+  else:
+    x, y = helpers.synthetic_task(rng, n, d)
+    if case == 'large_targets': y = 1e4 * y + 3e4
+    data = {0: defs.SubDataset(x, y)}
+  def evaluate(dt, params):
+    ds = {k: defs.SubDataset(np.asarray(v.x, dtype=dt), np.asarray(v.y, dtype=dt), aligned=v.aligned) for k, v in data.items()}
+    if case == 'ekl':
+      return objectives.ekl.value_and_grad(mean_f, kern_f, defs.GPParams(model=params, config={'mlp_features': helpers.MLP_FEATURES}), ds, utils.DEFAULT_WARP_FUNC)
+    return objectives.nll_value_and_grad(mean_f, kern_f, defs.GPParams(model=params, config={'mlp_features': helpers.MLP_FEATURES}), ds, utils.DEFAULT_WARP_FUNC)
+  to32 = lambda t: {k: to32(v) for k, v in t.items()} if isinstance(t, dict) else np.asarray(t, dtype=np.float32)
+  v64, g64 = evaluate(np.float64, model)
+  f64 = helpers.flatten(g64)
+  out, err = {}, {}
+  try:
+    for on in (0, 1):
+      gpu_ctx.set_option('chol_f16x2', on)
+      v, g = evaluate(np.float32, to32(model))
+      out[on] = (v, helpers.flatten(g))
+      err[on] = (abs(v - v64) / max(abs(v64), 1.0), np.max(np.abs(out[on][1] - f64)) / np.max(np.abs(f64)))
+  finally:
+    gpu_ctx.set_option('chol_f16x2', 1)
+  assert np.isfinite(out[1][0]) and np.isfinite(out[1][1]).all()
+  if case == 'dot':
+    assert out[0][0] == out[1][0] and np.array_equal(out[0][1], out[1][1])      # not a constant diagonal: the option does not apply
+    return
+  assert out[0][0] != out[1][0] or not np.array_equal(out[0][1], out[1][1])     # the other path did run
+  assert err[1][0] <= 3 * err[0][0] + 2e-6 and err[1][1] <= 3 * err[0][1] + 2e-6, err
+  print(case, 'fp32 vs fp64 (value, gradient / max): bf16x3', err[0], 'f16x2', err[1])
+
+
 def test_largest_single_matrix_closed_form(gpu_ctx):
   """N = 131072 fp64: the Gram matrix (137 GB) is factorised in place on one GPU's 288 GB -- the largest single matrix the path
   takes without tiling over devices (1024 blocks: every tile / block index at its maximum).  Same closed form as the cfg-5 test
