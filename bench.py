@@ -219,7 +219,7 @@ def bench_cfg3(ctx, stages=False):
           'factor_frac_fp32': round(float(n)**3 / 3 / (pf['potrf'][0] * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
           'note': 'wall times include the host<->device copies of x_query / EI; post_gemm = V = L^-1 Kxq (algorithmic fp32 flops N^2 M); '
                   'frac_f16_executed = 3 x algorithmic flops (the fp16 MFMAs the product executes) against the dense fp16 / bf16 MFMA peak; '
-                  'factor_frac_fp32 = N^3/3 over the potrf stage time against the fp32 MFMA peak'}
+                  'factor_frac_fp32 = N^3/3 over the potrf stage time against the fp32 MFMA peak; trailing updates of the factorisation and products of the inverse run as f16x2 too (round 5: factor 21.5 -> 18.4 ms)'}
   chunks = ps_['cross_gram'][1]
   xg_ms = ps_['cross_gram'][0] / chunks
   ch = m // chunks
@@ -274,8 +274,9 @@ def bench_cfg5(ctx):
 
 def bench_fp32_objective(ctx):
   """The headline workload in the reference's DEFAULT dtype (float32 unless JAX_ENABLE_X64): cfg-2 shape, fp32
-  NLL + gradient, theta changing every evaluation; the large products run on the bf16 matrix cores from exact three-way
-  splits (option bf16x3).  Error against the fp64 evaluation of the same theta beside it."""
+  NLL + gradient, theta changing every evaluation; the large products (trailing updates, inverse, K^-1 = W^T W) run on the fp16
+  matrix cores from two-way splits scaled by powers of two (hbo_tune chol_f16x2; the dot-product kernel and hbo_spd_* keep the
+  exact three-way bf16 splits).  Error against the fp64 evaluation of the same theta beside it."""
   from hyperbo_amd.basics import definitions as defs
   from hyperbo_amd.gp_utils import kernel, mean, objectives, utils
   x, y, raw = cfg2_inputs()
@@ -295,7 +296,7 @@ def bench_fp32_objective(ctx):
                                            utils.DEFAULT_WARP_FUNC)
   d64.close()
   flat = lambda t: np.concatenate([np.ravel(np.asarray(t[k], dtype=np.float64)) for k in sorted(t)])
-  return {'workload': f'cfg-2 shape in fp32 (N={x.shape[0]}, D={x.shape[1]}): NLL+grad, products on the bf16 matrix cores (bf16x3)',
+  return {'workload': f'cfg-2 shape in fp32 (N={x.shape[0]}, D={x.shape[1]}): NLL+grad, products on the fp16 matrix cores (f16x2: 3 MFMAs per product; round 4: bf16x3, 6)',
           'ms_per_eval': round(el / steps * 1e3, 3), 'evals_per_s': round(steps / el, 2),
           'nll_rel_err_vs_fp64': float(abs(v32 - v64) / abs(v64)),
           'grad_err_over_max_vs_fp64': float(np.max(np.abs(flat(g32) - flat(g64))) / np.max(np.abs(flat(g64))))}
