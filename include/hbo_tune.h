@@ -25,6 +25,10 @@
  *   sweep_big     >=0      sweep launches of small / batched shapes with at least this many 128-tiles (x tasks) use 128-tiles (4000)
  *   post_f16x2    0/1      fp32 posterior product of the stationary covariances on the fp16 matrix cores from two-way splits (post2h.hip;
  *                          default 1; 0 = bf16x3's exact three-way split)
+ *   chol_f16x2    0/1      fp32 factorisations of the stationary covariances (the objective / factor paths, which know max A_ii = signal variance +
+ *                          noise + jitter): trailing updates, the inverse's bf16-core levels and K^-1 = W^T W from two-way fp16 splits
+ *                          (post3.hip: syrk3_kernel<true>; default 1; 0 = the exact three-way bf16 splits, which hbo_spd_* and the
+ *                          dot-product kernel always use)
  *   post_serial   0/1      streamed posterior: features + cross Gram of chunk i+1 on the SAME stream as the product of chunk i
  *                          (nothing overlaps: the stage times of hbo_profile are then each kernel's isolated time; bench.py cfg3)
  *   small_fused   0/1      batches whose tasks all have n <= 128: the single-workgroup evaluation (small.hip; default 1)
