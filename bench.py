@@ -219,7 +219,7 @@ def bench_cfg3(ctx, stages=False):
           'factor_frac_fp32': round(float(n)**3 / 3 / (pf['potrf'][0] * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS, 4),
           'note': 'wall times include the host<->device copies of x_query / EI; post_gemm = V = L^-1 Kxq (algorithmic fp32 flops N^2 M); '
                   'frac_f16_executed = 3 x algorithmic flops (the fp16 MFMAs the product executes) against the dense fp16 / bf16 MFMA peak; '
-                  'factor_frac_fp32 = N^3/3 over the potrf stage time against the fp32 MFMA peak; trailing updates of the factorisation and products of the inverse run as f16x2 too (round 5: factor 21.5 -> 18.4 ms)'}
+                  'factor_frac_fp32 = N^3/3 over the potrf stage time against the fp32 MFMA peak; trailing updates of the factorisation and products of the inverse run as f16x2 too (round 5: factor 21.5 -> 17.6 ms)'}
   chunks = ps_['cross_gram'][1]
   xg_ms = ps_['cross_gram'][0] / chunks
   ch = m // chunks

@@ -79,6 +79,7 @@ struct hbo_ctx {
   void* d_mlp_b[HBO_MAX_MLP_LAYERS] = {nullptr};
   size_t mlp_w_bytes[HBO_MAX_MLP_LAYERS] = {0};
   size_t mlp_b_bytes[HBO_MAX_MLP_LAYERS] = {0};
+  int opt_group_inner = -1;  // two-level panel groups: column updates on the chain inside inner groups of this many panels (0: one level; -1: auto, see run_potrf)
   int opt_group = 0;         // 128-wide panels per trailing update (K = 128*group); 0: auto, see run_potrf
   int prof_level = 0;
   std::vector<ProfEntry> prof_pending;

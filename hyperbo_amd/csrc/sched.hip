@@ -47,7 +47,14 @@ void run_potrf(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, int m
   //  trailing update, the plain right-looking form: N = 512 / 1024 / 2048: 0.399 -> 0.383, 0.686 -> 0.654, 1.33 -> 1.28 ms; up to
   //  eight tasks -- 64 tasks of 4 blocks: 0.761 with groups of three, 0.796 with one)
   const bool la_on = use_lookahead(c, ntasks, max_nblk);
-  const int q = c->opt_group > 0 ? c->opt_group : ((!la_on && ntasks <= 8) ? 1 : (small_mat ? 3 : ((max_nblk >= 256 || s3_large) ? 8 : 4)));
+  //   round 5 (tools/ab_suite.py; fp64 one matrix, group 3 / 5 / 6 / 7 / 8): N = 8192 10.57 / 10.54 / 10.58 / 10.56 / 10.56 (flat), 12288 31.98 / 31.21 / 31.16 /
+  //   30.97 / 31.02; fp32 with the trailing updates on the fp16 cores (they are short: the chain and the launch count decide): N = 8192 group 3 / 6 / 8 / 12
+  //   6.09 / 5.82-5.87 / 5.92 / 6.16-6.19; N = 16384 (factor, ms) 8 / 12 / 16 18.5 / 18.3-18.5 / 18.7-19.0 and, with two-level groups (outer / inner: see
+  //   group_inner below), 16 / 8 18.0-18.2, 12 / 6 18.2-18.5, 8 / 4 18.6
+  const bool s3_one = dtype == HBO_F32 && c->opt_syrk_bf16x3 && ntasks == 1;
+  const int q_small = (s3_one && max_nblk >= 56) ? 6 : ((ntasks == 1 && max_nblk > 64) ? 7 : 3);
+  const int q = c->opt_group > 0 ? c->opt_group : ((!la_on && ntasks <= 8) ? 1 : (small_mat ? q_small : (s3_large ? 16 : (max_nblk >= 256 ? 8 : 4))));
+  const int q_inner = c->opt_group_inner >= 0 ? c->opt_group_inner : ((s3_large && q == 16) ? 8 : 0);
   //   with the CU yield (below): N = 8192 (3, 64) 12.58, (3, 48) 12.52, (3, 32) 12.61, (3, 16) 13.24, (4, 48) 12.66
   //   round 2 (chain kernels mark their CUs, background workgroups there pause): 32 beats 48 at N = 8192 (11.73 / 11.81)
   const int persist_free = c->opt_persist_free >= 0 ? c->opt_persist_free : 32;
@@ -132,16 +139,40 @@ void run_potrf(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, int m
     if (use_s3) s3a.Xp = s3buf[grp_index & 1];
     if (s3a.h2) s3a.aug_scale = h2_aug + (grp_index & 1) * s3a.aug_stride * ntasks;
     if (la && ev_f1) hipStreamWaitEvent(sp, ev_f1, 0);
+    // two-level groups (group_inner = qi, 0 < qi < q): the chain's column updates stay short -- inside the inner group [gi, gi + qi) --
+    // and at every inner boundary ONE update brings the group's remaining columns up to date with the inner group just finished
+    // (K = 128 qi, on the chain); the trailing updates F1 / F2 keep the outer group's K = 128 q
+    const int qi = (q_inner > 0 && q_inner < q && !c->opt_syrk3_col) ? q_inner : 0;
     for (int p = g0; p < g1; ++p) {
+      const int gi = qi ? g0 + (p - g0) / qi * qi : g0;   // first panel of p's inner group
+      if (qi && p == gi && p > g0) {
+        if (use_s3) {   // the inner group just finished, as split planes (its rows below; blocks [gi - qi - g0 ..) of the buffer)
+          ProfScope ps(c, "split3", 2, sp);
+          Syrk3Args a = s3a; a.kcol0 = (gi - qi) * HBO_TILE; a.nk_split = qi * (HBO_TILE / 16); a.r_lo = gi; a.kb_off = (gi - qi - g0) * (HBO_TILE / 16);
+          launch_split3_panel(a, max_nblk + 1 - gi, ntasks, sp);
+        }
+        if (ev_f1b) { hipStreamWaitEvent(sp, ev_f1b, 0); ev_f1b = nullptr; }
+        ProfScope ps(c, "syrk_inner", 2, sp);
+        if (use_s3) {
+          Syrk3Args a = s3a; a.kb_off = (gi - qi - g0) * (HBO_TILE / 16); a.nk = qi * (HBO_TILE / 16); a.c_lo = gi; a.c_hi = g1;
+          a.yield_mark = chain_mark;
+          launch_syrk3(a, tiles_of(gi, g1), ntasks, sp);
+        } else {
+          GemmArgs a = {}; a.tasks = d_tasks; a.mode = GEMM_SYRK; a.p0 = gi - qi; a.kt = qi; a.c_lo = gi; a.c_hi = g1; a.aug = 1;
+          a.small_tiles = (int64_t)(max_nblk + 1 - gi) * (g1 - gi) * ntasks < 600;
+          a.yield_mark = chain_mark;
+          launch_gemm(dtype, a, dim3(max_nblk + 1 - gi, g1 - gi, ntasks), sp);
+        }
+      }
       if (p > g0 && use_s3 && c->opt_syrk3_col) {
         ProfScope ps(c, "syrk_col", 2, sp);
         Syrk3Args a = s3a; a.kb_off = 0; a.nk = (p - g0) * (HBO_TILE / 16); a.c_lo = p; a.c_hi = p + 1;
         a.yield_mark = chain_mark;
         launch_syrk3(a, tiles_of(p, p + 1), ntasks, sp);
-      } else if (p > g0) {  // left-looking update of block column p with the group's earlier panels
+      } else if (p > gi) {  // left-looking update of block column p with the (inner) group's earlier panels
         if (ev_f1b) { hipStreamWaitEvent(sp, ev_f1b, 0); ev_f1b = nullptr; }   // (the previous group's contribution to this column)
         ProfScope ps(c, "syrk_col", 2, sp);
-        GemmArgs a = {}; a.tasks = d_tasks; a.mode = GEMM_SYRK; a.p0 = g0; a.kt = p - g0; a.c_lo = p; a.c_hi = p + 1; a.aug = 1; a.small_tiles = 1;
+        GemmArgs a = {}; a.tasks = d_tasks; a.mode = GEMM_SYRK; a.p0 = gi; a.kt = p - gi; a.c_lo = p; a.c_hi = p + 1; a.aug = 1; a.small_tiles = 1;
         a.yield_mark = chain_mark;
         launch_gemm(dtype, a, dim3(max_nblk + 1 - p, 1, ntasks), sp);
       }
@@ -156,7 +187,7 @@ void run_potrf(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, int m
           // the column updates inside the group stay on fp32 MFMA (64x64 tiles): ONE split of the whole group behind its last
           // solve, for the wide updates (F1, F2) -- or, with syrk3_col, one per panel for the column updates too
           ProfScope ps(c, "split3", 2, sp);
-          const int pfirst = c->opt_syrk3_col ? p : g0;
+          const int pfirst = c->opt_syrk3_col ? p : gi;   // (two-level groups: the earlier inner groups were split at their boundaries)
           Syrk3Args a = s3a; a.kcol0 = pfirst * HBO_TILE; a.nk_split = (p + 1 - pfirst) * (HBO_TILE / 16); a.r_lo = p + 1; a.kb_off = (pfirst - g0) * (HBO_TILE / 16);
           launch_split3_panel(a, max_nblk + 1 - (p + 1), ntasks, sp);
         }

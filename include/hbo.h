@@ -230,7 +230,7 @@ int hbo_profile_get(hbo_ctx* ctx, char names[][32], double* ms, int32_t* launche
  *                         the stationary covariances goes one step further (hbo_tune post_f16x2, default on): two-way fp16 splits of
  *                         operands scaled by powers of two, three fp16 MFMAs per product (2^-22 per product: as close to fp64 as
  *                         the fp32-MFMA product) -- cfg 3's EI 97 -> 59 ms; and so do the factorisation's trailing updates, the inverse's
- *                         upper levels and K^-1 = W^T W of those covariances (hbo_tune chol_f16x2, default on: cfg 3's factor 21.5 -> 18.4 ms) */
+ *                         upper levels and K^-1 = W^T W of those covariances (hbo_tune chol_f16x2, default on: cfg 3's factor 21.5 -> 17.6 ms) */
 int hbo_set_option(hbo_ctx* ctx, const char* name, int64_t value);
 
 /* ---- multi-GPU: one process per GPU; sum-all-reduce of [nll, grads] over RCCL (xGMI) ------ */

@@ -25,6 +25,9 @@
  *   sweep_big     >=0      sweep launches of small / batched shapes with at least this many 128-tiles (x tasks) use 128-tiles (4000)
  *   post_f16x2    0/1      fp32 posterior product of the stationary covariances on the fp16 matrix cores from two-way splits (post2h.hip;
  *                          default 1; 0 = bf16x3's exact three-way split)
+ *   group_inner   -1..16   two-level panel groups: the chain's left-looking column updates stay inside inner groups of this many panels, one
+ *                          update per inner boundary brings the rest of the (outer, potrf_group) group up to date; 0 = one level, -1 = auto
+ *                          (8 inside groups of 16 for one fp32 matrix above 96 blocks: cfg 3's factor 18.5 -> 18.1 ms)
  *   chol_f16x2    0/1      fp32 factorisations of the stationary covariances (the objective / factor paths, which know max A_ii = signal variance +
  *                          noise + jitter): trailing updates, the inverse's bf16-core levels and K^-1 = W^T W from two-way fp16 splits
  *                          (post3.hip: syrk3_kernel<true>; default 1; 0 = the exact three-way bf16 splits, which hbo_spd_* and the

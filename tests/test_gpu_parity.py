@@ -711,9 +711,9 @@ def test_fp32_factorisation_on_bf16_matrix_cores_is_as_accurate_as_fp32_mfma(gpu
   assert err['bf16x3'][0] < 1e-3        # kappa * eps_fp32 ~ 6e-2 bounds the solve; the factor itself stays accurate
 
 
-@pytest.mark.parametrize('n', [4225, 5633])
+@pytest.mark.parametrize('n', [4225, 5633, 7300])
 def test_fp32_bf16x3_paths_at_odd_block_counts(gpu_ctx, n):
-  """34 and 45 blocks: partial groups at several levels of the inverse, an odd number of row tiles in K^-1 = W^T W and in the
+  """34, 45 and 58 blocks (the last: panel groups of six, the last one cut): partial groups at several levels of the inverse, an odd number of row tiles in K^-1 = W^T W and in the
   trailing updates' trapezoids (syrk3_kernel modes 0-3, split3_* edge handling).  Factor, solve and inverse of a
   well-conditioned fp32 matrix against fp64 LAPACK (linalg.py:29-33); measured 1e-6 / 5e-6 / 5e-6 (tools/sweep32.py: nine sizes
   from 33 to 66 blocks, 2-3x closer to fp64 than the fp32-MFMA kernels)."""

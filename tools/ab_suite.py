@@ -31,7 +31,7 @@ def apply(setting):
         ctx.set_option(k, int(v))
 
 
-DEFAULTS = {'lookahead': 1, 'overlap_trtri': 1, 'potrf_group': 0, 'persist_free': -1, 'small_nblk': -1, 'cu_yield': 2, 'trtri_free': 48,
+DEFAULTS = {'lookahead': 1, 'overlap_trtri': 1, 'potrf_group': 0, 'group_inner': -1, 'persist_free': -1, 'small_nblk': -1, 'cu_yield': 2, 'trtri_free': 48,
             'trtri_at': 0, 'sweep': 1, 'sweep_qs': 0, 'batch_bg': -1, 'sweep_big': 4000, 'split_f1': 1, 'sweep_side': 1, 'lauum_persist': 1, 'sweep_free': 24}
 
 
