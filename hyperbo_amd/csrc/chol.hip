@@ -243,11 +243,12 @@ __device__ __forceinline__ void potf2_body(const TaskDesc& t, int p, int* info_s
 #endif
 }
 template <typename T>
-__global__ __launch_bounds__(POTF2_THREADS) void potf2_kernel(const TaskDesc* tasks, int p, int* info, int* yield_flag) {
+__global__ __launch_bounds__(POTF2_THREADS) void potf2_kernel(const TaskDesc* tasks, int p, int* info, int* yield_flag, unsigned long long* tl) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __builtin_amdgcn_s_setprio(3);            // critical path: outrank co-resident GEMM waves
   const TaskDesc& t = tasks[blockIdx.x];
   if (p >= t.nblk) return;
+  tl_begin(tl);
   // single matrix: count this workgroup into the yield table entry of its CU -- background GEMM workgroups that share the
   // CU pause at their next K step (potf2's small MFMAs queue behind their 64-cycle ones and its LDS traffic behind theirs:
   // 50 us beside them, 22 us alone)
@@ -258,6 +259,7 @@ __global__ __launch_bounds__(POTF2_THREADS) void potf2_kernel(const TaskDesc* ta
     __syncthreads();
     if (threadIdx.x == 0) yield_leave(yield_flag, tok);
   }
+  tl_end(tl);
 }
 
 template <typename T>
@@ -390,7 +392,7 @@ __device__ __forceinline__ void trsm_body(const TaskDesc& t, int p, int64_t row0
   }
 }
 template <typename T, bool IDENT>
-__global__ __launch_bounds__(256) void trsm_kernel(const TaskDesc* tasks, int p_arg, int* yield_tab, SplitOut so) {
+__global__ __launch_bounds__(256) void trsm_kernel(const TaskDesc* tasks, int p_arg, int* yield_tab, SplitOut so, unsigned long long* tl) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   __builtin_amdgcn_s_setprio(3);                // critical path: outrank co-resident GEMM waves
   const TaskDesc& t = tasks[blockIdx.z];
@@ -418,12 +420,14 @@ __global__ __launch_bounds__(256) void trsm_kernel(const TaskDesc* tasks, int p_
     row0 = first + bx * 64;
   }
   int tok = 0;
+  tl_begin(tl);
   if (yield_tab && threadIdx.x == 0) tok = yield_enter(yield_tab);
   trsm_body<T, IDENT>(t, p, row0, smem, true, so.xp ? so.xp + (int64_t)blockIdx.z * so.task_stride : nullptr, so.nkb, so.kb_off);
   if (yield_tab) {
     __syncthreads();
     if (threadIdx.x == 0) yield_leave(yield_tab, tok);
   }
+  tl_end(tl);
 #ifdef HBO_POTF2_TIMING
   if (dbg) hbo_dbg_trsm[3 * blockIdx.x + 1] = wall_clock64();
 #endif
@@ -443,18 +447,18 @@ void set_attrs() {
 }
 
 template <typename T>
-void potf2_t(const TaskDesc* tasks, int ntasks, int p, int* info, hipStream_t st, int* yield_flag) {
+void potf2_t(const TaskDesc* tasks, int ntasks, int p, int* info, hipStream_t st, int* yield_flag, unsigned long long* tl) {
   set_attrs<T>();
   hipLaunchKernelGGL((potf2_kernel<T>), dim3(ntasks), dim3(POTF2_THREADS), potf2_lds_bytes<T>(), st, tasks, p, info,
-                     yield_flag);
+                     yield_flag, tl);
 }
 template <typename T>
-void trsm_t(const TaskDesc* tasks, int ntasks, int p, int max_nblk, hipStream_t st, int* yield_tab, const SplitOut& so) {
+void trsm_t(const TaskDesc* tasks, int ntasks, int p, int max_nblk, hipStream_t st, int* yield_tab, const SplitOut& so, unsigned long long* tl) {
   set_attrs<T>();
   const int nrows = (max_nblk + 1 - (p + 1)) * NB;
   if (nrows <= 0) return;
   hipLaunchKernelGGL((trsm_kernel<T, false>), dim3(nrows / 64, 1, ntasks), dim3(256), trsm_lds_bytes<T>(), st,
-                     tasks, p, yield_tab, so);
+                     tasks, p, yield_tab, so, tl);
 }
 template <typename T>
 void trtri_diag_t(const TaskDesc* tasks, int ntasks, int p_lo, int p_hi, hipStream_t st) {
@@ -462,7 +466,7 @@ void trtri_diag_t(const TaskDesc* tasks, int ntasks, int p_lo, int p_hi, hipStre
   if (p_hi <= p_lo) return;
   SplitOut none; memset(&none, 0, sizeof none);
   hipLaunchKernelGGL((trsm_kernel<T, true>), dim3(2, p_hi - p_lo, ntasks), dim3(256), trsm_lds_bytes<T>(), st,
-                     tasks, p_lo, (int*)nullptr, none);
+                     tasks, p_lo, (int*)nullptr, none, (unsigned long long*)nullptr);
 }
 
 #endif  // HBO_DEVICE_ONLY
@@ -477,15 +481,16 @@ extern "C" void hbo_dbg_trsm_wall(unsigned long long* host, int panel) {
 }
 extern "C" void hbo_dbg_potf2_wall(unsigned long long* host) { hipMemcpyFromSymbol(host, HIP_SYMBOL(hbo_dbg_wall), sizeof(unsigned long long) * 3 * 256); }
 #endif
-void launch_potf2(int dtype, const TaskDesc* tasks, int ntasks, int p, int* info, hipStream_t st, int* yield_flag) {
-  if (dtype == HBO_F64) potf2_t<double>(tasks, ntasks, p, info, st, yield_flag);
-  else potf2_t<float>(tasks, ntasks, p, info, st, yield_flag);
+void launch_potf2(int dtype, const TaskDesc* tasks, int ntasks, int p, int* info, hipStream_t st, int* yield_flag, unsigned long long* tl) {
+  if (dtype == HBO_F64) potf2_t<double>(tasks, ntasks, p, info, st, yield_flag, tl);
+  else potf2_t<float>(tasks, ntasks, p, info, st, yield_flag, tl);
 }
-void launch_trsm(int dtype, const TaskDesc* tasks, int ntasks, int p, int max_nblk, hipStream_t st, int* yield_tab, const SplitOut* so) {
+void launch_trsm(int dtype, const TaskDesc* tasks, int ntasks, int p, int max_nblk, hipStream_t st, int* yield_tab, const SplitOut* so,
+                 unsigned long long* tl) {
   SplitOut o; memset(&o, 0, sizeof o);
   if (so) o = *so;
-  if (dtype == HBO_F64) trsm_t<double>(tasks, ntasks, p, max_nblk, st, yield_tab, o);
-  else trsm_t<float>(tasks, ntasks, p, max_nblk, st, yield_tab, o);
+  if (dtype == HBO_F64) trsm_t<double>(tasks, ntasks, p, max_nblk, st, yield_tab, o, tl);
+  else trsm_t<float>(tasks, ntasks, p, max_nblk, st, yield_tab, o, tl);
 }
 void launch_trtri_diag(int dtype, const TaskDesc* tasks, int ntasks, int p_lo, int p_hi, hipStream_t st) {
   if (dtype == HBO_F64) trtri_diag_t<double>(tasks, ntasks, p_lo, p_hi, st);

@@ -885,8 +885,7 @@ __device__ unsigned long long hbo_dbg_gemm[4 * 8192];   // per workgroup of the 
 int g_dbg_mode = -1, g_dbg_index = 0, g_dbg_seen = 0;   // host: trace the g_dbg_index-th launch of g_dbg_mode (+100: persistent)
 #endif
 template <typename T, bool AKC, bool BKC, int TM>
-__global__ __launch_bounds__(256, TM == 64 ? (sizeof(T) == 8 ? HBO_LB64 : 4) : 2) void gemm_kernel(GemmArgs g) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+__device__ __forceinline__ void gemm_kernel_body(const GemmArgs& g, unsigned char* smem) {
   TileJob<T> job;
   job.yield_flag = g.yield_flag;
 #ifdef HBO_GEMM_TIMING
@@ -971,6 +970,14 @@ __global__ __launch_bounds__(256, TM == 64 ? (sizeof(T) == 8 ? HBO_LB64 : 4) : 2
 #ifdef HBO_GEMM_TIMING
   if (dbg) { hbo_dbg_gemm[4 * dbg_id + 1] = wall_clock64(); hbo_dbg_gemm[4 * dbg_id + 3] = (unsigned long long)job.ksteps; }
 #endif
+}
+
+template <typename T, bool AKC, bool BKC, int TM>
+__global__ __launch_bounds__(256, TM == 64 ? (sizeof(T) == 8 ? HBO_LB64 : 4) : 2) void gemm_kernel(GemmArgs g) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  tl_begin(g.tl);
+  gemm_kernel_body<T, AKC, BKC, TM>(g, smem);
+  tl_end(g.tl);
 }
 
 #ifndef HBO_DEVICE_ONLY

@@ -104,6 +104,7 @@ struct GemmArgs {
   // POST with few column tiles (kchunk > 0): the K range of a row tile is cut into chunks of kchunk 128-blocks, one workgroup per
   // (row tile, chunk); chunk ch of row tile i writes its partial product to V + (ch * npad + i * 128) * ldb (no colsq): split-K
   int kchunk;
+  unsigned long long* tl;   // HBO_TIMELINE builds: [first start, last end] of this launch's workgroups (100 MHz wall clock), or null
 };
 
 #ifdef __HIPCC__
@@ -149,6 +150,17 @@ __device__ __forceinline__ int yield_enter(int* tab) {
 __device__ __forceinline__ void yield_leave(int* tab, int tok) {
   __hip_atomic_fetch_add(tab + tok, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// debug builds (-DHBO_TIMELINE, tools/timeline.py): every workgroup of a tagged launch folds its start / end into the launch's slot pair
+__device__ __forceinline__ void tl_begin(unsigned long long* tl) {
+#ifdef HBO_TIMELINE
+  if (tl && threadIdx.x == 0) atomicMin(tl, (unsigned long long)wall_clock64());
+#endif
+}
+__device__ __forceinline__ void tl_end(unsigned long long* tl) {
+#ifdef HBO_TIMELINE
+  if (tl && threadIdx.x == 0) atomicMax(tl + 1, (unsigned long long)wall_clock64());
+#endif
+}
 #endif
 
 // hipFuncSetAttribute is per device: a launcher sets its kernels' dynamic-LDS limit the first time it runs on EACH device of the
@@ -167,9 +179,12 @@ void launch_gemm(int dtype, const GemmArgs& a, dim3 grid, hipStream_t st);
 // fp32: the panel solve also writes the solved panel as three bf16 planes (the operand of the bf16x3 trailing updates, post3.hip):
 // element (row, k) of panel block column kb_off.. -> ((row / 128 * nkb + kb_off + k / 16) * 3 + plane) * 2048 + (row % 128) * 16 + k % 16
 struct SplitOut { unsigned short* xp; int64_t task_stride; int nkb, kb_off; };
-void launch_potf2(int dtype, const TaskDesc* tasks, int ntasks, int p, int* info, hipStream_t st, int* yield_flag = nullptr);
+void launch_potf2(int dtype, const TaskDesc* tasks, int ntasks, int p, int* info, hipStream_t st, int* yield_flag = nullptr,
+                  unsigned long long* tl = nullptr);
 void launch_trsm(int dtype, const TaskDesc* tasks, int ntasks, int p, int max_nblk, hipStream_t st, int* yield_tab = nullptr,
-                 const SplitOut* so = nullptr);
+                 const SplitOut* so = nullptr, unsigned long long* tl = nullptr);
+// HBO_TIMELINE builds: the slot pair of the next tagged launch (sched.hip), null when no recording is on
+unsigned long long* tl_slot(const char* name, int p);
 // inverses of the diagonal blocks p in [p_lo, p_hi)
 void launch_trtri_diag(int dtype, const TaskDesc* tasks, int ntasks, int p_lo, int p_hi, hipStream_t st);
 

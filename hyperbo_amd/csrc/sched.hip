@@ -7,6 +7,43 @@
 #include <algorithm>
 #include <cmath>
 
+// ---- debug timeline (-DHBO_TIMELINE builds only; tools/timeline.py) ----------------------------------------------------------------
+// Every tagged launch gets a pair of device words [first workgroup start, last workgroup end] (100 MHz wall clock) and a host-side
+// label; hbo_dbg_timeline(1) starts a recording, hbo_dbg_timeline(0, times, names, ps) ends it and copies everything out.
+#ifdef HBO_TIMELINE
+namespace {
+constexpr int TL_MAX = 16384;
+unsigned long long* g_tl_dev = nullptr;
+int g_tl_n = 0;
+bool g_tl_on = false;
+struct TlEntry { char name[16]; int p; };
+TlEntry g_tl_entries[TL_MAX];
+}
+unsigned long long* tl_slot(const char* name, int p) {
+  if (!g_tl_on || g_tl_n >= TL_MAX) return nullptr;
+  strncpy(g_tl_entries[g_tl_n].name, name, 15); g_tl_entries[g_tl_n].name[15] = 0;
+  g_tl_entries[g_tl_n].p = p;
+  return g_tl_dev + 2 * g_tl_n++;
+}
+extern "C" int hbo_dbg_timeline(int begin, unsigned long long* times, char* names, int* ps) {
+  if (begin) {
+    if (!g_tl_dev && hipMalloc(reinterpret_cast<void**>(&g_tl_dev), sizeof(unsigned long long) * 2 * TL_MAX) != hipSuccess) return -1;
+    static unsigned long long init[2 * TL_MAX];
+    for (int i = 0; i < TL_MAX; ++i) { init[2 * i] = ~0ull; init[2 * i + 1] = 0; }
+    hipMemcpy(g_tl_dev, init, sizeof init, hipMemcpyHostToDevice);
+    g_tl_n = 0; g_tl_on = true;
+    return 0;
+  }
+  g_tl_on = false;
+  hipDeviceSynchronize();
+  if (times) hipMemcpy(times, g_tl_dev, sizeof(unsigned long long) * 2 * g_tl_n, hipMemcpyDeviceToHost);
+  for (int i = 0; i < g_tl_n; ++i) { if (names) memcpy(names + 16 * i, g_tl_entries[i].name, 16); if (ps) ps[i] = g_tl_entries[i].p; }
+  return g_tl_n;
+}
+#else
+unsigned long long* tl_slot(const char*, int) { return nullptr; }
+#endif
+
 // ---- blocked factorisation drivers -----------------------------------------------------------
 
 hipEvent_t pool_event(hbo_ctx* c, size_t i) {
@@ -160,7 +197,7 @@ void run_potrf(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, int m
         } else {
           GemmArgs a = {}; a.tasks = d_tasks; a.mode = GEMM_SYRK; a.p0 = gi - qi; a.kt = qi; a.c_lo = gi; a.c_hi = g1; a.aug = 1;
           a.small_tiles = (int64_t)(max_nblk + 1 - gi) * (g1 - gi) * ntasks < 600;
-          a.yield_mark = chain_mark;
+          a.yield_mark = chain_mark; a.tl = tl_slot("syrk_inner", p);
           launch_gemm(dtype, a, dim3(max_nblk + 1 - gi, g1 - gi, ntasks), sp);
         }
       }
@@ -173,16 +210,16 @@ void run_potrf(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, int m
         if (ev_f1b) { hipStreamWaitEvent(sp, ev_f1b, 0); ev_f1b = nullptr; }   // (the previous group's contribution to this column)
         ProfScope ps(c, "syrk_col", 2, sp);
         GemmArgs a = {}; a.tasks = d_tasks; a.mode = GEMM_SYRK; a.p0 = gi; a.kt = p - gi; a.c_lo = p; a.c_hi = p + 1; a.aug = 1; a.small_tiles = 1;
-        a.yield_mark = chain_mark;
+        a.yield_mark = chain_mark; a.tl = tl_slot("syrk_col", p);
         launch_gemm(dtype, a, dim3(max_nblk + 1 - p, 1, ntasks), sp);
       }
-      { ProfScope ps(c, "potf2", 2, sp); launch_potf2(dtype, d_tasks, ntasks, p, d_info, sp, yield_flag); }
+      { ProfScope ps(c, "potf2", 2, sp); launch_potf2(dtype, d_tasks, ntasks, p, d_info, sp, yield_flag, tl_slot("potf2", p)); }
       {
         // (fp32 + bf16x3 updates: the solve writes its panel as three bf16 planes too -- no separate split launch on the chain)
         SplitOut so = {};
         if (use_s3) { so.xp = s3a.Xp; so.task_stride = s3a.task_stride; so.nkb = s3a.nkb; so.kb_off = (p - g0) * (HBO_TILE / 16); }
         const bool fused = use_s3 && !c->opt_syrk3_sep && c->opt_syrk3_col && !s3a.h2;   // (the f16x2 split needs the augmented rows' maxima first: a kernel of its own)
-        { ProfScope ps(c, "trsm", 2, sp); launch_trsm(dtype, d_tasks, ntasks, p, max_nblk, sp, chain_mark, fused ? &so : nullptr); }
+        { ProfScope ps(c, "trsm", 2, sp); launch_trsm(dtype, d_tasks, ntasks, p, max_nblk, sp, chain_mark, fused ? &so : nullptr, tl_slot("trsm", p)); }
         if (use_s3 && !fused && p + 1 < max_nblk && (c->opt_syrk3_col || p + 1 == g1)) {
           // the column updates inside the group stay on fp32 MFMA (64x64 tiles): ONE split of the whole group behind its last
           // solve, for the wide updates (F1, F2) -- or, with syrk3_col, one per panel for the column updates too
@@ -236,6 +273,7 @@ void run_potrf(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, int m
           hipEventRecord(e, sp); hipStreamWaitEvent(c->stream3, e, 0);
           GemmArgs b = a; b.c_lo = a.c_lo + 1;
           b.small_tiles = (int64_t)(max_nblk + 1 - b.c_lo) * (b.c_hi - b.c_lo) * ntasks < 600;
+          b.tl = tl_slot("f1b", g1);
           launch_gemm(dtype, b, dim3(max_nblk + 1 - b.c_lo, b.c_hi - b.c_lo, ntasks), c->stream3);
           ev_f1b = pool_event(c, evi++);
           hipEventRecord(ev_f1b, c->stream3);
@@ -243,7 +281,9 @@ void run_potrf(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, int m
         }
         // few tiles (one group's block columns, or a small remainder): 64x64 tiles for latency
         a.small_tiles = (int64_t)(max_nblk + 1 - a.c_lo) * (a.c_hi - a.c_lo) * ntasks < 600;
+        a.tl = tl_slot("f1", g1);
         launch_gemm(dtype, a, dim3(max_nblk + 1 - a.c_lo, a.c_hi - a.c_lo, ntasks), s1);
+        a.tl = nullptr;
         }
       }
       if (la) {
@@ -286,8 +326,9 @@ void run_potrf(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, int m
               const int64_t rem = ntiles % pblocks;
               if (rem > 0 && rem * 2 <= pblocks) a.n_big = (int)(ntiles - rem);
             }
+            a.tl = tl_slot("f2", g1);
             launch_gemm(dtype, a, dim3(max_nblk + 1 - a.c_lo, a.c_hi - a.c_lo, ntasks), sb);
-            a.persistent = 0; a.work_counter = nullptr; a.n_big = 0;
+            a.persistent = 0; a.work_counter = nullptr; a.n_big = 0; a.tl = nullptr;
             }
           }
           hipEvent_t e2 = pool_event(c, evi++);
@@ -428,12 +469,13 @@ static void trtri_level(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntas
       }
     }
   };
-  if (do_a && xa > 0) { a.mode = GEMM_TRTRI_A; persist((int64_t)xa * s * tmul); launch_gemm(dtype, a, dim3(xa, s, ntasks), st); }
+  if (do_a && xa > 0) { a.mode = GEMM_TRTRI_A; persist((int64_t)xa * s * tmul); a.tl = tl_slot("trtri_a", s); launch_gemm(dtype, a, dim3(xa, s, ntasks), st); }
   if (do_b) {
     a.mode = GEMM_TRTRI_B;
     const int vy = ngroups == 1 ? vlast : s;
     a.kt = vy;   // valid tile rows when there is a single group (blockIdx.y counts down from them)
     persist((int64_t)ngroups * s * vy * tmul);
+    a.tl = tl_slot("trtri_b", s);
     launch_gemm(dtype, a, dim3(ngroups * s, vy, ntasks), st);
   }
 }
@@ -536,7 +578,7 @@ void sweep_advance(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, i
     if (b0 > 0) {                                                                                    // (b)
       ProfScope ps(c, "sweep_b", 2, st);
       pick((int64_t)b0 * (b1 - b0)); a.small_tiles = small;
-      a.mode = GEMM_SWEEP_B; place(a, (int64_t)b0 * (b1 - b0) * U * U);
+      a.mode = GEMM_SWEEP_B; place(a, (int64_t)b0 * (b1 - b0) * U * U); a.tl = tl_slot("sweep_b", b1);
       launch_gemm(dtype, a, dim3(b0, b1 - b0, ntasks), st);
     }
     if (b1 == max_nblk && w_done) hipEventRecord(w_done, st);
@@ -544,7 +586,7 @@ void sweep_advance(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, i
     if (b1 < max_nblk) {                                                                             // (c)
       ProfScope ps(c, "sweep_t", 2, st);
       pick((int64_t)(max_nblk - b1) * b1); a.small_tiles = small;
-      a.mode = GEMM_SWEEP_T; place(a, (int64_t)(max_nblk - b1) * b1 * U * U);
+      a.mode = GEMM_SWEEP_T; place(a, (int64_t)(max_nblk - b1) * b1 * U * U); a.tl = tl_slot("sweep_t", b1);
       launch_gemm(dtype, a, dim3(max_nblk - b1, b1, ntasks), st);
       sw.ev_c = sweep_event(c, sw); hipEventRecord(sw.ev_c, st); sw.st_c = st;
     }
@@ -553,6 +595,7 @@ void sweep_advance(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, i
       pick((int64_t)b1 * (b1 + 1) / 2); a.small_tiles = small;
       a.mode = GEMM_SWEEP_C; place(a, small ? 2 * (int64_t)b1 * (b1 + 1) : (int64_t)b1 * (b1 + 1) / 2);
       if (sw.ev_d && sw.st_d != sd) hipStreamWaitEvent(sd, sw.ev_d, 0);   // the previous group's update of the same K^-1 tiles
+      a.tl = tl_slot("sweep_c", b1);
       launch_gemm(dtype, a, dim3(b1, 1, ntasks), sd);
       if (b1 < max_nblk) { sw.ev_d = sweep_event(c, sw); hipEventRecord(sw.ev_d, sd); sw.st_d = sd; }
     }
@@ -609,5 +652,6 @@ void run_lauum(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, int m
       a.persistent = 2 * (c->n_cus - (c->opt_lauum_persist > 1 ? c->opt_lauum_persist : 16));
     }
   }
+  a.tl = tl_slot("lauum", 0);
   launch_gemm(dtype, a, dim3(max_nblk, max_nblk, ntasks), s);
 }
