@@ -39,6 +39,7 @@ extern "C" int hbo_factor(hbo_ctx* c, const hbo_model* m, const void* x, int64_t
   int inf = INT_MAX;
   HIPCHK_K(hipMemcpy(k->d_info, &inf, sizeof(int), hipMemcpyHostToDevice));
 
+  if (c->opt_poison) launch_poison(dtype, k->d_desc, 1, t->npad, st);
   { ProfScope ps(c, "features", 1);
     if (needs_mlp(m)) run_mlp(c, m, t->X, n, t->feat.acts.data());
     launch_aug_rows(dtype, k->d_desc, 1, t->npad, c->d_model, st); }

@@ -400,6 +400,35 @@ void launch_mean(int dtype, const void* fm, int64_t n, int fmean, const ModelDev
   if (dtype == HBO_F64) hipLaunchKernelGGL((mean_kernel<double>), grid, dim3(256), 0, st, (const double*)fm, n, fmean, md, (double*)mu);
   else hipLaunchKernelGGL((mean_kernel<float>), grid, dim3(256), 0, st, (const float*)fm, n, fmean, md, (float*)mu);
 }
+// hbo_tune "poison" (tests): everything an evaluation is about to recompute is set to NaN first -- the lower triangles of A (Gram -> L)
+// and W (L^-1; the zeros above its diagonal are an invariant of the buffer and stay), all of S (scratch -> K^-1), alpha and d f / d mu.
+// A launch that silently skips work (a tile counter shared by two launches, a K range cut short) then shows up as NaN instead of hiding
+// behind the previous evaluation's identical numbers in the same buffers.  The augmented tile-row (rows npad...) is left alone: its
+// unused rows are independent of every result, and the fp32 split's scale measurement reads the whole tile-row.
+template <typename T>
+__global__ __launch_bounds__(256) void poison_kernel(const TaskDesc* tasks) {
+  const TaskDesc& t = tasks[blockIdx.z];
+  const int64_t row = blockIdx.x;
+  if (row >= t.npad) return;
+  const T nanv = (T)NAN;
+  T* A = static_cast<T*>(t.A) + row * t.ld;
+  T* W = t.W ? static_cast<T*>(t.W) + row * t.ld : nullptr;
+  T* S = t.S ? static_cast<T*>(t.S) + row * t.ld : nullptr;
+  for (int64_t cc = threadIdx.x; cc < t.npad; cc += blockDim.x) {
+    if (cc <= row) { A[cc] = nanv; if (W) W[cc] = nanv; }
+    if (S) S[cc] = nanv;
+  }
+  if (row == 0) {
+    const int ncol = t.nvec ? t.nvec : (t.naug > 0 ? t.naug : 1);
+    if (t.svec) for (int64_t cc = threadIdx.x; cc < (int64_t)t.npad * ncol; cc += blockDim.x) static_cast<T*>(t.svec)[cc] = nanv;
+    if (t.dmu) for (int64_t cc = threadIdx.x; cc < t.npad; cc += blockDim.x) static_cast<double*>(t.dmu)[cc] = (double)NAN;
+  }
+}
+void launch_poison(int dtype, const TaskDesc* tasks, int ntasks, int max_npad, hipStream_t st) {
+  dim3 grid(max_npad, 1, ntasks);
+  if (dtype == HBO_F64) hipLaunchKernelGGL((poison_kernel<double>), grid, dim3(256), 0, st, tasks);
+  else hipLaunchKernelGGL((poison_kernel<float>), grid, dim3(256), 0, st, tasks);
+}
 void launch_aug_rows(int dtype, const TaskDesc* tasks, int ntasks, int max_npad, const ModelDev* md, hipStream_t st, int model_stride) {
   dim3 grid((max_npad + 255) / 256, 1, ntasks);
   if (dtype == HBO_F64) hipLaunchKernelGGL((aug_rows_kernel<double>), grid, dim3(256), 0, st, tasks, md, model_stride);

@@ -208,6 +208,7 @@ void launch_dense_tanh(int dtype, const void* in, const void* w, const void* b, 
 void launch_mean(int dtype, const void* fm, int64_t n, int fmean, const ModelDev* model, void* mu,
                  hipStream_t st);
 void launch_aug_rows(int dtype, const TaskDesc* tasks, int ntasks, int max_npad, const ModelDev* md, hipStream_t st, int model_stride = 0);
+void launch_poison(int dtype, const TaskDesc* tasks, int ntasks, int max_npad, hipStream_t st);   // hbo_tune "poison": NaN into everything about to be recomputed
 void launch_nll_reduce(int dtype, const TaskDesc* tasks, int ntasks, const int* info, double* out,
                        hipStream_t st);
 // s = W^T z_a (z_a = augmented row a of A) -> tasks[t].svec[out_col*out_ld + j]; uses wscr as scratch

@@ -183,6 +183,7 @@ static int objective_local(hbo_ctx* c, const hbo_model* m_in, hbo_dataset* ds, i
     launch_small_eval(dtype, ds->d_desc, T, c->d_model, m->kernel_id, feature_dim(m), ds->d_info, ds->d_nll,
                       want_grad ? ds->d_gradout : nullptr, out_stride, want_grad && needs_mlp(m), st);
   } else {
+  if (c->opt_poison) launch_poison(dtype, ds->d_desc, T, max_npad, st);
   {
     ProfScope ps(c, "features", 1);
     if (needs_mlp(m)) mlp_forward();

@@ -35,6 +35,10 @@
  *   post_serial   0/1      streamed posterior: features + cross Gram of chunk i+1 on the SAME stream as the product of chunk i
  *                          (nothing overlaps: the stage times of hbo_profile are then each kernel's isolated time; bench.py cfg3)
  *   small_fused   0/1      batches whose tasks all have n <= 128: the single-workgroup evaluation (small.hip; default 1)
+ *   poison        0/1      tests: an evaluation (objective / factor paths on the blocked pipeline) first fills what it is about to recompute --
+ *                          the lower triangles of A and W, all of S, alpha, d f / d mu -- with NaN, so that a launch that skips work shows up
+ *                          as NaN instead of hiding behind an earlier evaluation's identical numbers in the same pooled buffers; tests/conftest.py
+ *                          turns it on for the whole GPU tier (default 0)
  *   fault_shard   0..2     ONE-SHOT fault injection into the next hbo_objective_sharded call of this context (tests of the failure
  *                          paths): 1 = the rank's local part counts as failed -> it joins the all-reduce with NaN in every slot;
  *                          2 = and it cannot produce that buffer either -> ncclCommAbort, the peers' all-reduce fails, later sharded

@@ -235,6 +235,43 @@ def test_every_scheduling_option_gives_the_same_answer(gpu_ctx, opts):
       gpu_ctx.set_option(k, v)
 
 
+def test_poisoned_workspaces_change_nothing(gpu_ctx):
+  """hbo_tune "poison" (on for the whole GPU tier, tests/conftest.py) fills the lower triangles of A and W, all of S, alpha and d f / d mu with
+  NaN before every evaluation.  An evaluation that reads anything it did not recompute would turn NaN; one that is complete gives the
+  same bits with and without it -- for a single matrix (block-recursive inverse), one that takes the one-sweep inverse, a ragged batch
+  and a factor + posterior."""
+  defs, acfun, gp, kernel, mean, objectives, utils = _native()
+  rng = np.random.default_rng(123)
+  d = 4
+  model = helpers.make_model(rng, 'constant', False, d)
+  pn = defs.GPParams(model=model)
+  cases = [{0: helpers.synthetic_task(rng, 7000, d)}, {0: helpers.synthetic_task(rng, 2900, d)},
+           {k: helpers.synthetic_task(rng, n, d) for k, n in enumerate((700, 130, 1, 515, 300, 1290))}]
+  try:
+    for data in cases:
+      dsn = {k: defs.SubDataset(x, y) for k, (x, y) in data.items()}
+      dev = objectives.DeviceDataset(dsn)
+      out = []
+      for poison in (1, 0, 1):
+        gpu_ctx.set_option('poison', poison)
+        v, g = objectives.nll_value_and_grad(mean.constant, kernel.squared_exponential, pn, dev, utils.DEFAULT_WARP_FUNC)
+        out.append((v, helpers.flatten(g)))
+      assert np.isfinite(out[0][0]) and np.all(np.isfinite(out[0][1]))
+      for v, g in out[1:]:
+        assert v == out[0][0] and np.array_equal(g, out[0][1])
+    x, y = cases[1][0]
+    xq = rng.uniform(size=(40, d))
+    post = []
+    for poison in (1, 0):
+      gpu_ctx.set_option('poison', poison)
+      m = gp.GP({0: defs.SubDataset(x, y)}, mean.constant, kernel.squared_exponential, pn, utils.DEFAULT_WARP_FUNC)
+      mu, var = m.predict(xq, 0, with_noise=False, unbiased=False)
+      post.append((np.asarray(mu), np.asarray(var)))
+    assert np.all(np.isfinite(post[0][0])) and np.array_equal(post[0][0], post[1][0]) and np.array_equal(post[0][1], post[1][1])
+  finally:
+    gpu_ctx.set_option('poison', 1)
+
+
 def test_one_device_dataset_many_models_and_objectives(gpu_ctx):
   """The same HBM-resident dataset evaluated in turn with different covariances (scalar and ARD length-scales: the
   packed result block changes size), means, objectives and with / without gradient: descriptors are re-uploaded only when
