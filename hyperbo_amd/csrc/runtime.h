@@ -37,6 +37,19 @@ enum WsSlot { WS_XQ = 1, WS_MU0, WS_KD, WS_MU, WS_VAR, WS_ACQ, WS_K, WS_COLSQ, W
 // every slot is distinct by construction (auto-numbered; the per-layer range WS_FQ0.. is closed by WS_FQ_LAST before WS_K3), and the
 // posterior's per-lane offset (cache.hip: 4096 * lane) must clear the whole range
 static_assert(WS_FQ0 + HBO_MAX_MLP_LAYERS <= WS_K3 && WS_SLOT_END < 4096, "workspace slots overlap a lane offset");
+// hbo_tune "poison" (tests): the numeric scratch buffers -- fetched once per call and fully rewritten before they are read -- come back
+// filled with NaN, so that a product that skips tiles cannot hide behind what the previous call left there.  (Synchronous memset on the
+// null stream: ordered against every stream of the context.)  Tables, counters and reduction buffers that a call fetches again while
+// they hold live data are not in the list.
+static inline bool ws_poisonable(int slot) {
+  switch (slot % 4096) {
+    case WS_MU0: case WS_KD: case WS_MU: case WS_VAR: case WS_ACQ: case WS_K: case WS_COLSQ: case WS_V: case WS_KQQ: case WS_COV:
+    case WS_VPART: case WS_MUPART: case WS_K3: case WS_SYRK3_A: case WS_SYRK3_B: case WS_TRTRI3_X: case WS_TRTRI3_Y: case WS_LAUUM3:
+    case WS_AG_K: case WS_AG_L: case WS_AG_B: case WS_EXTRA_Z:
+      return true;
+    default: return false;
+  }
+}
 static inline void* ws_get(hbo_ctx* c, int slot, size_t bytes) {
   auto& e = c->ws[slot];
   if (e.second < bytes || !e.first) {
@@ -46,6 +59,7 @@ static inline void* ws_get(hbo_ctx* c, int slot, size_t bytes) {
     if (err != hipSuccess) { c->err = std::string("hipMalloc failed: ") + hipGetErrorString(err); e.first = nullptr; return nullptr; }
     e.second = bytes;
   }
+  if (c->opt_poison && bytes && ws_poisonable(slot)) hipMemset(e.first, 0xFF, bytes);
   return e.first;
 }
 
