@@ -1,5 +1,5 @@
 """Determinism soak: the same evaluation repeated many times must return the same bits (a race in a persistent kernel, a
-missed event or a stale workspace would show up as a differing value sooner or later).  soak.py [seconds per case]"""
+missed event or a stale workspace would show up as a differing value sooner or later).  soak.py [seconds per case] [poison]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -9,6 +9,8 @@ from hyperbo_amd.basics import definitions as defs
 from hyperbo_amd.gp_utils import gp, kernel, mean, objectives, utils
 from tests.helpers import flatten
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 8.0
+if 'poison' in sys.argv[2:]:   # every evaluation recomputes into NaN-filled buffers: skipped work cannot repeat the previous bits
+    nat.default_context().set_option('poison', 1)
 def run(name, f):
     v0, g0 = f(); g0 = flatten(g0)
     t0 = time.perf_counter(); k = 0; bad = 0
