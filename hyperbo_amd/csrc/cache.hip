@@ -563,6 +563,7 @@ extern "C" int hbo_acq_samples(hbo_ctx* c, const hbo_model* models, int32_t S, c
   HIPCHK_S(hipMemcpyAsync(d_batch, h_batch.data(), sizeof(TaskDesc) * S, hipMemcpyHostToDevice, st));
   HIPCHK_S(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(d_infos), INT_MAX, S, st));
   // ---- one batched pipeline: features (per sample: its own weights), residual rows, Gram, factorisation, inverse, alpha
+  if (c->opt_poison) launch_poison(dtype, d_batch, S, npad, st);
   { ProfScope ps(c, "features", 1);
     if (mlp) for (int s = 0; s < S; ++s) run_mlp(c, m0, ks[s]->t->X, n, ks[s]->t->feat.acts.data(), &w_dev[(size_t)s * HBO_MAX_MLP_LAYERS], &b_dev[(size_t)s * HBO_MAX_MLP_LAYERS]);
     launch_aug_rows(dtype, d_batch, S, npad, d_models, st, 1); }
