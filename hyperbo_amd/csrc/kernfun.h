@@ -93,14 +93,22 @@ __device__ __forceinline__ void stage_x(T* s, const T* __restrict__ x, int64_t n
                                         int d0, const double* inv_ls, bool scale, int tid) {
   const int dd = tid & 15, rr0 = tid >> 4;
   const int d = d0 + dd;
-  const T sc = (scale && d < fdim) ? (T)inv_ls[d] : (T)1;
+  const bool dok = d < fdim;
+  const T sc = (scale && dok) ? (T)inv_ls[d] : (T)1;
+  // every load is issued -- from a clamped, always valid address -- before the first one is waited for: with the bounds test around the
+  // load the compiler put each in a branch of its own with a full wait behind it (8 L2 round trips in a row per operand and chunk)
+  const int dc = dok ? d : 0;
+  T v[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const int64_t row = r0 + rr0 + 16 * q;
+    const int64_t rc = row < n ? row : (n > 0 ? n - 1 : 0);   // (callers never come here with n = 0: empty sub-datasets are skipped)
+    v[q] = gld(x + rc * fdim + dc);
+  }
 #pragma unroll
   for (int q = 0; q < NQ; ++q) {
     const int rr = rr0 + 16 * q;
-    const int64_t row = r0 + rr;
-    T v = (T)0;
-    if (row < n && d < fdim) v = gld(x + row * fdim + d) * sc;
-    s[dd * SXS + rr] = v;
+    s[dd * SXS + rr] = (r0 + rr < n && dok) ? v[q] * sc : (T)0;
   }
 }
 
