@@ -386,6 +386,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   constexpr int LDS_BYTES = 2 * 2 * NP * P3_ARR;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const TaskDesc& t = g.tasks[blockIdx.z];
+  // (the leading dimension in a register: read through the descriptor reference inside the epilogue it was re-fetched -- a vector load
+  //  with a full wait behind it -- before every one of a lane's 64 C elements, each then a serial pair of L2 round trips)
+  const int64_t ldc = __builtin_amdgcn_readfirstlane((int)t.ld);
   // tile (r, c) of the trapezoid c in [c_lo, c_hi), r in [c, nblk]: linear index, column-major (consecutive workgroups share B)
   const int nrt = t.nblk + 1;
   const int chi = g.c_hi < t.nblk ? g.c_hi : t.nblk;
@@ -599,13 +602,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         const int row = wm * 64 + a * 32 + (q & 3) + 8 * (q >> 2) + 4 * lh;
-        old[q] = cbeta ? gld(C + (int64_t)row * t.ld + wn * 64 + b * 32 + l32) : 0.f;
+        old[q] = cbeta ? gld(C + (int64_t)row * ldc + wn * 64 + b * 32 + l32) : 0.f;
       }
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         const int row = wm * 64 + a * 32 + (q & 3) + 8 * (q >> 2) + 4 * lh;
         const float v = old[q] + csign * (H2 ? acc[a][b][q] * unscale[a][q >> 3] : acc[a][b][q]);
-        gst(C + (int64_t)row * t.ld + wn * 64 + b * 32 + l32, v);
+        gst(C + (int64_t)row * ldc + wn * 64 + b * 32 + l32, v);
         if (H2) tmax = fmaxf(tmax, fabsf(v));
       }
     }
