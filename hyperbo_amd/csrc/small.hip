@@ -29,11 +29,11 @@ constexpr int small_lds_bytes() {
          + (SMALL_WAVES * (DC + 4) + SM_RED) * (int)sizeof(double);
 }
 
-// (I, J) of the lower 16 x 16 tiles in tri_index order
-struct SmallTiles {
-  static constexpr int I[36] = {0, 1, 1, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 4, 5, 5, 5, 5, 5, 5, 6, 6, 6, 6, 6, 6, 6, 7, 7, 7, 7, 7, 7, 7, 7};
-  static constexpr int J[36] = {0, 0, 1, 0, 1, 2, 0, 1, 2, 3, 0, 1, 2, 3, 4, 0, 1, 2, 3, 4, 5, 0, 1, 2, 3, 4, 5, 6, 0, 1, 2, 3, 4, 5, 6, 7};
-};
+// (I, J) of the lower 16 x 16 tiles in tri_index order, as arithmetic on a compile-time index.  (As constexpr tables the compiler turned
+// `thalf ? I[2 e + 1] : I[2 e]` into a LOAD of I[2 e + thalf] from constant memory: two dependent loads with a wait per element and
+// phase -- 18 of them in a row in the Gram phase, again in the contraction -- where two immediates and a select were meant.)
+#define HBO_TRI_I(k) ((k) < 1 ? 0 : (k) < 3 ? 1 : (k) < 6 ? 2 : (k) < 10 ? 3 : (k) < 15 ? 4 : (k) < 21 ? 5 : (k) < 28 ? 6 : 7)
+#define HBO_TRI_J(k) ((k) - HBO_TRI_I(k) * (HBO_TRI_I(k) + 1) / 2)
 struct SmallArgs {
   const TaskDesc* tasks;
   const ModelDev* md;
@@ -121,8 +121,8 @@ __global__ __launch_bounds__(SMALL_THREADS) void small_eval_kernel(SmallArgs g) 
   for (int e = 0; e < EPT; ++e) uu[e] = (T)0;
   // row / column of element e: tile thalf + 2 e -- e is a compile-time index in the unrolled loops and thalf is uniform per wave,
   // so the tile's (I, J) are two scalar selects from the tables (kept as index arrays they cost 36 registers for the whole kernel)
-#define EROW(e) (16 * (thalf ? SmallTiles::I[2 * (e) + 1] : SmallTiles::I[2 * (e)]) + ri)
-#define ECOL(e) (16 * (thalf ? SmallTiles::J[2 * (e) + 1] : SmallTiles::J[2 * (e)]) + ci)
+#define EROW(e) (16 * (thalf ? HBO_TRI_I(2 * (e) + 1) : HBO_TRI_I(2 * (e))) + ri)
+#define ECOL(e) (16 * (thalf ? HBO_TRI_J(2 * (e) + 1) : HBO_TRI_J(2 * (e))) + ci)
   for (int d0 = 0; d0 < fdim; d0 += DC) {
     __syncthreads();
     stage(d0, !is_dot);
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(SMALL_THREADS) void small_eval_kernel(SmallArgs g) 
       for (int e = 0; e < EPT; ++e) xb[e] = sX[dd * SXS + ECOL(e)];
 #pragma unroll
       for (int e = 0; e < EPT; ++e) {
-        const T a = thalf ? xa[SmallTiles::I[2 * e + 1]] : xa[SmallTiles::I[2 * e]], b = xb[e];
+        const T a = thalf ? xa[HBO_TRI_I(2 * e + 1)] : xa[HBO_TRI_I(2 * e)], b = xb[e];
         if (is_dot) uu[e] += a * b;
         else { const T df = a - b; uu[e] += df * df; }
       }
