@@ -444,31 +444,33 @@ __global__ __launch_bounds__(256) void grad_finalize_kernel(const TaskDesc* task
   const bool is_dot = (md->kernel_id == HBO_KERNEL_DOT);
   int pos = 0;
   double ls_total = 0;
-  // column sums of the per-tile partials [ntile][nacc], QW columns at a time (was: one strided pass and two barriers per
-  // column, 55 us at cfg 2)
-  __shared__ double s_col[4][32];
+  // column sums of the per-tile partials [ntile][nacc]: thread = (column of a 32-wide strip, one of 8 row lanes); a row lane walks every
+  // 8th row with independent, coalesced loads, the lanes meet in LDS in a fixed order (deterministic).  (Before: a thread summed 32
+  // columns of every 256th row -- 32 loads with a wait behind each -- and every column went through a wave reduction: 12-25 us at the
+  // tail of every evaluation of the blocked pipeline.)
+  __shared__ double s_col[8][32];
   __shared__ double s_tot[HBO_MAX_FEATURE_DIM + 4];   // nacc <= 2 + HBO_MAX_FEATURE_DIM + 1
   constexpr int QW = 32;
   for (int q0 = 0; q0 < nacc; q0 += QW) {
-    // a thread sums QW columns of every 256th tile (independent loads), then the columns are reduced over the block
-    double sacc[QW];
-#pragma unroll
-    for (int u = 0; u < QW; ++u) sacc[u] = 0;
-    for (int tl = threadIdx.x; tl < ntile; tl += 256) {
-      const double* pt = part + (int64_t)tl * nacc + q0;
-#pragma unroll
-      for (int u = 0; u < QW; ++u) if (q0 + u < nacc) sacc[u] += pt[u];
+    const int col = q0 + (threadIdx.x & 31), rl = threadIdx.x >> 5;
+    double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    if (col < nacc) {
+      int tl = rl;
+      for (; tl + 24 < ntile; tl += 32) {
+        a0 += part[(int64_t)tl * nacc + col]; a1 += part[(int64_t)(tl + 8) * nacc + col];
+        a2 += part[(int64_t)(tl + 16) * nacc + col]; a3 += part[(int64_t)(tl + 24) * nacc + col];
+      }
+      for (; tl < ntile; tl += 8) a0 += part[(int64_t)tl * nacc + col];
     }
-#pragma unroll
-    for (int u = 0; u < QW; ++u) sacc[u] = wave_sum(sacc[u]);
+    s_col[rl][threadIdx.x & 31] = (a0 + a1) + (a2 + a3);
     __syncthreads();
-    if ((threadIdx.x & 63) == 0) {
+    if (threadIdx.x < QW && q0 + (int)threadIdx.x < nacc) {
+      double tsum = 0;
 #pragma unroll
-      for (int u = 0; u < QW; ++u) s_col[threadIdx.x >> 6][u] = sacc[u];
+      for (int r8 = 0; r8 < 8; ++r8) tsum += s_col[r8][threadIdx.x];
+      s_tot[q0 + threadIdx.x] = tsum;
     }
     __syncthreads();
-    if (threadIdx.x < QW && q0 + (int)threadIdx.x < nacc)
-      s_tot[q0 + threadIdx.x] = (s_col[0][threadIdx.x] + s_col[1][threadIdx.x]) + (s_col[2][threadIdx.x] + s_col[3][threadIdx.x]);
   }
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -500,7 +502,14 @@ __global__ __launch_bounds__(256) void grad_finalize_kernel(const TaskDesc* task
   // mean parameters from d objective / d mu_i (dmu_kernel)
   const double* dmu = static_cast<const double*>(t.dmu);
   double ssum = 0;
-  for (int64_t i = threadIdx.x; i < t.n; i += 256) ssum += dmu[i];
+  {   // (four loads in flight per thread: one workgroup walks all n entries, 32 dependent round trips at n = 8192 otherwise)
+    const int64_t nn = t.n;
+    double s1 = 0, s2 = 0, s3 = 0;
+    int64_t i = threadIdx.x;
+    for (; i + 768 < nn; i += 1024) { ssum += dmu[i]; s1 += dmu[i + 256]; s2 += dmu[i + 512]; s3 += dmu[i + 768]; }
+    for (; i < nn; i += 256) ssum += dmu[i];
+    ssum = (ssum + s1) + (s2 + s3);
+  }
   ssum = block_sum(ssum, sred);
   if (threadIdx.x == 0) {
     o[pos] = (md->mean_id == HBO_MEAN_CONSTANT) ? ssum : 0.0;     // constant
@@ -510,7 +519,17 @@ __global__ __launch_bounds__(256) void grad_finalize_kernel(const TaskDesc* task
   const T* fm = static_cast<const T*>(t.Fm);
   for (int d = 0; d < t.fmean; ++d) {
     double s = 0;
-    if (lin) for (int64_t i = threadIdx.x; i < t.n; i += 256) s += dmu[i] * (double)fm[i * t.fmean + d];
+    if (lin) {
+      const int64_t nn = t.n; const int fmn = t.fmean;
+      double s1 = 0, s2 = 0, s3 = 0;
+      int64_t i = threadIdx.x;
+      for (; i + 768 < nn; i += 1024) {
+        s += dmu[i] * (double)fm[i * fmn + d]; s1 += dmu[i + 256] * (double)fm[(i + 256) * fmn + d];
+        s2 += dmu[i + 512] * (double)fm[(i + 512) * fmn + d]; s3 += dmu[i + 768] * (double)fm[(i + 768) * fmn + d];
+      }
+      for (; i < nn; i += 256) s += dmu[i] * (double)fm[i * fmn + d];
+      s = (s + s1) + (s2 + s3);
+    }
     s = block_sum(s, sred);
     if (threadIdx.x == 0) o[lin0 + d] = s;
   }
