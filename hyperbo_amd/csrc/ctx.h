@@ -55,6 +55,7 @@ struct hbo_ctx {
   int opt_lauum_persist = 1;   // one large matrix: K^-1 = W^T W as a resident grid drawing its tiles from a counter (0: plain grid; 1: two workgroups
                                // on all but 16 CUs; n > 1: on all but n CUs)
   int opt_trtri_free = 48;   // CUs the inverse products that co-run with the panel chain leave free (0: one tile per workgroup)
+  int post_counter_next = 0;   // sched.hip: post_counter
   int* trtri_counters = nullptr; int trtri_counter_next = 0;   // run_potrf -> trtri_level: tile counters of those launches
   int n_cus = 256;
   std::vector<hipEvent_t> ev_pool;

@@ -139,6 +139,7 @@ void run_potrf(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, int m
   if (counters) hipMemsetAsync(counters, 0, sizeof(int) * HBO_N_COUNTERS, sm);
   c->trtri_counters = counters ? counters + HBO_N_BULK_COUNTERS : nullptr;   // the rest: the persistent inverse products (trtri_level, sweep_advance)
   c->trtri_counter_next = 0;
+  c->post_counter_next = 0;   // (post_counter: the launches behind this factorisation)
   // fp32: every trailing update on the bf16 matrix cores from an exact three-way split of the group's panels (post3.hip:
   // syrk3_kernel; 1.4x the fp32-MFMA rate at fp32 accuracy).  Each panel is split right behind its solve; two buffers alternate
   // by group, because the bulk update of group g still reads its panels while group g + 1 is being solved.
@@ -350,6 +351,16 @@ void run_potrf(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, int m
     hipStreamWaitEvent(sm, e, 0);
   }
 }
+// A zeroed tile counter for a resident launch BEHIND the factorisation (the big levels of the inverse, K^-1 = W^T W): run_potrf clears the
+// whole counter array once per factorisation, and these launches take the words of its top region in turn -- each used to clear its
+// own word with a fill kernel on its stream first (6.5 us + a launch boundary, three of them on the tail of a cfg-2 evaluation).
+static int* post_counter(hbo_ctx* c, int* counters, hipStream_t st) {
+  constexpr int POST_POOL = 400;
+  if (c->post_counter_next < POST_POOL) return counters + HBO_N_COUNTERS - 16 - c->post_counter_next++;
+  int* p = counters + HBO_N_COUNTERS - 1;   // (pool exhausted: a word of its own, cleared on the spot)
+  hipMemsetAsync(p, 0, sizeof(int), st);
+  return p;
+}
 // The same level on the bf16 matrix cores (fp32, one matrix): both operands of each product are split exactly into three bf16
 // planes (post3.hip) -- A: S21 = L21 W11 from row blocks of L and the transpose of W11, B: W21 = -W22 S21 from row blocks of
 // W22 and the transpose of S21 -- then one launch per product over all groups of the level.
@@ -387,12 +398,11 @@ static bool trtri_level3(hbo_ctx* c, const TaskDesc* d_tasks, const TaskDesc& h,
   auto launch = [&](int mode) {
     g.mode = mode; g.persistent = 0; g.work_counter = nullptr;
     g.yield_flag = (st == c->stream4) ? c->gemm_yield : nullptr;
-    if (corun && ntiles > pblocks && c->trtri_counter_next < HBO_N_COUNTERS - HBO_N_BULK_COUNTERS - 8) { g.persistent = pblocks; g.work_counter = c->trtri_counters + c->trtri_counter_next++; }
+    if (corun && ntiles > pblocks && c->trtri_counter_next < HBO_N_COUNTERS - HBO_N_BULK_COUNTERS - 512) { g.persistent = pblocks; g.work_counter = c->trtri_counters + c->trtri_counter_next++; }
     else if (!corun && c->opt_lauum_persist && ntiles >= 4 * c->n_cus) {   // behind the factorisation: as trtri_level's big levels
       int* counters = (int*)ws_get(c, WS_COUNTERS, sizeof(int) * HBO_N_COUNTERS);
       if (counters) {
-        g.work_counter = counters + HBO_N_COUNTERS - 2 - (mode == 2 ? 1 : 0);
-        hipMemsetAsync(g.work_counter, 0, sizeof(int), st);
+        g.work_counter = post_counter(c, counters, st);
         g.persistent = 2 * c->n_cus;
       }
     }
@@ -457,14 +467,13 @@ static void trtri_level(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntas
   int post_slot = 0;
   auto persist = [&](int64_t tiles) {
     a.persistent = 0; a.work_counter = nullptr;
-    if (corun && tiles > pblocks && c->trtri_counter_next < HBO_N_COUNTERS - HBO_N_BULK_COUNTERS - 8) { a.persistent = pblocks; a.work_counter = c->trtri_counters + c->trtri_counter_next++; }
+    if (corun && tiles > pblocks && c->trtri_counter_next < HBO_N_COUNTERS - HBO_N_BULK_COUNTERS - 512) { a.persistent = pblocks; a.work_counter = c->trtri_counters + c->trtri_counter_next++; }
     else if (!corun && ntasks == 1 && !a.small_tiles && c->opt_lauum_persist && tiles >= 4 * c->n_cus) {
       // behind the factorisation, one large matrix: the big levels as a resident grid drawing tiles from a counter, like K^-1 = W^T W
       // (run_lauum); the counters below the very last one are kept for this
       int* counters = (int*)ws_get(c, WS_COUNTERS, sizeof(int) * HBO_N_COUNTERS);
       if (counters && post_slot < 2) {
-        a.work_counter = counters + HBO_N_COUNTERS - 2 - post_slot++;
-        hipMemsetAsync(a.work_counter, 0, sizeof(int), st);
+        a.work_counter = post_counter(c, counters, st); ++post_slot;
         a.persistent = 2 * c->n_cus;
       }
     }
@@ -560,7 +569,7 @@ void sweep_advance(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, i
   auto place = [&](GemmArgs& a, int64_t tiles) {
     a.persistent = 0; a.work_counter = nullptr;
     a.yield_flag = (st == c->stream4) ? c->gemm_yield : nullptr;
-    if (corun && tiles * ntasks > pblocks && c->trtri_counter_next < HBO_N_COUNTERS - HBO_N_BULK_COUNTERS - 8) {
+    if (corun && tiles * ntasks > pblocks && c->trtri_counter_next < HBO_N_COUNTERS - HBO_N_BULK_COUNTERS - 512) {
       a.persistent = pblocks; a.work_counter = c->trtri_counters + c->trtri_counter_next++;
     }
   };
@@ -630,8 +639,7 @@ void run_lauum(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, int m
       const int nt = max_nblk * (max_nblk + 1) / 2;
       int* counters = c->opt_lauum_persist && nt > 4 * c->n_cus ? (int*)ws_get(c, WS_COUNTERS, sizeof(int) * HBO_N_COUNTERS) : nullptr;
       if (counters) {   // a resident grid drawing the tiles from a counter, as the fp64 form below
-        g.work_counter = counters + HBO_N_COUNTERS - 1;
-        hipMemsetAsync(g.work_counter, 0, sizeof(int), s);
+        g.work_counter = post_counter(c, counters, s);
         g.persistent = 2 * (c->n_cus - (c->opt_lauum_persist > 1 ? c->opt_lauum_persist : 16));
       }
       launch_syrk3(g, nt, 1, s);
@@ -645,8 +653,7 @@ void run_lauum(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, int m
     // one large matrix: a resident grid of two workgroups per CU draws the tiles from a counter (gemm.hip: launch_gemm_t)
     int* counters = (int*)ws_get(c, WS_COUNTERS, sizeof(int) * HBO_N_COUNTERS);
     if (counters) {
-      a.work_counter = counters + HBO_N_COUNTERS - 1;   // the last one: never handed out by run_potrf (bulk updates / inverse products)
-      hipMemsetAsync(a.work_counter, 0, sizeof(int), s);
+      a.work_counter = post_counter(c, counters, s);
       // (16 CUs stay free for alpha = W^T z and d nll / d mu, which run beside this launch on the panel stream: isolated the
       //  launch takes the same time with 480 as with 512 workgroups)
       a.persistent = 2 * (c->n_cus - (c->opt_lauum_persist > 1 ? c->opt_lauum_persist : 16));
