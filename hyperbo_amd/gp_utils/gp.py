@@ -139,11 +139,12 @@ def infer_parameters(mean_func, cov_func, init_params, dataset, warp_func=None,
           else:
             batch = next(dataset_iter)
           dev = make_device(batch)
-        current_loss, grads = loss_and_grad(unflatten(x), dev)
+        model_now = unflatten(x)   # (one tree per step: it is evaluated, then kept as the last finite parameters -- nothing writes into it)
+        current_loss, grads = loss_and_grad(model_now, dev)
         if np.isnan(current_loss) and i == 0:
           raise ValueError(f'Encountered NaN in loss function. current_loss = {current_loss}, grads = {grads}.')
         if np.isfinite(current_loss):
-          params.model = unflatten(x)
+          params.model = model_now
         else:
           break
         gvec, _ = lbfgs_lib.tree_flatten(grads)

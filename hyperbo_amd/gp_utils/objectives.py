@@ -148,7 +148,7 @@ class DeviceDataset:
     if per_task:
       vals = dict(zip(self.device_order_keys, list(pt)[:self.num_tasks]))
       key2nll = {k: vals[k] for k in self.keys}
-    grad = np.array(list(g)[:bm.layout.total], dtype=np.float64) if want_grad else None
+    grad = np.frombuffer(g, dtype=np.float64, count=bm.layout.total).copy() if want_grad else None
     return nll.value, key2nll, grad, bm
 
 
