@@ -141,36 +141,56 @@ def hgp_sample_values(model, sub_dataset_key, x_queries, acq_id, acfun_param):
   return out
 
 
-def _hgp_sample_caches(model, sub_dataset_key, samples, dtype):
-  """Factorisations of one sub-dataset under every parameter sample, kept on the model until the samples or the sub-dataset
-  change: bayesopt()'s inner L-BFGS-B (bayesopt.py:116-125) differentiates the acquisition dozens of times with the model fixed,
-  and the reference would re-factorise all S samples every time (gp.py:676-678 drops the cache per sample)."""
-  from hyperbo_amd.basics import linalg
-  sd = model.dataset[sub_dataset_key]
-  finger = (_samples_fingerprint(model, samples, dtype), sub_dataset_key, id(sd.x), id(sd.y), np.shape(sd.x))
+def _array_digest(*arrays):
+  import hashlib
+  h = hashlib.blake2b(digest_size=16)
+  for a in arrays:
+    a = np.ascontiguousarray(a)
+    h.update(a.dtype.str.encode()); h.update(repr(a.shape).encode()); h.update(a.tobytes())
+  return h.digest()
+
+
+def drop_sample_caches(model):
+  """Close the per-sample factorisations an HGP acquisition gradient left on the model (called when its dataset changes)."""
   cached = getattr(model, '_hbo_sample_caches', None)
-  if cached is not None and cached[0] == finger:
-    return cached[1]
   if cached is not None:
     for h in cached[1]:
       h.close()
     model._hbo_sample_caches = None
+
+
+def _hgp_sample_caches(model, sub_dataset_key, samples, dtype):
+  """Factorisations of one sub-dataset under the parameter samples, kept on the model until the samples or the observations
+  change (CONTENT fingerprint of x / y: an in-place edit of the observations must not be served a stale factor): bayesopt()'s inner
+  L-BFGS-B (bayesopt.py:116-125) differentiates the acquisition dozens of times with the model fixed, and the reference would
+  re-factorise all S samples every time (gp.py:676-678 drops the cache per sample).  Only as many samples as fit HALF of the
+  device memory are kept (`_samples_per_call`, the budget of hgp_sample_values); the caller factorises the rest per call."""
+  from hyperbo_amd.basics import linalg
+  sd = model.dataset[sub_dataset_key]
+  finger = (_samples_fingerprint(model, samples, dtype), sub_dataset_key, _array_digest(sd.x, sd.y))
+  cached = getattr(model, '_hbo_sample_caches', None)
+  if cached is not None and cached[0] == finger:
+    return cached[1]
+  drop_sample_caches(model)
+  keep = _samples_per_call(np.shape(sd.x)[0], dtype, len(samples))
   handles = []
   try:
-    for smp in samples:
+    for smp in samples[:keep]:
       ps = defs.GPParams(config=model.params.config, model=smp)
       handles.append(linalg.factor(model.mean_func, model.cov_func, ps, sd.x, sd.y, model.warp_func))
-  except Exception:
-    for h in handles:
-      h.close()
-    raise
+  except nat.HboError:
+    # out of device memory after all: keep the factors that were built, the rest go one at a time
+    if not handles:
+      raise
   model._hbo_sample_caches = (finger, handles)
   return handles
 
 
 def _hgp_value_and_grad(model, sub_dataset_key, x_queries, acq_id, acfun_param):
   """Mean over the parameter samples of (acquisition, d acquisition / d x): what jax differentiates when bayesopt() runs on an
-  HGP (acfun.py:72-82 under bayesopt.py:116-125).  One hbo_acq_grad per sample against that sample's cached factor."""
+  HGP (acfun.py:72-82 under bayesopt.py:116-125).  One hbo_acq_grad per sample against that sample's cached factor (samples
+  beyond the cache budget: factorised, used and released on the spot)."""
+  from hyperbo_amd.basics import linalg
   samples = model.get_model_params_samples()
   has_obs = model.has_observations(sub_dataset_key)
   dtype = _model.infer_dtype(model.dataset[sub_dataset_key].x, model.dataset[sub_dataset_key].y) if has_obs \
@@ -182,16 +202,25 @@ def _hgp_value_and_grad(model, sub_dataset_key, x_queries, acq_id, acfun_param):
   if nq == 0:
     return val.astype(dtype), grad
   built, noises = _sample_models(model, samples, dtype)
-  handles = _hgp_sample_caches(model, sub_dataset_key, samples, dtype) if has_obs else [None] * len(samples)
+  handles = _hgp_sample_caches(model, sub_dataset_key, samples, dtype) if has_obs else []
   _, scale = model.predict_noise_and_scale(True, True)
   out = np.empty((nq, 1), dtype=dtype)
   g = np.zeros((nq, model.input_dim), dtype=np.float64)
   ctx = nat.default_context()
-  for bm, noise, h in zip(built, noises, handles):
-    c = h.ctx if h is not None else ctx
-    c.check(nat.lib().hbo_acq_grad(c.handle, bm.ref(), h.handle if h is not None else None, nat.ptr(xq), nq, int(acq_id),
-                                   float(acfun_param), float(noise), float(scale), nat.ptr(out),
-                                   g.ctypes.data_as(nat.C.POINTER(nat.C.c_double))))
+  for i, (bm, noise) in enumerate(zip(built, noises)):
+    h, transient = (handles[i] if i < len(handles) else None), False
+    if h is None and has_obs:
+      sd = model.dataset[sub_dataset_key]
+      ps = defs.GPParams(config=model.params.config, model=samples[i])
+      h, transient = linalg.factor(model.mean_func, model.cov_func, ps, sd.x, sd.y, model.warp_func), True
+    try:
+      c = h.ctx if h is not None else ctx
+      c.check(nat.lib().hbo_acq_grad(c.handle, bm.ref(), h.handle if h is not None else None, nat.ptr(xq), nq, int(acq_id),
+                                     float(acfun_param), float(noise), float(scale), nat.ptr(out),
+                                     g.ctypes.data_as(nat.C.POINTER(nat.C.c_double))))
+    finally:
+      if transient:
+        h.close()
     val += out
     grad += g
   model.update_model_params(samples[-1])     # the side effect of the reference's loop over samples (gp.py:674-678)

@@ -33,7 +33,14 @@ EPS = 1e-6
 HYPERBO_DATASETS = {'pd1': data.pd1, 'random': data.random}   # const.py:54-59
 INPUT_SAMPLERS = {}                                             # const.py:61 (empty in the reference too)
 
-# Of the method names of the reference's offline experiment manager (const.py:63-81) only what this package reads: which method draws
-# hyper-parameter samples (an HGP instead of a GP, bayesopt.py).  The experiment manager itself is out of scope.
-HBO_SS = 'hyperbo_ss'
+# Method names of the reference's offline experiment manager (const.py:63-81).  The experiment manager itself is out of scope
+# (SURVEY section 8); the names stay importable for user code written against hyperbo.bo_utils.const.  This package only reads
+# USE_HGP (which method draws hyper-parameter samples: an HGP instead of a GP, bayesopt.py).
+RAND, STBO, MTBO, STBOV = 'rand', 'stbo', 'mtbo', 'gp'
+HBO, HBO_SS, HBO_NLL, HBO_NLLKL, HBO_NLLEUC = 'hyperbo', 'hyperbo_ss', 'hyperbo_nll', 'hyperbo_nllkl', 'hyperbo_nlleuc'
+CONTEXTUAL_METHODS = ['rfgp', 'mimo', STBOV]
+HBO_METHODS = [HBO_SS, HBO_NLL, HBO_NLLKL, HBO_NLLEUC]
+OFFLINE_METHODS = [RAND, STBO, MTBO, HBO, HBO_SS] + CONTEXTUAL_METHODS
+ONLINE_METHODS = [STBO, MTBO] + HBO_METHODS
 USE_HGP = [HBO_SS]
+ST_METHODS = [STBO, STBOV]

@@ -53,6 +53,7 @@ extern "C" int hbo_ctx_create(int device, hbo_ctx** out) {
   { hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess) {
       c->n_cus = prop.multiProcessorCount;
+      c->lds_per_block = (int)std::min<size_t>(prop.sharedMemPerBlock, (size_t)1 << 30);
       // parked buffers of freed datasets / caches: at most a quarter of the device memory (option pool_cap_mb)
       c->pool_cap = std::min<size_t>(c->pool_cap, (size_t)prop.totalGlobalMem / 4);
     } }

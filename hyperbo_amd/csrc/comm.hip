@@ -19,8 +19,11 @@ static void* rccl_open() {
   if (lib) return lib;
   // $HBO_RCCL_LIB: another library with the same five entry points (ncclGetUniqueId, ncclCommInitRank, ncclAllReduce,
   // ncclCommDestroy, ncclCommAbort) -- how tests/fake_rccl.c lets two ranks share ONE GPU, which RCCL itself refuses
+  // TEST HOOK, not a deployment knob: honoured only together with HBO_TEST_HOOKS=1, so that a stray variable in a production
+  // environment cannot redirect the collectives (a dynamic linker path can redirect librccl.so itself -- as for any shared library)
+  const char* hooks = getenv("HBO_TEST_HOOKS");
   if (const char* over = getenv("HBO_RCCL_LIB")) {
-    if (*over) { lib = dlopen(over, RTLD_NOW | RTLD_GLOBAL); return lib; }
+    if (*over && hooks && hooks[0] == '1') { lib = dlopen(over, RTLD_NOW | RTLD_GLOBAL); return lib; }
   }
   for (const char* name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
     lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);

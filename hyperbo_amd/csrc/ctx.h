@@ -92,6 +92,7 @@ struct hbo_ctx {
   // RCCL
   void* rccl_lib = nullptr;
   void* comm = nullptr;
+  int lds_per_block = 160 * 1024;   // hipDeviceProp_t::sharedMemPerBlock of the context's device (hbo_ctx_create)
   int opt_small_fused = 1;     // hbo_tune("small_fused"): batches whose tasks all have n <= 128 take the single-workgroup evaluation (small.hip)
   int opt_post_serial = 0;     // hbo_tune("post_serial"): the streamed posterior's producer side (cross Gram) on the SAME stream as its products: isolated stage times
   int opt_fault_shard = 0;     // hbo_tune("fault_shard"): ONE-SHOT fault injection for the tests of the sharded objective's failure paths

@@ -235,6 +235,7 @@ void launch_dense_bwd(int dtype, const void* in, const void* out, const void* w,
 // NLL (+ gradient block in grad_finalize's layout) of a batch whose tasks all have n <= 128: one workgroup per task (small.hip).
 // write_back: also store K^-1 (full n x n square in S), s = K^-1 r (svec) and d f / d mu (dmu) for the feature-gradient kernels of
 // an MLP model (grad_feat_kernel, grad_feat_mean_kernel), which follow as launches of their own
+int small_eval_lds(int dtype);
 void launch_small_eval(int dtype, const TaskDesc* tasks, int ntasks, const ModelDev* md, int kernel_id, int fdim, int* info,
                        double* nll_out, double* grad_out, int out_stride, int write_back, hipStream_t st);
 // MLP basis of a whole batch, one launch per layer (mlp.hip): per-task pointers

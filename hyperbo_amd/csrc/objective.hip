@@ -75,7 +75,10 @@ static int objective_local(hbo_ctx* c, const hbo_model* m_in, hbo_dataset* ds, i
   // workspaces + descriptors.  A batch that takes the single-workgroup evaluation (small.hip) without an MLP keeps its matrices in
   // LDS: no A / W / S / alpha buffers at all (a freshly sub-sampled batch per Adam step paid ~150 pool operations and two fills for
   // buffers its one launch never reads); the leaf inverses that leaf_cholesky4 also stores go to one shared scratch block
-  const bool lds_only = obj == OBJ_NLL && ds->max_nblk == 1 && c->opt_small_fused && !needs_mlp(m);
+  // (the single-workgroup evaluation needs 132 KB (fp64) / 68 KB (fp32) of LDS in one workgroup: a device that cannot give it -- any
+  //  ARCH other than gfx950 the Makefile is pointed at -- takes the blocked pipeline instead of failing at launch)
+  const bool small_ok = c->opt_small_fused && ds && small_eval_lds(ds->dtype) <= c->lds_per_block;
+  const bool lds_only = obj == OBJ_NLL && ds->max_nblk == 1 && small_ok && !needs_mlp(m);
   void* small_scratch = nullptr;
   if (lds_only) {
     small_scratch = ws_get(c, WS_SMALL_W, (size_t)HBO_TILE * padded_ld(HBO_TILE, ds->dtype) * esize(ds->dtype));
@@ -103,7 +106,9 @@ static int objective_local(hbo_ctx* c, const hbo_model* m_in, hbo_dataset* ds, i
   for (int k = 0; k < T; ++k) {
     TaskHost* t = ds->tasks[k];
     if (!lds_only) {
-      rc = ensure_task_workspace(c, dtype, t, (want_grad || (extras && t->m + 1 > HBO_TILE)) && !euc, obj == OBJ_NLL ? 1 : t->m + 1);
+      // (a batch with extra rows runs the inverse over ALL its tasks, value-only calls too: GEMM_TRTRI_A stores S21 of every task with
+      //  two or more blocks, so every task of such a batch needs S -- not only the ones with more than 127 aligned columns)
+      rc = ensure_task_workspace(c, dtype, t, (want_grad || extras) && !euc, obj == OBJ_NLL ? 1 : t->m + 1);
       if (rc) return rc;
     }
     if (needs_mlp(m)) { rc = t->feat.ensure(c, m, t->n); if (rc) return rc; }
@@ -164,12 +169,12 @@ static int objective_local(hbo_ctx* c, const hbo_model* m_in, hbo_dataset* ds, i
     ds->h_desc_dev = ds->h_desc;
   }
   // (a batch that takes the single-workgroup evaluation sets its info words itself: one launch less on a 60 us path)
-  if (!(obj == OBJ_NLL && ds->max_nblk == 1 && c->opt_small_fused)) HIPCHK(c, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ds->d_info), INT_MAX, T, st));
+  if (!(obj == OBJ_NLL && ds->max_nblk == 1 && small_ok)) HIPCHK(c, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ds->d_info), INT_MAX, T, st));
 
   const int max_nblk = ds->max_nblk, max_npad = max_nblk * HBO_TILE;
   // every task fits one 128-block (the reference's training regime: sub-sampled tasks of 50-100 points): ONE launch, one workgroup
   // per task does Gram -> factorisation -> inverse -> K^-1 -> contraction in LDS (small.hip) instead of the 13 launches below
-  const bool fused_small = obj == OBJ_NLL && max_nblk == 1 && c->opt_small_fused;
+  const bool fused_small = obj == OBJ_NLL && max_nblk == 1 && small_ok;
   auto mlp_forward = [&]() {   // the basis of every task, one launch per layer
     int fin = m->input_dim;
     for (int l = 0; l < m->n_layers; ++l) {

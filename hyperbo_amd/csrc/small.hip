@@ -473,6 +473,9 @@ void small_eval_t(const SmallArgs& a, int ntasks, int kernel_id, hipStream_t st)
 }
 }  // namespace
 
+// dynamic LDS one workgroup of small_eval_kernel asks for (fp64 132 KB, fp32 68 KB: gfx950's 160 KB holds both; the callers compare it
+// with the device's per-workgroup limit and send the batch through the blocked pipeline where it does not fit)
+int small_eval_lds(int dtype) { return dtype == HBO_F64 ? small_lds_bytes<double>() : small_lds_bytes<float>(); }
 // NLL (+ gradient block) of every task of a batch whose tasks all have n <= 128, one workgroup per task, one launch.
 void launch_small_eval(int dtype, const TaskDesc* tasks, int ntasks, const ModelDev* md, int kernel_id, int fdim, int* info,
                        double* nll_out, double* grad_out, int out_stride, int write_back, hipStream_t st) {

@@ -263,10 +263,18 @@ class GP:
     """Reset GP dataset (gp.py:403-419); clears the cache."""
     self.dataset = {}
     self._drop_cache()
+    self._drop_sample_caches()
     if isinstance(dataset, list):
       dataset = {i: dataset[i] for i in range(len(dataset))}
     for key, val in dataset.items():
       self.dataset[key] = SubDataset(*val)
+
+  def _drop_sample_caches(self):
+    """Per-sample factorisations an HGP acquisition gradient keeps (bo_utils/acfun.py): released when the observations change
+    or the model is re-trained; update_model_params keeps them -- they are keyed by the SAMPLES' content, not by params.model."""
+    if getattr(self, '_hbo_sample_caches', None) is not None:
+      from hyperbo_amd.bo_utils import acfun as _acfun
+      _acfun.drop_sample_caches(self)
 
   def _drop_cache(self):
     for c in getattr(self.params, 'cache', {}).values():
@@ -292,6 +300,7 @@ class GP:
       self.dataset[sub_dataset_key] = SubDataset(x=new_x, y=new_y)
     else:
       self.dataset[sub_dataset_key] = sub_dataset
+    self._drop_sample_caches()
     if sub_dataset_key in self.params.cache:
       cache = self.params.cache[sub_dataset_key]
       cache.needs_update = True
@@ -309,6 +318,7 @@ class GP:
         self.rng = np.random.default_rng(0)
       key = self.rng
     self._drop_cache()
+    self._drop_sample_caches()
     self.params = infer_parameters(
         mean_func=self.mean_func, cov_func=self.cov_func, init_params=self.params, dataset=self.dataset,
         warp_func=self.warp_func, objective=self.params.config['objective'], key=key,

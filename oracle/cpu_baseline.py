@@ -118,3 +118,86 @@ def nll_and_grad_se_ard_constant_omp(x, y, raw, eps=1e-6):
       'constant': np.asarray(-float(alpha.sum())),
   }
   return nll, grad
+
+
+# ---- all-core form (round 6): potrf / trtri / lauum over tiles, one single-threaded BLAS call per tile, OpenMP across every core ----
+def _blas_fns():
+  """Function pointers of dgemm / dtrsm / dsyrk / dpotrf / dtrtri out of SciPy's Cython BLAS / LAPACK capsules (the OpenBLAS SciPy
+  ships), packed as oracle/cpu_port.c: hbo_blas_fns."""
+  import ctypes as C
+  import scipy.linalg.cython_blas as cb
+  import scipy.linalg.cython_lapack as cl
+  C.pythonapi.PyCapsule_GetPointer.restype = C.c_void_p
+  C.pythonapi.PyCapsule_GetPointer.argtypes = [C.py_object, C.c_char_p]
+  C.pythonapi.PyCapsule_GetName.restype = C.c_char_p
+  C.pythonapi.PyCapsule_GetName.argtypes = [C.py_object]
+  def ptr(mod, name):
+    cap = mod.__pyx_capi__[name]
+    return C.pythonapi.PyCapsule_GetPointer(cap, C.pythonapi.PyCapsule_GetName(cap))
+  return (C.c_void_p * 5)(ptr(cb, 'dgemm'), ptr(cb, 'dtrsm'), ptr(cb, 'dsyrk'), ptr(cl, 'dpotrf'), ptr(cl, 'dtrtri'))
+
+
+def omp_threads():
+  import ctypes as C
+  lib = _lib()
+  lib.hbo_cpu_omp_threads.restype = C.c_int
+  return int(lib.hbo_cpu_omp_threads())
+
+
+def nll_and_grad_se_ard_constant_tiled(x, y, raw, eps=1e-6, nb=128, timings=None):
+  """The same algorithm as nll_and_grad_se_ard_constant_omp with potrf / potri replaced by the tile algorithms of
+  oracle/cpu_port.c (hbo_cpu_potrf_tiled / trtri_tiled / lauum_tiled): OpenMP over ALL host cores, every tile product one
+  single-threaded OpenBLAS call -- SciPy's OpenBLAS build stops at 64 threads, which left 3/4 of a 256-core host idle."""
+  import ctypes as C
+  import time
+  from threadpoolctl import threadpool_limits
+  dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))
+  lib = _lib()
+  for nm in ('hbo_cpu_potrf_tiled', 'hbo_cpu_trtri_tiled'):
+    getattr(lib, nm).argtypes = [C.POINTER(C.c_double), C.c_int64, C.c_int, C.c_void_p]
+    getattr(lib, nm).restype = C.c_int
+  lib.hbo_cpu_lauum_tiled.argtypes = [C.POINTER(C.c_double), C.c_int64, C.c_int, C.c_void_p, C.POINTER(C.c_double)]
+  lib.hbo_cpu_lauum_tiled.restype = None
+  fns = _blas_fns()
+  n, d = x.shape
+  assert d <= 64
+  sp = lambda v: np.logaddexp(np.asarray(v, dtype=np.float64), 0.0) + 1e-10
+  ls, sv, noise = sp(raw['lengthscale']), float(sp(raw['signal_variance'])), float(sp(raw['noise_variance']))
+  const = float(np.asarray(raw['constant']))
+  xs = np.ascontiguousarray(x / ls)
+  t = [time.perf_counter()]
+  k = np.empty((n, n))
+  lib.hbo_cpu_gram_se(dp(xs), n, d, sv, noise + eps, dp(k))
+  t.append(time.perf_counter())
+  r = y - const
+  # the C-ordered symmetric buffer read as a column-major matrix: its UPPER factor U (K = U^T U) is the lower factor in C order
+  with threadpool_limits(limits=1, user_api='blas'):
+    info = lib.hbo_cpu_potrf_tiled(dp(k), n, nb, fns)
+  t.append(time.perf_counter())
+  if info != 0:
+    return float('nan'), None
+  kf = k.T                                                   # Fortran-ordered view of the same buffer
+  alpha, info = lapack.dpotrs(kf, np.asfortranarray(r), lower=0)
+  nll = float(0.5 * (r.T @ alpha)[0, 0] + np.sum(np.log(np.diagonal(k))) + 0.5 * n * np.log(2 * np.pi))
+  kinv = np.empty((n, n))
+  with threadpool_limits(limits=1, user_api='blas'):
+    info = lib.hbo_cpu_trtri_tiled(dp(k), n, nb, fns)
+    t.append(time.perf_counter())
+    lib.hbo_cpu_lauum_tiled(dp(k), n, nb, fns, dp(kinv))
+  t.append(time.perf_counter())
+  # kinv: column-major upper tiles valid == the triangle {row >= col} in C order that hbo_cpu_contract_se reads -- except inside the
+  # diagonal tiles, where the GEMM wrote both triangles (symmetric): valid either way
+  out = np.zeros(2 + d)
+  a1 = np.ascontiguousarray(alpha[:, 0])
+  lib.hbo_cpu_contract_se(dp(xs), n, d, sv, dp(kinv), dp(a1), dp(out))
+  t.append(time.perf_counter())
+  if timings is not None:
+    timings.append(dict(zip(('gram', 'potrf', 'trtri', 'lauum', 'contract'), np.diff(t))))
+  sig = spsp.expit
+  grad = {
+      'lengthscale': (-0.5) * out[2:] * (-2.0 / ls) * sig(np.asarray(raw['lengthscale'], dtype=np.float64)),
+      'signal_variance': np.asarray(out[0] / sv * sig(float(raw['signal_variance']))),
+      'noise_variance': np.asarray(out[1] * sig(float(raw['noise_variance']))),
+      'constant': np.asarray(-float(alpha.sum())),
+  }
+  return nll, grad

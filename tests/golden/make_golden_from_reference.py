@@ -12,6 +12,11 @@ writes `<case>_ref.npz` next to them:
   gp.predict (diagonal and full covariance)                 hyperbo/gp_utils/gp.py:242-305
   acfun.expected_improvement / probability_of_improvement / ucb on a gp.GP   hyperbo/bo_utils/acfun.py:36-185
   obj.multivariate_normal_divergence (ekl) / _euc_distance and their jax.grad   objectives.py:29-106
+  gp.infer_parameters: every callback (step, params, loss) of Adam and L-BFGS       gp.py:53-195, basics/lbfgs.py:186-349
+      for the four row-f1 cases (TRAIN_CASES below; batch_size above every sub-dataset's size, so that no jax.random
+      permutation enters and the trajectory is a function of the inputs alone) -> train_<case>_<method>_ref.npz
+  acfun.* on a gp.HGP with parameter samples: the mean over samples                  bo_utils/acfun.py:72-82, gp.py:666-682
+      -> hgp_<acq>_ref.npz
 
 tests/test_oracle_pins.py::test_golden_fixtures_match_reference compares oracle/hyperbo_oracle.py with every
 `*_ref.npz` it finds; with those files committed the parity chain  HIP == oracle == reference  is closed.
@@ -35,6 +40,32 @@ TESTS = os.path.dirname(HERE)
 sys.path.insert(0, TESTS)
 sys.path.insert(0, os.path.dirname(TESTS))   # the repo root: bench.cfg4_inputs()
 import helpers  # noqa: E402
+
+
+# Row f1 / a15 inputs of the widened pin: plain NumPy draws, stored INSIDE the *_ref.npz next to the reference's outputs, so that the
+# consuming test (tests/test_oracle_pins.py::test_golden_fixtures_match_reference) re-runs the oracle on exactly these numbers.
+TRAIN_CASES = [('squared_exponential', 'constant'), ('matern32', 'zero'), ('matern52_mlp', 'linear_mlp'), ('dot_product_mlp', 'linear')]
+TRAIN_METHODS = [('adam', 10, 2e-2), ('lbfgs', 3, None)]
+TRAIN_SIZES = (100, 64, 130, 80, 45)
+TRAIN_BATCH = 500   # above every size: data_utils.py:72-100 leaves the sub-datasets whole
+
+
+def train_inputs(kname, mname):
+  rng = np.random.default_rng(33)
+  d = 2
+  model = helpers.make_model(rng, mname, kname.endswith('_mlp'), d)
+  data = [helpers.synthetic_task(rng, n, d) for n in TRAIN_SIZES]
+  return model, data
+
+
+def hgp_inputs():
+  rng = np.random.default_rng(41)
+  d, S = 3, 4
+  samples = [helpers.make_model(np.random.default_rng(300 + i), 'constant', False, d) for i in range(S)]
+  x, y = helpers.synthetic_task(rng, 60, d)
+  x2, y2 = helpers.synthetic_task(rng, 20, d)
+  xq = rng.uniform(size=(9, d))
+  return samples, x, y, x2, y2, xq
 
 
 def _load(name):
@@ -140,6 +171,41 @@ def main(reference_root='/root/reference'):
                       nll_per_task=np.asarray([float(key2nll4[k]) for k in sorted(data)]), nll_mean=float(nll4),
                       grad_mean_flat=helpers.flatten(jax.tree.map(to_np, g4)))
   written.append('cfg4_t64_oracle')
+  # ---- row f1: the training driver's trajectory (every callback of gp.infer_parameters) ----
+  for kname, mname in TRAIN_CASES:
+    for method, steps, lr in TRAIN_METHODS:
+      model, data = train_inputs(kname, mname)
+      cfg = {'method': method, 'batch_size': TRAIN_BATCH, 'max_training_step': steps, 'learning_rate': lr,
+             'mlp_features': helpers.MLP_FEATURES}
+      ds = {i: defs.SubDataset(jnp.asarray(xx), jnp.asarray(yy)) for i, (xx, yy) in enumerate(data)}
+      log = []
+      def cb(*a, **k):   # Adam: callback(i, params.model, loss); L-BFGS: callback(step, params, loss) -- positional or by name
+        step = k.get('step', a[0] if a else None)
+        prm = k.get('params', k.get('model_params', a[1] if len(a) > 1 else None))
+        loss = k.get('loss', a[2] if len(a) > 2 else None)
+        log.append((int(step), helpers.flatten(jax.tree.map(to_np, prm)), float(loss)))
+      out = gp.infer_parameters(getattr(mean, mname), getattr(kernel, kname), defs.GPParams(model=to_jnp(model), config=dict(cfg)), ds,
+                                warp_func=wf, objective=obj.neg_log_marginal_likelihood, key=jax.random.PRNGKey(12), callback=cb)
+      name = f'train_{kname}_{mname}_{method}'
+      arrays = {f'x{i}': xx for i, (xx, yy) in enumerate(data)}
+      arrays.update({f'y{i}': yy for i, (xx, yy) in enumerate(data)})
+      np.savez_compressed(os.path.join(HERE, name + '_ref.npz'), kname=kname, mname=mname, method=method, steps=steps,
+                          learning_rate=np.nan if lr is None else lr, batch_size=TRAIN_BATCH, model_flat=helpers.flatten(model),
+                          cb_steps=np.asarray([r[0] for r in log]), cb_params=np.asarray([r[1] for r in log]),
+                          cb_losses=np.asarray([r[2] for r in log]), final_flat=helpers.flatten(jax.tree.map(to_np, out.model)), **arrays)
+      written.append(name)
+  # ---- row a15: acquisition on an HGP = mean over the parameter samples ----
+  samples, hx, hy, hx2, hy2, hxq = hgp_inputs()
+  hds = {'test': defs.SubDataset(jnp.asarray(hx), jnp.asarray(hy)), 'other': defs.SubDataset(jnp.asarray(hx2), jnp.asarray(hy2)),
+         'third': defs.SubDataset(jnp.asarray(hx2[:5]), jnp.asarray(hy2[:5]))}
+  jsamples = [to_jnp(smp) for smp in samples]
+  hgp = gp.HGP(dataset=hds, mean_func=mean.constant, cov_func=kernel.matern52,
+               params=defs.GPParams(model=jsamples[0], samples=jsamples, config={}), warp_func=wf)
+  hout = {'x': hx, 'y': hy, 'x2': hx2, 'y2': hy2, 'xq': hxq, 'samples_flat': np.asarray([helpers.flatten(smp) for smp in samples])}
+  for name_, key_ in (('expected_improvement', 'ei'), ('probability_of_improvement', 'pi'), ('ucb', 'ucb')):
+    hout[key_] = to_np(getattr(acfun, name_)(model=hgp, sub_dataset_key='test', x_queries=jnp.asarray(hxq)))
+  np.savez_compressed(os.path.join(HERE, 'hgp_matern52_constant_ref.npz'), **hout)
+  written.append('hgp_matern52_constant')
   print('make_golden_from_reference: wrote *_ref.npz for', ', '.join(written), f'(jax {jax.__version__})')
   return 0
 

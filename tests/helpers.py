@@ -60,6 +60,57 @@ def unflatten_like(tree, vec):
   return rec(tree)
 
 
+def tree_leaves(tree, prefix=''):
+  """(path, float64 array) of every leaf, in flatten()'s order."""
+  if isinstance(tree, dict):
+    for k in sorted(tree):
+      yield from tree_leaves(tree[k], prefix + '/' + str(k) if prefix else str(k))
+  else:
+    yield prefix, np.asarray(tree, dtype=np.float64)
+
+
+def grad_leaf_errors(got, ref):
+  """Per leaf: (path, max |got - ref|, ||ref leaf||_inf).  Either side may be a flat vector in flatten()'s order."""
+  if not isinstance(ref, dict) and isinstance(got, dict):
+    ref = unflatten_like(got, np.asarray(ref, dtype=np.float64).ravel())
+  if not isinstance(got, dict) and isinstance(ref, dict):
+    got = unflatten_like(ref, np.asarray(got, dtype=np.float64).ravel())
+  if not isinstance(ref, dict):
+    got, ref = {'flat': got}, {'flat': ref}
+  gl, rl = dict(tree_leaves(got)), dict(tree_leaves(ref))
+  assert set(gl) == set(rl), (sorted(gl), sorted(rl))
+  out = []
+  for path, r in rl.items():
+    g = gl[path]
+    assert g.size == r.size, (path, g.shape, r.shape)
+    out.append((path, float(np.max(np.abs(g.ravel() - r.ravel()))) if r.size else 0.0, float(np.max(np.abs(r))) if r.size else 0.0))
+  return out
+
+
+def assert_grad_close(got, ref, tol, floor_rel=1e-3, label=''):
+  """PER-LEAF gradient check: every leaf L must satisfy max|got_L - ref_L| <= tol * max(||ref_L||_inf, floor_rel * max|ref|).
+  (A bound relative to the largest entry of the FLATTENED tree lets a wrong leaf that is 1e4 x smaller than the lengthscale
+  gradient pass; the floor keeps leaves that are zero by cancellation testable: their error scales with the un-cancelled terms.)
+  The failure message names the worst leaf; with HBO_GRAD_LOG=<file> every call appends its worst ratio (tolerance audits)."""
+  errs = grad_leaf_errors(got, ref)
+  gmax = max((n for _, _, n in errs), default=0.0)
+  worst = (0.0, '', 0.0, 0.0)
+  for path, err, norm in errs:
+    if not np.isfinite(err):
+      raise AssertionError(f'{label}: leaf {path} is not finite')
+    bound = tol * max(norm, floor_rel * gmax, 1e-300)
+    if err / bound > worst[0]:
+      worst = (err / bound, path, err, norm)
+  import os
+  log = os.environ.get('HBO_GRAD_LOG')
+  if log:
+    with open(log, 'a') as f:
+      test = os.environ.get('PYTEST_CURRENT_TEST', '').split(' ')[0]
+      f.write(f'{worst[0]:.3e} tol={tol:g} leaf={worst[1]} err={worst[2]:.3e} norm={worst[3]:.3e} gmax={gmax:.3e} {label} {test}\n')
+  assert worst[0] <= 1.0, (f'{label}: worst leaf {worst[1]}: |err| {worst[2]:.3e} = {worst[0]:.2f} x the bound '
+                           f'(tol {tol:g}, leaf norm {worst[3]:.3e}, max|g| {gmax:.3e})')
+
+
 def rel_err(a, b):
   a = np.asarray(a, dtype=np.float64)
   b = np.asarray(b, dtype=np.float64)

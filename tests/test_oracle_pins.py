@@ -486,24 +486,128 @@ def test_config_fixtures_reproduce():
   assert abs(vk - f4['nll_per_task'][k]) <= 1e-11 * abs(vk)
 
 
+def _load_ref_script():
+  import importlib.util
+  spec = importlib.util.spec_from_file_location('make_golden_from_reference', os.path.join(GOLDEN, 'make_golden_from_reference.py'))
+  mod = importlib.util.module_from_spec(spec)
+  spec.loader.exec_module(mod)
+  return mod
+
+
+def _oracle_train_record(kname, mname, method, steps, lr, batch_size, model, data):
+  """What make_golden_from_reference.py records of gp.infer_parameters, from the ORACLE's driver on the same inputs."""
+  from oracle import train_oracle as to
+  cfg = {'method': method, 'batch_size': batch_size, 'max_training_step': steps, 'learning_rate': lr, 'mlp_features': helpers.MLP_FEATURES}
+  ds = {i: o.SubDataset(xx, yy) for i, (xx, yy) in enumerate(data)}
+  log = []
+  def cb(*a, **k):
+    step = k.get('step', a[0] if a else None)
+    prm = k.get('params', k.get('model_params', a[1] if len(a) > 1 else None))
+    loss = k.get('loss', a[2] if len(a) > 2 else None)
+    log.append((int(step), helpers.flatten(prm), float(loss)))
+  whole = iter(lambda: ds, None)          # batch_size above every size: the sub-sampling leaves the sub-datasets whole
+  out = to.infer_parameters(getattr(o, mname), getattr(o, kname), o.GPParams(model=to.tree_copy(model), config=cfg), ds, WF,
+                            dataset_iter=whole, callback=cb)
+  return dict(cb_steps=np.asarray([r[0] for r in log]), cb_params=np.asarray([r[1] for r in log]),
+              cb_losses=np.asarray([r[2] for r in log]), final_flat=helpers.flatten(out.model))
+
+
+def _oracle_hgp_record(samples, x, y, x2, y2, xq):
+  """acfun.py:72-82 on an HGP, from the oracle: mean over the parameter samples of the acquisition on the noisy, unbiased posterior."""
+  dso = {'test': o.SubDataset(x, y), 'other': o.SubDataset(x2, y2), 'third': o.SubDataset(x2[:5], y2[:5])}
+  out = {'ei': [], 'pi': [], 'ucb': []}
+  for smp in samples:
+    po = o.GPParams(model=smp, config={})
+    mu, var = o.predict(o.constant, o.matern52, po, x, y, xq, WF)
+    mu, var = o.gp_predict_postprocess(po, dso, mu, var, WF, False, True, True)
+    std = np.sqrt(var)
+    out['ei'].append(o.expected_improvement_sub(mu, std, o.ei_callback_default(dso, 'test')))
+    out['pi'].append(o.probability_of_improvement_sub(mu, std, o.pi_callback_default(dso, 'test')))
+    out['ucb'].append(o.ucb_sub(mu, std, 3.0))
+  return {k: np.mean(v, axis=0) for k, v in out.items()}
+
+
+def _check_ref_file(path):
+  """One `<case>_ref.npz` (outputs of the JAX reference, tests/golden/make_golden_from_reference.py) against the oracle: the oracle's
+  committed fixture `<case>.npz` for the per-function cases, the oracle's training driver / HGP mean re-run on the inputs stored in
+  the file for the `train_*` / `hgp_*` cases.  ASSERTS -- a reference file that disagrees is a failure, never a skip."""
+  base = os.path.basename(path)
+  ref = np.load(path)
+  if base.startswith('train_'):
+    n_sub = len([k for k in ref.files if k[0] == 'x' and k[1:].isdigit()])
+    data = [(ref[f'x{i}'], ref[f'y{i}']) for i in range(n_sub)]
+    kname, mname, method = str(ref['kname']), str(ref['mname']), str(ref['method'])
+    lr = float(ref['learning_rate'])
+    template = helpers.make_model(np.random.default_rng(0), mname, kname.endswith('_mlp'), data[0][0].shape[1])
+    model = helpers.unflatten_like(template, ref['model_flat'])
+    mine = _oracle_train_record(kname, mname, method, int(ref['steps']), None if np.isnan(lr) else lr, int(ref['batch_size']), model, data)
+    assert np.array_equal(mine['cb_steps'], ref['cb_steps']), base
+    for k, t in (('cb_losses', 1e-8), ('cb_params', 1e-7), ('final_flat', 1e-7)):
+      scale = max(float(np.max(np.abs(ref[k]))), 1.0)
+      assert mine[k].shape == ref[k].shape and np.max(np.abs(mine[k] - ref[k])) <= t * scale, f'{base}:{k}'
+    return
+  if base.startswith('hgp_'):
+    template = helpers.make_model(np.random.default_rng(0), 'constant', False, ref['x'].shape[1])
+    samples = [helpers.unflatten_like(template, f) for f in ref['samples_flat']]
+    mine = _oracle_hgp_record(samples, ref['x'], ref['y'], ref['x2'], ref['y2'], ref['xq'])
+    for k in ('ei', 'pi', 'ucb'):
+      scale = max(float(np.max(np.abs(ref[k]))), 1e-300)
+      assert np.max(np.abs(mine[k].reshape(ref[k].shape) - ref[k])) <= 1e-8 * scale, f'{base}:{k}'
+    return
+  tol = {'grad_flat': 1e-7, 'ekl_grad_flat': 1e-6, 'euc_grad_flat': 1e-6, 'kinvy': 1e-7, 'cov': 1e-7, 'var': 1e-7}
+  mine = np.load(path.replace('_ref.npz', '.npz'))
+  for k in ref.files:
+    if k not in mine.files:
+      continue
+    t = tol.get(k, 1e-9)
+    scale = max(float(np.max(np.abs(ref[k]))), 1e-300)
+    assert np.max(np.abs(np.asarray(mine[k], dtype=np.float64).reshape(ref[k].shape) - ref[k])) <= t * scale, f'{base}:{k}'
+
+
 def test_golden_fixtures_match_reference():
   """Closes the parity chain when tests/golden/make_golden_from_reference.py has run once where jax is importable:
-  every `<case>_ref.npz` (outputs of the JAX reference itself) must agree with the oracle's fixture `<case>.npz`.
-  Until then there is nothing to compare and the oracle stays 'parity unpinned' (DESIGN.md section 0)."""
+  every `<case>_ref.npz` (outputs of the JAX reference itself: per-function outputs, the training trajectories of row f1, the HGP
+  mean over samples) must agree with the oracle -- a file that is there and disagrees FAILS.  Only the absence of every such file
+  skips: then there is nothing to compare and the oracle stays 'parity unpinned' (DESIGN.md section 0)."""
   import glob
   refs = sorted(glob.glob(os.path.join(GOLDEN, '*_ref.npz')))
   if not refs:
     pytest.skip('no *_ref.npz: the JAX reference has not been run (jax is not installable here)')
-  tol = {'grad_flat': 1e-7, 'ekl_grad_flat': 1e-6, 'euc_grad_flat': 1e-6, 'kinvy': 1e-7, 'cov': 1e-7, 'var': 1e-7}
   for path in refs:
-    ref = np.load(path)
-    mine = np.load(path.replace('_ref.npz', '.npz'))
-    for k in ref.files:
-      if k not in mine.files:
-        continue
-      t = tol.get(k, 1e-9)
-      scale = max(float(np.max(np.abs(ref[k]))), 1e-300)
-      assert np.max(np.abs(np.asarray(mine[k], dtype=np.float64).reshape(ref[k].shape) - ref[k])) <= t * scale, f'{os.path.basename(path)}:{k}'
+    _check_ref_file(path)
+
+
+def test_reference_pin_consumer_on_oracle_made_stand_ins(tmp_path):
+  """The consumer above has never seen a real `*_ref.npz` (no jax here), so its code paths for the training trajectories and the HGP
+  mean are exercised on STAND-INS: files of the reference script's exact layout, filled from the oracle itself (so they must agree),
+  then with one number moved (so they must fail).  This pins the plumbing -- file layout, input reconstruction, tolerances -- not
+  the oracle: nothing written here is a fixture, and the label 'parity unpinned' does not move."""
+  ref = _load_ref_script()
+  kname, mname = ref.TRAIN_CASES[2]
+  for method, steps, lr in ref.TRAIN_METHODS:
+    model, data = ref.train_inputs(kname, mname)
+    rec = _oracle_train_record(kname, mname, method, steps, lr, ref.TRAIN_BATCH, model, data)
+    arrays = {f'x{i}': xx for i, (xx, yy) in enumerate(data)}
+    arrays.update({f'y{i}': yy for i, (xx, yy) in enumerate(data)})
+    path = str(tmp_path / f'train_{kname}_{mname}_{method}_ref.npz')
+    np.savez_compressed(path, kname=kname, mname=mname, method=method, steps=steps, learning_rate=np.nan if lr is None else lr,
+                        batch_size=ref.TRAIN_BATCH, model_flat=helpers.flatten(model), **rec, **arrays)
+    assert len(rec['cb_losses']) >= steps
+    _check_ref_file(path)
+    rec['cb_losses'] = rec['cb_losses'] * (1 + 1e-6)
+    np.savez_compressed(path, kname=kname, mname=mname, method=method, steps=steps, learning_rate=np.nan if lr is None else lr,
+                        batch_size=ref.TRAIN_BATCH, model_flat=helpers.flatten(model), **rec, **arrays)
+    with pytest.raises(AssertionError):
+      _check_ref_file(path)
+  samples, x, y, x2, y2, xq = ref.hgp_inputs()
+  rec = _oracle_hgp_record(samples, x, y, x2, y2, xq)
+  path = str(tmp_path / 'hgp_matern52_constant_ref.npz')
+  np.savez_compressed(path, x=x, y=y, x2=x2, y2=y2, xq=xq, samples_flat=np.asarray([helpers.flatten(smp) for smp in samples]), **rec)
+  _check_ref_file(path)
+  rec['ucb'] = rec['ucb'] + 1e-5
+  np.savez_compressed(path, x=x, y=y, x2=x2, y2=y2, xq=xq, samples_flat=np.asarray([helpers.flatten(smp) for smp in samples]), **rec)
+  with pytest.raises(AssertionError):
+    _check_ref_file(path)
 
 
 def test_cpu_baseline_port_matches_oracle():
@@ -523,6 +627,13 @@ def test_cpu_baseline_port_matches_oracle():
   assert abs(v2 - vo) <= 1e-10 * abs(vo)
   for k in go:
     np.testing.assert_allclose(g2[k], go[k], rtol=1e-8, atol=1e-10)
+  # the all-core form (tile algorithms for potrf / trtri / lauum over OpenMP, one single-threaded BLAS call per tile): tile sizes
+  # that divide n, that do not, and one tile for the whole matrix
+  for nb in (64, 128, 100, 512):
+    v3, g3 = cpu_baseline.nll_and_grad_se_ard_constant_tiled(x, y, raw, nb=nb)
+    assert abs(v3 - vo) <= 1e-10 * abs(vo), nb
+    for k in go:
+      np.testing.assert_allclose(g3[k], go[k], rtol=1e-8, atol=1e-10, err_msg=str(nb))
 
 
 # ---- an independent third-party implementation of the same Gaussian-process formulas ------------------------------------------
