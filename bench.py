@@ -184,16 +184,29 @@ def bench_cfg3(ctx, stages=False):
   g = gp.GP({0: defs.SubDataset(x, y)}, mean.linear_mlp, kernel.matern52_mlp,
             defs.GPParams(model=to32(model), config={'mlp_features': (f,)}), utils.DEFAULT_WARP_FUNC)
   ctx.profile_enable(1)
-  best = None
-  for _ in range(3):
-    g.update_model_params(g.params.model)        # drops the cache -> re-factorise
-    t0 = time.perf_counter(); g.setup_predictor(0); t1 = time.perf_counter()
-    pf = ctx.profile_get()
-    ei = acfun.expected_improvement(model=g, sub_dataset_key=0, x_queries=xq); t2 = time.perf_counter()
-    pe = ctx.profile_get()
-    cur = (t1 - t0, t2 - t1, pf, pe)
-    if best is None or cur[0] + cur[1] < best[0] + best[1]:
-      best = cur
+  def timed(reps):
+    best = None
+    for _ in range(reps):
+      g.update_model_params(g.params.model)        # drops the cache -> re-factorise
+      t0 = time.perf_counter(); g.setup_predictor(0); t1 = time.perf_counter()
+      pf = ctx.profile_get()
+      ei = acfun.expected_improvement(model=g, sub_dataset_key=0, x_queries=xq); t2 = time.perf_counter()
+      pe = ctx.profile_get()
+      cur = (t1 - t0, t2 - t1, pf, pe)
+      if best is None or cur[0] + cur[1] < best[0] + best[1]:
+        best = cur
+    mu, var = g.predict(xq, 0)
+    return best, (np.asarray(mu, dtype=np.float64), np.asarray(var, dtype=np.float64), np.asarray(ei, dtype=np.float64))
+  # BOTH fp32 forms of the matrix-core products (round-5 review): the default two-way fp16 split (3 MFMAs, 2^-22 per product) and
+  # the exact three-way bf16 split (6 MFMAs, every fp32 bit of both operands), each timed and each compared with the fp64 run below
+  paths = {}
+  ctx.set_option('post_f16x2', 0); ctx.set_option('chol_f16x2', 0)
+  try:
+    paths['bf16x3'] = timed(2)
+  finally:
+    ctx.set_option('post_f16x2', 1); ctx.set_option('chol_f16x2', 1)
+  paths['f16x2'] = timed(3)
+  best, (_, _, ei) = paths['f16x2']
   # every stage of the streamed posterior ALONE on the machine (hbo_tune post_serial: the cross Gram of chunk i + 1 no longer runs
   # beside the product of chunk i): what the co-running cross-Gram kernel costs in isolation, and what the product loses beside it
   ctx.set_option('post_serial', 1)
@@ -234,6 +247,27 @@ def bench_cfg3(ctx, stages=False):
       'ei_ms_serialised': round(te_serial * 1e3, 2),
       'note': 'isolated = hbo_tune post_serial 1 (producer and consumer of the streamed posterior on one stream); the default overlaps '
               'the cross Gram of chunk i + 1 with the product of chunk i, where it runs in the slots the resident product grid leaves'}
+  # the same model and candidates in fp64 on the device: the yardstick both fp32 forms are held to (max abs differences over all 65 536
+  # candidates; tests/test_gpu_parity.py::test_cfg3_full_size_against_host_lapack holds the fp64 run itself to host LAPACK)
+  g64 = gp.GP({0: defs.SubDataset(x.astype(np.float64), y.astype(np.float64))}, mean.linear_mlp, kernel.matern52_mlp,
+              defs.GPParams(model=model, config={'mlp_features': (f,)}), utils.DEFAULT_WARP_FUNC)
+  xq64 = xq.astype(np.float64)
+  mu64, var64 = g64.predict(xq64, 0)
+  ei64 = np.asarray(acfun.expected_improvement(model=g64, sub_dataset_key=0, x_queries=xq64), dtype=np.float64)
+  mu64, var64 = np.asarray(mu64, dtype=np.float64), np.asarray(var64, dtype=np.float64)
+  del g64
+  out['default_path'] = 'f16x2'
+  out['paths'] = {}
+  for name, ((tf_, te_, pf_, pe_), (mu_, var_, ei_)) in paths.items():
+    out['paths'][name] = {
+        'factor_ms': round(tf_ * 1e3, 2), 'potrf_ms': round(pf_['potrf'][0], 2), 'ei_ms': round(te_ * 1e3, 2), 'post_gemm_ms': round(pe_['post_gemm'][0], 2),
+        'mfmas_per_product': 3 if name == 'f16x2' else 6, 'bits_per_product': 22 if name == 'f16x2' else 24,
+        'max_abs_dmu_vs_fp64': float(np.max(np.abs(mu_ - mu64))), 'max_abs_dvar_vs_fp64': float(np.max(np.abs(var_ - var64))),
+        'max_abs_dei_vs_fp64': float(np.max(np.abs(ei_ - ei64))),
+        'scale_mu_var_ei': [float(np.max(np.abs(mu64))), float(np.max(np.abs(var64))), float(np.max(np.abs(ei64)))]}
+  out['paths_note'] = ('f16x2 (default for the stationary covariances): two-way fp16 split of operands scaled by powers of two, 3 fp16 MFMAs per product; '
+                       'bf16x3 (hbo_tune post_f16x2 = chol_f16x2 = 0; always used by the dot-product kernel and hbo_spd_*): exact three-way bf16 split, '
+                       '6 MFMAs per product = strict fp32.  Top-level factor_ms / ei_ms of this object are the DEFAULT path.')
   if stages:
     out['stages_ei'] = {k: (round(v[0], 3), v[1]) for k, v in pe.items()}
     out['stages_factor'] = {k: (round(v[0], 3), v[1]) for k, v in pf.items()}
@@ -578,21 +612,22 @@ def main():
   roofline = None
   if 'syrk_bulk' in prof and prof['syrk_bulk'][1] > 0 and fl:
     tot_ms, launches = prof['syrk_bulk']
-    assert launches == len(fl) * args.steps, (launches, len(fl), args.steps)
+    # (hbo_tune f2_split puts a bulk update's leading columns in a launch of their own: more launches, the same tiles and flops)
+    assert launches >= len(fl) * args.steps and launches % args.steps == 0, (launches, len(fl), args.steps)
     flops_total = sum(fl) * args.steps
     achieved = flops_total / (tot_ms * 1e-3) / 1e12
     roofline = {'bound': 'mfma', 'kernel': f'gemm_kernel<double,true,true,128> (bulk Cholesky trailing update, syrk K={128 * group})',
                 'achieved': round(achieved, 3), 'peak': FP64_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': round(achieved / FP64_MFMA_PEAK_TFLOPS, 4), 'traffic': None,
                 'launches': launches, 'avg_launch_ms': round(tot_ms / launches, 4),
-                'algorithmic_gflop_per_launch': round(sum(fl) / len(fl) / 1e9, 3),
+                'algorithmic_gflop_per_launch': round(flops_total / launches / 1e9, 3), 'launches_per_eval': launches // args.steps,
                 'note': 'HIP events around each launch on its own stream inside the timed region; the launches '
                         'overlap with the look-ahead panel chain and the early triangular inverse on other streams'}
   if roofline is not None:
     # HBM traffic per launch from committed rocprofv3 PMC passes of this same command (separate
     # --pmc FETCH_SIZE / WRITE_SIZE runs; FETCH_SIZE doubled per MI355X_MICROARCH.md: on gfx950 it
     # reports half the bytes of wide coalesced streaming reads).  bench.py cannot run rocprof itself.
-    pmc_path = next((pth for pth in (os.path.join(ROOT, 'profiles', f) for f in ('r05_pmc_hbm.json', 'r04_pmc_hbm.json', 'r03_pmc_hbm.json')) if os.path.exists(pth)), None)
+    pmc_path = next((pth for pth in (os.path.join(ROOT, 'profiles', f) for f in ('r06_pmc_hbm.json', 'r05_pmc_hbm.json', 'r04_pmc_hbm.json', 'r03_pmc_hbm.json')) if os.path.exists(pth)), None)
     if pmc_path:
       pmc_all = json.load(open(pmc_path))
       pmc = pmc_all.get('gemm_kernel<double, true, true, 128>')
@@ -630,7 +665,7 @@ def main():
                    'flops': float(args.n)**3, 'ms': round(ms_per_step, 4), 'achieved': round(eval_tf, 3), 'peak': FP64_MFMA_PEAK_TFLOPS,
                    'unit': 'TFLOP/s', 'frac': round(eval_tf / FP64_MFMA_PEAK_TFLOPS, 4)}
   def gram_traffic():
-    pth = next((q for q in (os.path.join(ROOT, 'profiles', f) for f in ('r05_pmc_hbm.json', 'r04_pmc_hbm.json')) if os.path.exists(q)), None)
+    pth = next((q for q in (os.path.join(ROOT, 'profiles', f) for f in ('r06_pmc_hbm.json', 'r05_pmc_hbm.json', 'r04_pmc_hbm.json')) if os.path.exists(q)), None)
     if pth is None:
       return None
     g = json.load(open(pth)).get('gram_kernel<double, true, 0>')
@@ -834,6 +869,12 @@ def main():
                                       'model_imbalance': round(max(model_ms) / (sum(model_ms) / len(model_ms)), 4),
                                       'model': dict(parallel.SHARD_COST_MODEL, form='c0 + a * max nblk + b * sum n^3 [ms]')})
       dev8.close()
+      # PROJECTION, NOT MEASURED (no multi-GPU node has run this): T = 64 on one GPU over (heaviest shard of 8 alone + the all-reduce);
+      # comm_us_assumed = 30 us for one ~200-byte ncclAllReduce over xGMI (an assumption: the xGMI transport has never been exercised)
+      comm_assumed_us = 30.0
+      multitask['projected_8gpu'] = {'label': 'projection, not measured', 'speedup': round(multitask['ms_per_eval'] / (multitask['shard_of_8']['ms_per_eval'] + comm_assumed_us * 1e-3), 3),
+                                     'formula': 'T64_ms / (shard_ms + comm_us / 1000)', 'T64_ms': multitask['ms_per_eval'],
+                                     'shard_ms': multitask['shard_of_8']['ms_per_eval'], 'comm_us_assumed': comm_assumed_us}
     dev4.close()
 
   # ---------------- cfg 3 and cfg 5 (rank 0, N=1 only; driver-timed instead of builder-tool numbers) ----------

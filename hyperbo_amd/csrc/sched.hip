@@ -311,31 +311,56 @@ void run_potrf(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, int m
               launch_syrk3(b, nt, ntasks, sb);
             } else {
             // "syrk_bulk" = the 128x128-tile bulk trailing update (the roofline kernel of bench.py)
-            ProfScope ps(c, a.small_tiles ? "syrk_trailing" : "syrk_bulk", 1, sb);
-            // persistent form (single task, enough tiles to fill the machine): leave CUs for the panel chain
-            const int64_t ntiles = (m * (m + 1) / 2 + m) * (a.small_tiles ? 4 : 1);
             const int pblocks = 2 * (c->n_cus - persist_free);
-            // (for large trailing matrices the bulk update dominates and gets the whole machine)
-            a.persistent = (ntasks == 1 && persist_free > 0 && ntiles > pblocks && m <= 96) ? pblocks : 0;
-            // (beyond that the whole machine, but still as a resident grid drawing tiles from the counter: see launch_gemm_t, LAUUM)
-            if (!a.persistent && ntasks == 1 && persist_free > 0 && m > 96 && c->opt_lauum_persist && !a.small_tiles) a.persistent = 2 * c->n_cus;
-            a.work_counter = (a.persistent && counters && n_counter < HBO_N_BULK_COUNTERS) ? counters + n_counter++ : nullptr;
-            a.n_big = 0;
-            if (a.persistent && a.work_counter && !a.small_tiles) {
-              // a partly filled last round (fewer than half of the workgroups would get a 128-tile) runs on 64-tiles
-              // (the whole last round on 64-tiles, or never: measured equal or slower, profiles/r02_potrf_chain.md)
-              const int64_t rem = ntiles % pblocks;
-              if (rem > 0 && rem * 2 <= pblocks) a.n_big = (int)(ntiles - rem);
+            // Two launches (hbo_tune f2_split): the NEXT F1 accumulates into block columns [g2, g3) only, which this update writes FIRST
+            // (column-major tile order) -- but an event fires at the end of a launch, so the chain's next F1 waited for the whole bulk
+            // update and the bulk update for F1: F1 -> hop -> F2 -> hop per group (profiles/r05_chain_timeline.md).  With the leading
+            // columns -- at least the next group's, and about one resident round of tiles -- as a launch of their own and the event
+            // behind THAT, the chain runs up to one bulk launch ahead and neither stream waits for the other at every group.
+            int c_split = max_nblk;
+            if (c->opt_f2_split && (ntasks == 1 || c->opt_f2_split >= 2) && !a.small_tiles) {
+              const int g3 = std::min(g2 + q, max_nblk);
+              int cs = g3;
+              while (cs < max_nblk && tiles_of(g2, cs) < pblocks) ++cs;
+              // (what is left must be worth a launch: at least half a resident round, or the update stays whole)
+              if (cs < max_nblk && tiles_of(cs, max_nblk) * 2 >= pblocks) c_split = cs;
             }
-            a.tl = tl_slot("f2", g1);
-            launch_gemm(dtype, a, dim3(max_nblk + 1 - a.c_lo, a.c_hi - a.c_lo, ntasks), sb);
-            a.persistent = 0; a.work_counter = nullptr; a.n_big = 0; a.tl = nullptr;
+            for (int part = 0; part < 2; ++part) {
+              a.c_lo = part == 0 ? g2 : c_split; a.c_hi = part == 0 ? c_split : max_nblk;
+              if (a.c_lo >= a.c_hi) continue;
+              {
+              ProfScope ps(c, a.small_tiles ? "syrk_trailing" : "syrk_bulk", 1, sb);
+              // persistent form (single task, enough tiles to fill the machine): leave CUs for the panel chain
+              const int64_t ntiles = (int64_t)tiles_of(a.c_lo, a.c_hi) * (a.small_tiles ? 4 : 1);
+              // (for large trailing matrices the bulk update dominates and gets the whole machine)
+              a.persistent = (ntasks == 1 && persist_free > 0 && ntiles > pblocks && m <= 96) ? pblocks : 0;
+              // (beyond that the whole machine, but still as a resident grid drawing tiles from the counter: see launch_gemm_t, LAUUM)
+              if (!a.persistent && ntasks == 1 && persist_free > 0 && m > 96 && c->opt_lauum_persist && !a.small_tiles) a.persistent = 2 * c->n_cus;
+              a.work_counter = (a.persistent && counters && n_counter < HBO_N_BULK_COUNTERS) ? counters + n_counter++ : nullptr;
+              a.n_big = 0;
+              if (a.persistent && a.work_counter && !a.small_tiles) {
+                // a partly filled last round (fewer than half of the workgroups would get a 128-tile) runs on 64-tiles
+                // (the whole last round on 64-tiles, or never: measured equal or slower, profiles/r02_potrf_chain.md)
+                const int64_t rem = ntiles % pblocks;
+                if (rem > 0 && rem * 2 <= pblocks) a.n_big = (int)(ntiles - rem);
+              }
+              a.tl = tl_slot(part == 0 ? "f2" : "f2b", g1);
+              launch_gemm(dtype, a, dim3(max_nblk + 1 - a.c_lo, a.c_hi - a.c_lo, ntasks), sb);
+              a.persistent = 0; a.work_counter = nullptr; a.n_big = 0; a.tl = nullptr;
+              }
+              if (part == 0) {   // what the next F1 (and nothing else on the chain) waits for
+                hipEvent_t e2 = pool_event(c, evi++);
+                hipEventRecord(e2, sb);
+                ev_f2 = e2;
+              }
+            }
             }
           }
-          hipEvent_t e2 = pool_event(c, evi++);
-          hipEventRecord(e2, sb);
-          hipStreamWaitEvent(sm, e2, 0);   // later F1 / final consumers on the main stream
-          ev_f2 = e2;
+          if (use_s3) {
+            hipEvent_t e2 = pool_event(c, evi++);
+            hipEventRecord(e2, sb);
+            ev_f2 = e2;
+          }
         }
       }
     }

@@ -1329,7 +1329,7 @@ def test_value_only_ekl_small_m_task_of_two_blocks_beside_a_big_m_task(gpu_ctx):
   vo, go = o.divergence_value_and_grad('ekl', o.constant, o.matern52, po, dso, WFO)
   v_only = objectives.ekl(mean.constant, kernel.matern52, pn, dsn, utils.DEFAULT_WARP_FUNC)   # first call on this dataset: value only
   assert abs(v_only - vo) <= 5e-9 * max(abs(vo), 1.0), (v_only, vo)
-  dev = objectives.DeviceDataset(dsn)
+  dev = objectives.DeviceDataset(dsn, only_aligned=True)
   v1 = objectives.ekl(mean.constant, kernel.matern52, pn, dev, utils.DEFAULT_WARP_FUNC)
   vn, gn = objectives.ekl.value_and_grad(mean.constant, kernel.matern52, pn, dev, utils.DEFAULT_WARP_FUNC)
   dev.close()
