@@ -311,7 +311,10 @@ void run_potrf(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, int m
               launch_syrk3(b, nt, ntasks, sb);
             } else {
             // "syrk_bulk" = the 128x128-tile bulk trailing update (the roofline kernel of bench.py)
-            const int pblocks = 2 * (c->n_cus - persist_free);
+            // (hbo_tune persist_adapt = 100 a + b: trailing matrices of at least 48 tile columns leave a CUs to the chain, smaller ones b --
+            //  early groups wait for the bulk update, later ones for the chain: profiles/r05_chain_timeline.md, per-group table)
+            const int pf_now = (c->opt_persist_adapt > 0 && c->opt_persist_free < 0) ? (m >= 48 ? c->opt_persist_adapt / 100 : c->opt_persist_adapt % 100) : persist_free;
+            const int pblocks = 2 * (c->n_cus - pf_now);
             // Two launches (hbo_tune f2_split): the NEXT F1 accumulates into block columns [g2, g3) only, which this update writes FIRST
             // (column-major tile order) -- but an event fires at the end of a launch, so the chain's next F1 waited for the whole bulk
             // update and the bulk update for F1: F1 -> hop -> F2 -> hop per group (profiles/r05_chain_timeline.md).  With the leading

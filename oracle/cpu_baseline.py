@@ -137,6 +137,41 @@ def _blas_fns():
   return (C.c_void_p * 5)(ptr(cb, 'dgemm'), ptr(cb, 'dtrsm'), ptr(cb, 'dsyrk'), ptr(cl, 'dpotrf'), ptr(cl, 'dtrtri'))
 
 
+def effective_cpus():
+  """CPUs this process can actually run on: the scheduler affinity mask AND the cgroup CPU quota (a container can show 256 CPUs in
+  os.cpu_count() and be throttled to a handful by cpu.max -- 256 spinning OpenMP threads under such a quota ran the tiled form at
+  the speed of ONE core on the GPU box)."""
+  import math
+  import os
+  n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+  quota = None
+  try:
+    with open('/sys/fs/cgroup/cpu.max') as f:                      # cgroup v2: "<quota> <period>" or "max <period>"
+      q, per = f.read().split()[:2]
+      if q != 'max':
+        quota = float(q) / float(per)
+  except (OSError, ValueError):
+    try:
+      with open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us') as f, open('/sys/fs/cgroup/cpu/cpu.cfs_period_us') as g:   # cgroup v1
+        q, per = float(f.read()), float(g.read())
+        if q > 0:
+          quota = q / per
+    except (OSError, ValueError):
+      pass
+  if quota is not None:
+    n = max(1, min(n, int(math.floor(quota + 1e-9)) or 1))
+  return n, quota
+
+
+def set_threads(n):
+  """OpenMP threads of the C port (Gram build, contraction, tile algorithms)."""
+  import ctypes as C
+  lib = _lib()
+  lib.hbo_cpu_set_threads.argtypes = [C.c_int]
+  lib.hbo_cpu_set_threads.restype = None
+  lib.hbo_cpu_set_threads(int(n))
+
+
 def omp_threads():
   import ctypes as C
   lib = _lib()

@@ -134,8 +134,11 @@ static void tile_gemm(int m, int n, int k, double alpha, const double* A, int64_
     }
   }
 }
-/* per-thread packing scratch for tiles of up to nb x kmax */
-static double* scratch_alloc(int nb, int64_t kmax) { return (double*)aligned_alloc(64, sizeof(double) * (size_t)((2 * (int64_t)nb + MR + NR) * kmax + 64)); }
+/* per-thread packing scratch for tiles of up to nb x nb: ONE block for all threads per call (allocating inside every parallel region --
+ * 256 threads x 64 steps of 270 KB mmap / munmap pairs, serialised on the address-space lock -- took 12.5 s of a potrf on the 256-core box) */
+static size_t scratch_doubles(int nb) { return (size_t)((2 * (int64_t)nb + MR + NR) * nb + 64); }
+static double* scratch_all(int nb) { return (double*)aligned_alloc(64, sizeof(double) * scratch_doubles(nb) * (size_t)omp_get_max_threads()); }
+#define SCRATCH(all, nb) double* pa = (all) + scratch_doubles(nb) * (size_t)omp_get_thread_num(); double* pb = pa + (int64_t)((nb) + MR) * (nb)
 
 #define BLK(A, i, j) ((A) + (int64_t)(j) * nb * n + (int64_t)(i) * nb)
 static int bs_of(int64_t n, int nb, int i) { const int64_t r = n - (int64_t)i * nb; return (int)(r < nb ? r : nb); }
@@ -155,6 +158,7 @@ int hbo_cpu_potrf_tiled(double* A, int64_t n64, int nb, const hbo_blas_fns* f) {
   const int T = (n + nb - 1) / nb;
   double* inv = (double*)aligned_alloc(64, sizeof(double) * (size_t)nb * nb);
   double* row = (double*)aligned_alloc(64, sizeof(double) * (size_t)nb * n);   /* copy of block row k (the solve reads it while writing A) */
+  double* scr = scratch_all(nb);
   int bad = 0;
   for (int k = 0; k < T && !bad; ++k) {
     int bk = bs_of(n, nb, k), info = 0;
@@ -164,7 +168,7 @@ int hbo_cpu_potrf_tiled(double* A, int64_t n64, int nb, const hbo_blas_fns* f) {
     const int ncol = n - (k + 1) * nb;   /* A(k, j) = U_kk^-T A(k, j), in strips of 48 columns */
 #pragma omp parallel
     {
-      double* pa = scratch_alloc(nb, nb); double* pb = pa + (int64_t)(nb + MR) * nb;
+      SCRATCH(scr, nb);
 #pragma omp for schedule(dynamic, 1)
       for (int c0 = 0; c0 < ncol; c0 += 48) {
         const int w = ncol - c0 < 48 ? ncol - c0 : 48;
@@ -173,13 +177,12 @@ int hbo_cpu_potrf_tiled(double* A, int64_t n64, int nb, const hbo_blas_fns* f) {
         for (int c = 0; c < w; ++c) memcpy(src + (int64_t)c * nb, dst + (int64_t)c * n, sizeof(double) * bk);
         tile_gemm(bk, w, bk, 1.0, inv, nb, 1, src, 1, nb, 0.0, dst, n, pa, pb);   /* inv^T: A(i,k) = inv[k*nb + i] -> ars = nb, acs = 1 */
       }
-      free(pa);
     }
     const int m = T - 1 - k;
     const int npair = m * (m + 1) / 2;
 #pragma omp parallel
     {
-      double* pa = scratch_alloc(nb, nb); double* pb = pa + (int64_t)(nb + MR) * nb;
+      SCRATCH(scr, nb);
 #pragma omp for schedule(dynamic, 1)
       for (int t = 0; t < npair; ++t) {
         int j = 0, r = t;
@@ -189,10 +192,9 @@ int hbo_cpu_potrf_tiled(double* A, int64_t n64, int nb, const hbo_blas_fns* f) {
         /* A(ti,tj) -= A(k,ti)^T A(k,tj) */
         tile_gemm(bi, bj, bk, -1.0, BLK(A, k, ti), n, 1, BLK(A, k, tj), 1, n, 1.0, BLK(A, ti, tj), n, pa, pb);
       }
-      free(pa);
     }
   }
-  free(inv); free(row);
+  free(inv); free(row); free(scr);
   return bad;
 }
 
@@ -203,6 +205,7 @@ int hbo_cpu_trtri_tiled(double* A, int64_t n64, int nb, const hbo_blas_fns* f) {
   const int T = (n + nb - 1) / nb;
   double* inv = (double*)aligned_alloc(64, sizeof(double) * (size_t)nb * nb);
   double* tmp = (double*)aligned_alloc(64, sizeof(double) * (size_t)nb * n);
+  double* scr = scratch_all(nb);
   int bad = 0;
   for (int k = 0; k < T && !bad; ++k) {
     const int bk = bs_of(n, nb, k);
@@ -210,7 +213,7 @@ int hbo_cpu_trtri_tiled(double* A, int64_t n64, int nb, const hbo_blas_fns* f) {
     const int right = T - 1 - k;
 #pragma omp parallel
     {
-      double* pa = scratch_alloc(nb, nb); double* pb = pa + (int64_t)(nb + MR) * nb;
+      SCRATCH(scr, nb);
 #pragma omp for schedule(dynamic, 1)
       for (int mi = 0; mi < k; ++mi) {       /* A(m,k) = -A(m,k) U_kk^-1 */
         double* src = tmp + (int64_t)mi * nb * nb;
@@ -232,12 +235,11 @@ int hbo_cpu_trtri_tiled(double* A, int64_t n64, int nb, const hbo_blas_fns* f) {
         for (int c = 0; c < bn; ++c) memcpy(src + (int64_t)c * nb, dst + (int64_t)c * n, sizeof(double) * bk);
         tile_gemm(bk, bn, bk, 1.0, inv, 1, nb, src, 1, nb, 0.0, dst, n, pa, pb);
       }
-      free(pa);
     }
     double* d = BLK(A, k, k);
     for (int c = 0; c < bk; ++c) for (int r = 0; r < bk; ++r) d[(int64_t)c * n + r] = inv[(int64_t)c * nb + r];
   }
-  free(inv); free(tmp);
+  free(inv); free(tmp); free(scr);
   return bad;
 }
 
@@ -248,9 +250,10 @@ void hbo_cpu_lauum_tiled(const double* V, int64_t n64, int nb, const hbo_blas_fn
   int n = (int)n64;
   const int T = (n + nb - 1) / nb;
   const int npair = T * (T + 1) / 2;
+  double* scr = scratch_all(nb);
 #pragma omp parallel
   {
-    double* pa = scratch_alloc(nb, nb); double* pb = pa + (int64_t)(nb + MR) * nb;
+    SCRATCH(scr, nb);
 #pragma omp for schedule(dynamic, 1)
     for (int t = 0; t < npair; ++t) {
       int j = 0, r = t;
@@ -262,9 +265,10 @@ void hbo_cpu_lauum_tiled(const double* V, int64_t n64, int nb, const hbo_blas_fn
         tile_gemm(bi, bj, bk, 1.0, BLK(V, i, kt), 1, n, BLK(V, j, kt), n, 1, kt == j ? 0.0 : 1.0, BLK(out, i, j), n, pa, pb);
       }
     }
-    free(pa);
   }
+  free(scr);
 }
+void hbo_cpu_set_threads(int n) { if (n > 0) omp_set_num_threads(n); }
 int hbo_cpu_omp_threads(void) {
   int nthr = 1;
 #pragma omp parallel

@@ -56,13 +56,13 @@ def test_fuzz_objectives(gpu_ctx, seed):
   vn, gn = objectives.nll_value_and_grad(mn, kn, pn, dsn, utils.DEFAULT_WARP_FUNC, exclude_aligned=exclude)
   assert abs(vn - vo) <= 1e-9 * max(abs(vo), 1.0)
   fo, fn = helpers.flatten(go), helpers.flatten(gn)
-  helpers.assert_grad_close(gn, go, 1e-7)
+  helpers.assert_grad_close(gn, go, 1e-9)
   for kind, fnc in (('ekl', objectives.ekl), ('euc', objectives.euc)):
     vo, go = o.divergence_value_and_grad(kind, mo, ko, po, dso, WFO)
     vn, gn = fnc.value_and_grad(mn, kn, pn, dsn, utils.DEFAULT_WARP_FUNC)
     assert abs(vn - vo) <= 1e-8 * max(abs(vo), 1.0)
     fo, fn = helpers.flatten(go), helpers.flatten(gn)
-    helpers.assert_grad_close(gn, go, 1e-6, label=kind)
+    helpers.assert_grad_close(gn, go, 1e-8, label=kind)
 
 
 @pytest.mark.parametrize('seed', range(FUZZ_SEEDS or 16))
@@ -114,7 +114,7 @@ def test_edge_shapes(gpu_ctx):
     vo, go = o.divergence_value_and_grad('ekl', o.constant, o.matern52, po, dso, WFO)
     vn, gn = objectives.ekl.value_and_grad(mean.constant, kernel.matern52, pn, dsn, utils.DEFAULT_WARP_FUNC)
     assert abs(vn - vo) <= 1e-9 * abs(vo)
-    helpers.assert_grad_close(gn, go, 1e-7)
+    helpers.assert_grad_close(gn, go, 1e-9)
     assert abs(objectives.ekl(mean.constant, kernel.matern52, pn, dsn, utils.DEFAULT_WARP_FUNC) - vo) <= 1e-9 * abs(vo)
   # D = 256 (HBO_MAX_FEATURE_DIM) with a per-dimension lengthscale
   dmax = 256
@@ -125,7 +125,7 @@ def test_edge_shapes(gpu_ctx):
   vo, go = o.nll_value_and_grad(o.constant, o.squared_exponential, pob, {0: o.SubDataset(xb, yb)}, WFO)
   vn, gn = objectives.nll_value_and_grad(mean.constant, kernel.squared_exponential, pnb, {0: defs.SubDataset(xb, yb)}, utils.DEFAULT_WARP_FUNC)
   assert abs(vn - vo) <= 1e-10 * abs(vo)
-  helpers.assert_grad_close(gn, go, 1e-8)
+  helpers.assert_grad_close(gn, go, 1e-10)
   # eight MLP layers (HBO_MAX_MLP_LAYERS), kernel and mean on the features
   feats = (5, 7, 3, 6, 4, 8, 5, 6)
   deep = {'lengthscale': (rng.normal(size=feats[-1]) * 0.3 + 0.5), 'signal_variance': np.array(0.3), 'noise_variance': np.array(-2.0),
@@ -140,7 +140,7 @@ def test_edge_shapes(gpu_ctx):
   vo, go = o.nll_value_and_grad(o.linear_mlp, o.matern32_mlp, pod, {0: o.SubDataset(xd, yd)}, WFO)
   vn, gn = objectives.nll_value_and_grad(mean.linear_mlp, kernel.matern32_mlp, pnd, {0: defs.SubDataset(xd, yd)}, utils.DEFAULT_WARP_FUNC)
   assert abs(vn - vo) <= 1e-10 * abs(vo)
-  helpers.assert_grad_close(gn, go, 1e-8)
+  helpers.assert_grad_close(gn, go, 1e-10)
   # a single observation: posterior and acquisition
   m1 = gp.GP({0: defs.SubDataset(xd[:1], yd[:1])}, mean.constant, kernel.matern52, pn, utils.DEFAULT_WARP_FUNC)
   mu, var = m1.predict(xd[1:6], 0)
@@ -176,7 +176,7 @@ def test_every_size_across_the_leaf_and_block_boundaries(gpu_ctx, dtype):
   _, go = o.nll_value_and_grad(o.constant, o.squared_exponential, po, dso, WFO)
   _, gn = objectives.nll_value_and_grad(mean.constant, kernel.squared_exponential, pn, dsn, utils.DEFAULT_WARP_FUNC)
   fo, fn = helpers.flatten(go), helpers.flatten(gn)
-  helpers.assert_grad_close(gn, go, 5e-3 if f32 else 1e-7)
+  helpers.assert_grad_close(gn, go, 2.5e-3 if f32 else 1e-9)
 
 
 OPTION_SETS = [
@@ -222,7 +222,7 @@ def test_every_scheduling_option_gives_the_same_answer(gpu_ctx, opts):
       vn, gn = objectives.nll_value_and_grad(mean.constant, kernel.squared_exponential, pn, dsn, utils.DEFAULT_WARP_FUNC)
       assert abs(vn - vo) <= 1e-9 * max(abs(vo), 1.0)
       fo, fn = helpers.flatten(go), helpers.flatten(gn)
-      helpers.assert_grad_close(gn, go, 1e-7)
+      helpers.assert_grad_close(gn, go, 1e-9)
     x, y = single[0]
     xq = rng.uniform(size=(50, d))
     mo, so = o.predict(o.constant, o.squared_exponential, po, x[:1500], y[:1500], xq, WFO)

@@ -19,8 +19,8 @@ from oracle import hyperbo_oracle as o
 pytestmark = pytest.mark.gpu
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
 WFO = o.DEFAULT_WARP_FUNC
-FP64_GRAD_TOL = 1e-8   # per leaf (helpers.assert_grad_close)
-FP32_GRAD_TOL = 5e-3
+FP64_GRAD_TOL = 1e-10   # per leaf (helpers.assert_grad_close); worst measured over the suite: 4.4e-12 of its bound (round 6, gpurun_out/grad_log.txt)
+FP32_GRAD_TOL = 2.5e-3   # worst measured: 2.3e-4
 FP32_REGISTRY_LEAF_TOL = 2e-3   # worst leaf of the fp32 registry sweep, relative to max(leaf norm, 1e-2 max|g|)
 
 
@@ -620,17 +620,34 @@ def test_cfg3_full_size_against_host_lapack(gpu_ctx):
   to32 = lambda t: {k_: to32(v_) for k_, v_ in t.items()} if isinstance(t, dict) else np.asarray(t, dtype=np.float32)
   g32 = gp.GP({0: defs.SubDataset(x.astype(np.float32), y.astype(np.float32))}, mean.linear_mlp, kernel.matern52_mlp,
               defs.GPParams(model=to32(model), config=dict(cfg)), utils.DEFAULT_WARP_FUNC)
+  # three fp32 forms of the posterior product + factorisation: the default two-way fp16 split (f16x2: 3 MFMAs per product), the exact
+  # three-way bf16 split (bf16x3: hbo_tune post_f16x2 = chol_f16x2 = 0, 6 MFMAs = strict fp32 products) and the fp32-MFMA product.
+  # Bounds = 10 x the errors measured at full size in round 6 (bench.py cfg3.paths, vs fp64: |d mu| 1.7e-5 on a scale of 3.5,
+  # |d var| 2e-6 on 0.86, |d EI| 1.1e-5 on 1.3 -- the same for f16x2 and bf16x3): mean 5e-5, variance 3e-5, EI 1e-4, relative as below
+  # (round 5 asserted 5e-3 for all three).
+  TOL_MU, TOL_VAR, TOL_EI = 5e-5, 3e-5, 1e-4
   errs = {}
-  for opt in (1, 0):
-    gpu_ctx.set_option('post_bf16x3', opt)
-    mu32, var32 = g32.predict(xq.astype(np.float32), 0)
-    ei32 = acfun.expected_improvement(model=g32, sub_dataset_key=0, x_queries=xq.astype(np.float32))
-    errs[opt] = (np.max(np.abs(mu32 - mu_ref)) / (1 + np.max(np.abs(mu_ref))), np.max(np.abs(var32 - var_ref_n)) / np.max(np.abs(var_ref_n)),
-                 np.max(np.abs(ei32 - ei_ref)) / (np.max(np.abs(ei_ref)) + 1e-3))
-    assert errs[opt][0] < 5e-3 and errs[opt][1] < 5e-3 and errs[opt][2] < 5e-3, errs
-  gpu_ctx.set_option('post_bf16x3', 1)
-  # the split product is as accurate as the fp32-MFMA one against the INDEPENDENT reference too
-  assert errs[1][1] <= 1.5 * errs[0][1] + 1e-6 and errs[1][0] <= 1.5 * errs[0][0] + 1e-6, errs
+  forms = {'f16x2': {}, 'bf16x3': {'post_f16x2': 0, 'chol_f16x2': 0}, 'fp32_mfma': {'post_bf16x3': 0}}
+  defaults = {'post_f16x2': 1, 'chol_f16x2': 1, 'post_bf16x3': 1}
+  try:
+    for name, opts in forms.items():
+      for k_, v_ in dict(defaults, **opts).items():
+        gpu_ctx.set_option(k_, v_)
+      g32.update_model_params(g32.params.model)     # drops the cache: the factorisation runs in this form too
+      mu32, var32 = g32.predict(xq.astype(np.float32), 0)
+      ei32 = acfun.expected_improvement(model=g32, sub_dataset_key=0, x_queries=xq.astype(np.float32))
+      errs[name] = (np.max(np.abs(mu32 - mu_ref)) / (1 + np.max(np.abs(mu_ref))), np.max(np.abs(var32 - var_ref_n)) / np.max(np.abs(var_ref_n)),
+                    np.max(np.abs(ei32 - ei_ref)) / (np.max(np.abs(ei_ref)) + 1e-3))
+      assert errs[name][0] < TOL_MU and errs[name][1] < TOL_VAR and errs[name][2] < TOL_EI, errs
+  finally:
+    for k_, v_ in defaults.items():
+      gpu_ctx.set_option(k_, v_)
+  if os.environ.get('HBO_GRAD_LOG'):
+    with open(os.environ['HBO_GRAD_LOG'], 'a') as f_:
+      f_.write('0 tol=cfg3_full_size (mu, var, ei) relative errors vs host LAPACK fp64: %r\n' % ({k_: tuple(float('%.3e' % e) for e in v_) for k_, v_ in errs.items()},))
+  # the split products are as accurate as the fp32-MFMA one against the INDEPENDENT reference too
+  for name in ('f16x2', 'bf16x3'):
+    assert errs[name][1] <= 1.5 * errs['fp32_mfma'][1] + 1e-6 and errs[name][0] <= 1.5 * errs['fp32_mfma'][0] + 1e-6, errs
 
 
 @pytest.mark.parametrize('noise_target', [1e-3, 1e-6])
@@ -1286,7 +1303,7 @@ def test_divergence_with_more_than_127_aligned_columns(gpu_ctx, kind, kname, mlp
   vo, go = o.divergence_value_and_grad(kind, getattr(o, mname), ko, po, dso, WFO)
   fn = objectives.ekl if kind == 'ekl' else objectives.euc
   vn, gn = fn.value_and_grad(getattr(mean, mname), kn, pn, dsn, utils.DEFAULT_WARP_FUNC)
-  vtol, gtol = (1e-10 * (50 if kind == 'ekl' else 1), FP64_GRAD_TOL) if dtype == np.float64 else (2e-3, 2e-2)
+  vtol, gtol = (1e-10 * (50 if kind == 'ekl' else 1), FP64_GRAD_TOL) if dtype == np.float64 else (2e-3, 2e-3)
   assert abs(vn - vo) <= vtol * max(abs(vo), 1.0), (vn, vo)
   fo, fng = helpers.flatten(go), helpers.flatten(gn)
   helpers.assert_grad_close(gn, go, gtol, label=kind)
@@ -1430,7 +1447,7 @@ def test_divergence_fp32_and_no_aligned_data(gpu_ctx):
     vn, gn = fn.value_and_grad(mean.constant, kernel.matern52, pn, dsn, utils.DEFAULT_WARP_FUNC)
     assert abs(vn - vo) <= 2e-3 * max(abs(vo), 1.0)
     fo, fng = helpers.flatten(go), helpers.flatten(gn)
-    helpers.assert_grad_close(gn, go, 2e-2, label=kind)
+    helpers.assert_grad_close(gn, go, 2e-3, label=kind)
   only_iid = {'iid': defs.SubDataset(*helpers.synthetic_task(rng, 10, d))}
   p64 = defs.GPParams(model=model, config={})
   assert objectives.ekl(mean.constant, kernel.matern52, p64, only_iid, utils.DEFAULT_WARP_FUNC) == 0.
@@ -2307,7 +2324,7 @@ def test_pooled_device_buffers_are_safe_to_reuse(gpu_ctx):
     dev = objectives.DeviceDataset(dsn)
     vn, gn = objectives.nll_value_and_grad(mean.constant, kernel.matern32, pn, dev, wf)
     dev.close()
-    tol_v, tol_g = (1e-10, FP64_GRAD_TOL) if dt == np.float64 else (3e-4, 1e-2)
+    tol_v, tol_g = (1e-10, FP64_GRAD_TOL) if dt == np.float64 else (3e-4, 1e-3)
     assert abs(vn - vo) <= tol_v * max(abs(vo), 1.0), (step, n, dt)
     fo, fn = helpers.flatten(go), helpers.flatten(gn)
     helpers.assert_grad_close(gn, go, tol_g, label=str((step, n, dt)))
@@ -2365,6 +2382,9 @@ def test_fp32_registry_value_grad_posterior_vs_oracle(gpu_ctx, kname, mlp, mname
   e_var = np.max(np.abs(var - var_o)) / np.max(np.abs(var_o))
   e_ei = np.max(np.abs(ei - ei_o)) / max(np.max(np.abs(ei_o)), 1e-3)
   _FP32_ERR[(kname, mlp, mname)] = (e_val, e_grad, e_mu, e_var, e_ei)
+  if os.environ.get('HBO_GRAD_LOG'):
+    with open(os.environ['HBO_GRAD_LOG'], 'a') as f_:
+      f_.write('%.3e tol=registry32 value %.3e grad_leaf %.3e mu %.3e var %.3e ei %.3e %s\n' % (e_grad / FP32_REGISTRY_LEAF_TOL, e_val, e_grad, e_mu, e_var, e_ei, (kname, mlp, mname)))
   assert e_val <= 1e-5 and e_grad <= FP32_REGISTRY_LEAF_TOL and e_mu <= 5e-4 and e_var <= 1e-4 and e_ei <= 2e-3, _FP32_ERR[(kname, mlp, mname)]
 
 
