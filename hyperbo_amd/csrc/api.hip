@@ -113,18 +113,13 @@ extern "C" int hbo_tune(hbo_ctx* c, const char* name, int64_t value) {
   static const Knob knobs[] = {
       {"overlap_trtri", &hbo_ctx::opt_overlap_trtri, 0, 1}, {"cu_yield", &hbo_ctx::opt_cu_yield, 0, 2},
       {"persist_free", &hbo_ctx::opt_persist_free, -1, 200}, {"trtri_at", &hbo_ctx::opt_trtri_at, 0, 63},
-      {"trtri_free", &hbo_ctx::opt_trtri_free, 0, 200}, {"lauum_persist", &hbo_ctx::opt_lauum_persist, 0, 128}, {"split_f1", &hbo_ctx::opt_split_f1, 0, 2}, {"f2_split", &hbo_ctx::opt_f2_split, 0, 2}, {"persist_adapt", &hbo_ctx::opt_persist_adapt, 0, 20000}, {"poison", &hbo_ctx::opt_poison, 0, 1},
+      {"trtri_free", &hbo_ctx::opt_trtri_free, 0, 200}, {"lauum_persist", &hbo_ctx::opt_lauum_persist, 0, 128}, {"split_f1", &hbo_ctx::opt_split_f1, 0, 2}, {"f2_split", &hbo_ctx::opt_f2_split, 0, 2}, {"poison", &hbo_ctx::opt_poison, 0, 1},
       {"sweep", &hbo_ctx::opt_sweep, 0, 2}, {"sweep_qs", &hbo_ctx::opt_sweep_qs, 0, 16}, {"sweep_side", &hbo_ctx::opt_sweep_side, 0, 1}, {"sweep_free", &hbo_ctx::opt_sweep_free, 1, 200}, {"sweep_big", &hbo_ctx::opt_sweep_big, 0, 1 << 30}, {"batch_bg", &hbo_ctx::opt_batch_bg, -1, 2},
       {"post_bf16x3", &hbo_ctx::opt_post_bf16x3, 0, 1}, {"post_f16x2", &hbo_ctx::opt_post_f16x2, 0, 1}, {"chol_f16x2", &hbo_ctx::opt_chol_f16x2, 0, 1}, {"group_inner", &hbo_ctx::opt_group_inner, -1, 16}, {"syrk_bf16x3", &hbo_ctx::opt_syrk_bf16x3, 0, 1},
       {"trtri_bf16x3", &hbo_ctx::opt_trtri_bf16x3, 0, 1}, {"lauum_bf16x3", &hbo_ctx::opt_lauum_bf16x3, 0, 1}, {"trtri3_min_s", &hbo_ctx::opt_trtri3_min_s, 1, 1024},
       {"fault_shard", &hbo_ctx::opt_fault_shard, 0, 2}, {"small_fused", &hbo_ctx::opt_small_fused, 0, 1}, {"post_serial", &hbo_ctx::opt_post_serial, 0, 1},
       {"syrk3_col", &hbo_ctx::opt_syrk3_col, 0, 1}, {"syrk3_sep", &hbo_ctx::opt_syrk3_sep, 0, 1}, {"syrk3_free", &hbo_ctx::opt_syrk3_free, 0, 200},
   };
-  if (!strcmp(name, "tile64_w1")) {   // process-wide: the 64-tile GEMM launches as one-wave workgroups (gemm.hip: gemm_tile4), x resident-grid factor
-    if (value < 0 || value > 8) return fail(c, HBO_ERR_ARG, "tile64_w1 in 0..8");
-    gemm_set_tile64_w1((int)value);
-    return HBO_OK;
-  }
   for (const Knob& k : knobs)
     if (!strcmp(name, k.name)) {
       if (value < k.lo || value > k.hi) return fail(c, HBO_ERR_ARG, std::string(name) + " out of range");

@@ -50,7 +50,6 @@ struct hbo_ctx {
   int opt_batch_bg = -1;       // batches: the sweep's launches beside the panel chain are 0 plain grids, 1 persistent and slot-limited (-1: auto = 1 up to 8 tasks),
                                // (tiles x tasks from one counter), 2 also yielding to the chain's kernels through the per-CU table
   int opt_poison = 0;          // tests: every evaluation first fills what it is about to recompute with NaN (gram.hip: poison_kernel)
-  int opt_persist_adapt = 0;   // hbo_tune("persist_adapt"): 100 a + b, see run_potrf (0: off)
   int opt_f2_split = 0;        // hbo_tune("f2_split"): the bulk update F2 in two launches -- the columns the NEXT F1 accumulates into first, with the
                                // event behind them -- so that the panel chain runs up to one bulk launch ahead (1: one matrix, 2: batches too)
   int opt_split_f1 = 1;        // panel chain: F1 updates only the next block column on the panel stream, the group's later columns on a third stream:

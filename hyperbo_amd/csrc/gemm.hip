@@ -835,158 +835,10 @@ __device__ __forceinline__ void gemm_tile3(const TileJob<T>& job, unsigned char*
         }
   }
 }
-// ---- the one-wave 64-tile core (round 6) -------------------------------------------------------------------------------------------
-// The 64 x 64 tile computed by ONE wave (a 64-thread workgroup): the 4 x 4 accumulator block of the 128-tile's waves, fed from the
-// wave's own LDS slab.  What it buys over gemm_tile3's four waves of 2 x 2 blocks: half the LDS fragment reads per MFMA (8 fragments
-// feed 16 MFMAs instead of 4 feeding 4), no workgroup barrier at all (a wave's LDS operations execute in order: the slab is
-// overwritten right behind its last fragment read), and placement by the SIMD instead of by the CU -- up to eight such workgroups on
-// a CU, each finding room on its own (a CU that holds one 256-VGPR bulk workgroup has room for four of them).  The small launches of
-// the panel chain (column updates, F1) and the batched / small-matrix products are throughput-bound on few CUs: that is where the
-// 64-tile kernels ran at 0.24 of the fp64 MFMA peak (BENCH_r05 roofline_small).  A lone tile is no faster (its one SIMD executes
-// all 64 MFMAs of a slab).  Same ascending-k order per accumulator: bit-identical results.
-// LDS image of one operand slab of the one-wave core: UNPADDED (the LDS-DMA writes wave-uniform base + 16 lane), swizzled on the
-// global side and on the read side by the same involution.
-//   k-contiguous operand: [64 rows][128 bytes]; the 16-byte chunk c of row r sits at slot c ^ ((r >> 1) & 7)
-//   m-contiguous operand: [BKE k rows][64 elements]; chunk c of k row k at slot c ^ ((CPR / 4) (k & 1)), CPR = chunks per row
-// fp64 fragment reads (ds_read_b64, lane groups {0-31} {32-63}, 64 banks): 16 rows x 2 k (or 2 k rows x 16 elements) per group land
-// on 64 distinct banks.
-template <typename T, bool KC>
-__device__ __forceinline__ int w1_lds_off(int mn, int k) {   // element offset of (row / column mn, k) inside the operand's slab image
-  constexpr int VEC = 16 / sizeof(T);
-  if (KC) return mn * (128 / (int)sizeof(T)) + (((k / VEC) ^ ((mn >> 1) & 7)) * VEC) + (k % VEC);
-  constexpr int CPR = 64 / VEC;
-  return k * 64 + ((((mn / VEC) ^ ((CPR / 4) * (k & 1)))) * VEC) + (mn % VEC);
-}
-// piece q (1 KB: 8 rows of a k-contiguous operand, 1024 / (64 sizeof T) k rows of an m-contiguous one) of a slab: this lane's byte
-// offset from the slab origin -- the part that depends on q beyond q * (uniform stride) is the swizzle of a k-contiguous operand,
-// which alternates between two values (q even / odd)
-template <typename T, bool KC>
-__device__ __forceinline__ void w1_voffsets(int64_t ld, int lane, int (&voff)[2], int& qstride) {
-  constexpr int VEC = 16 / sizeof(T);
-  if (KC) {
-    const int row = lane >> 3, slot = lane & 7;
-#pragma unroll
-    for (int par = 0; par < 2; ++par) {
-      const int f = ((4 * par) + (row >> 1)) & 7;           // ((8 q + row) >> 1) & 7 for q of parity par
-      voff[par] = (int)(((int64_t)row * ld + (slot ^ f) * VEC) * (int64_t)sizeof(T));
-    }
-    qstride = (int)(8 * ld * (int64_t)sizeof(T));
-  } else {
-    constexpr int CPR = 64 / VEC, RPP = 64 / CPR;
-    const int kr = lane / CPR, slot = lane % CPR;
-    voff[0] = voff[1] = (int)(((int64_t)kr * ld + (slot ^ ((CPR / 4) * (kr & 1))) * VEC) * (int64_t)sizeof(T));   // (k & 1 == kr & 1: RPP is even)
-    qstride = (int)(RPP * ld * (int64_t)sizeof(T));
-  }
-}
-template <typename T, bool AKC, bool BKC>
-__device__ __forceinline__ void gemm_tile4(const TileJob<T>& job, unsigned char* smem) {
-  typedef typename Mma<T>::acc_t acc_t;
-  constexpr int BKE = 128 / sizeof(T);
-  constexpr int KK = BKE / 4;
-  constexpr int MI = 4;                  // 16 x 16 MFMA tiles per dimension: the whole 64 x 64 tile
-  constexpr int SLAB = 8192;             // bytes of one operand slab: 64 x 128 bytes either way
-  static_assert(KK >= 4 && KK % 2 == 0, "k steps per slab");
-  const int lane = threadIdx.x & 63;
-  const int l15 = lane & 15, lq = lane >> 4;
-
-  int voa[2], vob[2], qsa, qsb;
-  w1_voffsets<T, AKC>(job.lda, lane, voa, qsa);
-  w1_voffsets<T, BKC>(job.ldb, lane, vob, qsb);
-  qsa = __builtin_amdgcn_readfirstlane(qsa); qsb = __builtin_amdgcn_readfirstlane(qsb);
-  unsigned long long slabA = uniform_addr(job.A), slabB = uniform_addr(job.B);   // origin of the next slab to be requested
-  const unsigned long long stepA = uniform_addr(reinterpret_cast<const char*>((AKC ? (int64_t)BKE : (int64_t)BKE * job.lda) * (int64_t)sizeof(T)));
-  const unsigned long long stepB = uniform_addr(reinterpret_cast<const char*>((BKC ? (int64_t)BKE : (int64_t)BKE * job.ldb) * (int64_t)sizeof(T)));
-  typedef __attribute__((address_space(3))) void* lds_ptr_t;
-  // 16 LDS-DMA loads (1 KB each): slab -> LDS stage `st` ([A 8 KB][B 8 KB]); no staging registers, no ds_write
-  auto request = [&](int st) {
-    unsigned char* base = smem + st * (2 * SLAB);
-    const __amdgpu_buffer_rsrc_t ra = tile_rsrc(slabA), rb = tile_rsrc(slabB);
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr_t)(base + q * 1024), 16, voa[q & 1], q * qsa, 0, 0);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_ptr_t)(base + SLAB + q * 1024), 16, vob[q & 1], q * qsb, 0, 0);
-    }
-    slabA += stepA; slabB += stepB;
-  };
-  const int nk = job.ksteps;
-  request(0);
-
-  // accumulators start from C/alpha when the tile is accumulated into C (beta = 1), fetched behind the first slab's requests
-  acc_t acc[MI][MI];
-  if (job.beta) {
-    const T inv_alpha = (T)1 / job.alpha;
-#pragma unroll
-    for (int a = 0; a < MI; ++a)
-#pragma unroll
-      for (int b = 0; b < MI; ++b)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          acc[a][b][r] = gld(job.C + (int64_t)(a * 16 + Mma<T>::crow(lane, r)) * job.ldc + b * 16 + l15) * inv_alpha;
-  } else {
-#pragma unroll
-    for (int a = 0; a < MI; ++a)
-#pragma unroll
-      for (int b = 0; b < MI; ++b) acc[a][b] = (acc_t){0, 0, 0, 0};
-  }
-
-  T af[2][MI], bf[2][MI];
-#define HBO_SB() __builtin_amdgcn_sched_barrier(0)
-  const int* const yslot = job.yield_flag ? job.yield_flag + cu_token() : nullptr;
-  int ypoll = 0;
-  for (int kt = 0; kt < nk; ++kt) {
-    const T* sA = reinterpret_cast<const T*>(smem + (kt & 1) * (2 * SLAB));
-    const T* sB = reinterpret_cast<const T*>(smem + (kt & 1) * (2 * SLAB) + SLAB);
-    if (yslot) {
-      // a panel-chain workgroup is running on this CU: stay off its MFMA / LDS paths until it is done (bounded wait; see gemm_tile)
-      if (ypoll != 0)
-        for (int spin = 0; spin < 256 && __hip_atomic_load(yslot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0; ++spin)
-          __builtin_amdgcn_s_sleep(16);
-      ypoll = __hip_atomic_load(yslot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    // the next slab goes to the other stage (its last reader, slab kt - 1, has issued all its MFMAs: every fragment read is complete),
-    // then this slab must have landed: loads return in order, so "all but the 16 just requested"
-    HBO_SB();
-    if (kt + 1 < nk) { request((kt + 1) & 1); __builtin_amdgcn_s_waitcnt(0x4F70); }   // vmcnt(16)
-    else __builtin_amdgcn_s_waitcnt(0x0F70);                                            // vmcnt(0)
-    HBO_SB();
-    auto frag = [&](int set, int kk, int i) {   // fragment i of k step kk (0-3: A, 4-7: B)
-      const int k = kk * 4 + lq;
-      if (i < MI) af[set][i] = sA[w1_lds_off<T, AKC>(i * 16 + l15, k)];
-      else bf[set][i - MI] = sB[w1_lds_off<T, BKC>((i - MI) * 16 + l15, k)];
-    };
-    auto mma = [&](int set, int i) {   // serpentine over the 4 x 4 accumulators: consecutive MFMAs share an operand register
-      const int a = i / MI, b = (a & 1) ? MI - 1 - i % MI : i % MI;
-      acc[a][b] = Mma<T>::mma(af[set][a], bf[set][b], acc[a][b]);
-    };
-#pragma unroll
-    for (int i = 0; i < 2 * MI; ++i) frag(0, 0, i);
-#pragma unroll
-    for (int kk = 0; kk < KK; ++kk) {
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        mma(kk & 1, i);
-        if (kk + 1 < KK && i < 4) { HBO_SB(); frag((kk + 1) & 1, kk + 1, 2 * i); frag((kk + 1) & 1, kk + 1, 2 * i + 1); HBO_SB(); }
-      }
-    }
-    HBO_SB();
-  }
-#undef HBO_SB
-
-  if (job.C) {
-#pragma unroll
-    for (int a = 0; a < MI; ++a)
-#pragma unroll
-      for (int b = 0; b < MI; ++b)
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-          gst(job.C + (int64_t)(a * 16 + Mma<T>::crow(lane, r)) * job.ldc + b * 16 + l15, job.alpha * acc[a][b][r]);
-  }
-}
 // which core a tile takes: the pipelined ones (128-tile: gemm_tile2, 64-tile: gemm_tile3; fp32 has 8 k steps per slab where fp64
 // has 4, everything else is the same); gemm_tile stays for the A/B builds (-DHBO_GEMM_V1, -DHBO_GEMM_F32_V1, -DHBO_GEMM_NO64)
-template <typename T, bool AKC, bool BKC, int TM, bool W1 = false>
+template <typename T, bool AKC, bool BKC, int TM>
 __device__ __forceinline__ void run_tile(const TileJob<T>& job, unsigned char* smem) {
-  if constexpr (W1) { static_assert(TM == 64, "the one-wave core is a 64-tile core"); gemm_tile4<T, AKC, BKC>(job, smem); return; }
 #ifndef HBO_GEMM_V1
 #ifdef HBO_GEMM_F32_V1
   if constexpr (sizeof(T) == 4) gemm_tile<T, AKC, BKC, TM>(job, smem);
@@ -1032,7 +884,7 @@ __device__ __forceinline__ bool decode_syrk_linear(const GemmArgs& g, int tix, T
 __device__ unsigned long long hbo_dbg_gemm[4 * 8192];   // per workgroup of the traced launch: start, end, HW_ID, ksteps
 int g_dbg_mode = -1, g_dbg_index = 0, g_dbg_seen = 0;   // host: trace the g_dbg_index-th launch of g_dbg_mode (+100: persistent)
 #endif
-template <typename T, bool AKC, bool BKC, int TM, bool W1 = false>
+template <typename T, bool AKC, bool BKC, int TM>
 __device__ __forceinline__ void gemm_kernel_body(const GemmArgs& g, unsigned char* smem) {
   TileJob<T> job;
   job.yield_flag = g.yield_flag;
@@ -1075,7 +927,7 @@ __device__ __forceinline__ void gemm_kernel_body(const GemmArgs& g, unsigned cha
         continue;
       }
       if (!decode_syrk_linear<T, TM>(g, tix, job)) break;
-      run_tile<T, AKC, BKC, TM, W1>(job, smem);
+      run_tile<T, AKC, BKC, TM>(job, smem);
 #ifdef HBO_GEMM_TIMING
       dbg_ks += (unsigned long long)job.ksteps;
 #endif
@@ -1103,14 +955,14 @@ __device__ __forceinline__ void gemm_kernel_body(const GemmArgs& g, unsigned cha
       __syncthreads();
       if (tix >= total) break;
       const int tile = tix / nt, task = g.ptasks > 1 ? tix % nt : (int)blockIdx.z;
-      if (decode_job<T, TM>(g, job, tile % g.pgx, tile / g.pgx, g.pgx, task)) run_tile<T, AKC, BKC, TM, W1>(job, smem);
+      if (decode_job<T, TM>(g, job, tile % g.pgx, tile / g.pgx, g.pgx, task)) run_tile<T, AKC, BKC, TM>(job, smem);
     }
     return;
   }
   if (!decode_job<T, TM>(g, job, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x, (int)blockIdx.z)) return;
   int ytok = 0;
   if (g.yield_mark && threadIdx.x == 0) ytok = yield_enter(g.yield_mark);
-  run_tile<T, AKC, BKC, TM, W1>(job, smem);
+  run_tile<T, AKC, BKC, TM>(job, smem);
   if (g.yield_mark) {
     __syncthreads();
     if (threadIdx.x == 0) yield_leave(g.yield_mark, ytok);
@@ -1128,27 +980,13 @@ __global__ __launch_bounds__(256, TM == 64 ? (sizeof(T) == 8 ? HBO_LB64 : 4) : 2
   tl_end(g.tl);
 }
 
-// the 64-tile kernels as one-wave workgroups (gemm_tile4): two waves per SIMD at most (256 registers each)
-template <typename T, bool AKC, bool BKC>
-__global__ __launch_bounds__(64, 2) void gemm_kernel_w1(GemmArgs g) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  tl_begin(g.tl);
-  gemm_kernel_body<T, AKC, BKC, 64, true>(g, smem);
-  tl_end(g.tl);
-}
-
 #ifndef HBO_DEVICE_ONLY
-// hbo_tune tile64_w1 = m > 0: every 64-tile launch takes the one-wave kernel; a resident grid of w workgroups becomes m w of them (a
-// one-wave workgroup holds a quarter of the waves and half of the LDS of a four-wave one).  0: the four-wave core gemm_tile3.
-int g_tile64_w1 = 0;
 template <typename T, bool AKC, bool BKC>
 void launch_tile64(dim3 grid, int lds64, hipStream_t st, const GemmArgs& a) {
-  if (g_tile64_w1 > 0) {
-    if (a.persistent > 0) grid.x *= (unsigned)g_tile64_w1;
-    hipLaunchKernelGGL((gemm_kernel_w1<T, AKC, BKC>), grid, dim3(64), 32768, st, a);
-  } else {
-    hipLaunchKernelGGL((gemm_kernel<T, AKC, BKC, 64>), grid, dim3(256), lds64, st, a);
-  }
+  // (round 6: the same tile on ONE wave -- a 64-thread workgroup with the 128-tile's 4 x 4 accumulator block, LDS-DMA staging, no barrier --
+  //  was built, bit-identical, and slower everywhere: these launches are bound by the latency of a tile, and one SIMD then executes all
+  //  64 MFMAs of a slab: N = 4096 2.57 -> 4.58 ms, N = 8192 10.65 -> 13.5, shard of 8 2.45 -> 3.55; profiles/r06_tile64_one_wave.md)
+  hipLaunchKernelGGL((gemm_kernel<T, AKC, BKC, 64>), grid, dim3(256), lds64, st, a);
 }
 template <typename T>
 void launch_gemm_t(const GemmArgs& a_in, dim3 grid, hipStream_t st) {
@@ -1303,7 +1141,6 @@ extern "C" void hbo_dbg_gemm_wall(unsigned long long* host, int mode, int index)
   g_dbg_mode = mode; g_dbg_index = index; g_dbg_seen = 0;
 }
 #endif
-void gemm_set_tile64_w1(int m) { g_tile64_w1 = m; }
 void launch_gemm(int dtype, const GemmArgs& a_in, dim3 grid, hipStream_t st) {
   GemmArgs a = a_in;
 #ifdef HBO_GEMM_TIMING

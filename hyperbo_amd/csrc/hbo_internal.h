@@ -174,7 +174,6 @@ static inline bool hbo_first_use_on_device(unsigned long long& seen) {
 }
 
 // ---- launchers (defined in the .hip files) ---------------------------------------------
-void gemm_set_tile64_w1(int m);   // hbo_tune tile64_w1
 void launch_gemm(int dtype, const GemmArgs& a, dim3 grid, hipStream_t st);
 
 // fp32: the panel solve also writes the solved panel as three bf16 planes (the operand of the bf16x3 trailing updates, post3.hip):

@@ -311,15 +311,17 @@ void run_potrf(hbo_ctx* c, int dtype, const TaskDesc* d_tasks, int ntasks, int m
               launch_syrk3(b, nt, ntasks, sb);
             } else {
             // "syrk_bulk" = the 128x128-tile bulk trailing update (the roofline kernel of bench.py)
-            // (hbo_tune persist_adapt = 100 a + b: trailing matrices of at least 48 tile columns leave a CUs to the chain, smaller ones b --
-            //  early groups wait for the bulk update, later ones for the chain: profiles/r05_chain_timeline.md, per-group table)
-            const int pf_now = (c->opt_persist_adapt > 0 && c->opt_persist_free < 0) ? (m >= 48 ? c->opt_persist_adapt / 100 : c->opt_persist_adapt % 100) : persist_free;
-            const int pblocks = 2 * (c->n_cus - pf_now);
+            // (round 6: leaving the chain 16 CUs while the trailing matrix has >= 48 tile columns and 48-64 afterwards -- early groups wait for the bulk
+            //  update, later ones for the chain -- measured neutral: N = 8192 10.64 -> 10.57-10.75 ms, N = 6144 5.60 -> 5.54-5.60; removed)
+            const int pblocks = 2 * (c->n_cus - persist_free);
             // Two launches (hbo_tune f2_split): the NEXT F1 accumulates into block columns [g2, g3) only, which this update writes FIRST
             // (column-major tile order) -- but an event fires at the end of a launch, so the chain's next F1 waited for the whole bulk
             // update and the bulk update for F1: F1 -> hop -> F2 -> hop per group (profiles/r05_chain_timeline.md).  With the leading
             // columns -- at least the next group's, and about one resident round of tiles -- as a launch of their own and the event
             // behind THAT, the chain runs up to one bulk launch ahead and neither stream waits for the other at every group.
+            // MEASURED NEUTRAL (round 6, profiles/r06_f2_split.md): identical values, N = 8192 10.51 -> 10.57-10.59 ms, N = 6144 5.55 -> 5.58, shard 2.412 ->
+            // 2.410, 64 tasks 13.95 -> 13.94.  The timeline shows why: the two launches take 457 us where the one took 414 (two ramps, two
+            // partly filled last rounds), which is what the shorter idle gap of the bulk stream (75 -> 49 us per group) gives back.  Off by default.
             int c_split = max_nblk;
             if (c->opt_f2_split && (ntasks == 1 || c->opt_f2_split >= 2) && !a.small_tiles) {
               const int g3 = std::min(g2 + q, max_nblk);
