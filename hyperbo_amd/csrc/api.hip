@@ -120,6 +120,11 @@ extern "C" int hbo_tune(hbo_ctx* c, const char* name, int64_t value) {
       {"fault_shard", &hbo_ctx::opt_fault_shard, 0, 2}, {"small_fused", &hbo_ctx::opt_small_fused, 0, 1}, {"post_serial", &hbo_ctx::opt_post_serial, 0, 1},
       {"syrk3_col", &hbo_ctx::opt_syrk3_col, 0, 1}, {"syrk3_sep", &hbo_ctx::opt_syrk3_sep, 0, 1}, {"syrk3_free", &hbo_ctx::opt_syrk3_free, 0, 200},
   };
+  if (!strcmp(name, "gram_mfma")) {   // process-wide: fp32 Gram matrices with at least `value` features on the matrix cores (gram.hip: gram_mfma_kernel); 0: never
+    if (value < 0 || value > 4096) return fail(c, HBO_ERR_ARG, "gram_mfma in 0..4096");
+    gram_set_mfma_min_features((int)value);
+    return HBO_OK;
+  }
   for (const Knob& k : knobs)
     if (!strcmp(name, k.name)) {
       if (value < k.lo || value > k.hi) return fail(c, HBO_ERR_ARG, std::string(name) + " out of range");

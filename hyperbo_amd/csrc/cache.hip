@@ -366,6 +366,10 @@ static int posterior(hbo_ctx* c, const hbo_model* m, hbo_cache* k, const void* x
     { ProfScope ps(c, "cross_gram", 1, sb);
       GramArgs g = {}; g.kernel_id = m->kernel_id; g.x1 = k->h_desc.F; g.x2 = Fq; g.out = K_d; g.n1 = t->n; g.n2 = mc; g.ldo = ldq;
       g.n1pad = t->npad; g.n2pad = mpad; g.fdim = fdim; g.symmetric = 0; g.padded = 1;
+      // the producer of a streamed posterior runs BESIDE the product of the previous chunk, in the slots its resident grid leaves: there the
+      // matrix-core form (62 KB of LDS per workgroup, the product's own MFMA pipes) is the slower one -- cfg 3: EI 58.5 ms with the direct
+      // form, 59.0 with it, although alone it takes 0.33 ms per chunk against 0.58 (round 6)
+      g.direct_form = nbuf == 2;
       launch_gram(dtype, g, md, dim3(mpad / HBO_TILE, t->nblk, 1), sb); }
     unsigned short* K3_d = use3 ? d_K3 + (size_t)b * (k3_b / sizeof(unsigned short)) : nullptr;
     if (use3) {

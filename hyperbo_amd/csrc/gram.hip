@@ -153,6 +153,183 @@ __global__ __launch_bounds__(256) void gram_kernel(GramArgs g, const ModelDev* _
   }
 }
 
+// ---- fp32 Gram of a stationary covariance on the matrix cores (round 6) ----------------------------------------------------------
+// With 32 or more features the distance loop of gram_kernel -- two VALU instructions per pair and feature -- is what the fp32 Gram
+// costs (cfg 3: 64 tanh features, cross Gram 0.58 ms per chunk of 8192 candidates = 0.93 TB/s written).  Here the pair term comes off
+// the bf16 matrix cores: u_ij = |a_i|^2 + |b_j|^2 - 2 a_i . b_j with a = x / lengthscale in fp32, the norms summed in fp32 by the
+// thread that stages the row, and the dot product from the EXACT three-way bf16 split of both operands (hbo_split3: six
+// v_mfma_f32_32x32x16_bf16 per product, fp32 accumulate -- every bit of both fp32 factors, as post3.hip).  128 x 128 tile per
+// workgroup, 4 waves of 2 x 2 MFMA blocks, features staged 32 at a time.  What changes against the direct form sum (a - b)^2 is the
+// ROUNDING of u for close pairs (absolute error ~ 1e-7 |a|^2 instead of relative 1e-7): measured on cfg 3's features max |dK| 7.5e-6
+// against fp64 where the direct fp32 form has 1.2e-7 -- inside the 2e-5 the fp32 Gram is held to, which is why fp64 and narrow
+// feature spaces keep gram_kernel.  The diagonal of a symmetric Gram gets u = 0 exactly.  Reference: kernel.py:63-123.
+typedef __bf16 gm_bf16x8 __attribute__((ext_vector_type(8)));
+typedef float gm_f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned short gm_u16x8 __attribute__((ext_vector_type(8)));
+constexpr int GM_KC = 32;     // features per staged chunk (two MFMA k steps)
+constexpr int GM_ROWB = 80;   // bytes of one LDS row of one plane: 32 bf16 + 16 bytes (b128 reads of 16 rows and b128 writes of 8 rows hit distinct banks)
+template <int KID>
+__global__ __launch_bounds__(256) void gram_mfma_kernel(GramArgs g, const ModelDev* __restrict__ md) {
+  __shared__ __attribute__((aligned(16))) unsigned char sP[2 * 3 * 128 * GM_ROWB];   // [operand][plane][row]
+  __shared__ float sN[2][128];
+  const int ti = blockIdx.y;
+  const int tj = g.symmetric ? (int)((blockIdx.x + blockIdx.y) % gridDim.x) : (int)blockIdx.x;
+  const float* x1; const float* x2; float* out; int64_t n1, n2, ldo; int64_t e1, e2;
+  if (g.tasks) {
+    const TaskDesc& t = g.tasks[blockIdx.z];
+    md += (int64_t)blockIdx.z * g.model_stride;
+    if (ti >= t.nblk || tj >= t.nblk) return;
+    x1 = x2 = static_cast<const float*>(t.F);
+    out = static_cast<float*>(t.A);
+    n1 = n2 = t.n; ldo = t.ld; e1 = e2 = t.npad;
+  } else {
+    x1 = static_cast<const float*>(g.x1); x2 = static_cast<const float*>(g.x2); out = static_cast<float*>(g.out);
+    n1 = g.n1; n2 = g.n2; ldo = g.ldo; e1 = g.padded ? g.n1pad : g.n1; e2 = g.padded ? g.n2pad : g.n2;
+  }
+  const int64_t r0 = (int64_t)ti * HBO_TILE, c0 = (int64_t)tj * HBO_TILE;
+  if (g.symmetric && tj > ti) return;   // entirely above the diagonal
+  if (r0 >= e1 || c0 >= e2) return;
+  const int fdim = g.fdim;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1, l32 = lane & 31, lh = lane >> 5;
+
+  // staging: 8 consecutive lanes read the 128 bytes (32 features) of one row, a pass of the 256 threads covers 32 rows; passes 0-3
+  // are the tile's rows (x1), 4-7 its columns (x2).  Every thread keeps the partial |row|^2 of its 8 pieces; 8-lane sums at the end.
+  const int sc4 = tid & 7, srow = tid >> 3;
+  const bool vec_ok = (fdim & 3) == 0 && ((reinterpret_cast<unsigned long long>(x1) | reinterpret_cast<unsigned long long>(x2)) & 15) == 0;
+  float nrm[8];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) nrm[q] = 0.f;
+  auto load_chunk = [&](int d0, float4 (&v)[8]) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int opq = q >> 2, rr = srow + 32 * (q & 3);
+      const float* src = opq ? x2 : x1;
+      const int64_t nrow = opq ? n2 : n1;
+      const int64_t gr = (opq ? c0 : r0) + rr;
+      const float* xr = src + (gr < nrow ? gr : (nrow > 0 ? nrow - 1 : 0)) * (int64_t)fdim;   // (clamped: always a valid address)
+      const int d = d0 + 4 * sc4;
+      if (vec_ok && d + 4 <= fdim) v[q] = *reinterpret_cast<const float4*>(xr + d);
+      else { v[q].x = d < fdim ? xr[d] : 0.f; v[q].y = d + 1 < fdim ? xr[d + 1] : 0.f; v[q].z = d + 2 < fdim ? xr[d + 2] : 0.f; v[q].w = d + 3 < fdim ? xr[d + 3] : 0.f; }
+      if (gr >= nrow) v[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  gm_f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[a][b][q] = 0.f;
+
+  float4 vcur[8];
+  load_chunk(0, vcur);
+  for (int d0 = 0; d0 < fdim; d0 += GM_KC) {
+    const int d = d0 + 4 * sc4;
+    float isc[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) isc[e] = (d + e < fdim) ? (float)md->inv_ls[d + e] : 0.f;
+    __syncthreads();   // the previous chunk's fragments are read
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const float sx[4] = {vcur[q].x * isc[0], vcur[q].y * isc[1], vcur[q].z * isc[2], vcur[q].w * isc[3]};
+      unsigned short ph[4], pm[4], pl[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { nrm[q] = fmaf(sx[e], sx[e], nrm[q]); hbo_split3(sx[e], ph[e], pm[e], pl[e]); }
+      const int opq = q >> 2, rr = srow + 32 * (q & 3);
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        const unsigned short* w = p == 0 ? ph : (p == 1 ? pm : pl);
+        uint2 pk;
+        pk.x = (unsigned)w[0] | ((unsigned)w[1] << 16); pk.y = (unsigned)w[2] | ((unsigned)w[3] << 16);
+        *reinterpret_cast<uint2*>(sP + (size_t)((opq * 3 + p) * 128 + rr) * GM_ROWB + 8 * sc4) = pk;
+      }
+    }
+    if (d0 + GM_KC < fdim) load_chunk(d0 + GM_KC, vcur);   // in flight beside this chunk's products
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < GM_KC / 16; ++ks) {
+      // the COLUMN block is the MFMA's row operand: a lane then holds 4 consecutive Gram columns of one Gram row (16-byte stores)
+      gm_bf16x8 fa[3][2], fb[3][2];
+#pragma unroll
+      for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          fa[p][t] = *reinterpret_cast<const gm_bf16x8*>(sP + (size_t)((1 * 3 + p) * 128 + wn * 64 + t * 32 + l32) * GM_ROWB + ks * 32 + lh * 16);
+          fb[p][t] = *reinterpret_cast<const gm_bf16x8*>(sP + (size_t)((0 * 3 + p) * 128 + wm * 64 + t * 32 + l32) * GM_ROWB + ks * 32 + lh * 16);
+        }
+      constexpr int PA[6] = {2, 0, 1, 1, 0, 0};   // smallest products first: l h', h l', m m', m h', h m', h h'
+      constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+      for (int q = 0; q < 6; ++q)
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < 2; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA[q]][a], fb[PB[q]][b], acc[a][b], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    float s_ = nrm[q];
+    s_ += __shfl_xor(s_, 1); s_ += __shfl_xor(s_, 2); s_ += __shfl_xor(s_, 4);
+    if (sc4 == 0) sN[q >> 2][srow + 32 * (q & 3)] = s_;
+  }
+  __syncthreads();
+
+  const float sv = (float)md->sv;
+  const float diag_add = (float)(md->noise + md->eps);
+  const bool on_diag = g.symmetric && ti == tj;
+  const bool interior = r0 + HBO_TILE <= n1 && c0 + HBO_TILE <= n2 && !on_diag && (ldo & 3) == 0 && (reinterpret_cast<unsigned long long>(out) & 15) == 0;
+  // the covariance of u on the fast hardware functions (v_sqrt_f32, v_exp_f32: ~1 ulp each; the fp32 Gram is held to 2e-5)
+  auto cov = [&](float u) -> float {
+    if (KID == HBO_KERNEL_SE) return sv * __builtin_amdgcn_exp2f(u * (-0.5f * 1.44269504088896341f));
+    const float r = __builtin_amdgcn_sqrtf((KID == HBO_KERNEL_MATERN32 ? 3.f : 5.f) * u);
+    const float e = sv * __builtin_amdgcn_exp2f(r * -1.44269504088896341f);
+    return KID == HBO_KERNEL_MATERN32 ? e * (1.f + r) : e * fmaf(r, fmaf(r, 1.f / 3.f, 1.f), 1.f);
+  };
+  // accumulator layout of v_mfma_f32_32x32x16_bf16 with the operands swapped: Gram row = lane & 31 of block b, Gram column =
+  // (q & 3) + 8 (q >> 2) + 4 (lane >> 5) of block a
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    const int rl = wm * 64 + b * 32 + l32;
+    const float na = sN[0][rl];
+    const int64_t gr = r0 + rl;
+    float* orow = out + gr * ldo + c0;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      __builtin_amdgcn_sched_barrier(0);   // (one block of 16 elements at a time)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int cl = wn * 64 + a * 32 + 8 * j + 4 * lh;
+        const float4 nb4 = *reinterpret_cast<const float4*>(&sN[1][cl]);
+        const float nbv[4] = {nb4.x, nb4.y, nb4.z, nb4.w};
+        float val[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float u = fmaxf(na + nbv[e] - 2.f * acc[a][b][4 * j + e], 0.f);
+          if (interior) { val[e] = cov(u); continue; }
+          const int64_t gcol = c0 + cl + e;
+          if (on_diag && gr == gcol) u = 0.f;   // a point and itself: exactly sv (+ noise + jitter)
+          if (gr < n1 && gcol < n2) {
+            val[e] = cov(u);
+            if (on_diag && gr == gcol) val[e] += diag_add;
+          } else {
+            val[e] = (g.symmetric && gr == gcol) ? 1.f : 0.f;   // identity / zero padding
+          }
+        }
+        if (interior) {
+          { V16<float>::type vv; vv[0] = val[0]; vv[1] = val[1]; vv[2] = val[2]; vv[3] = val[3]; gst(reinterpret_cast<V16<float>::type*>(orow + cl), vv); }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (gr < e1 && c0 + cl + e < e2) gst(orow + cl + e, val[e]);
+        }
+      }
+    }
+  }
+}
+
 template <typename T>
 __global__ void kdiag_kernel(const T* __restrict__ f, int64_t n, int fdim, const ModelDev* __restrict__ md,
                              T* out) {
@@ -351,8 +528,21 @@ void launch_gram_k(const GramArgs& a, const ModelDev* md, dim3 grid, hipStream_t
   if (a.padded || a.tasks) hipLaunchKernelGGL((gram_kernel<T, true, KID>), grid, dim3(256), 0, st, a, md);
   else hipLaunchKernelGGL((gram_kernel<T, false, KID>), grid, dim3(256), 0, st, a, md);
 }
+// hbo_tune gram_mfma (process-wide): fp32 Gram matrices of the stationary covariances with at least this many features take
+// gram_mfma_kernel (0: never)
+int g_gram_mfma_min_f = 32;
 template <typename T>
 void launch_gram_t(const GramArgs& a, const ModelDev* md, dim3 grid, hipStream_t st) {
+  if constexpr (sizeof(T) == 4) {
+    if (g_gram_mfma_min_f > 0 && a.fdim >= g_gram_mfma_min_f && a.kernel_id != HBO_KERNEL_DOT && !a.direct_form) {
+      switch (a.kernel_id) {
+        case HBO_KERNEL_SE: hipLaunchKernelGGL((gram_mfma_kernel<HBO_KERNEL_SE>), grid, dim3(256), 0, st, a, md); break;
+        case HBO_KERNEL_MATERN32: hipLaunchKernelGGL((gram_mfma_kernel<HBO_KERNEL_MATERN32>), grid, dim3(256), 0, st, a, md); break;
+        default: hipLaunchKernelGGL((gram_mfma_kernel<HBO_KERNEL_MATERN52>), grid, dim3(256), 0, st, a, md); break;
+      }
+      return;
+    }
+  }
   grid.y *= HBO_TILE / GTR;   // callers size the grid in 128x128 tiles; the kernel tiles rows by GTR
   switch (a.kernel_id) {
     case HBO_KERNEL_SE: launch_gram_k<T, HBO_KERNEL_SE>(a, md, grid, st); break;
@@ -367,6 +557,7 @@ void launch_gram_t(const GramArgs& a, const ModelDev* md, dim3 grid, hipStream_t
 #define DISPATCH(dtype, FN, ...) \
   do { if ((dtype) == HBO_F64) FN<double>(__VA_ARGS__); else FN<float>(__VA_ARGS__); } while (0)
 
+void gram_set_mfma_min_features(int f) { g_gram_mfma_min_f = f; }
 void launch_gram(int dtype, const GramArgs& a, const ModelDev* md, dim3 grid, hipStream_t st) {
   DISPATCH(dtype, launch_gram_t, a, md, grid, st);
 }

@@ -197,9 +197,11 @@ struct GramArgs {
   int symmetric;           // lower tiles only + (noise+eps) on the diagonal + identity padding
   int padded;              // out has a padded ld/extent (16-byte vector stores, zero fill)
   int kernel_id;           // covariance of the model behind the ModelDev pointer (selects the kernel instantiation)
+  int direct_form;         // fp32: keep the VALU kernel's sum (a - b)^2 even where gram_mfma_kernel would apply (see launch_gram_t)
   int model_stride;        // batched mode: task z reads the model at md + z * model_stride (0: one model for the batch; 1: one
                            // ModelDev per task -- S hyper-parameter samples of one model family factorised as one batch)
 };
+void gram_set_mfma_min_features(int f);   // hbo_tune gram_mfma
 void launch_gram(int dtype, const GramArgs& a, const ModelDev* model, dim3 grid, hipStream_t st);
 void launch_kdiag(int dtype, const void* f, int64_t n, int fdim, const ModelDev* model, void* out,
                   hipStream_t st);

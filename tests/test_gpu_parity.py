@@ -102,6 +102,49 @@ def test_gram_vs_oracle(gpu_ctx, kname, mlp, dtype, tol):
   assert kn(pn, np.zeros((0, d), dtype), warp_func=utils.DEFAULT_WARP_FUNC).shape == (0, 0)
 
 
+@pytest.mark.parametrize('kname', ['squared_exponential', 'matern32', 'matern52'])
+@pytest.mark.parametrize('d', [32, 40, 64])
+def test_fp32_gram_on_the_matrix_cores_vs_oracle(gpu_ctx, kname, d):
+  """fp32 Gram matrices of the stationary covariances with >= 32 features take gram_mfma_kernel (csrc/gram.hip, round 6):
+  u = |a|^2 + |b|^2 - 2 a.b with the dot product from the exact three-way bf16 split on the matrix cores.  Symmetric and cross
+  Gram, sizes off the 128-tile grid, a feature count that is not a multiple of the 32-feature chunk, duplicated rows (u ~ 0, where
+  the expansion loses what the direct form keeps): against the fp64 oracle at the fp32 Gram's 2e-5, and against the direct-form
+  kernel (hbo_tune gram_mfma = 0) -- whose own error is recorded beside it."""
+  defs, _, _, _, kernel, _, _, utils = _native()
+  rng = np.random.default_rng(100 + d)
+  model = {'lengthscale': helpers.inv_softplus(rng.uniform(1.5, 3.0, size=d)).astype(np.float32), 'signal_variance': np.float32(helpers.inv_softplus(0.8)),
+           'noise_variance': np.float32(-3.0)}
+  x1 = rng.uniform(-1, 1, size=(300, d)).astype(np.float32)
+  x2 = rng.uniform(-1, 1, size=(150, d)).astype(np.float32)
+  x2[:20] = x1[:20]                                                   # exact duplicates across the two sets
+  x2[20:40] = x1[20:40] + np.float32(1e-3) * rng.normal(size=(20, d)).astype(np.float32)   # near-duplicates
+  x1[280:] = x1[:20]                                                  # duplicates inside the symmetric Gram
+  pn = defs.GPParams(model=model)
+  po = o.GPParams(model=helpers.unflatten_like(model, helpers.flatten(model)))
+  kn, ko = getattr(kernel, kname), getattr(o, kname)
+  ref_s = ko(po, x1.astype(np.float64), warp_func=WFO)
+  ref_c = ko(po, x1.astype(np.float64), x2.astype(np.float64), warp_func=WFO)
+  errs = {}
+  try:
+    for name, minf in (('mfma', 32), ('direct', 0)):
+      gpu_ctx.set_option('gram_mfma', minf)
+      gs = kn(pn, x1, warp_func=utils.DEFAULT_WARP_FUNC)
+      gc = kn(pn, x1, x2, warp_func=utils.DEFAULT_WARP_FUNC)
+      assert gs.dtype == np.float32 and gs.shape == (300, 300) and gc.shape == (300, 150)
+      errs[name] = (helpers.rel_err(gs, ref_s), helpers.rel_err(gc, ref_c))
+      assert errs[name][0] < 2e-5 and errs[name][1] < 2e-5, errs
+      np.testing.assert_allclose(gs, gs.T, atol=2e-5)
+      if name == 'mfma':
+        sv = float(np.log1p(np.exp(float(model['signal_variance']))) + 1e-10)
+        assert np.max(np.abs(np.diag(gs) - sv)) <= 2e-5 * sv               # a point and itself (hbo_gram's direct mode has no exact-zero rule: that is the symmetric factor path)
+        assert np.max(np.abs(gc[:20, :20].diagonal() - sv)) <= 2e-5 * sv     # exact duplicates across the sets: u ~ 1e-7 |a|^2
+  finally:
+    gpu_ctx.set_option('gram_mfma', 32)
+  if os.environ.get('HBO_GRAD_LOG'):
+    with open(os.environ['HBO_GRAD_LOG'], 'a') as f_:
+      f_.write('0 tol=gram32 %s d=%d (symmetric, cross) rel. error vs fp64: mfma %.3e %.3e direct %.3e %.3e\n' % ((kname, d) + errs['mfma'] + errs['direct']))
+
+
 def test_device_exp_against_numpy(gpu_ctx):
   """The pair kernels' own fp64 exp (csrc/kernfun.h: hbo_exp) through the one place it is observable in isolation: the squared
   exponential with unit length-scale and amplitude on 1-D inputs against the origin is exp(-x^2 / 2), and -x^2 / 2 is formed
