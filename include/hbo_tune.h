@@ -43,6 +43,12 @@
  *                          paths): 1 = the rank's local part counts as failed -> it joins the all-reduce with NaN in every slot;
  *                          2 = and it cannot produce that buffer either -> ncclCommAbort, the peers' all-reduce fails, later sharded
  *                          calls return HBO_ERR_COMM until hbo_comm_init
+ *   f2_split      0..2     round 6: the bulk trailing update's leading block columns -- at least the next group's, about one resident round of tiles --
+ *                          as a launch of their own with the event the next F1 waits for behind THAT launch (1: one matrix, 2: batches too).
+ *                          Identical values; measured neutral (N = 8192 10.51 -> 10.57 ms: profiles/r06_f2_split.md); default 0
+ *   gram_mfma     0..4096  PROCESS-WIDE: fp32 Gram matrices of the stationary covariances with at least this many features take gram_mfma_kernel
+ *                          (u = |a|^2 + |b|^2 - 2 a.b, the dot product from exact three-way bf16 splits on the matrix cores; default 32;
+ *                          0 = always the direct form sum (a - b)^2; profiles/r06_gram_mfma.md)
  *   batch_bg      -1..2    batches: the sweep's launches beside the chain as plain grids (0), persistent over tiles x tasks
  *                          from one counter (1), and also polling the per-CU yield table the chain's kernels then fill (2);
  *                          -1 (default): 1 up to 8 tasks, 0 above (8 tasks 2.52 -> 2.44 ms, 64 tasks 14.13 / 14.31) */

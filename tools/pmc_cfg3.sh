@@ -14,7 +14,7 @@ for grp in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES" "GRBM_GUI_ACTIVE"; do
   echo "== $grp   ($*)"
   [ -n "$f" ] && python3 - "$f" "$k" <<'PY'
 import csv, sys, collections, re
-clean = lambda n: re.sub(r'\(.*$', '', re.sub(r'^void \(anonymous namespace\)::', '', n))
+clean = lambda n: re.sub(r'\(.*$', '', n.replace('(anonymous namespace)::', '').replace('void ', ''))
 per = collections.defaultdict(lambda: collections.defaultdict(float)); disp = collections.defaultdict(set)
 for r in csv.DictReader(open(sys.argv[1])):
     n = clean(r['Kernel_Name'])

@@ -13,7 +13,7 @@ for grp in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES" "SQ_INSTS_VALU_MFMA_MOPS
 import csv,sys,collections,re
 per=collections.defaultdict(lambda: collections.defaultdict(float)); disp=collections.defaultdict(set)
 for r in csv.DictReader(open(sys.argv[1])):
-    n=re.sub(r'^void \(anonymous namespace\)::','',r['Kernel_Name']); n=re.sub(r'\(.*$','',n)
+    n=r['Kernel_Name'].replace('(anonymous namespace)::','').replace('void ',''); n=re.sub(r'\(.*$','',n)
     per[n][r['Counter_Name']]+=float(r['Counter_Value']); disp[n].add(r['Dispatch_Id'])
 names=sorted({c for d in per.values() for c in d})
 for n,d in sorted(per.items(), key=lambda kv:-sum(kv[1].values()))[:9]:
