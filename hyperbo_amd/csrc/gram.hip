@@ -166,10 +166,14 @@ __global__ __launch_bounds__(256) void gram_kernel(GramArgs g, const ModelDev* _
 typedef __bf16 gm_bf16x8 __attribute__((ext_vector_type(8)));
 typedef float gm_f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned short gm_u16x8 __attribute__((ext_vector_type(8)));
-constexpr int GM_KC = 32;     // features per staged chunk (two MFMA k steps)
-constexpr int GM_ROWB = 80;   // bytes of one LDS row of one plane: 32 bf16 + 16 bytes (b128 reads of 16 rows and b128 writes of 8 rows hit distinct banks)
+constexpr int GM_KC = 16;     // features per staged chunk (one MFMA k step): 38 KB of LDS, FOUR workgroups per CU -- with 32 (62 KB, two per CU) the
+                              // waves spent half of their 41 000 cycles waiting (SQ_WAIT_ANY / SQ_WAVE_CYCLES, profiles/r06_gram_mfma.md)
+constexpr int GM_ROWB = 2 * GM_KC + 16;   // bytes of one LDS row of one plane: the chunk's bf16 + 16 bytes (the b128 fragment reads of a lane group cover all 64 banks once)
+constexpr int GM_LPR = GM_KC / 4;         // lanes per row of the staging (one float4 each)
+constexpr int GM_RPP = 256 / GM_LPR;      // rows per staging pass
+constexpr int GM_NQ = 256 / GM_RPP;       // passes: the tile's 128 rows, then its 128 columns
 template <int KID>
-__global__ __launch_bounds__(256) void gram_mfma_kernel(GramArgs g, const ModelDev* __restrict__ md) {
+__global__ __launch_bounds__(256, 3) void gram_mfma_kernel(GramArgs g, const ModelDev* __restrict__ md) {
   __shared__ __attribute__((aligned(16))) unsigned char sP[2 * 3 * 128 * GM_ROWB];   // [operand][plane][row]
   __shared__ float sN[2][128];
   const int ti = blockIdx.y;
@@ -193,17 +197,18 @@ __global__ __launch_bounds__(256) void gram_mfma_kernel(GramArgs g, const ModelD
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1, l32 = lane & 31, lh = lane >> 5;
 
-  // staging: 8 consecutive lanes read the 128 bytes (32 features) of one row, a pass of the 256 threads covers 32 rows; passes 0-3
-  // are the tile's rows (x1), 4-7 its columns (x2).  Every thread keeps the partial |row|^2 of its 8 pieces; 8-lane sums at the end.
-  const int sc4 = tid & 7, srow = tid >> 3;
+  // staging: GM_LPR consecutive lanes read the chunk's features of one row (a float4 each), a pass of the 256 threads covers GM_RPP rows;
+  // the first half of the passes are the tile's rows (x1), the second half its columns (x2).  Every thread keeps the partial |row|^2 of its
+  // pieces; GM_LPR-lane sums at the end.
+  const int sc4 = tid % GM_LPR, srow = tid / GM_LPR;
   const bool vec_ok = (fdim & 3) == 0 && ((reinterpret_cast<unsigned long long>(x1) | reinterpret_cast<unsigned long long>(x2)) & 15) == 0;
-  float nrm[8];
+  float nrm[GM_NQ];
 #pragma unroll
-  for (int q = 0; q < 8; ++q) nrm[q] = 0.f;
-  auto load_chunk = [&](int d0, float4 (&v)[8]) {
+  for (int q = 0; q < GM_NQ; ++q) nrm[q] = 0.f;
+  auto load_chunk = [&](int d0, float4 (&v)[GM_NQ]) {
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int opq = q >> 2, rr = srow + 32 * (q & 3);
+    for (int q = 0; q < GM_NQ; ++q) {
+      const int opq = q / (GM_NQ / 2), rr = srow + GM_RPP * (q % (GM_NQ / 2));
       const float* src = opq ? x2 : x1;
       const int64_t nrow = opq ? n2 : n1;
       const int64_t gr = (opq ? c0 : r0) + rr;
@@ -222,7 +227,7 @@ __global__ __launch_bounds__(256) void gram_mfma_kernel(GramArgs g, const ModelD
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc[a][b][q] = 0.f;
 
-  float4 vcur[8];
+  float4 vcur[GM_NQ];
   load_chunk(0, vcur);
   for (int d0 = 0; d0 < fdim; d0 += GM_KC) {
     const int d = d0 + 4 * sc4;
@@ -231,12 +236,12 @@ __global__ __launch_bounds__(256) void gram_mfma_kernel(GramArgs g, const ModelD
     for (int e = 0; e < 4; ++e) isc[e] = (d + e < fdim) ? (float)md->inv_ls[d + e] : 0.f;
     __syncthreads();   // the previous chunk's fragments are read
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
+    for (int q = 0; q < GM_NQ; ++q) {
       const float sx[4] = {vcur[q].x * isc[0], vcur[q].y * isc[1], vcur[q].z * isc[2], vcur[q].w * isc[3]};
       unsigned short ph[4], pm[4], pl[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) { nrm[q] = fmaf(sx[e], sx[e], nrm[q]); hbo_split3(sx[e], ph[e], pm[e], pl[e]); }
-      const int opq = q >> 2, rr = srow + 32 * (q & 3);
+      const int opq = q / (GM_NQ / 2), rr = srow + GM_RPP * (q % (GM_NQ / 2));
 #pragma unroll
       for (int p = 0; p < 3; ++p) {
         const unsigned short* w = p == 0 ? ph : (p == 1 ? pm : pl);
@@ -270,10 +275,11 @@ __global__ __launch_bounds__(256) void gram_mfma_kernel(GramArgs g, const ModelD
     }
   }
 #pragma unroll
-  for (int q = 0; q < 8; ++q) {
+  for (int q = 0; q < GM_NQ; ++q) {
     float s_ = nrm[q];
-    s_ += __shfl_xor(s_, 1); s_ += __shfl_xor(s_, 2); s_ += __shfl_xor(s_, 4);
-    if (sc4 == 0) sN[q >> 2][srow + 32 * (q & 3)] = s_;
+#pragma unroll
+    for (int o = 1; o < GM_LPR; o *= 2) s_ += __shfl_xor(s_, o);
+    if (sc4 == 0) sN[q / (GM_NQ / 2)][srow + GM_RPP * (q % (GM_NQ / 2))] = s_;
   }
   __syncthreads();
 
